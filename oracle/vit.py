@@ -23,7 +23,7 @@ class _MHA(nn.Module):
 
     def __init__(self, d, heads):
         super().__init__()
-        self.in_proj_weight = nn.Parameter(torch.empty(3 * d, d))
+        self.in_proj_weight = nn.Parameter(torch.randn(3 * d, d) * d ** -0.5)
         self.in_proj_bias = nn.Parameter(torch.zeros(3 * d))
         self.out_proj = nn.Linear(d, d)
         self.heads = heads
