@@ -1,0 +1,171 @@
+/* unimp_hip.h -- C ABI of libunimp_hip.so: the MI355X (gfx950) kernels behind UniMP's Flamingo train step.
+ *
+ * The reference (weitianxin/UniMP) has no native FFI: its hot path is reached through the Python API of
+ * the pip package open-flamingo==2.0.1 (UniMP/mmrec.py:20-22,476-524 construction; :177-181 forward;
+ * :190-213 loss; :215-256 backward/clip/AdamW).  Each entry point below names the reference arithmetic it
+ * replaces.  The Python package `unimp_amd` (the open_flamingo-surface drop-in) is the only caller.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer on the current HIP device unless marked host;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises;
+ *   - bf16 tensors are row-major with an explicit leading dimension in ELEMENTS; vector-accessed bases
+ *     must be 16-byte aligned and leading dimensions multiples of 8 unless stated;
+ *   - no ownership transfer, no allocation inside any entry point (graph-capture safe);
+ *   - return 0 on success, a UNIMP_ERR_* code otherwise (message via unimp_last_error()).
+ */
+#ifndef UNIMP_HIP_H
+#define UNIMP_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UNIMP_ABI_VERSION 1
+enum { UNIMP_OK = 0, UNIMP_ERR_ARG = 1, UNIMP_ERR_SHAPE = 2, UNIMP_ERR_ALIGN = 3, UNIMP_ERR_LAUNCH = 4,
+       UNIMP_ERR_UNSUPPORTED = 5 };
+enum { UNIMP_ACT_NONE = 0, UNIMP_ACT_GELU = 1, UNIMP_ACT_QUICKGELU = 2, UNIMP_ACT_RELU = 3, UNIMP_ACT_SILU = 4 };
+enum { UNIMP_MASK_NONE = 0, UNIMP_MASK_CAUSAL = 1, UNIMP_MASK_SEGMENT = 2 };
+
+int unimp_abi_version(void);
+const char* unimp_last_error(void);          /* thread-local, valid until the next failing call */
+/* internal helpers shared by the translation units (exported for the tests' benefit only) */
+int unimp_set_error(int code, const char* msg);
+int unimp_check_launch(const char* what);
+
+/* ---- dense layers: nn.Linear forward / dX / dW, ViT conv1-as-GEMM --------------------------------------
+ * replaces: F.linear in every tower (clip.py:98-141,144-156; gpt_neox modelling :180-283; open_flamingo
+ * helpers to_q/to_kv/to_out/ff), their autograd backward, and the lm-head GEMM (mmrec.py:177-190).
+ *   C[M,N] = epi( alpha * sum_k A(m,k) B(n,k) )
+ *   a_kstrided=0: A(m,k)=A[m*lda+k]   a_kstrided=1: A(m,k)=A[k*lda+m]      (same for B with n)
+ *   epi: v += bias[n]; pre[m,n] = v; v = act(v); v *= act'(aux[m,n]) (dact); v *= tanh(*gate);
+ *        v += res[m,n]; if accumulate v += C[m,n]; C = bf16(v) or f32(v)
+ */
+typedef struct {
+  const void* A; const void* B; void* C;
+  int M, N, K;
+  int64_t lda, ldb, ldc;
+  int a_kstrided, b_kstrided;
+  const void* bias;
+  const void* res; int64_t ldres;
+  const void* aux; int64_t ldaux;
+  void* pre; int64_t ldpre;
+  const void* gate;
+  float alpha;
+  int act, dact;
+  int out_f32, accumulate;
+} unimp_gemm_desc;
+int unimp_gemm_bf16(const unimp_gemm_desc* d, void* stream);
+
+/* ---- LayerNorm / RMSNorm ---------------------------------------------------------------------------------
+ * replaces nn.LayerNorm (clip.py:164-166,423; gpt_neox input/post_attention/final LN; open_flamingo norms)
+ * and LlamaRMSNorm (llama.py:101-118).  rows x D, one wave per row, statistics in fp32.
+ * Output row r goes to row (r / grp) * grp_stride + (r % grp) + grp_off of y (grp = 0: identity) so the
+ * Perceiver's cat(x, latents) (open_flamingo PerceiverAttention) is written in place.
+ * bwd: dx = LN'(dy) (+ dres if given); dgamma/dbeta (bf16 [D], overwritten) through `partial` (fp32
+ * [partial_blocks*2*D]) when gamma grads are wanted (dgamma != NULL); dy rows are read through the same row map.
+ */
+int unimp_layernorm_fwd(const void* x, int64_t ldx, const void* gamma, const void* beta, void* y, int64_t ldy,
+                        float* mean, float* rstd, int rows, int D, float eps, int rms,
+                        int grp, int grp_stride, int grp_off, void* stream);
+int unimp_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* gamma,
+                        const float* mean, const float* rstd, const void* dres, int64_t lddres,
+                        void* dx, int64_t lddx, void* dgamma, void* dbeta, float* partial, int partial_blocks,
+                        int rows, int D, int rms, int grp, int grp_stride, int grp_off, void* stream);
+
+/* ---- rotary embedding, GPT-NeoX / Llama half-split (gpt_neox modelling :107-160; llama.py:121-182) ------
+ * in place on x viewed as [rows = B*L][heads][head_stride]; rotates the first `rot` dims of the `nvec`
+ * vectors (q and k) found at element offsets vec_off[0..nvec) inside each head slot; position = row % L.
+ * inverse != 0 applies the transpose rotation (backward).  cos/sin: fp32 [L][rot/2].
+ */
+int unimp_rope_halfsplit(void* x, int64_t row_stride, int64_t head_stride, int rows, int L, int heads, int rot,
+                         int nvec, int vec_off0, int vec_off1, const float* cos_t, const float* sin_t, int inverse,
+                         void* stream);
+
+/* ---- attention (flash-style, MFMA) -------------------------------------------------------------------------
+ * replaces xformers.ops.memory_efficient_attention (clip.py:130-136; llama.py:287-301), the GPT-NeoX causal
+ * SDPA, open_flamingo PerceiverAttention and MaskedCrossAttention softmax(QK^T)V.
+ * q/k/v/o are [B][S][H][D] views with element strides (batch, seq, head); D in {64, 80, 128}.
+ *   MASK_NONE   : keys j < kv_len[b] (kv_len NULL: all Sk)
+ *   MASK_CAUSAL : keys j <= i and j < kv_len[b]
+ *   MASK_SEGMENT: query i attends keys [(t-1)*seg_len, t*seg_len) with t = seg[b*Sq+i]; t == 0: output 0
+ *                 (open_flamingo only_attend_immediate_media=True, rows before the first <image> zeroed)
+ * lse: fp32 [B][H][Sq] (natural log; -inf for empty rows).
+ */
+typedef struct {
+  const void* q; const void* k; const void* v; void* o; float* lse;
+  int64_t q_bs, q_ss, q_hs, k_bs, k_ss, k_hs, v_bs, v_ss, v_hs, o_bs, o_ss, o_hs;
+  int B, H, Sq, Sk, D;
+  float scale;
+  int mask_mode;
+  const int32_t* kv_len;
+  const int32_t* seg; int seg_len;
+  /* backward only */
+  const void* d_o; void* dq; void* dk; void* dv; float* delta;   /* delta: fp32 [B][H][Sq] workspace */
+  int64_t do_bs, do_ss, do_hs, dq_bs, dq_ss, dq_hs, dk_bs, dk_ss, dk_hs, dv_bs, dv_ss, dv_hs;
+} unimp_attn_desc;
+int unimp_attn_fwd(const unimp_attn_desc* d, void* stream);
+int unimp_attn_bwd(const unimp_attn_desc* d, void* stream);
+
+/* ---- token embedding (gpt_neox.embed_in / OPT embed_tokens+embed_positions) -------------------------------
+ * fwd: out[r] = W[ids[r]] (+ P[pos[r]]);  bwd: dW[ids[r]] += dout[r]  (fp32 atomics into dW32, then cast)
+ */
+int unimp_embedding_fwd(const int64_t* ids, const void* W, int64_t ldw, const int64_t* pos, const void* P, int64_t ldp,
+                        void* out, int64_t ldo, int rows, int D, int vocab, void* stream);
+int unimp_embedding_bwd(const int64_t* ids, const void* dout, int64_t lddo, float* dW32, int64_t lddw,
+                        int rows, int D, int vocab, void* stream);
+
+/* ---- ViT input path: conv1(k=s=P, no bias) as im2col + GEMM, class token, position embedding ------------
+ * (clip.py:60-84).  patchify: pixels [N,3,Hi,Wi] (fp32 or bf16) -> cols [N*g*g][ldc] bf16, k = c*P*P+py*P+px,
+ * zero padded to ldc.  assemble: x[n][0] = cls + pos[0]; x[n][1+i] = patch[n*g*g+i] + pos[1+i].
+ */
+int unimp_vit_patchify(const void* pixels, int pixels_f32, void* cols, int64_t ldc, int N, int Hi, int Wi, int P,
+                       void* stream);
+int unimp_vit_assemble(const void* patch, int64_t ldp, const void* cls, const void* pos, void* x, int N, int n_patch,
+                       int D, void* stream);
+
+/* ---- elementwise helpers ----------------------------------------------------------------------------------*/
+int unimp_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream);            /* out = a + b */
+int unimp_cast_f32_to_bf16(const float* src, void* dst, int64_t n, float scale, void* stream);
+int unimp_swiglu_fwd(const void* gate_up, int64_t ld, void* out, int64_t ldo, int rows, int F, void* stream);
+int unimp_swiglu_bwd(const void* gate_up, int64_t ld, const void* dout, int64_t lddo, void* dgate_up, int64_t ldd,
+                     int rows, int F, void* stream);
+/* out[0] += sum(a*b) over n elements (fp32, out zeroed by the caller): d tanh-gate = dot(dy, y_pre_gate) */
+int unimp_dot_bf16(const void* a, const void* b, int64_t n, float* out, void* stream);
+/* out[r] = src[r % period] (Perceiver latents repeat "n d -> b T n d") and its adjoint out[j] = sum_{r%period==j} src[r] (bf16) */
+int unimp_bcast_rows(const void* src, void* out, int64_t ldo, int rows, int period, int D, void* stream);
+int unimp_reduce_rows_periodic(const void* src, int64_t lds_, void* out, int rows, int period, int D, void* stream);
+
+/* ---- training-step host logic moved to the device ---------------------------------------------------------
+ * label mask state machine (mmrec.py:143-168): labels[b][j] = keep ? ids : -100, one thread block per row.
+ * media_time (open_flamingo MaskedCrossAttention text_time = cumsum(ids == media_id)) int32 [B][L].
+ */
+int unimp_label_mask(const int64_t* ids, int64_t* labels, int32_t* media_time, int B, int L, int64_t answer_id,
+                     int64_t eoc_id, int64_t pad_id, int64_t media_id, void* stream);
+
+/* ---- weighted focal cross-entropy (mmrec.py:190-213) -------------------------------------------------------
+ * logits bf16 [B][L][ldv] (V valid columns); labels int64 [B][L] (un-shifted; row (b,j) is scored against
+ * labels[b][j+1], j < L-1); weights fp32 [B].
+ * fwd: per-row stats (lse, z_y) + out[0] = sum_rows w*ce*(1-pt)^gamma, out[1] = #valid, out[2] = sum ce (HF mean CE numerator).
+ * bwd: dlogits[b][j][k] = gscale/out[1] * w_b * (p_k - [k==y]) * coef  (focal term NOT detached); rows without a
+ *      label and pad columns [V,ldv) are written as zeros.  dlogits may alias logits.
+ */
+int unimp_focal_ce_fwd(const void* logits, int64_t ldv, const int64_t* labels, const float* weights, float gamma,
+                       int use_reweight, float* row_lse, float* row_zy, float* out3, int B, int L, int V, void* stream);
+int unimp_focal_ce_bwd(const void* logits, int64_t ldv, const int64_t* labels, const float* weights, float gamma,
+                       int use_reweight, const float* row_lse, const float* row_zy, const float* out3,
+                       const float* gscale, void* dlogits, int B, int L, int V, void* stream);
+
+/* ---- optimizer (mmrec.py:247-256,609-631,671): global-norm clip + AdamW, flat buffers ---------------------
+ * sumsq: out[0] += sum(g^2) (fp32; caller zeroes out[0]; out[1..1025) is scratch for the ordered reduction).  adamw: for i in [0,n): g = grad[i]*gscale*clip,
+ * clip = min(1, max_norm/(sqrt(sumsq[0])*gscale + 1e-6)); decoupled weight decay `wd` for i < n_decay, 0 after;
+ * fp32 master/m/v updated, bf16 shadow param rewritten, grad zeroed when zero_grad != 0.  step is 1-based.
+ */
+int unimp_sumsq_bf16(const void* g, int64_t n, float* out, void* stream);
+int unimp_adamw_flat(float* master, float* m, float* v, void* param_bf16, void* grad_bf16, int64_t n, int64_t n_decay,
+                     float lr, float beta1, float beta2, float eps, float wd, int step, const float* sumsq,
+                     float gscale, float max_norm, int zero_grad, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

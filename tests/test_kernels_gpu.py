@@ -1,0 +1,406 @@
+"""Per-kernel parity on a real MI355X: every C-ABI kernel against fp32 CPU math on the same seeded inputs.
+
+Tolerances are written per test: inputs are bf16-representable, the kernels accumulate in fp32 and round the
+result to bf16 once, so the bound is a few bf16 ulps (2^-8 relative) of the result scale; integer outputs are bit-exact.
+"""
+import math
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+bf16 = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from unimp_amd import ops as o
+    return o
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(bf16)
+
+
+def close(got, want, rel=2 ** -7, name=""):
+    got, want = got.float().cpu(), want.float().cpu()
+    assert got.shape == want.shape, (got.shape, want.shape)
+    assert torch.isfinite(got).all(), name + " non-finite"
+    err = (got - want).abs().max().item()
+    scale = want.abs().max().item() + 1e-6
+    assert err <= rel * scale, f"{name}: max err {err:.4g} vs scale {scale:.4g} (rel {err / scale:.3g} > {rel:.3g})"
+
+
+def act_ref(name, x):
+    if name == "gelu":
+        return torch.nn.functional.gelu(x)
+    if name == "quick_gelu":
+        return x * torch.sigmoid(1.702 * x)
+    if name == "relu":
+        return torch.relu(x)
+    if name == "silu":
+        return torch.nn.functional.silu(x)
+    return x
+
+
+# ------------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (300, 200, 72), (1, 8, 8), (1024, 2560, 2560),
+                                   (77, 1000, 600), (513, 136, 1032)])
+@pytest.mark.parametrize("a_ks,b_ks", [(False, False), (False, True), (True, True), (True, False)])
+def test_gemm_layouts(ops, M, N, K, a_ks, b_ks):
+    if (a_ks and M % 8) or (b_ks and N % 8):
+        pytest.skip("k-strided operands need rows % 8 == 0")
+    a, b = rnd(M, K, seed=1), rnd(N, K, seed=2)
+    want = a.float() @ b.float().t()
+    ad = (a.t().contiguous() if a_ks else a).cuda()
+    bd = (b.t().contiguous() if b_ks else b).cuda()
+    got = ops.gemm(ad, bd, a_ks=a_ks, b_ks=b_ks)
+    close(got, want, name=f"gemm {M}x{N}x{K} {a_ks}{b_ks}")
+    got32 = ops.gemm(ad, bd, a_ks=a_ks, b_ks=b_ks, out_f32=True)
+    close(got32, want, rel=1e-5, name="gemm f32 out")
+
+
+def test_gemm_asymmetric_identity(ops):
+    """A = I with an asymmetric B catches a transposed C write (cdna guide §3)."""
+    n = 128
+    a = torch.eye(n).to(bf16)
+    b = (torch.arange(n)[:, None] * 2 + torch.arange(n)[None, :] % 7).float().to(bf16)   # asymmetric
+    got = ops.gemm(a.cuda(), b.cuda())          # C = A @ B^T = B^T
+    assert torch.equal(got.float().cpu(), b.float().t())
+
+
+@pytest.mark.parametrize("act", [None, "gelu", "quick_gelu", "relu"])
+def test_gemm_epilogue_bias_act_pre(ops, act):
+    M, N, K = 200, 264, 136
+    a, b, bias = rnd(M, K, seed=3), rnd(N, K, seed=4, scale=0.2), rnd(N, seed=5)
+    z = a.float() @ b.float().t() + bias.float()
+    pre = torch.empty(M, N, dtype=bf16, device="cuda")
+    got = ops.gemm(a.cuda(), b.cuda(), bias=bias.cuda(), act=act, pre=pre)
+    close(pre, z, name="pre")
+    close(got, act_ref(act, z), name=f"act {act}")
+
+
+def test_gemm_epilogue_gate_res_dact_accum(ops):
+    M, N, K = 136, 200, 264
+    a, b = rnd(M, K, seed=6), rnd(N, K, seed=7, scale=0.2)
+    res, aux = rnd(M, N, seed=8), rnd(M, N, seed=9)
+    gate = torch.tensor([0.7]).to(bf16)
+    z = a.float() @ b.float().t()
+    want = z * math.tanh(float(gate.float())) + res.float()
+    got = ops.gemm(a.cuda(), b.cuda(), gate=gate.cuda(), res=res.cuda())
+    close(got, want, name="gate+res")
+    x = aux.float().requires_grad_(True)
+    torch.nn.functional.gelu(x).sum().backward()
+    got = ops.gemm(a.cuda(), b.cuda(), aux=aux.cuda(), dact="gelu")
+    close(got, z * x.grad, name="dact gelu")
+    x = aux.float().requires_grad_(True)
+    (x * torch.sigmoid(1.702 * x)).sum().backward()
+    got = ops.gemm(a.cuda(), b.cuda(), aux=aux.cuda(), dact="quick_gelu")
+    close(got, z * x.grad, name="dact quick_gelu")
+    acc = torch.full((M, N), 3.0, dtype=torch.float32, device="cuda")
+    ops.gemm(a.cuda(), b.cuda(), out=acc, accumulate=True, alpha=0.5)
+    close(acc, 0.5 * z + 3.0, rel=1e-5, name="accumulate f32")
+
+
+def test_gemm_padded_vocab_like(ops):
+    """lm-head shape class: N odd (74053-like), padded ldc; dX/dW read the padded dlogits."""
+    M, V, H = 96, 1005, 128
+    ldv = 1008
+    h, w = rnd(M, H, seed=10), rnd(V, H, seed=11, scale=0.3)
+    logits = ops.gemm(h.cuda(), w.cuda(), ldc=ldv)
+    assert logits.shape == (M, V) and logits.stride(0) == ldv
+    close(logits, h.float() @ w.float().t(), name="head fwd")
+    dl = torch.zeros(M, ldv, dtype=bf16)
+    dl[:, :V] = rnd(M, V, seed=12)
+    dld = dl.cuda()
+    dh = ops.gemm(dld[:, :V], w.cuda(), b_ks=True)                   # [M,V] @ [V,H]
+    close(dh, dl[:, :V].float() @ w.float(), name="head dX")
+    dw = ops.gemm(dld[:, :V], h.cuda(), a_ks=True, b_ks=True)        # dl^T @ h -> [V,H]
+    close(dw, dl[:, :V].float().t() @ h.float(), name="head dW")
+
+
+def test_gemm_rejects_bad_args(ops):
+    from unimp_amd._lib import UnimpHipError
+    a = rnd(16, 12).cuda()      # K = 12: ld not a multiple of 8
+    with pytest.raises(UnimpHipError):
+        ops.gemm(a, a)
+    with pytest.raises(UnimpHipError):
+        ops.gemm(rnd(8, 8), rnd(8, 8))       # CPU tensors: no fallback
+
+
+# ------------------------------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("rows,D", [(5, 64), (300, 1024), (257, 768), (130, 2560), (33, 4096)])
+@pytest.mark.parametrize("rms", [False, True])
+def test_layernorm_fwd_bwd(ops, rows, D, rms):
+    x, g, b, dy = rnd(rows, D, seed=1, scale=2.0), (1 + 0.3 * rnd(D, seed=2).float()).to(bf16), rnd(D, seed=3), rnd(rows, D, seed=4)
+    eps = 1e-5
+    xr = x.float().requires_grad_(True)
+    gr, br = g.float().requires_grad_(True), b.float().requires_grad_(True)
+    if rms:
+        y = gr * (xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + eps))
+    else:
+        y = torch.nn.functional.layer_norm(xr, (D,), gr, br, eps)
+    y.backward(dy.float())
+    out, mean, rstd = ops.layernorm_fwd(x.cuda(), g.cuda(), None if rms else b.cuda(), eps, rms=rms)
+    close(out, y.detach(), name="ln fwd")
+    res = rnd(rows, D, seed=5)
+    dx, dg, db = ops.layernorm_bwd(dy.cuda(), x.cuda(), g.cuda(), mean, rstd, dres=res.cuda(), want_wgrad=True,
+                                   has_beta=not rms, rms=rms)
+    close(dx, xr.grad + res.float(), name="ln dx+res")
+    close(dg, gr.grad, rel=2 ** -6, name="ln dgamma")
+    if not rms:
+        close(db, br.grad, rel=2 ** -6, name="ln dbeta")
+    dx2, _, _ = ops.layernorm_bwd(dy.cuda(), x.cuda(), g.cuda(), mean, rstd, rms=rms)
+    close(dx2, xr.grad, name="ln dx")
+
+
+def test_layernorm_grouped_rows(ops):
+    """Perceiver cat(x, latents): two LNs write into one [G, 5, D] buffer."""
+    G, D = 7, 128
+    xa, xb = rnd(G * 3, D, seed=1), rnd(G * 2, D, seed=2)
+    g, b = rnd(D, seed=3), rnd(D, seed=4)
+    buf = torch.zeros(G * 5, D, dtype=bf16, device="cuda")
+    ops.layernorm_fwd(xa.cuda(), g.cuda(), b.cuda(), 1e-5, out=buf, grp=3, grp_stride=5, grp_off=0)
+    ops.layernorm_fwd(xb.cuda(), g.cuda(), b.cuda(), 1e-5, out=buf, grp=2, grp_stride=5, grp_off=3)
+    ya = torch.nn.functional.layer_norm(xa.float(), (D,), g.float(), b.float())
+    yb = torch.nn.functional.layer_norm(xb.float(), (D,), g.float(), b.float())
+    want = torch.cat([ya.view(G, 3, D), yb.view(G, 2, D)], 1).reshape(G * 5, D)
+    close(buf, want, name="grouped ln")
+
+
+# ------------------------------------------------------------------------------------------------- attention
+def attn_ref(q, k, v, scale, mode, kv_len=None, seg=None, seg_len=0):
+    """q [B,Sq,H,D] etc, fp32 reference with explicit masks; fully-masked rows -> 0."""
+    B, Sq, H, D = q.shape
+    Sk = k.shape[1]
+    s = torch.einsum("bqhd,bkhd->bhqk", q, k) * scale
+    ok = torch.ones(B, 1, Sq, Sk, dtype=torch.bool)
+    kk = torch.arange(Sk)[None, None, None, :]
+    if kv_len is not None:
+        ok = ok & (kk < kv_len[:, None, None, None])
+    if mode == 1:
+        ok = ok & (kk <= torch.arange(Sq)[None, None, :, None])
+    if mode == 2:
+        t = seg[:, None, :, None]
+        ok = ok & (kk >= (t - 1) * seg_len) & (kk < t * seg_len) & (t > 0)
+    s = s.masked_fill(~ok, float("-inf"))
+    p = torch.softmax(s, -1)
+    p = torch.nan_to_num(p, nan=0.0)
+    return torch.einsum("bhqk,bkhd->bqhd", p, v)
+
+
+ATTN_CASES = [
+    # B, H, Sq, Sk, D, mode
+    (2, 3, 64, 64, 64, 0), (2, 2, 257, 257, 64, 0), (1, 2, 64, 320, 64, 0), (2, 4, 200, 200, 80, 1),
+    (1, 2, 512, 512, 80, 1), (2, 2, 130, 130, 128, 1), (2, 8, 100, 192, 64, 2), (1, 2, 96, 96, 64, 1),
+]
+
+
+@pytest.mark.parametrize("B,H,Sq,Sk,D,mode", ATTN_CASES)
+def test_attention_fwd_bwd(ops, B, H, Sq, Sk, D, mode):
+    g = torch.Generator().manual_seed(Sq * 7 + D)
+    # packed [B, S, H, 3D] buffer like the fused QKV GEMM output: exercises strided views
+    if Sq == Sk:
+        qkv = (torch.randn(B, Sq, H, 3 * D, generator=g)).to(bf16)
+        q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+    else:
+        q = torch.randn(B, Sq, H, D, generator=g).to(bf16)
+        kv = torch.randn(B, Sk, 2, H, D, generator=g).to(bf16)
+        k, v = kv[:, :, 0], kv[:, :, 1]
+    kv_len = seg = None
+    seg_len = 0
+    if mode in (0, 1) and Sq == Sk and B > 1:
+        kv_len = torch.tensor([Sk, max(1, Sk - 37)][:B], dtype=torch.int32)
+    if mode == 2:
+        seg_len = 64
+        T = Sk // seg_len
+        seg = torch.zeros(B, Sq, dtype=torch.int32)
+        for b in range(B):
+            cuts = sorted(torch.randint(3, Sq, (T,), generator=g).tolist())
+            for c in cuts:
+                seg[b, c:] += 1
+        seg.clamp_(max=T)
+    scale = D ** -0.5
+    qr, kr, vr = (t.float().requires_grad_(True) for t in (q, k, v))
+    want = attn_ref(qr, kr, vr, scale, mode, kv_len.long() if kv_len is not None else None, seg.long() if seg is not None else None, seg_len)
+    do = torch.randn(B, Sq, H, D, generator=g).to(bf16)
+    want.backward(do.float())
+    dev = lambda t: None if t is None else t.cuda()
+    if Sq == Sk:
+        qkv_d = qkv.cuda()
+        qd, kd, vd = qkv_d[..., :D], qkv_d[..., D:2 * D], qkv_d[..., 2 * D:]
+    else:
+        qd, kvd = q.cuda(), kv.cuda()
+        kd, vd = kvd[:, :, 0], kvd[:, :, 1]
+    out, lse = ops.attn_fwd(qd, kd, vd, scale, mode, dev(kv_len), dev(seg), seg_len)
+    close(out, want.detach(), rel=2 ** -6, name="attn fwd")
+    if Sq == Sk:
+        dqkv = torch.full_like(qkv_d, float("nan"))
+        dq, dk, dv = dqkv[..., :D], dqkv[..., D:2 * D], dqkv[..., 2 * D:]
+    else:
+        dq = torch.full_like(qd, float("nan"))
+        dkv = torch.full_like(kvd, float("nan"))
+        dk, dv = dkv[:, :, 0], dkv[:, :, 1]
+    ops.attn_bwd(qd, kd, vd, out, lse, do.cuda(), dq, dk, dv, scale, mode, dev(kv_len), dev(seg), seg_len)
+    close(dq, qr.grad, rel=2 ** -5, name="attn dq")
+    close(dk, kr.grad, rel=2 ** -5, name="attn dk")
+    close(dv, vr.grad, rel=2 ** -5, name="attn dv")
+
+
+def test_attention_spiked_row_online_softmax(ops):
+    """force the running-max rescale branch: one key far above the rest in a late tile (cdna guide rule 26)."""
+    B, H, S, D = 1, 1, 256, 64
+    g = torch.Generator().manual_seed(0)
+    q, k, v = (torch.randn(B, S, H, D, generator=g).to(bf16) for _ in range(3))
+    k[0, 200, 0] = q[0, 5, 0] * 6.0
+    want = attn_ref(q.float(), k.float(), v.float(), D ** -0.5, 0)
+    out, _ = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), D ** -0.5, 0)
+    close(out, want, rel=2 ** -6, name="spiked")
+
+
+# ------------------------------------------------------------------------------------------------- RoPE
+@pytest.mark.parametrize("hd,rot", [(80, 80), (64, 64), (64, 32), (96, 24)])
+def test_rope(ops, hd, rot):
+    from oracle.lm import neox_rope_tables, rotate_half
+    B, L, nh = 2, 37, 3
+    qkv = rnd(B * L, nh * 3 * hd, seed=1)
+    cos, sin = neox_rope_tables(L, rot, 10000.0)
+    x = qkv.float().view(B, L, nh, 3 * hd)
+    want = x.clone()
+    for off in (0, hd):
+        r = x[..., off:off + rot]
+        want[..., off:off + rot] = r * cos[None, :, None] + rotate_half(r) * sin[None, :, None]
+    d = qkv.cuda().clone()
+    half = rot // 2
+    ct, st = cos[:, :half].contiguous().cuda(), sin[:, :half].contiguous().cuda()
+    ops.rope_(d, L, nh, 3 * hd, rot, (0, hd), ct, st)
+    close(d, want.view(B * L, -1), name="rope")
+    ops.rope_(d, L, nh, 3 * hd, rot, (0, hd), ct, st, inverse=True)
+    close(d, qkv.float(), rel=2 ** -6, name="rope inverse")
+
+
+# ------------------------------------------------------------------------------------------------- embedding / misc
+def test_embedding_fwd_bwd(ops):
+    V, D, n = 50, 64, 300
+    W, P = rnd(V, D, seed=1), rnd(20, D, seed=2)
+    ids = torch.randint(0, V, (n,))
+    pos = torch.randint(0, 20, (n,))
+    out = ops.embedding_fwd(ids.cuda(), W.cuda())
+    assert torch.equal(out.cpu(), W[ids])
+    out = ops.embedding_fwd(ids.cuda(), W.cuda(), pos.cuda(), P.cuda())
+    close(out, W[ids].float() + P[pos].float(), name="emb+pos")
+    dout = rnd(n, D, seed=3)
+    dW = ops.embedding_bwd(ids.cuda(), dout.cuda(), V)
+    want = torch.zeros(V, D).index_add_(0, ids, dout.float())
+    close(dW, want, name="emb bwd")
+
+
+def test_vit_patchify_assemble(ops):
+    N, P, Hi = 3, 14, 56
+    px = torch.randn(N, 3, Hi, Hi)
+    K = 3 * P * P
+    ld = (K + 7) // 8 * 8
+    cols = ops.vit_patchify(px.cuda(), P, ld)
+    want = torch.nn.functional.unfold(px, P, stride=P).transpose(1, 2).reshape(-1, K)   # (N*g*g, c*P*P+py*P+px)
+    close(cols[:, :K], want, name="patchify")
+    assert (cols[:, K:] == 0).all()
+    D, g2 = 64, (Hi // P) ** 2
+    patch, cls, pos = rnd(N * g2, D, seed=1), rnd(D, seed=2), rnd(g2 + 1, D, seed=3)
+    x = ops.vit_assemble(patch.cuda(), cls.cuda(), pos.cuda(), N, g2)
+    want = torch.cat([cls.float().expand(N, 1, D), patch.float().view(N, g2, D)], 1) + pos.float()
+    close(x, want, name="assemble")
+
+
+def test_small_elementwise(ops):
+    a, b = rnd(1000, 24, seed=1), rnd(1000, 24, seed=2)
+    close(ops.add(a.cuda(), b.cuda()), a.float() + b.float(), name="add")
+    close(ops.dot(a.cuda(), b.cuda()), (a.float() * b.float()).sum()[None], rel=1e-4, name="dot")
+    f = torch.randn(1003)
+    close(ops.cast_bf16(f.cuda(), 0.5), (f * 0.5), name="cast")
+    src = rnd(4, 64, seed=3)
+    out = ops.bcast_rows(src.cuda(), 20)
+    assert torch.equal(out.cpu(), src.repeat(5, 1))
+    big = rnd(20, 64, seed=4)
+    close(ops.reduce_rows_periodic(big.cuda(), 4), big.float().view(5, 4, 64).sum(0), name="reduce periodic")
+    gu = rnd(50, 2 * 40, seed=5)
+    close(ops.swiglu_fwd(gu.cuda(), 40), torch.nn.functional.silu(gu.float()[:, :40]) * gu.float()[:, 40:], name="swiglu")
+    x = gu.float().requires_grad_(True)
+    dout = rnd(50, 40, seed=6)
+    (torch.nn.functional.silu(x[:, :40]) * x[:, 40:]).backward(dout.float())
+    close(ops.swiglu_bwd(gu.cuda(), dout.cuda(), 40), x.grad, name="swiglu bwd")
+
+
+# ------------------------------------------------------------------------------------------------- train step kernels
+def test_label_mask_bit_exact(ops):
+    from oracle import train_step as ts
+    rng = np.random.default_rng(0)
+    for L in (24, 64, 130, 512):
+        ids = rng.integers(0, 12, size=(5, L))
+        want = ts.label_mask_loop(ids, 8, 9, 10, 11)
+        labels, mt = ops.label_mask(torch.from_numpy(ids).cuda(), 8, 9, 10, 11)
+        assert np.array_equal(labels.cpu().numpy(), want)
+        assert np.array_equal(mt.cpu().numpy(), np.cumsum(ids == 11, 1))
+
+
+def test_label_mask_golden(ops, golden_dir):
+    import os
+    z = np.load(os.path.join(golden_dir, "train_step_g2_rw1.npz"))
+    ANS, EOC, PAD, IMG = [int(v) for v in z["special"]]
+    labels, _ = ops.label_mask(torch.from_numpy(z["ids"]).cuda(), ANS, EOC, PAD, IMG)
+    assert np.array_equal(labels.cpu().numpy(), z["labels"])
+
+
+@pytest.mark.parametrize("gamma,rw", [(0, 0), (0, 1), (2, 0), (2, 1)])
+def test_focal_ce_golden(ops, golden_dir, gamma, rw):
+    """reference-captured loss / dlogits (mmrec.train_one_epoch) with bf16-rounded logits as input."""
+    import os
+    from oracle import train_step as ts
+    z = np.load(os.path.join(golden_dir, f"train_step_g{gamma}_rw{rw}.npz"))
+    logits = torch.from_numpy(z["logits"]).to(bf16)
+    labels, weights = torch.from_numpy(z["labels"]), torch.from_numpy(z["weights"])
+    B, L, V = logits.shape
+    ldv = (V + 7) // 8 * 8 + 8
+    buf = torch.full((B, L, ldv), 7.0, dtype=bf16)
+    buf[..., :V] = logits
+    d = buf.cuda()
+    lse, zy, out3 = ops.focal_ce_fwd(d[..., :V], V, labels.cuda(), weights.cuda(), float(gamma), bool(rw))
+    want = ts.weighted_focal_ce(logits.float(), labels, weights, gamma, bool(rw))
+    o = out3.cpu()
+    assert abs(o[0] / o[1] - want) <= 1e-4 * abs(want), (o, want)
+    assert o[1] == (labels[:, 1:] != -100).sum()
+    gs = torch.ones(1, device="cuda")
+    ops.focal_ce_bwd(d[..., :V], V, labels.cuda(), weights.cuda(), float(gamma), bool(rw), lse, zy, out3, gs, d[..., :V])
+    wantg = ts.focal_ce_dlogits(logits.float(), labels, weights, gamma, bool(rw))
+    close(d[..., :V], wantg, name="dlogits")
+    assert (d[..., V:] == 0).all()
+    # against the reference's own fp32 capture (inputs differ by bf16 rounding of the logits only)
+    assert abs(o[0] / o[1] - float(z["loss"])) <= 5e-3 * abs(float(z["loss"]))
+
+
+def test_sumsq_adamw(ops):
+    from oracle import train_step as ts
+    n, n_decay = 10007, 4096
+    g = rnd(n, seed=1, scale=0.05)
+    p0 = torch.randn(n, generator=torch.Generator().manual_seed(2))
+    master, m, v = p0.clone().cuda(), torch.zeros(n).cuda(), torch.zeros(n).cuda()
+    p16 = p0.to(bf16).cuda()
+    pr, mr, vr = p0.clone(), torch.zeros(n), torch.zeros(n)
+    buf = torch.zeros(1025, device="cuda")
+    for step in (1, 2, 3):
+        gd = g.cuda().clone()
+        buf[0] = 0
+        ops.sumsq(gd, buf)
+        tot, coef = ts.clip_coef([g.float() * 0.5], 1.0)
+        assert abs(buf[0].item() ** 0.5 * 0.5 - tot) < 1e-3 * tot
+        ops.adamw_flat(master, m, v, p16, gd, n_decay, 1e-2, 0.9, 0.999, 1e-8, 0.1, step, buf, 0.5, 1.0, True)
+        geff = g.float() * 0.5 * coef
+        ts.adamw_step(pr[:n_decay], geff[:n_decay], mr[:n_decay], vr[:n_decay], step, 1e-2, 0.1)
+        ts.adamw_step(pr[n_decay:], geff[n_decay:], mr[n_decay:], vr[n_decay:], step, 1e-2, 0.0)
+        assert (gd == 0).all()
+    assert torch.allclose(master.cpu(), pr, rtol=1e-4, atol=1e-6)
+    assert torch.allclose(m.cpu(), mr, rtol=1e-4, atol=1e-7) and torch.allclose(v.cpu(), vr, rtol=1e-4, atol=1e-9)
+    assert torch.equal(p16.cpu(), master.cpu().to(bf16))

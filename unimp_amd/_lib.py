@@ -1,0 +1,94 @@
+"""ctypes binding of libunimp_hip.so (C ABI declared in include/unimp_hip.h).
+
+There is NO fallback: if the shared library is missing, or a tensor is not on a HIP device, the call
+raises.  PyTorch is used only to own device memory and streams.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libunimp_hip.so")
+
+c_p, c_i, c_l, c_f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("A", c_p), ("B", c_p), ("C", c_p), ("M", c_i), ("N", c_i), ("K", c_i),
+                ("lda", c_l), ("ldb", c_l), ("ldc", c_l), ("a_kstrided", c_i), ("b_kstrided", c_i),
+                ("bias", c_p), ("res", c_p), ("ldres", c_l), ("aux", c_p), ("ldaux", c_l),
+                ("pre", c_p), ("ldpre", c_l), ("gate", c_p), ("alpha", c_f), ("act", c_i), ("dact", c_i),
+                ("out_f32", c_i), ("accumulate", c_i)]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [("q", c_p), ("k", c_p), ("v", c_p), ("o", c_p), ("lse", c_p)] + \
+               [(n, c_l) for n in ("q_bs", "q_ss", "q_hs", "k_bs", "k_ss", "k_hs", "v_bs", "v_ss", "v_hs",
+                                   "o_bs", "o_ss", "o_hs")] + \
+               [("B", c_i), ("H", c_i), ("Sq", c_i), ("Sk", c_i), ("D", c_i), ("scale", c_f), ("mask_mode", c_i),
+                ("kv_len", c_p), ("seg", c_p), ("seg_len", c_i),
+                ("d_o", c_p), ("dq", c_p), ("dk", c_p), ("dv", c_p), ("delta", c_p)] + \
+               [(n, c_l) for n in ("do_bs", "do_ss", "do_hs", "dq_bs", "dq_ss", "dq_hs", "dk_bs", "dk_ss", "dk_hs",
+                                   "dv_bs", "dv_ss", "dv_hs")]
+
+
+# name -> argtypes (every entry point returns int status)
+_SIGS = {
+    "unimp_gemm_bf16": [C.POINTER(GemmDesc), c_p],
+    "unimp_layernorm_fwd": [c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_p, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_p],
+    "unimp_layernorm_bwd": [c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_i,
+                            c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "unimp_rope_halfsplit": [c_p, c_l, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p],
+    "unimp_attn_fwd": [C.POINTER(AttnDesc), c_p],
+    "unimp_attn_bwd": [C.POINTER(AttnDesc), c_p],
+    "unimp_embedding_fwd": [c_p, c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p],
+    "unimp_embedding_bwd": [c_p, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p],
+    "unimp_vit_patchify": [c_p, c_i, c_p, c_l, c_i, c_i, c_i, c_i, c_p],
+    "unimp_vit_assemble": [c_p, c_l, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
+    "unimp_add_bf16": [c_p, c_p, c_p, c_l, c_p],
+    "unimp_cast_f32_to_bf16": [c_p, c_p, c_l, c_f, c_p],
+    "unimp_swiglu_fwd": [c_p, c_l, c_p, c_l, c_i, c_i, c_p],
+    "unimp_swiglu_bwd": [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_p],
+    "unimp_dot_bf16": [c_p, c_p, c_l, c_p, c_p],
+    "unimp_bcast_rows": [c_p, c_p, c_l, c_i, c_i, c_i, c_p],
+    "unimp_reduce_rows_periodic": [c_p, c_l, c_p, c_i, c_i, c_i, c_p],
+    "unimp_label_mask": [c_p, c_p, c_p, c_i, c_i, c_l, c_l, c_l, c_l, c_p],
+    "unimp_focal_ce_fwd": [c_p, c_l, c_p, c_p, c_f, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
+    "unimp_focal_ce_bwd": [c_p, c_l, c_p, c_p, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
+    "unimp_sumsq_bf16": [c_p, c_l, c_p, c_p],
+    "unimp_adamw_flat": [c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_f, c_f, c_f, c_f, c_f, c_i, c_p, c_f, c_f, c_i, c_p],
+}
+
+_lib = None
+
+
+class UnimpHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libunimp_hip.so once.  Fails loudly -- there is no CPU or eager fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: the HIP extension is not built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C unimp_amd/csrc`).")
+        L = C.CDLL(LIB_PATH)
+        L.unimp_last_error.restype = C.c_char_p
+        L.unimp_abi_version.restype = c_i
+        for name, args in _SIGS.items():
+            fn = getattr(L, name)
+            fn.argtypes, fn.restype = args, c_i
+        if L.unimp_abi_version() != 1:
+            raise ImportError("libunimp_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise UnimpHipError(f"{what} failed (code {rc}): {lib().unimp_last_error().decode()}")
+
+
+def declared_symbols():
+    return ["unimp_abi_version", "unimp_last_error", "unimp_set_error", "unimp_check_launch"] + list(_SIGS)

@@ -1,0 +1,409 @@
+// Flash-style attention forward / backward on v_mfma_f32_16x16x32_bf16 for gfx950 (wave64).
+//
+// One code path serves every attention in the Flamingo step: ViT (non-causal, S=257, hd 64), the causal LM
+// (hd 80 / 64 / 128, key-padding via kv_len), the Perceiver resampler (64 latents x 320 keys) and the gated
+// cross-attention (each text token attends only the 64 latents of its own image: MASK_SEGMENT -- the
+// (L x T*64) masked score matrix of the reference is never formed, only the overlapping 64-key tiles run).
+//
+// Orientation trick (cdna guide §3 "accumulator tile as the next MFMA's operand"): scores are produced
+// TRANSPOSED, S^T = K·Q^T, so a lane holds 16 keys of ONE query row (q = lane&15).  Row max / row sum are
+// in-lane + two shuffles, and the probabilities already sit in the register layout the next MFMA wants as
+// its B operand (contraction over keys) if V is fetched in the matching permuted key order
+//     slot (g = lane>>4, j) of k-step ks  <->  key 16*(2ks + (j>>2)) + 4g + (j&3),
+// which is two ds_read_b64_tr_b16 of 4 consecutive V rows each.  P never touches LDS.
+// The backward uses the same trick for dQ (contraction over keys) and, with S = Q·K^T un-transposed, for
+// dK / dV (contraction over queries, P and dS stay in registers, Q / dO fetched transposed from LDS).
+// dQ and dK/dV are separate kernels: 7 instead of 5 MFMA products, but no atomics and bit-reproducible.
+#include "common.h"
+#include "unimp_hip.h"
+
+#define LOG2E 1.4426950408889634f
+#define LN2 0.6931471805599453f
+
+struct AttnP {
+  const bf16* q; const bf16* k; const bf16* v; bf16* o; float* lse;
+  long q_bs, q_ss, q_hs, k_bs, k_ss, k_hs, v_bs, v_ss, v_hs, o_bs, o_ss, o_hs;
+  int B, H, Sq, Sk, D;
+  float scale;
+  int mask_mode;
+  const int* kv_len; const int* seg; int seg_len;
+  const bf16* d_o; bf16* dq; bf16* dk; bf16* dv; float* delta;
+  long do_bs, do_ss, do_hs, dq_bs, dq_ss, dq_hs, dk_bs, dk_ss, dk_hs, dv_bs, dv_ss, dv_hs;
+};
+
+// key range [lo, hi) attended by query row `qr` of batch b
+__device__ __forceinline__ void key_range(const AttnP& p, int b, int qr, int& lo, int& hi) {
+  lo = 0; hi = 0;
+  if (qr >= p.Sq) return;
+  int kvl = p.kv_len ? p.kv_len[b] : p.Sk;
+  if (p.mask_mode == UNIMP_MASK_NONE) { hi = kvl; }
+  else if (p.mask_mode == UNIMP_MASK_CAUSAL) { hi = min(qr + 1, kvl); }
+  else { int t = p.seg[(long)b * p.Sq + qr]; if (t > 0) { lo = (t - 1) * p.seg_len; hi = min(t * p.seg_len, p.Sk); } }
+}
+
+// cooperative [rows x DPAD] bf16 tile load into LDS with row stride STR bytes; zero fill outside (nrows, D)
+template <int ROWS, int DPAD, int STR>
+__device__ __forceinline__ void load_tile(char* lds, const bf16* __restrict__ base, long row_stride, int row0, int nrows, int D) {
+  constexpr int CPR = DPAD / 8;
+  for (int q = threadIdx.x; q < ROWS * CPR; q += 256) {
+    int r = q / CPR, c = q - r * CPR;
+    u32x4 val = u32x4{0, 0, 0, 0};
+    if (row0 + r < nrows && c * 8 < D) val = *(const u32x4*)(base + (long)(row0 + r) * row_stride + c * 8);
+    *(u32x4*)(lds + r * STR + c * 16) = val;
+  }
+}
+
+// KC fragment: lane holds X[r0 + (l&15)][32*ks + 8*(l>>4) + j]
+template <int STR>
+__device__ __forceinline__ bf16x8 lfrag_kc(const char* tile, int r0, int ks) {
+  int l = lane_id();
+  return *(const bf16x8*)(tile + (r0 + (l & 15)) * STR + (ks * 32 + (l >> 4) * 8) * 2);
+}
+// transposed fragment in the permuted contraction order: lane (g,i=l&15) gets
+//   X[rbase + 4g + {0..3}][c0 + i]  ++  X[rbase + 16 + 4g + {0..3}][c0 + i]
+template <int STR>
+__device__ __forceinline__ bf16x8 lfrag_tr_perm(const char* tile, int rbase, int c0) {
+  int l = lane_id();
+  int g = l >> 4, qq = (l >> 2) & 3, pp = l & 3;
+  const char* a = tile + (rbase + 4 * g + qq) * STR + (c0 + 4 * pp) * 2;
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a + 16 * STR));
+  union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+  u.s.a = lo; u.s.b = hi;
+  return u.v;
+}
+
+__device__ __forceinline__ bf16x8 gfrag(const bf16* __restrict__ base, long row_stride, int row, int nrows, int ks, int D) {
+  int l = lane_id();
+  int d = ks * 32 + (l >> 4) * 8;
+  bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (row < nrows && d < D) return *(const bf16x8*)(base + (long)row * row_stride + d);
+  return z;
+}
+
+__device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
+  bf16x8 r = {f2bf(a[0]), f2bf(a[1]), f2bf(a[2]), f2bf(a[3]), f2bf(b[0]), f2bf(b[1]), f2bf(b[2]), f2bf(b[3])};
+  return r;
+}
+
+// block-uniform tile range of keys needed by query rows [q_first, q_last]
+__device__ __forceinline__ void block_key_tiles(const AttnP& p, int b, int q_first, int q_last, int& kt_lo, int& kt_hi) {
+  q_last = min(q_last, p.Sq - 1);
+  int kvl = p.kv_len ? p.kv_len[b] : p.Sk;
+  if (p.mask_mode == UNIMP_MASK_NONE) { kt_lo = 0; kt_hi = (kvl + 63) >> 6; }
+  else if (p.mask_mode == UNIMP_MASK_CAUSAL) { kt_lo = 0; kt_hi = (min(q_last + 1, kvl) + 63) >> 6; }
+  else {
+    int t0 = p.seg[(long)b * p.Sq + q_first], t1 = p.seg[(long)b * p.Sq + q_last];
+    if (t1 == 0) { kt_lo = 0; kt_hi = 0; }
+    else { kt_lo = (max(t0 - 1, 0) * p.seg_len) >> 6; kt_hi = (min(t1 * p.seg_len, p.Sk) + 63) >> 6; }
+  }
+}
+
+// ------------------------------------------------------------------------------------------- forward
+template <int DQK, int DV>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
+  constexpr int KSTR = DQK * 2 + 16, VSTR = DV * 2 + 16, NKS = DQK / 32, ND = DV / 16;
+  __shared__ __attribute__((aligned(16))) char smem[64 * KSTR + 64 * VSTR];
+  char* ks_t = smem; char* vs_t = smem + 64 * KSTR;
+  int b = blockIdx.z, h = blockIdx.y;
+  int wave = threadIdx.x >> 6, l = lane_id(), g = l >> 4;
+  int q0 = blockIdx.x * 64 + wave * 16;
+  int qr = q0 + (l & 15);
+  const bf16* qb = p.q + b * p.q_bs + h * p.q_hs;
+  const bf16* kb = p.k + b * p.k_bs + h * p.k_hs;
+  const bf16* vb = p.v + b * p.v_bs + h * p.v_hs;
+  bf16x8 qf[NKS];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) qf[ks] = gfrag(qb, p.q_ss, qr, p.Sq, ks, p.D);
+  int lo, hi;
+  key_range(p, b, qr, lo, hi);
+  int kt_lo, kt_hi;
+  block_key_tiles(p, b, blockIdx.x * 64, blockIdx.x * 64 + 63, kt_lo, kt_hi);
+  float sc2 = p.scale * LOG2E;
+  float m = -INFINITY, lsum = 0.f;
+  f32x4 o[ND];
+#pragma unroll
+  for (int nd = 0; nd < ND; ++nd) o[nd] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int kt = kt_lo; kt < kt_hi; ++kt) {
+    load_tile<64, DQK, KSTR>(ks_t, kb, p.k_ss, kt * 64, p.Sk, p.D);
+    load_tile<64, DV, VSTR>(vs_t, vb, p.v_ss, kt * 64, p.Sk, p.D);
+    __syncthreads();
+    f32x4 s[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      s[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) s[nt] = MFMA16(lfrag_kc<KSTR>(ks_t, nt * 16, ks), qf[ks], s[nt]);
+    }
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int key = kt * 64 + nt * 16 + g * 4 + r;
+        float v = (key >= lo && key < hi) ? s[nt][r] * sc2 : -INFINITY;
+        s[nt][r] = v;
+        mloc = fmaxf(mloc, v);
+      }
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    float mnew = fmaxf(m, mloc);
+    float muse = (mnew == -INFINITY) ? 0.f : mnew;
+    float alpha = exp2f(m - muse);
+    float rs = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { float e = exp2f(s[nt][r] - muse); s[nt][r] = e; rs += e; }
+    rs += __shfl_xor(rs, 16, 64);
+    rs += __shfl_xor(rs, 32, 64);
+    lsum = lsum * alpha + rs;
+    m = mnew;
+    bf16x8 pf[2] = {pack8(s[0], s[1]), pack8(s[2], s[3])};
+#pragma unroll
+    for (int nd = 0; nd < ND; ++nd) {
+      o[nd] *= alpha;
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) o[nd] = MFMA16(lfrag_tr_perm<VSTR>(vs_t, k2 * 32, nd * 16), pf[k2], o[nd]);
+    }
+    __syncthreads();
+  }
+  if (qr < p.Sq) {
+    float inv = lsum > 0.f ? 1.f / lsum : 0.f;
+    bf16* ob = p.o + b * p.o_bs + (long)qr * p.o_ss + h * p.o_hs;
+#pragma unroll
+    for (int nd = 0; nd < ND; ++nd) {
+      bf16x4 w = {f2bf(o[nd][0] * inv), f2bf(o[nd][1] * inv), f2bf(o[nd][2] * inv), f2bf(o[nd][3] * inv)};
+      *(bf16x4*)(ob + nd * 16 + g * 4) = w;
+    }
+    if (g == 0 && p.lse) p.lse[((long)b * p.H + h) * p.Sq + qr] = lsum > 0.f ? (m + log2f(lsum)) * LN2 : -INFINITY;
+  }
+}
+
+// ------------------------------------------------------------------------------------------- delta = rowsum(dO * O)
+__global__ void attn_delta_kernel(AttnP p) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long n = (long)p.B * p.H * p.Sq;
+  if (i >= n) return;
+  int qr = i % p.Sq; long t = i / p.Sq; int h = t % p.H; int b = t / p.H;
+  const bf16* o = p.o + b * p.o_bs + (long)qr * p.o_ss + h * p.o_hs;
+  const bf16* d = p.d_o + b * p.do_bs + (long)qr * p.do_ss + h * p.do_hs;
+  float acc = 0.f;
+  for (int c = 0; c < p.D; c += 8) {
+    bf16x8 a = *(const bf16x8*)(o + c), bb = *(const bf16x8*)(d + c);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc += bf2f(a[j]) * bf2f(bb[j]);
+  }
+  p.delta[i] = acc;
+}
+
+// ------------------------------------------------------------------------------------------- dQ
+template <int DQK, int DV>
+__global__ __launch_bounds__(256) void attn_dq_kernel(AttnP p) {
+  constexpr int STR = DQK * 2 + 16, NKS = DQK / 32, ND = DV / 16;
+  __shared__ __attribute__((aligned(16))) char smem[2 * 64 * STR];
+  char* ks_t = smem; char* vs_t = smem + 64 * STR;
+  int b = blockIdx.z, h = blockIdx.y;
+  int wave = threadIdx.x >> 6, l = lane_id(), g = l >> 4;
+  int q0 = blockIdx.x * 64 + wave * 16;
+  int qr = q0 + (l & 15);
+  const bf16* qb = p.q + b * p.q_bs + h * p.q_hs;
+  const bf16* kb = p.k + b * p.k_bs + h * p.k_hs;
+  const bf16* vb = p.v + b * p.v_bs + h * p.v_hs;
+  const bf16* dob = p.d_o + b * p.do_bs + h * p.do_hs;
+  bf16x8 qf[NKS], dof[NKS];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) { qf[ks] = gfrag(qb, p.q_ss, qr, p.Sq, ks, p.D); dof[ks] = gfrag(dob, p.do_ss, qr, p.Sq, ks, p.D); }
+  int lo, hi;
+  key_range(p, b, qr, lo, hi);
+  int kt_lo, kt_hi;
+  block_key_tiles(p, b, blockIdx.x * 64, blockIdx.x * 64 + 63, kt_lo, kt_hi);
+  float sc2 = p.scale * LOG2E;
+  long sidx = ((long)b * p.H + h) * p.Sq + min(qr, p.Sq - 1);
+  float lse2 = p.lse[sidx] * LOG2E, dl = p.delta[sidx];
+  f32x4 dq[ND];
+#pragma unroll
+  for (int nd = 0; nd < ND; ++nd) dq[nd] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int kt = kt_lo; kt < kt_hi; ++kt) {
+    load_tile<64, DQK, STR>(ks_t, kb, p.k_ss, kt * 64, p.Sk, p.D);
+    load_tile<64, DQK, STR>(vs_t, vb, p.v_ss, kt * 64, p.Sk, p.D);
+    __syncthreads();
+    f32x4 s[4], dp[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      s[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        s[nt] = MFMA16(lfrag_kc<STR>(ks_t, nt * 16, ks), qf[ks], s[nt]);
+        dp[nt] = MFMA16(lfrag_kc<STR>(vs_t, nt * 16, ks), dof[ks], dp[nt]);
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int key = kt * 64 + nt * 16 + g * 4 + r;
+        float pr = (key >= lo && key < hi) ? exp2f(s[nt][r] * sc2 - lse2) : 0.f;
+        s[nt][r] = pr * (dp[nt][r] - dl) * p.scale;
+      }
+    bf16x8 dsf[2] = {pack8(s[0], s[1]), pack8(s[2], s[3])};
+#pragma unroll
+    for (int nd = 0; nd < ND; ++nd)
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) dq[nd] = MFMA16(lfrag_tr_perm<STR>(ks_t, k2 * 32, nd * 16), dsf[k2], dq[nd]);
+    __syncthreads();
+  }
+  if (qr < p.Sq) {
+    bf16* ob = p.dq + b * p.dq_bs + (long)qr * p.dq_ss + h * p.dq_hs;
+#pragma unroll
+    for (int nd = 0; nd < ND; ++nd) {
+      bf16x4 w = {f2bf(dq[nd][0]), f2bf(dq[nd][1]), f2bf(dq[nd][2]), f2bf(dq[nd][3])};
+      *(bf16x4*)(ob + nd * 16 + g * 4) = w;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------- dK, dV
+template <int DQK, int DV>
+__global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p) {
+  constexpr int STR = DQK * 2 + 16, NKS = DQK / 32, ND = DV / 16;
+  __shared__ __attribute__((aligned(16))) char smem[2 * 32 * STR + 32 * 16];
+  char* qs_t = smem; char* dos_t = smem + 32 * STR;
+  float* st_lse = (float*)(smem + 2 * 32 * STR);     // [32] lse*log2e
+  float* st_dl = st_lse + 32;                          // [32] delta
+  int* st_lo = (int*)(st_dl + 32);                     // [32]
+  int* st_hi = st_lo + 32;                             // [32]
+  int b = blockIdx.z, h = blockIdx.y, kt = blockIdx.x;
+  int wave = threadIdx.x >> 6, l = lane_id(), g = l >> 4;
+  int key = kt * 64 + wave * 16 + (l & 15);
+  const bf16* qb = p.q + b * p.q_bs + h * p.q_hs;
+  const bf16* kb = p.k + b * p.k_bs + h * p.k_hs;
+  const bf16* vb = p.v + b * p.v_bs + h * p.v_hs;
+  const bf16* dob = p.d_o + b * p.do_bs + h * p.do_hs;
+  bf16x8 kf[NKS], vf[NKS];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) { kf[ks] = gfrag(kb, p.k_ss, key, p.Sk, ks, p.D); vf[ks] = gfrag(vb, p.v_ss, key, p.Sk, ks, p.D); }
+  f32x4 dk[ND], dv[ND];
+#pragma unroll
+  for (int nd = 0; nd < ND; ++nd) { dk[nd] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[nd] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  float sc2 = p.scale * LOG2E;
+  int nqt = (p.Sq + 31) >> 5;
+  int qt0 = 0;
+  if (p.mask_mode == UNIMP_MASK_CAUSAL) qt0 = (kt * 64) >> 5;
+  int kfirst = kt * 64, klast = kt * 64 + 63;
+
+  for (int qt = qt0; qt < nqt; ++qt) {
+    if (p.mask_mode == UNIMP_MASK_SEGMENT) {   // block-uniform skip of query tiles that cannot see this key tile
+      int ta = p.seg[(long)b * p.Sq + qt * 32], tb = p.seg[(long)b * p.Sq + min(qt * 32 + 31, p.Sq - 1)];
+      if (tb == 0 || tb * p.seg_len <= kfirst || (max(ta, 1) - 1) * p.seg_len > klast) continue;
+    }
+    load_tile<32, DQK, STR>(qs_t, qb, p.q_ss, qt * 32, p.Sq, p.D);
+    load_tile<32, DQK, STR>(dos_t, dob, p.do_ss, qt * 32, p.Sq, p.D);
+    if (threadIdx.x < 32) {
+      int qr = qt * 32 + threadIdx.x;
+      long sidx = ((long)b * p.H + h) * p.Sq + min(qr, p.Sq - 1);
+      st_lse[threadIdx.x] = p.lse[sidx] * LOG2E;
+      st_dl[threadIdx.x] = p.delta[sidx];
+      int lo, hi;
+      key_range(p, b, qr, lo, hi);
+      st_lo[threadIdx.x] = lo; st_hi[threadIdx.x] = hi;
+    }
+    __syncthreads();
+    f32x4 s[2], dp[2];
+#pragma unroll
+    for (int qb2 = 0; qb2 < 2; ++qb2) {
+      s[qb2] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[qb2] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        s[qb2] = MFMA16(lfrag_kc<STR>(qs_t, qb2 * 16, ks), kf[ks], s[qb2]);       // D[q][key]
+        dp[qb2] = MFMA16(lfrag_kc<STR>(dos_t, qb2 * 16, ks), vf[ks], dp[qb2]);
+      }
+    }
+    // lane holds S[q = 16*qb2 + 4g + r][key = l&15]
+#pragma unroll
+    for (int qb2 = 0; qb2 < 2; ++qb2)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int ql = qb2 * 16 + g * 4 + r;
+        float pr = (key >= st_lo[ql] && key < st_hi[ql]) ? exp2f(s[qb2][r] * sc2 - st_lse[ql]) : 0.f;
+        s[qb2][r] = pr;
+        dp[qb2][r] = pr * (dp[qb2][r] - st_dl[ql]) * p.scale;
+      }
+    bf16x8 pf = pack8(s[0], s[1]), dsf = pack8(dp[0], dp[1]);
+#pragma unroll
+    for (int nd = 0; nd < ND; ++nd) {
+      dv[nd] = MFMA16(lfrag_tr_perm<STR>(dos_t, 0, nd * 16), pf, dv[nd]);     // D[d][key]
+      dk[nd] = MFMA16(lfrag_tr_perm<STR>(qs_t, 0, nd * 16), dsf, dk[nd]);
+    }
+    __syncthreads();
+  }
+  if (key < p.Sk) {
+    bf16* okb = p.dk + b * p.dk_bs + (long)key * p.dk_ss + h * p.dk_hs;
+    bf16* ovb = p.dv + b * p.dv_bs + (long)key * p.dv_ss + h * p.dv_hs;
+#pragma unroll
+    for (int nd = 0; nd < ND; ++nd) {
+      bf16x4 a = {f2bf(dk[nd][0]), f2bf(dk[nd][1]), f2bf(dk[nd][2]), f2bf(dk[nd][3])};
+      bf16x4 c = {f2bf(dv[nd][0]), f2bf(dv[nd][1]), f2bf(dv[nd][2]), f2bf(dv[nd][3])};
+      *(bf16x4*)(okb + nd * 16 + g * 4) = a;
+      *(bf16x4*)(ovb + nd * 16 + g * 4) = c;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------- host
+static int fill(AttnP& p, const unimp_attn_desc* d, bool bwd) {
+  if (!d || !d->q || !d->k || !d->v || !d->o) return unimp_set_error(UNIMP_ERR_ARG, "attn: null pointer");
+  if (d->D != 64 && d->D != 80 && d->D != 128) return unimp_set_error(UNIMP_ERR_UNSUPPORTED, "attn: head dim must be 64, 80 or 128");
+  if (d->mask_mode == UNIMP_MASK_SEGMENT && (!d->seg || d->seg_len <= 0)) return unimp_set_error(UNIMP_ERR_ARG, "attn: segment mask needs seg/seg_len");
+  if (d->mask_mode == UNIMP_MASK_CAUSAL && d->Sq != d->Sk) return unimp_set_error(UNIMP_ERR_SHAPE, "attn: causal needs Sq == Sk");
+  int64_t strides[] = {d->q_bs, d->q_ss, d->q_hs, d->k_bs, d->k_ss, d->k_hs, d->v_bs, d->v_ss, d->v_hs, d->o_bs, d->o_ss, d->o_hs};
+  for (int64_t s : strides) if (s & 7) return unimp_set_error(UNIMP_ERR_ALIGN, "attn: strides must be multiples of 8 elements");
+  const void* ptrs[] = {d->q, d->k, d->v, d->o};
+  for (const void* q : ptrs) if ((uintptr_t)q & 15) return unimp_set_error(UNIMP_ERR_ALIGN, "attn: pointers must be 16-B aligned");
+  p.q = (const bf16*)d->q; p.k = (const bf16*)d->k; p.v = (const bf16*)d->v; p.o = (bf16*)d->o; p.lse = d->lse;
+  p.q_bs = d->q_bs; p.q_ss = d->q_ss; p.q_hs = d->q_hs; p.k_bs = d->k_bs; p.k_ss = d->k_ss; p.k_hs = d->k_hs;
+  p.v_bs = d->v_bs; p.v_ss = d->v_ss; p.v_hs = d->v_hs; p.o_bs = d->o_bs; p.o_ss = d->o_ss; p.o_hs = d->o_hs;
+  p.B = d->B; p.H = d->H; p.Sq = d->Sq; p.Sk = d->Sk; p.D = d->D; p.scale = d->scale; p.mask_mode = d->mask_mode;
+  p.kv_len = d->kv_len; p.seg = d->seg; p.seg_len = d->seg_len;
+  p.d_o = nullptr; p.dq = p.dk = p.dv = nullptr; p.delta = nullptr;
+  if (bwd) {
+    if (!d->d_o || !d->dq || !d->dk || !d->dv || !d->delta || !d->lse) return unimp_set_error(UNIMP_ERR_ARG, "attn_bwd: null pointer");
+    int64_t s2[] = {d->do_bs, d->do_ss, d->do_hs, d->dq_bs, d->dq_ss, d->dq_hs, d->dk_bs, d->dk_ss, d->dk_hs, d->dv_bs, d->dv_ss, d->dv_hs};
+    for (int64_t s : s2) if (s & 3) return unimp_set_error(UNIMP_ERR_ALIGN, "attn_bwd: strides must be multiples of 4 elements");
+    if ((d->do_bs | d->do_ss | d->do_hs) & 7) return unimp_set_error(UNIMP_ERR_ALIGN, "attn_bwd: dO strides must be multiples of 8");
+    p.d_o = (const bf16*)d->d_o; p.dq = (bf16*)d->dq; p.dk = (bf16*)d->dk; p.dv = (bf16*)d->dv; p.delta = d->delta;
+    p.do_bs = d->do_bs; p.do_ss = d->do_ss; p.do_hs = d->do_hs; p.dq_bs = d->dq_bs; p.dq_ss = d->dq_ss; p.dq_hs = d->dq_hs;
+    p.dk_bs = d->dk_bs; p.dk_ss = d->dk_ss; p.dk_hs = d->dk_hs; p.dv_bs = d->dv_bs; p.dv_ss = d->dv_ss; p.dv_hs = d->dv_hs;
+  }
+  return 0;
+}
+
+extern "C" int unimp_attn_fwd(const unimp_attn_desc* d, void* stream) {
+  AttnP p;
+  int e = fill(p, d, false);
+  if (e) return e;
+  if (p.B <= 0 || p.H <= 0 || p.Sq <= 0) return UNIMP_OK;
+  dim3 grid((p.Sq + 63) / 64, p.H, p.B), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (p.D == 64) hipLaunchKernelGGL((attn_fwd_kernel<64, 64>), grid, block, 0, s, p);
+  else if (p.D == 80) hipLaunchKernelGGL((attn_fwd_kernel<96, 80>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((attn_fwd_kernel<128, 128>), grid, block, 0, s, p);
+  return unimp_check_launch("attn_fwd");
+}
+
+extern "C" int unimp_attn_bwd(const unimp_attn_desc* d, void* stream) {
+  AttnP p;
+  int e = fill(p, d, true);
+  if (e) return e;
+  if (p.B <= 0 || p.H <= 0 || p.Sq <= 0) return UNIMP_OK;
+  hipStream_t s = (hipStream_t)stream;
+  long n = (long)p.B * p.H * p.Sq;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p);
+  dim3 gq((p.Sq + 63) / 64, p.H, p.B), gk((p.Sk + 63) / 64, p.H, p.B), block(256);
+  if (p.D == 64) { hipLaunchKernelGGL((attn_dq_kernel<64, 64>), gq, block, 0, s, p); hipLaunchKernelGGL((attn_dkv_kernel<64, 64>), gk, block, 0, s, p); }
+  else if (p.D == 80) { hipLaunchKernelGGL((attn_dq_kernel<96, 80>), gq, block, 0, s, p); hipLaunchKernelGGL((attn_dkv_kernel<96, 80>), gk, block, 0, s, p); }
+  else { hipLaunchKernelGGL((attn_dq_kernel<128, 128>), gq, block, 0, s, p); hipLaunchKernelGGL((attn_dkv_kernel<128, 128>), gk, block, 0, s, p); }
+  return unimp_check_launch("attn_bwd");
+}

@@ -1,0 +1,104 @@
+// Shared device helpers for the unimp_hip kernels (gfx950 / CDNA4 only, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define LDS_PTR(T, p) ((T __attribute__((address_space(3)))*)(p))
+
+__device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
+__device__ __forceinline__ bf16 f2bf(float x) { return (bf16)x; }   // v_cvt_pk_bf16_f32 (RNE, NaN-safe)
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// wave64 all-reduce helpers (butterfly over 64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- activations (fp32 math) -------------------------------------------------------------
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_QUICKGELU = 2, ACT_RELU = 3, ACT_SILU = 4 };
+
+__device__ __forceinline__ float act_fwd(int act, float x) {
+  switch (act) {
+    case ACT_GELU: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+    case ACT_QUICKGELU: return x / (1.0f + __expf(-1.702f * x));
+    case ACT_RELU: return x > 0.f ? x : 0.f;
+    case ACT_SILU: return x / (1.0f + __expf(-x));
+    default: return x;
+  }
+}
+__device__ __forceinline__ float act_bwd(int act, float x) {   // d act(x) / dx
+  switch (act) {
+    case ACT_GELU: {
+      float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+      return cdf + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+    }
+    case ACT_QUICKGELU: {
+      float s = 1.0f / (1.0f + __expf(-1.702f * x));
+      return s * (1.0f + 1.702f * x * (1.0f - s));
+    }
+    case ACT_RELU: return x > 0.f ? 1.f : 0.f;
+    case ACT_SILU: {
+      float s = 1.0f / (1.0f + __expf(-x));
+      return s * (1.0f + x * (1.0f - s));
+    }
+    default: return 1.f;
+  }
+}
+
+// ---- LDS tile images for 16x16x32 bf16 MFMA operands --------------------------------------
+// KC image: [rows][64 k] bf16, 128 B per row, eight 16-B chunks per row, chunk index XOR-swizzled
+//           so that the ds_read_b128 of 16 consecutive rows at one k-chunk is conflict-free.
+__device__ __forceinline__ int kc_off(int row, int chunk) {          // byte offset
+  return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+// KS image: [64 k][128 n] bf16 (operand stored k-strided in memory), 256 B per k-row, eight 32-B
+//           granules per row, granule index XOR-swizzled so that ds_read_b64_tr_b16 is conflict-free.
+__device__ __forceinline__ int ks_h(int krow) { return (krow & 3) | (((krow >> 3) & 1) << 2); }
+__device__ __forceinline__ int ks_off(int krow, int col) {          // col in elements, byte offset
+  return krow * 256 + ((((col >> 4) ^ ks_h(krow)) << 5) | ((col & 15) << 1));
+}
+
+// operand fragment (lane l holds X[r0 + (l&15)][k0 + 8*(l>>4) + j], j = 0..7) from a KC image
+__device__ __forceinline__ bf16x8 frag_kc(const char* tile, int r0, int kk) {
+  int l = lane_id();
+  int row = r0 + (l & 15);
+  return *(const bf16x8*)(tile + kc_off(row, kk * 4 + (l >> 4)));
+}
+// same fragment from a KS image (tile[k][n]); r0 multiple of 16; uses the transposing LDS read.
+__device__ __forceinline__ bf16x8 frag_ks(const char* tile, int r0, int kk) {
+  int l = lane_id();
+  int g = l >> 4, q = (l >> 2) & 3, p = l & 3;
+  int kr = kk * 32 + g * 8 + q;
+  int col = r0 + 4 * p;
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, tile + ks_off(kr, col)));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, tile + ks_off(kr + 4, col)));
+  union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+  u.s.a = lo; u.s.b = hi;
+  return u.v;
+}
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+// bijective XCD-aware remap of a 1-D block id: blocks that share an XCD (id % 8 equal) get a
+// contiguous range of logical ids (cdna guide T1, bijective form).
+__device__ __forceinline__ int xcd_remap(int id, int n) {
+  int q = n >> 3, r = n & 7, x = id & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
+}

@@ -1,0 +1,22 @@
+// Error state + launch check shared by every translation unit of libunimp_hip.so.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include "unimp_hip.h"
+
+static thread_local char g_err[512] = "";
+
+extern "C" int unimp_abi_version(void) { return UNIMP_ABI_VERSION; }
+extern "C" const char* unimp_last_error(void) { return g_err; }
+extern "C" int unimp_set_error(int code, const char* msg) {
+  snprintf(g_err, sizeof(g_err), "%s", msg ? msg : "");
+  return code;
+}
+extern "C" int unimp_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    snprintf(g_err, sizeof(g_err), "%s: launch failed: %s", what, hipGetErrorString(e));
+    return UNIMP_ERR_LAUNCH;
+  }
+  return UNIMP_OK;
+}

@@ -1,0 +1,321 @@
+// HBM-bound helpers: RoPE, embedding gather / scatter-add, ViT patchify + token assembly, adds, casts,
+// SwiGLU, dot, periodic row broadcast / reduction.  All 16-byte vectorised where the layout allows.
+#include <algorithm>
+#include "common.h"
+#include "unimp_hip.h"
+
+#define GRID1D(n, per) dim3((unsigned)std::min<long>(((n) + (per) - 1) / (per), 65535L * 16))
+
+// ------------------------------------------------------------------------------------------- RoPE (half-split)
+template <int CH>
+__global__ void rope_kernel(bf16* __restrict__ x, long row_stride, long head_stride, int rows, int L, int heads, int half,
+                            int nvec, int off0, int off1, const float* __restrict__ cs, const float* __restrict__ sn, int inverse) {
+  int cpr = half / CH;
+  long total = (long)rows * heads * nvec * cpr;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int c = i % cpr; long t = i / cpr;
+    int vsel = t % nvec; t /= nvec;
+    int h = t % heads; long r = t / heads;
+    int pos = r % L;
+    bf16* p = x + r * row_stride + h * head_stride + (vsel ? off1 : off0) + c * CH;
+    const float* cp = cs + (long)pos * half + c * CH;
+    const float* sp = sn + (long)pos * half + c * CH;
+    if (CH == 8) {
+      bf16x8 a = *(bf16x8*)p, b = *(bf16x8*)(p + half), oa, ob;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float co = cp[j], si = inverse ? -sp[j] : sp[j];
+        float x1 = bf2f(a[j]), x2 = bf2f(b[j]);
+        oa[j] = f2bf(x1 * co - x2 * si);
+        ob[j] = f2bf(x2 * co + x1 * si);
+      }
+      *(bf16x8*)p = oa; *(bf16x8*)(p + half) = ob;
+    } else {
+      float co = cp[0], si = inverse ? -sp[0] : sp[0];
+      float x1 = bf2f(p[0]), x2 = bf2f(p[half]);
+      p[0] = f2bf(x1 * co - x2 * si);
+      p[half] = f2bf(x2 * co + x1 * si);
+    }
+  }
+}
+
+extern "C" int unimp_rope_halfsplit(void* x, int64_t row_stride, int64_t head_stride, int rows, int L, int heads, int rot,
+                                    int nvec, int vec_off0, int vec_off1, const float* cos_t, const float* sin_t, int inverse,
+                                    void* stream) {
+  if (!x || !cos_t || !sin_t) return unimp_set_error(UNIMP_ERR_ARG, "rope: null pointer");
+  if (rot <= 0 || (rot & 1) || nvec < 1 || nvec > 2) return unimp_set_error(UNIMP_ERR_SHAPE, "rope: bad rot/nvec");
+  if (rows <= 0) return UNIMP_OK;
+  int half = rot / 2;
+  bool vec = (half % 8 == 0) && (row_stride % 8 == 0) && (head_stride % 8 == 0) && (vec_off0 % 8 == 0) && (vec_off1 % 8 == 0) &&
+             (((uintptr_t)x & 15) == 0);
+  hipStream_t s = (hipStream_t)stream;
+  if (vec) {
+    long total = (long)rows * heads * nvec * (half / 8);
+    hipLaunchKernelGGL((rope_kernel<8>), GRID1D(total, 256), dim3(256), 0, s, (bf16*)x, (long)row_stride, (long)head_stride, rows, L,
+                       heads, half, nvec, vec_off0, vec_off1, cos_t, sin_t, inverse);
+  } else {
+    long total = (long)rows * heads * nvec * half;
+    hipLaunchKernelGGL((rope_kernel<1>), GRID1D(total, 256), dim3(256), 0, s, (bf16*)x, (long)row_stride, (long)head_stride, rows, L,
+                       heads, half, nvec, vec_off0, vec_off1, cos_t, sin_t, inverse);
+  }
+  return unimp_check_launch("rope");
+}
+
+// ------------------------------------------------------------------------------------------- embedding
+__global__ void embedding_fwd_kernel(const int64_t* __restrict__ ids, const bf16* __restrict__ W, long ldw,
+                                     const int64_t* __restrict__ pos, const bf16* __restrict__ P, long ldp,
+                                     bf16* __restrict__ out, long ldo, int rows, int D, int vocab) {
+  int cpr = D >> 3;
+  long total = (long)rows * cpr;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int c = i % cpr; long r = i / cpr;
+    long id = ids[r];
+    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (id >= 0 && id < vocab) v = *(const bf16x8*)(W + id * ldw + c * 8);
+    if (P) {
+      bf16x8 q = *(const bf16x8*)(P + pos[r] * ldp + c * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(v[j]) + bf2f(q[j]));
+    }
+    *(bf16x8*)(out + r * ldo + c * 8) = v;
+  }
+}
+
+__global__ void embedding_bwd_kernel(const int64_t* __restrict__ ids, const bf16* __restrict__ dout, long lddo,
+                                     float* __restrict__ dW, long lddw, int rows, int D, int vocab) {
+  int cpr = D >> 2;   // 4 elements per thread: one wave-instruction adds 256 contiguous bytes of one row
+  long total = (long)rows * cpr;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int c = i % cpr; long r = i / cpr;
+    long id = ids[r];
+    if (id < 0 || id >= vocab) continue;
+    bf16x4 v = *(const bf16x4*)(dout + r * lddo + c * 4);
+    float* d = dW + id * lddw + c * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float f = bf2f(v[j]);
+      if (f != 0.f) atomicAdd(d + j, f);
+    }
+  }
+}
+
+extern "C" int unimp_embedding_fwd(const int64_t* ids, const void* W, int64_t ldw, const int64_t* pos, const void* P, int64_t ldp,
+                                   void* out, int64_t ldo, int rows, int D, int vocab, void* stream) {
+  if (!ids || !W || !out || (P && !pos)) return unimp_set_error(UNIMP_ERR_ARG, "embedding_fwd: null pointer");
+  if ((D & 7) || (ldw & 7) || (ldo & 7)) return unimp_set_error(UNIMP_ERR_SHAPE, "embedding_fwd: D, ld must be multiples of 8");
+  if (rows <= 0) return UNIMP_OK;
+  long total = (long)rows * (D >> 3);
+  hipLaunchKernelGGL(embedding_fwd_kernel, GRID1D(total, 256), dim3(256), 0, (hipStream_t)stream, ids, (const bf16*)W, (long)ldw, pos,
+                     (const bf16*)P, (long)ldp, (bf16*)out, (long)ldo, rows, D, vocab);
+  return unimp_check_launch("embedding_fwd");
+}
+
+extern "C" int unimp_embedding_bwd(const int64_t* ids, const void* dout, int64_t lddo, float* dW32, int64_t lddw, int rows, int D,
+                                   int vocab, void* stream) {
+  if (!ids || !dout || !dW32) return unimp_set_error(UNIMP_ERR_ARG, "embedding_bwd: null pointer");
+  if ((D & 3) || (lddo & 3)) return unimp_set_error(UNIMP_ERR_SHAPE, "embedding_bwd: D, ld must be multiples of 4");
+  if (rows <= 0) return UNIMP_OK;
+  long total = (long)rows * (D >> 2);
+  hipLaunchKernelGGL(embedding_bwd_kernel, GRID1D(total, 256), dim3(256), 0, (hipStream_t)stream, ids, (const bf16*)dout, (long)lddo,
+                     dW32, (long)lddw, rows, D, vocab);
+  return unimp_check_launch("embedding_bwd");
+}
+
+// ------------------------------------------------------------------------------------------- ViT input path
+template <typename T>
+__global__ void patchify_kernel(const T* __restrict__ px, bf16* __restrict__ cols, long ldc, int N, int Hi, int Wi, int P) {
+  int gx = Wi / P, gy = Hi / P, K = 3 * P * P;
+  int cpr = ldc >> 3;
+  long total = (long)N * gx * gy * cpr;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int c = i % cpr; long row = i / cpr;
+    int pxi = row % gx; long t = row / gx; int pyi = t % gy; long n = t / gy;
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      int k = c * 8 + j;
+      float v = 0.f;
+      if (k < K) {
+        int ch = k / (P * P), rem = k - ch * P * P, yy = rem / P, xx = rem - yy * P;
+        v = (float)px[((n * 3 + ch) * Hi + pyi * P + yy) * (long)Wi + pxi * P + xx];
+      }
+      o[j] = f2bf(v);
+    }
+    *(bf16x8*)(cols + row * ldc + c * 8) = o;
+  }
+}
+
+__global__ void vit_assemble_kernel(const bf16* __restrict__ patch, long ldp, const bf16* __restrict__ cls,
+                                    const bf16* __restrict__ pos, bf16* __restrict__ x, int N, int np, int D) {
+  int cpr = D >> 3;
+  long total = (long)N * (np + 1) * cpr;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int c = i % cpr; long t = i / cpr; int tok = t % (np + 1); long n = t / (np + 1);
+    bf16x8 a = tok == 0 ? *(const bf16x8*)(cls + c * 8) : *(const bf16x8*)(patch + (n * np + tok - 1) * ldp + c * 8);
+    bf16x8 b = *(const bf16x8*)(pos + (long)tok * D + c * 8), o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(a[j]) + bf2f(b[j]));
+    *(bf16x8*)(x + t * D + c * 8) = o;
+  }
+}
+
+extern "C" int unimp_vit_patchify(const void* pixels, int pixels_f32, void* cols, int64_t ldc, int N, int Hi, int Wi, int P, void* stream) {
+  if (!pixels || !cols) return unimp_set_error(UNIMP_ERR_ARG, "patchify: null pointer");
+  if (P <= 0 || Hi % P || Wi % P || (ldc & 7) || ldc < 3 * P * P) return unimp_set_error(UNIMP_ERR_SHAPE, "patchify: bad shape");
+  if (N <= 0) return UNIMP_OK;
+  long total = (long)N * (Hi / P) * (Wi / P) * (ldc >> 3);
+  hipStream_t s = (hipStream_t)stream;
+  if (pixels_f32) hipLaunchKernelGGL((patchify_kernel<float>), GRID1D(total, 256), dim3(256), 0, s, (const float*)pixels, (bf16*)cols, (long)ldc, N, Hi, Wi, P);
+  else hipLaunchKernelGGL((patchify_kernel<bf16>), GRID1D(total, 256), dim3(256), 0, s, (const bf16*)pixels, (bf16*)cols, (long)ldc, N, Hi, Wi, P);
+  return unimp_check_launch("patchify");
+}
+
+extern "C" int unimp_vit_assemble(const void* patch, int64_t ldp, const void* cls, const void* pos, void* x, int N, int n_patch, int D, void* stream) {
+  if (!patch || !cls || !pos || !x) return unimp_set_error(UNIMP_ERR_ARG, "vit_assemble: null pointer");
+  if ((D & 7) || (ldp & 7)) return unimp_set_error(UNIMP_ERR_SHAPE, "vit_assemble: D, ld must be multiples of 8");
+  if (N <= 0) return UNIMP_OK;
+  long total = (long)N * (n_patch + 1) * (D >> 3);
+  hipLaunchKernelGGL(vit_assemble_kernel, GRID1D(total, 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)patch, (long)ldp,
+                     (const bf16*)cls, (const bf16*)pos, (bf16*)x, N, n_patch, D);
+  return unimp_check_launch("vit_assemble");
+}
+
+// ------------------------------------------------------------------------------------------- add / cast / swiglu / dot
+__global__ void add_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b, bf16* __restrict__ o, long n) {
+  long nv = n >> 3;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+    bf16x8 x = *(const bf16x8*)(a + i * 8), y = *(const bf16x8*)(b + i * 8), z;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[j] = f2bf(bf2f(x[j]) + bf2f(y[j]));
+    *(bf16x8*)(o + i * 8) = z;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) { long i = (n & ~7L) + threadIdx.x; o[i] = f2bf(bf2f(a[i]) + bf2f(b[i])); }
+}
+
+__global__ void cast_kernel(const float* __restrict__ s, bf16* __restrict__ d, long n, float scale) {
+  long nv = n >> 3;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+    f32x4 x = *(const f32x4*)(s + i * 8), y = *(const f32x4*)(s + i * 8 + 4);
+    bf16x8 z = {f2bf(x[0] * scale), f2bf(x[1] * scale), f2bf(x[2] * scale), f2bf(x[3] * scale),
+                f2bf(y[0] * scale), f2bf(y[1] * scale), f2bf(y[2] * scale), f2bf(y[3] * scale)};
+    *(bf16x8*)(d + i * 8) = z;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) { long i = (n & ~7L) + threadIdx.x; d[i] = f2bf(s[i] * scale); }
+}
+
+extern "C" int unimp_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream) {
+  if (!a || !b || !out) return unimp_set_error(UNIMP_ERR_ARG, "add: null pointer");
+  if (n <= 0) return UNIMP_OK;
+  hipLaunchKernelGGL(add_kernel, GRID1D((n >> 3) + 1, 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)a, (const bf16*)b, (bf16*)out, (long)n);
+  return unimp_check_launch("add");
+}
+extern "C" int unimp_cast_f32_to_bf16(const float* src, void* dst, int64_t n, float scale, void* stream) {
+  if (!src || !dst) return unimp_set_error(UNIMP_ERR_ARG, "cast: null pointer");
+  if (n <= 0) return UNIMP_OK;
+  hipLaunchKernelGGL(cast_kernel, GRID1D((n >> 3) + 1, 256), dim3(256), 0, (hipStream_t)stream, src, (bf16*)dst, (long)n, scale);
+  return unimp_check_launch("cast");
+}
+
+// gate_up rows are [gate(F) | up(F)]  (llama.py:185-199 with gate_proj / up_proj outputs concatenated)
+__global__ void swiglu_fwd_kernel(const bf16* __restrict__ gu, long ld, bf16* __restrict__ out, long ldo, int rows, int F) {
+  int cpr = F >> 3; long total = (long)rows * cpr;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int c = i % cpr; long r = i / cpr;
+    bf16x8 g = *(const bf16x8*)(gu + r * ld + c * 8), u = *(const bf16x8*)(gu + r * ld + F + c * 8), o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = f2bf(act_fwd(ACT_SILU, bf2f(g[j])) * bf2f(u[j]));
+    *(bf16x8*)(out + r * ldo + c * 8) = o;
+  }
+}
+__global__ void swiglu_bwd_kernel(const bf16* __restrict__ gu, long ld, const bf16* __restrict__ dout, long lddo, bf16* __restrict__ dgu,
+                                  long ldd, int rows, int F) {
+  int cpr = F >> 3; long total = (long)rows * cpr;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int c = i % cpr; long r = i / cpr;
+    bf16x8 g = *(const bf16x8*)(gu + r * ld + c * 8), u = *(const bf16x8*)(gu + r * ld + F + c * 8);
+    bf16x8 d = *(const bf16x8*)(dout + r * lddo + c * 8), dg, du;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float gf = bf2f(g[j]), uf = bf2f(u[j]), df = bf2f(d[j]);
+      dg[j] = f2bf(df * uf * act_bwd(ACT_SILU, gf));
+      du[j] = f2bf(df * act_fwd(ACT_SILU, gf));
+    }
+    *(bf16x8*)(dgu + r * ldd + c * 8) = dg; *(bf16x8*)(dgu + r * ldd + F + c * 8) = du;
+  }
+}
+extern "C" int unimp_swiglu_fwd(const void* gate_up, int64_t ld, void* out, int64_t ldo, int rows, int F, void* stream) {
+  if (!gate_up || !out) return unimp_set_error(UNIMP_ERR_ARG, "swiglu: null pointer");
+  if ((F & 7) || (ld & 7) || (ldo & 7)) return unimp_set_error(UNIMP_ERR_SHAPE, "swiglu: F, ld must be multiples of 8");
+  if (rows <= 0) return UNIMP_OK;
+  hipLaunchKernelGGL(swiglu_fwd_kernel, GRID1D((long)rows * (F >> 3), 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)gate_up, (long)ld, (bf16*)out, (long)ldo, rows, F);
+  return unimp_check_launch("swiglu_fwd");
+}
+extern "C" int unimp_swiglu_bwd(const void* gate_up, int64_t ld, const void* dout, int64_t lddo, void* dgate_up, int64_t ldd, int rows, int F, void* stream) {
+  if (!gate_up || !dout || !dgate_up) return unimp_set_error(UNIMP_ERR_ARG, "swiglu_bwd: null pointer");
+  if ((F & 7) || (ld & 7) || (lddo & 7) || (ldd & 7)) return unimp_set_error(UNIMP_ERR_SHAPE, "swiglu_bwd: F, ld must be multiples of 8");
+  if (rows <= 0) return UNIMP_OK;
+  hipLaunchKernelGGL(swiglu_bwd_kernel, GRID1D((long)rows * (F >> 3), 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)gate_up, (long)ld, (const bf16*)dout, (long)lddo, (bf16*)dgate_up, (long)ldd, rows, F);
+  return unimp_check_launch("swiglu_bwd");
+}
+
+__global__ void dot_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b, long n, float* __restrict__ out) {
+  __shared__ float sh[4];
+  float acc = 0.f;
+  long nv = n >> 3;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+    bf16x8 x = *(const bf16x8*)(a + i * 8), y = *(const bf16x8*)(b + i * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc += bf2f(x[j]) * bf2f(y[j]);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) { long i = (n & ~7L) + threadIdx.x; acc += bf2f(a[i]) * bf2f(b[i]); }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, sh[0] + sh[1] + sh[2] + sh[3]);
+}
+extern "C" int unimp_dot_bf16(const void* a, const void* b, int64_t n, float* out, void* stream) {
+  if (!a || !b || !out) return unimp_set_error(UNIMP_ERR_ARG, "dot: null pointer");
+  if (n <= 0) return UNIMP_OK;
+  long blocks = std::min<long>(((n >> 3) + 255) / 256 + 1, 1024);
+  hipLaunchKernelGGL(dot_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)a, (const bf16*)b, (long)n, out);
+  return unimp_check_launch("dot");
+}
+
+// ------------------------------------------------------------------------------------------- periodic rows
+__global__ void bcast_rows_kernel(const bf16* __restrict__ src, bf16* __restrict__ out, long ldo, int rows, int period, int D) {
+  int cpr = D >> 3; long total = (long)rows * cpr;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int c = i % cpr; long r = i / cpr;
+    *(bf16x8*)(out + r * ldo + c * 8) = *(const bf16x8*)(src + (long)(r % period) * D + c * 8);
+  }
+}
+__global__ void reduce_rows_periodic_kernel(const bf16* __restrict__ src, long lds_, bf16* __restrict__ out, int rows, int period, int D) {
+  int cpr = D >> 3; long total = (long)period * cpr;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int c = i % cpr; int j = i / cpr;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (long r = j; r < rows; r += period) {
+    bf16x8 v = *(const bf16x8*)(src + r * lds_ + c * 8);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] += bf2f(v[k]);
+  }
+  bf16x8 o;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) o[k] = f2bf(acc[k]);
+  *(bf16x8*)(out + (long)j * D + c * 8) = o;
+}
+extern "C" int unimp_bcast_rows(const void* src, void* out, int64_t ldo, int rows, int period, int D, void* stream) {
+  if (!src || !out) return unimp_set_error(UNIMP_ERR_ARG, "bcast_rows: null pointer");
+  if ((D & 7) || (ldo & 7) || period <= 0) return unimp_set_error(UNIMP_ERR_SHAPE, "bcast_rows: bad shape");
+  if (rows <= 0) return UNIMP_OK;
+  hipLaunchKernelGGL(bcast_rows_kernel, GRID1D((long)rows * (D >> 3), 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)src, (bf16*)out, (long)ldo, rows, period, D);
+  return unimp_check_launch("bcast_rows");
+}
+extern "C" int unimp_reduce_rows_periodic(const void* src, int64_t lds_, void* out, int rows, int period, int D, void* stream) {
+  if (!src || !out) return unimp_set_error(UNIMP_ERR_ARG, "reduce_rows_periodic: null pointer");
+  if ((D & 7) || (lds_ & 7) || period <= 0) return unimp_set_error(UNIMP_ERR_SHAPE, "reduce_rows_periodic: bad shape");
+  long total = (long)period * (D >> 3);
+  hipLaunchKernelGGL(reduce_rows_periodic_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)src, (long)lds_, (bf16*)out, rows, period, D);
+  return unimp_check_launch("reduce_rows_periodic");
+}

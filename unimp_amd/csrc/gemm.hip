@@ -1,0 +1,242 @@
+// bf16 MFMA GEMM with fused epilogues for gfx950 (CDNA4, wave64).
+//
+//   C[M,N] = epilogue( alpha * sum_k A(m,k) * B(n,k) )
+//
+// Operand storage (each operand independently):
+//   KC ("k-contiguous"): X(r,k) = X[r*ld + k]     -- activations [M,K], nn.Linear weights [N,K]
+//   KS ("k-strided")   : X(r,k) = X[k*ld + r]     -- dX: W stored [N_out=k][K_in=r]; dW: dY,X stored [tokens=k][feat=r]
+// so forward  y = x W^T      is (KC,KC),
+//    dX      dx = dy W       is (KC,KS),
+//    dW      dW = dy^T x     is (KS,KS);  no transposed copies are ever materialised.
+//
+// Tile 128x128x64, 256 threads = 4 waves (2x2), 64x64 per wave as 4x4 v_mfma_f32_16x16x32_bf16.
+// Global->register->LDS staging (issue loads before the MFMA phase, write after: T14), two LDS
+// stages, one barrier per K-tile.  KC tiles are read with ds_read_b128 from an XOR-swizzled image,
+// KS tiles with ds_read_b64_tr_b16 (hardware transpose) from a granule-swizzled image; both
+// conflict-free (see common.h).  The MFMA is issued with the operands swapped (D = B_frag x A_frag)
+// so each lane ends up with 4 CONSECUTIVE n of one m: 8-byte bf16 / 16-byte f32 epilogue accesses.
+// Block ids are remapped XCD-contiguously and then swept in GROUP_M-row groups for L2 reuse.
+#include "common.h"
+#include "unimp_hip.h"
+
+struct GemmParams {
+  const bf16* A; const bf16* B; void* C;
+  int M, N, K;
+  long lda, ldb, ldc;
+  const bf16* bias;                 // [N] or null
+  const bf16* res;  long ldres;     // [M,N] or null: added last
+  const bf16* aux;  long ldaux;     // [M,N] or null: v *= act'(aux)   (dact)
+  bf16* pre;        long ldpre;     // [M,N] or null: receives v before act/gate/res
+  const bf16* gate;                 // device scalar or null: v *= tanh(*gate)
+  float alpha;
+  int act, dact, out_f32, accumulate;
+  int nbm, nbn;
+};
+
+#define BM 128
+#define BN 128
+#define BK 64
+#define GROUP_M 8
+#define STAGE_BYTES 32768          // A tile 16 KiB + B tile 16 KiB
+
+template <bool KS>
+__device__ __forceinline__ void g2r(const bf16* __restrict__ X, long ld, int r0, int k0, int R, int K,
+                                    u32x4 (&v)[4]) {
+  int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int q = tid + 256 * i;
+    if (!KS) {
+      int row = q >> 3, c = q & 7;
+      int gr = r0 + row, gk = k0 + c * 8;
+      if (gr < R && gk < K) v[i] = *(const u32x4*)(X + (long)gr * ld + gk);
+      else v[i] = u32x4{0, 0, 0, 0};
+    } else {
+      int kr = q >> 4, c = q & 15;
+      int gk = k0 + kr, gr = r0 + c * 8;
+      if (gk < K && gr < R) v[i] = *(const u32x4*)(X + (long)gk * ld + gr);
+      else v[i] = u32x4{0, 0, 0, 0};
+    }
+  }
+}
+
+template <bool KS>
+__device__ __forceinline__ void r2s(char* tile, const u32x4 (&v)[4]) {
+  int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int q = tid + 256 * i;
+    int off;
+    if (!KS) { int row = q >> 3, c = q & 7; off = kc_off(row, c); }
+    else     { int kr = q >> 4, c = q & 15; off = ks_off(kr, c * 8); }
+    *(u32x4*)(tile + off) = v[i];
+  }
+}
+
+template <bool AKS, bool BKS>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  // ---- block -> tile (XCD-contiguous, grouped along M)
+  int nwg = p.nbm * p.nbn;
+  int id = xcd_remap(blockIdx.x, nwg);
+  int per_group = GROUP_M * p.nbn;
+  int grp = id / per_group;
+  int first_m = grp * GROUP_M;
+  int gsz = min(p.nbm - first_m, GROUP_M);
+  int in_g = id - grp * per_group;
+  int tm = first_m + in_g % gsz, tn = in_g / gsz;
+  int m0 = tm * BM, n0 = tn * BN;
+
+  int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int wm = wave >> 1, wn = wave & 1;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  u32x4 ra[4], rb[4];
+  int nk = (p.K + BK - 1) / BK;
+
+  g2r<AKS>(p.A, p.lda, m0, 0, p.M, p.K, ra);
+  g2r<BKS>(p.B, p.ldb, n0, 0, p.N, p.K, rb);
+  r2s<AKS>(smem, ra);
+  r2s<BKS>(smem + 16384, rb);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    char* cur = smem + (kt & 1) * STAGE_BYTES;
+    char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
+    bool more = kt + 1 < nk;
+    if (more) {
+      g2r<AKS>(p.A, p.lda, m0, (kt + 1) * BK, p.M, p.K, ra);
+      g2r<BKS>(p.B, p.ldb, n0, (kt + 1) * BK, p.N, p.K, rb);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        fa[i] = AKS ? frag_ks(cur, wm * 64 + i * 16, kk) : frag_kc(cur, wm * 64 + i * 16, kk);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        fb[j] = BKS ? frag_ks(cur + 16384, wn * 64 + j * 16, kk) : frag_kc(cur + 16384, wn * 64 + j * 16, kk);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = MFMA16(fb[j], fa[i], acc[i][j]);   // D[n][m]
+    }
+    if (more) {
+      r2s<AKS>(nxt, ra);
+      r2s<BKS>(nxt + 16384, rb);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds C[m = .. + (lane&15)][n = .. + (lane>>4)*4 + r], r = 0..3
+  float gate = 1.f;
+  if (p.gate) gate = tanhf(bf2f(*p.gate));
+  bool n_vec_ok = (p.N & 3) == 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int m = m0 + wm * 64 + i * 16 + (lane & 15);
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+      if (n >= p.N) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * p.alpha;
+      bool full = n_vec_ok || (n + 4 <= p.N);        // all 4 columns valid & (when N%4==0) aligned rows
+      int nv = min(4, p.N - n);
+      if (p.bias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (r < nv) v[r] += bf2f(p.bias[n + r]);
+      }
+      if (p.pre) {
+        bf16* d = p.pre + (long)m * p.ldpre + n;
+        if (full && (p.ldpre & 3) == 0) { bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])}; *(bf16x4*)d = o; }
+        else { for (int r = 0; r < nv; ++r) d[r] = f2bf(v[r]); }
+      }
+      if (p.act) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = act_fwd(p.act, v[r]);
+      }
+      if (p.aux) {
+        const bf16* s = p.aux + (long)m * p.ldaux + n;
+        if (full && (p.ldaux & 3) == 0) { bf16x4 a = *(const bf16x4*)s;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= act_bwd(p.dact, bf2f(a[r])); }
+        else { for (int r = 0; r < nv; ++r) v[r] *= act_bwd(p.dact, bf2f(s[r])); }
+      }
+      if (p.gate) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= gate;
+      }
+      if (p.res) {
+        const bf16* s = p.res + (long)m * p.ldres + n;
+        if (full && (p.ldres & 3) == 0) { bf16x4 a = *(const bf16x4*)s;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += bf2f(a[r]); }
+        else { for (int r = 0; r < nv; ++r) v[r] += bf2f(s[r]); }
+      }
+      if (p.out_f32) {
+        float* d = (float*)p.C + (long)m * p.ldc + n;
+        if (full && (p.ldc & 3) == 0) {
+          f32x4 o = {v[0], v[1], v[2], v[3]};
+          if (p.accumulate) { f32x4 c = *(f32x4*)d; o += c; }
+          *(f32x4*)d = o;
+        } else {
+          for (int r = 0; r < nv; ++r) d[r] = p.accumulate ? d[r] + v[r] : v[r];
+        }
+      } else {
+        bf16* d = (bf16*)p.C + (long)m * p.ldc + n;
+        if (full && (p.ldc & 3) == 0) {
+          if (p.accumulate) { bf16x4 c = *(bf16x4*)d;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += bf2f(c[r]); }
+          bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+          *(bf16x4*)d = o;
+        } else {
+          for (int r = 0; r < nv; ++r) d[r] = f2bf(p.accumulate ? bf2f(d[r]) + v[r] : v[r]);
+        }
+      }
+    }
+  }
+}
+
+static int check_operand(const void* p, long ld, int ks, int rows) {
+  if (((uintptr_t)p & 15) != 0) return UNIMP_ERR_ALIGN;
+  if ((ld & 7) != 0) return UNIMP_ERR_ALIGN;
+  if (ks && ld < ((rows + 7) & ~7)) return UNIMP_ERR_SHAPE;
+  return 0;
+}
+
+extern "C" int unimp_gemm_bf16(const unimp_gemm_desc* d, void* stream) {
+  if (!d || !d->A || !d->B || !d->C) return unimp_set_error(UNIMP_ERR_ARG, "gemm: null pointer");
+  if (d->M <= 0 || d->N <= 0 || d->K <= 0) return unimp_set_error(UNIMP_ERR_SHAPE, "gemm: empty shape");
+  int e;
+  if ((e = check_operand(d->A, d->lda, d->a_kstrided, d->M)) || (e = check_operand(d->B, d->ldb, d->b_kstrided, d->N)))
+    return unimp_set_error(e, "gemm: operand base must be 16-B aligned, ld %% 8 == 0, k-strided ld >= roundup8(rows)");
+  if (!d->a_kstrided && d->lda < ((d->K + 7) & ~7)) return unimp_set_error(UNIMP_ERR_SHAPE, "gemm: lda < roundup8(K)");
+  if (!d->b_kstrided && d->ldb < ((d->K + 7) & ~7)) return unimp_set_error(UNIMP_ERR_SHAPE, "gemm: ldb < roundup8(K)");
+  GemmParams p;
+  p.A = (const bf16*)d->A; p.B = (const bf16*)d->B; p.C = d->C;
+  p.M = d->M; p.N = d->N; p.K = d->K; p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;
+  p.bias = (const bf16*)d->bias; p.res = (const bf16*)d->res; p.ldres = d->ldres;
+  p.aux = (const bf16*)d->aux; p.ldaux = d->ldaux; p.pre = (bf16*)d->pre; p.ldpre = d->ldpre;
+  p.gate = (const bf16*)d->gate; p.alpha = d->alpha; p.act = d->act; p.dact = d->dact;
+  p.out_f32 = d->out_f32; p.accumulate = d->accumulate;
+  p.nbm = (d->M + BM - 1) / BM; p.nbn = (d->N + BN - 1) / BN;
+  dim3 grid(p.nbm * p.nbn), block(256);
+  size_t lds = 2 * STAGE_BYTES;
+  hipStream_t s = (hipStream_t)stream;
+  if (!d->a_kstrided && !d->b_kstrided) hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, lds, s, p);
+  else if (!d->a_kstrided && d->b_kstrided) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, lds, s, p);
+  else if (d->a_kstrided && d->b_kstrided) hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, lds, s, p);
+  else hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, lds, s, p);
+  return unimp_check_launch("gemm");
+}

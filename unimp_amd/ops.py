@@ -1,0 +1,296 @@
+"""Raw (non-autograd) wrappers: torch tensors in, HIP kernels through the C ABI, torch tensors out.
+
+Every tensor must live on a HIP device; nothing here has a CPU or eager-PyTorch fallback.
+"""
+import ctypes as C
+import torch
+
+from . import _lib
+from ._lib import GemmDesc, AttnDesc, check
+
+ACT = {None: 0, "none": 0, "gelu": 1, "quick_gelu": 2, "relu": 3, "silu": 4}
+MASK_NONE, MASK_CAUSAL, MASK_SEGMENT = 0, 1, 2
+bf16 = torch.bfloat16
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t):
+    if not t.is_cuda:
+        raise _lib.UnimpHipError("unimp_amd ops need tensors on a HIP device (no CPU fallback exists)")
+    return t
+
+
+def _p(t):
+    return 0 if t is None else _dev(t).data_ptr()
+
+
+def _mat(t):
+    """2-D bf16 view with unit inner stride; returns (tensor, ld)."""
+    assert t.dim() == 2 and t.dtype == bf16, (t.shape, t.dtype)
+    if t.stride(1) != 1 or (t.shape[0] > 1 and t.stride(0) < t.shape[1]):
+        t = t.contiguous()
+    return t, (t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1]))
+
+
+def gemm(a, b, *, a_ks=False, b_ks=False, bias=None, act=None, res=None, aux=None, dact=None, pre=None,
+         gate=None, alpha=1.0, out=None, out_f32=False, accumulate=False, ldc=None):
+    """C[M,N] = epi(alpha * A B^T).  a: [M,K] (or [K,M] if a_ks); b: [N,K] (or [K,N] if b_ks)."""
+    a, lda = _mat(a)
+    b, ldb = _mat(b)
+    if a_ks:
+        K, M = a.shape
+    else:
+        M, K = a.shape
+    if b_ks:
+        Kb, N = b.shape
+    else:
+        N, Kb = b.shape
+    assert K == Kb, (a.shape, b.shape, a_ks, b_ks)
+    if out is None:
+        ldc = ldc or N
+        out = torch.empty((M, ldc), dtype=torch.float32 if out_f32 else bf16, device=a.device)
+        if ldc != N:
+            out = out[:, :N]
+    d = GemmDesc()
+    d.A, d.B, d.C = a.data_ptr(), b.data_ptr(), _dev(out).data_ptr()
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb, d.ldc = lda, ldb, out.stride(0)
+    d.a_kstrided, d.b_kstrided = int(a_ks), int(b_ks)
+    d.bias = _p(bias)
+    if res is not None:
+        d.res, d.ldres = res.data_ptr(), res.stride(0)
+    if aux is not None:
+        d.aux, d.ldaux = aux.data_ptr(), aux.stride(0)
+    if pre is not None:
+        d.pre, d.ldpre = pre.data_ptr(), pre.stride(0)
+    d.gate = _p(gate)
+    d.alpha = alpha
+    d.act, d.dact = ACT[act], ACT[dact]
+    d.out_f32, d.accumulate = int(out.dtype == torch.float32), int(accumulate)
+    check(_lib.lib().unimp_gemm_bf16(C.byref(d), _stream()), "gemm")
+    return out
+
+
+def layernorm_fwd(x, gamma, beta, eps, *, rms=False, out=None, grp=0, grp_stride=0, grp_off=0):
+    x, ldx = _mat(x)
+    rows, D = x.shape
+    if out is None:
+        out = torch.empty((rows, D), dtype=bf16, device=x.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(_lib.lib().unimp_layernorm_fwd(x.data_ptr(), ldx, _p(gamma), _p(beta), out.data_ptr(), out.stride(0),
+                                          mean.data_ptr(), rstd.data_ptr(), rows, D, eps, int(rms), grp, grp_stride,
+                                          grp_off, _stream()), "layernorm_fwd")
+    return out, mean, rstd
+
+
+_PARTIAL_BLOCKS = 256
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, *, dres=None, want_wgrad=False, has_beta=True, rms=False, grp=0,
+                  grp_stride=0, grp_off=0):
+    """returns dx, dgamma, dbeta (bf16; None when not wanted).  dy may be the grouped (concat) buffer."""
+    x, ldx = _mat(x)
+    rows, D = x.shape
+    assert dy.stride(-1) == 1
+    dx = torch.empty((rows, D), dtype=bf16, device=x.device)
+    dg = db = part = None
+    if want_wgrad:
+        dg = torch.empty(D, dtype=bf16, device=x.device)
+        db = torch.empty(D, dtype=bf16, device=x.device) if has_beta else None
+        part = torch.empty(_PARTIAL_BLOCKS * 2 * D, dtype=torch.float32, device=x.device)
+    check(_lib.lib().unimp_layernorm_bwd(dy.data_ptr(), dy.stride(-2), x.data_ptr(), ldx, _p(gamma), _p(mean), _p(rstd),
+                                          _p(dres), dres.stride(0) if dres is not None else 0, dx.data_ptr(), D,
+                                          _p(dg), _p(db), _p(part), _PARTIAL_BLOCKS, rows, D, int(rms), grp, grp_stride,
+                                          grp_off, _stream()), "layernorm_bwd")
+    return dx, dg, db
+
+
+def rope_(x2d, L, heads, head_stride, rot, offs, cos, sin, inverse=False):
+    """in place on x2d [rows, *]; offs: element offsets of the vectors to rotate inside each head slot."""
+    rows = x2d.shape[0]
+    o0 = offs[0]
+    o1 = offs[1] if len(offs) > 1 else 0
+    check(_lib.lib().unimp_rope_halfsplit(_dev(x2d).data_ptr(), x2d.stride(0), head_stride, rows, L, heads, rot, len(offs),
+                                           o0, o1, cos.data_ptr(), sin.data_ptr(), int(inverse), _stream()), "rope")
+    return x2d
+
+
+def _fill_attn(d, q, k, v, o, lse, B, H, Sq, Sk, D, scale, mask_mode, kv_len, seg, seg_len, qs, ks, vs, os_):
+    d.q, d.k, d.v, d.o, d.lse = q, k, v, o, lse
+    d.q_bs, d.q_ss, d.q_hs = qs
+    d.k_bs, d.k_ss, d.k_hs = ks
+    d.v_bs, d.v_ss, d.v_hs = vs
+    d.o_bs, d.o_ss, d.o_hs = os_
+    d.B, d.H, d.Sq, d.Sk, d.D = B, H, Sq, Sk, D
+    d.scale, d.mask_mode = scale, mask_mode
+    d.kv_len, d.seg, d.seg_len = _p(kv_len), _p(seg), seg_len
+
+
+def _view4(t):
+    """t: [B, S, H, D] strided view (last dim contiguous) -> (ptr, (bs, ss, hs))."""
+    assert t.dim() == 4 and t.stride(3) == 1 and t.dtype == bf16
+    return _dev(t).data_ptr(), (t.stride(0), t.stride(1), t.stride(2))
+
+
+def attn_fwd(q, k, v, scale, mask_mode=MASK_NONE, kv_len=None, seg=None, seg_len=0, out=None):
+    """q [B,Sq,H,D], k/v [B,Sk,H,D] strided views; returns o [B,Sq,H,D] (contiguous unless `out`), lse [B,H,Sq]."""
+    B, Sq, H, D = q.shape
+    Sk = k.shape[1]
+    if out is None:
+        out = torch.empty((B, Sq, H, D), dtype=bf16, device=q.device)
+    lse = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device)
+    d = AttnDesc()
+    (qp, qs), (kp, ks), (vp, vs), (op, os_) = _view4(q), _view4(k), _view4(v), _view4(out)
+    _fill_attn(d, qp, kp, vp, op, lse.data_ptr(), B, H, Sq, Sk, D, scale, mask_mode, kv_len, seg, seg_len, qs, ks, vs, os_)
+    check(_lib.lib().unimp_attn_fwd(C.byref(d), _stream()), "attn_fwd")
+    return out, lse
+
+
+def attn_bwd(q, k, v, o, lse, do, dq, dk, dv, scale, mask_mode=MASK_NONE, kv_len=None, seg=None, seg_len=0):
+    """writes dq/dk/dv (strided [B,S,H,D] views, every element of the views is overwritten)."""
+    B, Sq, H, D = q.shape
+    Sk = k.shape[1]
+    delta = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device)
+    d = AttnDesc()
+    (qp, qs), (kp, ks), (vp, vs), (op, os_) = _view4(q), _view4(k), _view4(v), _view4(o)
+    _fill_attn(d, qp, kp, vp, op, lse.data_ptr(), B, H, Sq, Sk, D, scale, mask_mode, kv_len, seg, seg_len, qs, ks, vs, os_)
+    d.d_o, (d.do_bs, d.do_ss, d.do_hs) = _view4(do)
+    d.dq, (d.dq_bs, d.dq_ss, d.dq_hs) = _view4(dq)
+    d.dk, (d.dk_bs, d.dk_ss, d.dk_hs) = _view4(dk)
+    d.dv, (d.dv_bs, d.dv_ss, d.dv_hs) = _view4(dv)
+    d.delta = delta.data_ptr()
+    check(_lib.lib().unimp_attn_bwd(C.byref(d), _stream()), "attn_bwd")
+
+
+def embedding_fwd(ids, W, pos=None, P=None):
+    rows = ids.numel()
+    D = W.shape[1]
+    out = torch.empty((rows, D), dtype=bf16, device=W.device)
+    check(_lib.lib().unimp_embedding_fwd(_dev(ids).data_ptr(), W.data_ptr(), W.stride(0), _p(pos), _p(P),
+                                          P.stride(0) if P is not None else 0, out.data_ptr(), D, rows, D, W.shape[0],
+                                          _stream()), "embedding_fwd")
+    return out
+
+
+def embedding_bwd(ids, dout, vocab):
+    """dense bf16 [vocab, D] gradient of the embedding table (fp32 scatter-add, then cast)."""
+    rows, D = dout.shape
+    acc = torch.zeros((vocab, D), dtype=torch.float32, device=dout.device)
+    check(_lib.lib().unimp_embedding_bwd(ids.data_ptr(), dout.data_ptr(), dout.stride(0), acc.data_ptr(), D, rows, D, vocab,
+                                          _stream()), "embedding_bwd")
+    return cast_bf16(acc)
+
+
+def cast_bf16(src, scale=1.0):
+    dst = torch.empty(src.shape, dtype=bf16, device=src.device)
+    check(_lib.lib().unimp_cast_f32_to_bf16(_dev(src).data_ptr(), dst.data_ptr(), src.numel(), scale, _stream()), "cast")
+    return dst
+
+
+def add(a, b, out=None):
+    assert a.is_contiguous() and b.is_contiguous() and a.shape == b.shape
+    if out is None:
+        out = torch.empty_like(a)
+    check(_lib.lib().unimp_add_bf16(_dev(a).data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream()), "add")
+    return out
+
+
+def dot(a, b):
+    """fp32 scalar tensor sum(a*b)."""
+    assert a.is_contiguous() and b.is_contiguous() and a.numel() == b.numel()
+    out = torch.zeros(1, dtype=torch.float32, device=a.device)
+    check(_lib.lib().unimp_dot_bf16(_dev(a).data_ptr(), b.data_ptr(), a.numel(), out.data_ptr(), _stream()), "dot")
+    return out
+
+
+def vit_patchify(pixels, P, ldc):
+    N, Cc, Hi, Wi = pixels.shape
+    assert Cc == 3 and pixels.is_contiguous() and pixels.dtype in (torch.float32, bf16)
+    g = (Hi // P) * (Wi // P)
+    cols = torch.empty((N * g, ldc), dtype=bf16, device=pixels.device)
+    check(_lib.lib().unimp_vit_patchify(_dev(pixels).data_ptr(), int(pixels.dtype == torch.float32), cols.data_ptr(), ldc, N, Hi,
+                                         Wi, P, _stream()), "patchify")
+    return cols
+
+
+def vit_assemble(patch, cls, pos, N, n_patch):
+    D = patch.shape[1]
+    x = torch.empty((N, n_patch + 1, D), dtype=bf16, device=patch.device)
+    check(_lib.lib().unimp_vit_assemble(_dev(patch).data_ptr(), patch.stride(0), cls.data_ptr(), pos.data_ptr(), x.data_ptr(), N,
+                                         n_patch, D, _stream()), "vit_assemble")
+    return x
+
+
+def swiglu_fwd(gu, F):
+    rows = gu.shape[0]
+    out = torch.empty((rows, F), dtype=bf16, device=gu.device)
+    check(_lib.lib().unimp_swiglu_fwd(_dev(gu).data_ptr(), gu.stride(0), out.data_ptr(), F, rows, F, _stream()), "swiglu_fwd")
+    return out
+
+
+def swiglu_bwd(gu, dout, F):
+    rows = gu.shape[0]
+    dgu = torch.empty((rows, 2 * F), dtype=bf16, device=gu.device)
+    check(_lib.lib().unimp_swiglu_bwd(_dev(gu).data_ptr(), gu.stride(0), dout.data_ptr(), dout.stride(0), dgu.data_ptr(), 2 * F,
+                                       rows, F, _stream()), "swiglu_bwd")
+    return dgu
+
+
+def bcast_rows(src, rows):
+    period, D = src.shape
+    out = torch.empty((rows, D), dtype=bf16, device=src.device)
+    check(_lib.lib().unimp_bcast_rows(_dev(src).data_ptr(), out.data_ptr(), D, rows, period, D, _stream()), "bcast_rows")
+    return out
+
+
+def reduce_rows_periodic(src, period):
+    rows, D = src.shape
+    out = torch.empty((period, D), dtype=bf16, device=src.device)
+    check(_lib.lib().unimp_reduce_rows_periodic(_dev(src).data_ptr(), src.stride(0), out.data_ptr(), rows, period, D, _stream()),
+          "reduce_rows_periodic")
+    return out
+
+
+def label_mask(ids, answer_id, eoc_id, pad_id, media_id, want_labels=True, want_media_time=True):
+    B, L = ids.shape
+    ids = _dev(ids).contiguous()
+    labels = torch.empty_like(ids) if want_labels else None
+    mt = torch.empty((B, L), dtype=torch.int32, device=ids.device) if want_media_time else None
+    check(_lib.lib().unimp_label_mask(ids.data_ptr(), _p(labels), _p(mt), B, L, answer_id, eoc_id, pad_id, media_id, _stream()),
+          "label_mask")
+    return labels, mt
+
+
+def focal_ce_fwd(logits, V, labels, weights, gamma, use_reweight):
+    """logits [B,L,ldv] bf16 (ldv >= V).  returns (row_lse, row_zy, out3 = [loss_sum, n_valid, ce_sum])."""
+    B, L, ldv = logits.shape[0], logits.shape[1], logits.stride(1)
+    lse = torch.empty(B * L, dtype=torch.float32, device=logits.device)
+    zy = torch.empty(B * L, dtype=torch.float32, device=logits.device)
+    out3 = torch.empty(3, dtype=torch.float32, device=logits.device)
+    check(_lib.lib().unimp_focal_ce_fwd(_dev(logits).data_ptr(), ldv, labels.data_ptr(), weights.data_ptr(), gamma, int(use_reweight),
+                                         lse.data_ptr(), zy.data_ptr(), out3.data_ptr(), B, L, V, _stream()), "focal_ce_fwd")
+    return lse, zy, out3
+
+
+def focal_ce_bwd(logits, V, labels, weights, gamma, use_reweight, lse, zy, out3, gscale, dlogits):
+    B, L, ldv = logits.shape[0], logits.shape[1], logits.stride(1)
+    assert dlogits.stride(1) == ldv
+    check(_lib.lib().unimp_focal_ce_bwd(logits.data_ptr(), ldv, labels.data_ptr(), weights.data_ptr(), gamma, int(use_reweight),
+                                         lse.data_ptr(), zy.data_ptr(), out3.data_ptr(), _p(gscale), dlogits.data_ptr(), B, L, V,
+                                         _stream()), "focal_ce_bwd")
+    return dlogits
+
+
+def sumsq(g, out):
+    """out: fp32 [1 + 1024]; out[0] += sum(g^2)."""
+    check(_lib.lib().unimp_sumsq_bf16(_dev(g).data_ptr(), g.numel(), out.data_ptr(), _stream()), "sumsq")
+
+
+def adamw_flat(master, m, v, p16, g16, n_decay, lr, beta1, beta2, eps, wd, step, sumsq_buf, gscale, max_norm, zero_grad=True):
+    check(_lib.lib().unimp_adamw_flat(_dev(master).data_ptr(), m.data_ptr(), v.data_ptr(), p16.data_ptr(), g16.data_ptr(),
+                                       master.numel(), n_decay, lr, beta1, beta2, eps, wd, step, _p(sumsq_buf), gscale, max_norm,
+                                       int(zero_grad), _stream()), "adamw")
