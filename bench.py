@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Throughput of UniMP's Flamingo train step (cfg2: 4b-instruct = ViT-L/14 + GPT-NeoX-3B, xattn every 2 layers,
+T=8 history images 224x224, L=512, V=74 053, bf16) on N MI355X, one process per GPU.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step = one full optimizer step over one synthetic batch already resident in HBM: label mask -> ViT (no grad) ->
+Perceiver -> 32-layer LM with 16 gated-xattn blocks -> lm head -> weighted focal CE -> backward (dX through the
+frozen tower, dW for xattn / Perceiver / embeddings / head) -> RCCL all-reduce (N>1) -> clip 1.0 -> AdamW.
+Prints ONE JSON line on rank 0 (contract in the task statement; roofline + cpu_baseline objects included).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA peak, MI355X_MICROARCH.md §Chip-level parameters
+
+
+def flops_per_sample(T, L, V, n_patch=256, P=14, Dv=1024, vit_layers=24, vit_mlp=4096, H=2560, F=10240, lm_layers=32,
+                     n_xattn=16, n_lat=64, perc_layers=6, inner=512, head_trainable=True):
+    """SURVEY.md §8d formulae (2MNK per GEMM, attention counted full; frozen: fwd + dX; trainable: fwd + dX + dW)."""
+    t = n_patch + 1
+    vit = T * (2 * n_patch * 3 * P * P * Dv + vit_layers * (2 * t * Dv * 3 * Dv + 4 * t * t * Dv + 2 * t * Dv * Dv + 4 * t * Dv * vit_mlp))
+    perc_l = 2 * n_lat * Dv * inner + 2 * (n_patch + n_lat) * Dv * 2 * inner + 4 * n_lat * (n_patch + n_lat) * inner + \
+        2 * n_lat * inner * Dv + 4 * n_lat * Dv * 4 * Dv
+    perc = 3 * T * perc_layers * perc_l
+    xb = 2 * L * H * inner + 2 * (n_lat * T) * Dv * 2 * inner + 4 * L * (n_lat * T) * inner + 2 * L * inner * H + 4 * L * H * 4 * H
+    xattn = 3 * n_xattn * xb
+    lm_gemm = lm_layers * (2 * L * H * 3 * H + 2 * L * H * H + 4 * L * H * F)
+    lm_attn = lm_layers * 4 * L * L * H
+    head = 2 * L * H * V
+    lm = 2 * (lm_gemm + lm_attn) + (3 if head_trainable else 2) * head
+    return dict(vit=vit, perceiver=perc, xattn=xattn, lm=lm, total=vit + perc + xattn + lm)
+
+
+def build_cfg2(device, gate=0.5, seed=0):
+    from unimp_amd.factory import create_model_and_transforms, SyntheticTokenizer
+    from unimp_amd.synthetic import TokenLayout
+    torch.manual_seed(seed)
+    layout = TokenLayout()                       # V = 74 053 (mmrec.py:538-581, subset "all")
+    model, _, tok = create_model_and_transforms("ViT-L-14", "openai", "togethercomputer/RedPajama-INCITE-Instruct-3B-v1",
+                                                "togethercomputer/RedPajama-INCITE-Instruct-3B-v1", cross_attn_every_n_layers=2,
+                                                device=device, tokenizer=SyntheticTokenizer())
+    model.lang_encoder.resize_token_embeddings(layout.vocab)            # mmrec.py:595 (new embeddings + head: trainable)
+    model.media_token_id, model.eoc_token_id = layout.media, layout.eoc
+    model.lang_encoder.media_token_id = layout.media
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.dim() >= 2 and "latents" not in n:
+                p.normal_(0, 0.02)
+        for g in model.lang_encoder.gated_cross_attn_layers:
+            if g is not None:
+                g.attn_gate.fill_(gate)
+                g.ff_gate.fill_(gate)
+    return model, layout
+
+
+def cpu_baseline(T, L, layout, fps):
+    """The CPU oracle (a port, fp32, all host cores) on a BOUNDED sample of cfg2: real widths, depth 1/8 and 2/8 of the
+    towers, b=1; the full-depth step time is the two-point linear extrapolation t(1/8) + 7*(t(2/8) - t(1/8))."""
+    from oracle import flamingo as ofl, lm as olm, vit as ovit, train_step as ots
+    from unimp_amd.synthetic import make_batch
+    from unimp_amd.optim import apply_decay
+    torch.set_num_threads(os.cpu_count())
+    cores = torch.get_num_threads()
+    batch = make_batch(layout, 1, T, L, seed=99)
+    sp = layout.special()
+    times = []
+    for k in (1, 2):
+        torch.manual_seed(0)
+        v = ovit.VisionTransformer(layers=3 * k)
+        lm = olm.GPTNeoXForCausalLM(olm.NeoXConfig(vocab_size=layout.vocab, num_hidden_layers=4 * k))
+        m = ofl.Flamingo(v, lm, layout.eoc, layout.media, vis_dim=1024, cross_attn_every_n_layers=2)
+        m.perceiver = ofl.PerceiverResampler(dim=1024, depth=k)
+        ofl.freeze_like_factory(m)
+        lm.embed_out.weight.requires_grad_(True)
+        params = [(n, p) for n, p in m.named_parameters() if p.requires_grad]
+        state = {n: (torch.zeros_like(p), torch.zeros_like(p)) for n, p in params}
+
+        def one_step(step):
+            labels = torch.from_numpy(ots.label_mask_loop(batch["lang_x"].numpy(), sp["answer_id"], sp["eoc_id"], sp["pad_id"], sp["media_id"]))
+            m.zero_grad()
+            out = m(batch["vision_x"], batch["lang_x"], batch["attention_mask"], labels=labels)
+            loss = ots.weighted_focal_ce(out["logits"], labels, batch["weights"], 2.0, True)
+            loss.backward()
+            _, coef = ots.clip_coef([p.grad for _, p in params], 1.0)
+            for n, p in params:
+                ots.adamw_step(p.data, p.grad * coef, state[n][0], state[n][1], step, 2e-4, 0.1 if apply_decay(n) else 0.0)
+        one_step(1)                                   # warm-up
+        t0 = time.time()
+        one_step(2)
+        times.append(time.time() - t0)
+        del m, v, lm, state, params
+    full = times[0] + 7.0 * (times[1] - times[0])
+    return {"value": 1.0 / full, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"oracle fp32, b=1, T={T}, L={L}, real widths, towers at depth 1/8 ({times[0]:.2f}s) and 2/8 ({times[1]:.2f}s) "
+                      f"of cfg2, one timed step each after one warm-up; full-depth step = t1 + 7*(t2-t1) = {full:.1f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("UNIMP_BENCH_BATCH", 16)), help="samples per GPU per step")
+    ap.add_argument("--images", type=int, default=8)
+    ap.add_argument("--seq", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    from unimp_amd import ops
+    from unimp_amd.synthetic import make_batch
+    from unimp_amd.train import Trainer
+
+    model, layout = build_cfg2(dev)
+    trainer = Trainer(model, layout.special(), lr=2e-4, weight_decay=0.1, gamma=2.0, use_reweight=True,
+                      lr_scheduler="cosine", warmup_steps=10, total_steps=10000)
+    n_train = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    T, L, B = args.images, args.seq, args.batch
+    pool = [make_batch(layout, B, T, L, seed=1234 + rank + 1000 * i, device=dev, vision_dtype=torch.bfloat16) for i in range(2)]
+    fps = flops_per_sample(T, L, layout.vocab)
+
+    for i in range(args.warmup):
+        trainer.step(pool[i % 2])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    if not args.no_roofline:
+        ops.GEMM_PROFILE = []
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss, stats = trainer.step(pool[i % 2])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    ms = dt / args.steps * 1e3
+    value = B * world * args.steps / dt
+
+    if rank == 0:
+        roofline = None
+        if prof:
+            tot_ms = sum(s.elapsed_time(e) for s, e, _ in prof)
+            tot_fl = sum(f for _, _, f in prof)
+            ach = tot_fl / (tot_ms * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": "gemm_bf16_kernel", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                        "launches_per_step": len(prof) // args.steps, "gemm_ms_per_step": round(tot_ms / args.steps, 2),
+                        "gemm_flop_per_step": tot_fl / args.steps}
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            cpu = cpu_baseline(T, L, layout, fps)
+        line = {"metric": "train samples/sec (user sequences) at 4B-instruct", "value": round(value, 3), "unit": "samples/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                "config": {"workload": "cfg2: 4b-instruct Flamingo (ViT-L/14 + GPT-NeoX-3B RedPajama dims, xattn every 2), "
+                                       "single-task rec, full optimizer step", "per_gpu_batch": B, "global_batch": B * world,
+                           "history_images": T, "seq_len": L, "vocab": layout.vocab, "trainable_params": n_train,
+                           "parallelism": f"dp{world}", "weights": "random-init", "loss": float(loss),
+                           "tflop_per_sample": round(fps["total"] / 1e12, 3),
+                           "model_tflops_per_gpu": round(value / world * fps["total"] / 1e12, 1),
+                           "mfma_frac_whole_step": round(value / world * fps["total"] / 1e12 / PEAK_BF16_TFLOPS, 4)},
+                "roofline": roofline, "cpu_baseline": cpu}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

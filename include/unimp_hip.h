@@ -62,12 +62,13 @@ int unimp_gemm_bf16(const unimp_gemm_desc* d, void* stream);
  * Output row r goes to row (r / grp) * grp_stride + (r % grp) + grp_off of y (grp = 0: identity) so the
  * Perceiver's cat(x, latents) (open_flamingo PerceiverAttention) is written in place.
  * bwd: dx = LN'(dy) (+ dres if given); dgamma/dbeta (bf16 [D], overwritten) through `partial` (fp32
- * [partial_blocks*2*D]) when gamma grads are wanted (dgamma != NULL); dy rows are read through the same row map.
+ * [partial_blocks*2*D]) when gamma grads are wanted (dgamma != NULL); dy rows are read through the same row map;
+ * dy2 (optional, plain row layout) is added to dy first (the Perceiver's norm_latents output feeds both q and kv).
  */
 int unimp_layernorm_fwd(const void* x, int64_t ldx, const void* gamma, const void* beta, void* y, int64_t ldy,
                         float* mean, float* rstd, int rows, int D, float eps, int rms,
                         int grp, int grp_stride, int grp_off, void* stream);
-int unimp_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* gamma,
+int unimp_layernorm_bwd(const void* dy, int64_t lddy, const void* dy2, int64_t lddy2, const void* x, int64_t ldx, const void* gamma,
                         const float* mean, const float* rstd, const void* dres, int64_t lddres,
                         void* dx, int64_t lddx, void* dgamma, void* dbeta, float* partial, int partial_blocks,
                         int rows, int D, int rms, int grp, int grp_stride, int grp_off, void* stream);

@@ -83,7 +83,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x,
 // dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat))      [LayerNorm]
 // dx = rstd * (g*dy - xhat * mean(g*dy*xhat))                   [RMSNorm, xhat = x*rstd]
 template <int MAXC, bool WGRAD>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy, long lddy, const bf16* __restrict__ x, long ldx,
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy, long lddy, const bf16* __restrict__ dy2, long lddy2,
+                                                     const bf16* __restrict__ x, long ldx,
                                                      const bf16* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const bf16* __restrict__ dres, long lddres,
                                                      bf16* __restrict__ dx, long lddx, float* __restrict__ partial,
@@ -106,6 +107,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
     float xv[MAXC][8], gy[MAXC][8];
     load_row<MAXC>(x + (long)r * ldx, nch, xv);
     load_row<MAXC>(dy + map_row(r, grp, grp_stride, grp_off) * lddy, nch, gy);
+    if (dy2) {
+      float g2[MAXC][8];
+      load_row<MAXC>(dy2 + (long)r * lddy2, nch, g2);
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gy[c][j] += g2[c][j];
+    }
     float mu = rms ? 0.f : mean[r];
     float rs = rstd[r];
     float s1 = 0.f, s2 = 0.f;
@@ -197,7 +206,7 @@ extern "C" int unimp_layernorm_fwd(const void* x, int64_t ldx, const void* gamma
   return unimp_check_launch("layernorm_fwd");
 }
 
-extern "C" int unimp_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* gamma,
+extern "C" int unimp_layernorm_bwd(const void* dy, int64_t lddy, const void* dy2, int64_t lddy2, const void* x, int64_t ldx, const void* gamma,
                                    const float* mean, const float* rstd, const void* dres, int64_t lddres, void* dx,
                                    int64_t lddx, void* dgamma, void* dbeta, float* partial, int partial_blocks, int rows,
                                    int D, int rms, int grp, int grp_stride, int grp_off, void* stream) {
@@ -213,7 +222,7 @@ extern "C" int unimp_layernorm_bwd(const void* dy, int64_t lddy, const void* x, 
   }
   dim3 g(nb), b(256);
   size_t lds = wg ? (size_t)4 * D * sizeof(float) : 0;
-#define LN_BWD(MC, WG) hipLaunchKernelGGL((ln_bwd_kernel<MC, WG>), g, b, lds, s, (const bf16*)dy, (long)lddy, (const bf16*)x, (long)ldx, \
+#define LN_BWD(MC, WG) hipLaunchKernelGGL((ln_bwd_kernel<MC, WG>), g, b, lds, s, (const bf16*)dy, (long)lddy, (const bf16*)dy2, (long)lddy2, (const bf16*)x, (long)ldx, \
       (const bf16*)gamma, mean, rstd, (const bf16*)dres, (long)lddres, (bf16*)dx, (long)lddx, partial, rows, D, rms, grp, grp_stride, grp_off)
   if (wg) { if (D <= 1024) LN_BWD(2, true); else if (D <= 2560) LN_BWD(5, true); else LN_BWD(8, true); }
   else    { if (D <= 1024) LN_BWD(2, false); else if (D <= 2560) LN_BWD(5, false); else LN_BWD(8, false); }

@@ -1,0 +1,416 @@
+"""Autograd building blocks of the Flamingo step, each one a fused forward/backward over the HIP kernels.
+
+Granularity is the residual sub-block (x -> x + f(LN(x))) so that the residual gradient add is fused into
+the LayerNorm backward kernel and no eager PyTorch arithmetic sits on the hot path.  Weight gradients are
+only computed for parameters whose ``requires_grad`` is set at call time (the LM tower is frozen in UniMP,
+so its backward is dX-only; SURVEY.md §0.6 / §7 "honour flags at step time").
+
+Arithmetic restated (reference file:line):
+  mlp_block          CLIPMLP clip.py:144-156 / GPTNeoXMLP / open_flamingo FeedForward (+ tanh gate)
+  neox_attn_block    GPTNeoXAttention + residual (transformers gpt_neox modelling :180-283)
+  gated_xattn        open_flamingo MaskedCrossAttention + attn_gate
+  perceiver_attn     open_flamingo PerceiverAttention (A.2)
+  focal_ce           UniMP/mmrec.py:190-213
+"""
+import torch
+from torch.autograd import Function
+
+from . import ops
+
+bf16 = torch.bfloat16
+
+
+def _need(ctx, i):
+    return ctx.needs_input_grad[i]
+
+
+def _gate_grad(dy, raw, gate):
+    """d/d gate of tanh(gate) * raw contracted with dy."""
+    d = ops.dot(dy, raw)
+    t = torch.tanh(gate.float())
+    return (d * (1 - t * t)).to(gate.dtype).view_as(gate)
+
+
+def _no_bias_grad(ctx, idx, name):
+    if idx is not None and _need(ctx, idx):
+        raise NotImplementedError(f"gradient w.r.t. dense-layer bias '{name}' is not implemented in unimp_amd "
+                                  "(no trainable Linear bias exists in the UniMP configuration)")
+
+
+# ----------------------------------------------------------------------------------------------- LayerNorm
+class LayerNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, w, b, eps, rms):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        y, mean, rstd = ops.layernorm_fwd(x2, w, b, eps, rms=rms)
+        ctx.save_for_backward(x2, w, mean, rstd)
+        ctx.rms, ctx.has_b, ctx.shp = rms, b is not None, shp
+        return y.view(shp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, mean, rstd = ctx.saved_tensors
+        dy2 = dy.reshape(-1, ctx.shp[-1])
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        wg = _need(ctx, 1) or (ctx.has_b and _need(ctx, 2))
+        dx, dg, db = ops.layernorm_bwd(dy2, x2, w, mean, rstd, want_wgrad=wg, has_beta=ctx.has_b, rms=ctx.rms)
+        return dx.view(ctx.shp), dg, db, None, None
+
+
+def layer_norm(x, w, b, eps=1e-5, rms=False):
+    return LayerNormFn.apply(x, w, b, eps, rms)
+
+
+# ----------------------------------------------------------------------------------------------- Linear (lm head etc.)
+class LinearFn(Function):
+    """y = x W^T (+ b); optional padded leading dimension for odd N (the vocabulary)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, ldc):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        y = ops.gemm(x2, w, bias=b, ldc=ldc)
+        ctx.save_for_backward(x2, w)
+        ctx.shp, ctx.b_idx = shp, (2 if b is not None else None)
+        return y.view(*shp[:-1], w.shape[0]) if ldc in (None, w.shape[0]) else \
+            y.as_strided((*shp[:-1], w.shape[0]), _lead_strides(shp[:-1], ldc) + (1,), y.storage_offset())
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        _no_bias_grad(ctx, ctx.b_idx, "bias")
+        N = w.shape[0]
+        dy2 = _as_matrix(dy, N)
+        dx = ops.gemm(dy2, w, b_ks=True).view(ctx.shp) if _need(ctx, 0) else None
+        dw = ops.gemm(dy2, x2, a_ks=True, b_ks=True) if _need(ctx, 1) else None
+        return dx, dw, None, None
+
+
+def _lead_strides(lead, ld):
+    st, acc = [], ld
+    for n in reversed(lead):
+        st.append(acc)
+        acc *= n
+    return tuple(reversed(st))
+
+
+def _as_matrix(t, N):
+    """[..., N] gradient -> 2-D bf16 matrix with unit inner stride and ld % 8 == 0 (repack only if needed)."""
+    if t.dtype != bf16:
+        t = t.to(bf16)
+    lead = t.shape[:-1]
+    rows = 1
+    for n in lead:
+        rows *= n
+    ld = t.stride(-2) if t.dim() >= 2 else N
+    uniform = t.stride(-1) == 1 and ld % 8 == 0 and t.data_ptr() % 16 == 0 and \
+        all(t.stride(i) == t.stride(i + 1) * t.shape[i + 1] for i in range(t.dim() - 2))
+    if uniform:
+        return t.as_strided((rows, N), (ld, 1), t.storage_offset())
+    ldp = (N + 7) // 8 * 8
+    buf = torch.zeros((rows, ldp), dtype=bf16, device=t.device)
+    buf[:, :N].copy_(t.reshape(rows, N))
+    return buf[:, :N]
+
+
+def linear(x, w, b=None, ldc=None):
+    return LinearFn.apply(x, w, b, ldc)
+
+
+# ----------------------------------------------------------------------------------------------- MLP sub-block
+class MLPBlockFn(Function):
+    """out = res + tanh(gate) * (act(LN(x) W1^T + b1) W2^T + b2);  res defaults to x, gate to 1."""
+
+    @staticmethod
+    def forward(ctx, x, res, ln_w, ln_b, w1, b1, w2, b2, gate, act, eps):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        r2 = x2 if res is None else res.reshape(-1, shp[-1])
+        h, mean, rstd = ops.layernorm_fwd(x2, ln_w, ln_b, eps)
+        M, F = x2.shape[0], w1.shape[0]
+        pre = torch.empty((M, F), dtype=bf16, device=x.device)
+        a = ops.gemm(h, w1, bias=b1, act=act, pre=pre)
+        raw = torch.empty_like(x2) if gate is not None else None
+        out = ops.gemm(a, w2, bias=b2, gate=gate, res=r2, pre=raw)
+        w1g, w2g = w1.requires_grad, w2.requires_grad
+        ctx.save_for_backward(x2, ln_w, mean, rstd, w1, w2, gate, pre, h if w1g else None, a if w2g else None, raw)
+        ctx.act, ctx.shp, ctx.res_is_x, ctx.has_lnb = act, shp, res is None, ln_b is not None
+        return out.view(shp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, ln_w, mean, rstd, w1, w2, gate, pre, h, a, raw = ctx.saved_tensors
+        _no_bias_grad(ctx, 5, "b1")
+        _no_bias_grad(ctx, 7, "b2")
+        dy2 = dy.reshape(-1, ctx.shp[-1])
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        dgate = _gate_grad(dy2, raw, gate) if gate is not None and _need(ctx, 8) else None
+        dpre = ops.gemm(dy2, w2, b_ks=True, gate=gate, aux=pre, dact=ctx.act)           # [M,F]
+        dw2 = ops.gemm(dy2, a, a_ks=True, b_ks=True, gate=gate) if _need(ctx, 6) else None
+        dw1 = ops.gemm(dpre, h, a_ks=True, b_ks=True) if _need(ctx, 4) else None
+        dh = ops.gemm(dpre, w1, b_ks=True)
+        del dpre
+        wg = _need(ctx, 2) or (ctx.has_lnb and _need(ctx, 3))
+        dx, dg, db = ops.layernorm_bwd(dh, x2, ln_w, mean, rstd, dres=dy2 if ctx.res_is_x else None, want_wgrad=wg,
+                                       has_beta=ctx.has_lnb)
+        dres = None if ctx.res_is_x else dy
+        return dx.view(ctx.shp), dres, dg, db, dw1, None, dw2, None, dgate, None, None
+
+
+def mlp_block(x, ln_w, ln_b, w1, b1, w2, b2, act, gate=None, res=None, eps=1e-5):
+    return MLPBlockFn.apply(x, res, ln_w, ln_b, w1, b1, w2, b2, gate, act, eps)
+
+
+# ----------------------------------------------------------------------------------------------- GPT-NeoX / OPT / Llama self-attention sub-block
+class SelfAttnBlockFn(Function):
+    """out = res + dense(causal_attn(rope(qkv(LN(x)))));  qkv layout [B, L, nh, 3*hd] (GPT-NeoX per-head interleave)
+    or [B, L, 3, nh, hd] (blocked q|k|v: OPT / Llama / ViT)."""
+
+    @staticmethod
+    def forward(ctx, x, res, ln_w, ln_b, wqkv, bqkv, wd, bd, rope, kv_len, nh, interleaved, causal, eps, rms, q_scale):
+        B, L, H = x.shape
+        hd = H // nh
+        x2 = x.reshape(B * L, H)
+        r2 = x2 if res is None else res.reshape(B * L, H)
+        h, mean, rstd = ops.layernorm_fwd(x2, ln_w, ln_b, eps, rms=rms)
+        qkv = ops.gemm(h, wqkv, bias=bqkv)
+        q, k, v, hs, offs = _split_qkv(qkv, B, L, nh, hd, interleaved)
+        if rope is not None:
+            cos, sin, rot = rope
+            ops.rope_(qkv, L, nh, hs, rot, offs, cos, sin)
+        o, lse = ops.attn_fwd(q, k, v, q_scale, ops.MASK_CAUSAL if causal else ops.MASK_NONE, kv_len)
+        o2 = o.view(B * L, H)
+        out = ops.gemm(o2, wd, bias=bd, res=r2)
+        ctx.save_for_backward(x2, ln_w, mean, rstd, wqkv, wd, qkv, o, lse, kv_len, h if wqkv.requires_grad else None,
+                              rope[0] if rope is not None else None, rope[1] if rope is not None else None)
+        ctx.cfg = (B, L, H, nh, hd, interleaved, causal, rms, q_scale, rope[2] if rope is not None else 0, res is None,
+                   ln_b is not None)
+        return out.view(B, L, H)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, ln_w, mean, rstd, wqkv, wd, qkv, o, lse, kv_len, h, cos, sin = ctx.saved_tensors
+        B, L, H, nh, hd, interleaved, causal, rms, q_scale, rot, res_is_x, has_lnb = ctx.cfg
+        _no_bias_grad(ctx, 5, "qkv bias")
+        _no_bias_grad(ctx, 7, "dense bias")
+        dy2 = dy.reshape(B * L, H)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        o2 = o.view(B * L, H)
+        do = ops.gemm(dy2, wd, b_ks=True).view(B, L, nh, hd)
+        dwd = ops.gemm(dy2, o2, a_ks=True, b_ks=True) if _need(ctx, 6) else None
+        q, k, v, hs, offs = _split_qkv(qkv, B, L, nh, hd, interleaved)
+        dqkv = torch.empty_like(qkv)
+        dq, dk, dv, _, _ = _split_qkv(dqkv, B, L, nh, hd, interleaved)
+        ops.attn_bwd(q, k, v, o, lse, do, dq, dk, dv, q_scale, ops.MASK_CAUSAL if causal else ops.MASK_NONE, kv_len)
+        if cos is not None:
+            ops.rope_(dqkv, L, nh, hs, rot, offs, cos, sin, inverse=True)
+        dwqkv = ops.gemm(dqkv, h, a_ks=True, b_ks=True) if _need(ctx, 4) else None
+        dh = ops.gemm(dqkv, wqkv, b_ks=True)
+        wg = _need(ctx, 2) or (has_lnb and _need(ctx, 3))
+        dx, dg, db = ops.layernorm_bwd(dh, x2, ln_w, mean, rstd, dres=dy2 if res_is_x else None, want_wgrad=wg,
+                                       has_beta=has_lnb, rms=rms)
+        dres = None if res_is_x else dy
+        return (dx.view(B, L, H), dres, dg, db, dwqkv, None, dwd, None) + (None,) * 8
+
+
+def _split_qkv(qkv, B, L, nh, hd, interleaved):
+    """strided [B, L, nh, hd] views of q, k, v inside the fused projection output + rope addressing."""
+    H = nh * hd
+    if interleaved:                      # [B, L, nh, 3*hd]
+        t = qkv.view(B, L, nh, 3 * hd)
+        return t[..., :hd], t[..., hd:2 * hd], t[..., 2 * hd:], 3 * hd, (0, hd)
+    t = qkv.view(B, L, 3, nh, hd)        # [B, L, 3, nh, hd]
+    return t[:, :, 0], t[:, :, 1], t[:, :, 2], hd, (0, H)
+
+
+def self_attn_block(x, ln_w, ln_b, wqkv, bqkv, wd, bd, nh, *, rope=None, kv_len=None, interleaved=True, causal=True,
+                    eps=1e-5, rms=False, res=None, q_scale=None):
+    hd = x.shape[-1] // nh
+    return SelfAttnBlockFn.apply(x, res, ln_w, ln_b, wqkv, bqkv, wd, bd, rope, kv_len, nh, interleaved, causal, eps, rms,
+                                 q_scale if q_scale is not None else hd ** -0.5)
+
+
+# ----------------------------------------------------------------------------------------------- gated cross-attention
+class GatedXAttnFn(Function):
+    """out = x + tanh(gate) * to_out(softmax_seg(to_q(LN(x)) to_kv(media)^T) V)   (open_flamingo MaskedCrossAttention)."""
+
+    @staticmethod
+    def forward(ctx, x, media, seg, ln_w, ln_b, wq, wkv, wo, gate, heads, n_lat, eps):
+        B, L, D = x.shape
+        Sk = media.shape[1]                       # media [B, T*n, Dv]
+        inner = wq.shape[0]
+        dh = inner // heads
+        x2 = x.reshape(B * L, D)
+        m2 = media.reshape(B * Sk, -1)
+        h, mean, rstd = ops.layernorm_fwd(x2, ln_w, ln_b, eps)
+        q = ops.gemm(h, wq)
+        kv = ops.gemm(m2, wkv)
+        kv5 = kv.view(B, Sk, 2, heads, dh)
+        o, lse = ops.attn_fwd(q.view(B, L, heads, dh), kv5[:, :, 0], kv5[:, :, 1], dh ** -0.5, ops.MASK_SEGMENT, None, seg, n_lat)
+        raw = torch.empty_like(x2)
+        out = ops.gemm(o.view(B * L, inner), wo, gate=gate, res=x2, pre=raw)
+        ctx.save_for_backward(x2, m2, seg, ln_w, mean, rstd, wq, wkv, wo, gate, h, q, kv, o, lse, raw)
+        ctx.cfg = (B, L, D, Sk, heads, dh, n_lat)
+        return out.view(B, L, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, m2, seg, ln_w, mean, rstd, wq, wkv, wo, gate, h, q, kv, o, lse, raw = ctx.saved_tensors
+        B, L, D, Sk, heads, dh, n_lat = ctx.cfg
+        inner = heads * dh
+        dy2 = dy.reshape(B * L, D)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        dgate = _gate_grad(dy2, raw, gate) if _need(ctx, 8) else None
+        o2 = o.view(B * L, inner)
+        do = ops.gemm(dy2, wo, b_ks=True, gate=gate).view(B, L, heads, dh)
+        dwo = ops.gemm(dy2, o2, a_ks=True, b_ks=True, gate=gate) if _need(ctx, 7) else None
+        dq = torch.empty_like(q)
+        dkv = torch.empty_like(kv)
+        kv5, dkv5 = kv.view(B, Sk, 2, heads, dh), dkv.view(B, Sk, 2, heads, dh)
+        ops.attn_bwd(q.view(B, L, heads, dh), kv5[:, :, 0], kv5[:, :, 1], o, lse, do, dq.view(B, L, heads, dh),
+                     dkv5[:, :, 0], dkv5[:, :, 1], dh ** -0.5, ops.MASK_SEGMENT, None, seg, n_lat)
+        dwq = ops.gemm(dq, h, a_ks=True, b_ks=True) if _need(ctx, 5) else None
+        dh_ = ops.gemm(dq, wq, b_ks=True)
+        dwkv = ops.gemm(dkv, m2, a_ks=True, b_ks=True) if _need(ctx, 6) else None
+        dmedia = ops.gemm(dkv, wkv, b_ks=True).view(B, Sk, -1) if _need(ctx, 1) else None
+        wg = _need(ctx, 3) or _need(ctx, 4)
+        dx, dg, db = ops.layernorm_bwd(dh_, x2, ln_w, mean, rstd, dres=dy2, want_wgrad=wg)
+        return dx.view(B, L, D), dmedia, None, dg, db, dwq, dwkv, dwo, dgate, None, None, None
+
+
+def gated_xattn(x, media, seg, ln_w, ln_b, wq, wkv, wo, gate, heads, n_lat, eps=1e-5):
+    return GatedXAttnFn.apply(x, media, seg, ln_w, ln_b, wq, wkv, wo, gate, heads, n_lat, eps)
+
+
+# ----------------------------------------------------------------------------------------------- Perceiver attention
+class PerceiverAttnFn(Function):
+    """out = latents + to_out(softmax(to_q(LN_l(lat)) [to_kv(LN_m(x)); to_kv(LN_l(lat))]^T) V)   (open_flamingo A.2).
+    x: [G, n1, D] media tokens of G = b*T images, lat: [G, n2, D]."""
+
+    @staticmethod
+    def forward(ctx, x, lat, nm_w, nm_b, nl_w, nl_b, wq, wkv, wo, heads, eps):
+        G, n1, D = x.shape
+        n2 = lat.shape[1]
+        inner = wq.shape[0]
+        dh = inner // heads
+        S = n1 + n2
+        x2, l2 = x.reshape(G * n1, D), lat.reshape(G * n2, D)
+        kvin = torch.empty((G * S, D), dtype=bf16, device=x.device)
+        _, mean_m, rstd_m = ops.layernorm_fwd(x2, nm_w, nm_b, eps, out=kvin, grp=n1, grp_stride=S, grp_off=0)
+        _, mean_l, rstd_l = ops.layernorm_fwd(l2, nl_w, nl_b, eps, out=kvin, grp=n2, grp_stride=S, grp_off=n1)
+        hl, _, _ = ops.layernorm_fwd(l2, nl_w, nl_b, eps)
+        q = ops.gemm(hl, wq)
+        kv = ops.gemm(kvin, wkv)
+        kv5 = kv.view(G, S, 2, heads, dh)
+        o, lse = ops.attn_fwd(q.view(G, n2, heads, dh), kv5[:, :, 0], kv5[:, :, 1], dh ** -0.5, ops.MASK_NONE)
+        out = ops.gemm(o.view(G * n2, inner), wo, res=l2)
+        ctx.save_for_backward(x2, l2, nm_w, nl_w, mean_m, rstd_m, mean_l, rstd_l, wq, wkv, wo, kvin, hl, q, kv, o, lse)
+        ctx.cfg = (G, n1, n2, D, heads, dh)
+        return out.view(G, n2, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, l2, nm_w, nl_w, mean_m, rstd_m, mean_l, rstd_l, wq, wkv, wo, kvin, hl, q, kv, o, lse = ctx.saved_tensors
+        G, n1, n2, D, heads, dh = ctx.cfg
+        inner, S = heads * dh, n1 + n2
+        dy2 = dy.reshape(G * n2, D)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        o2 = o.view(G * n2, inner)
+        do = ops.gemm(dy2, wo, b_ks=True).view(G, n2, heads, dh)
+        dwo = ops.gemm(dy2, o2, a_ks=True, b_ks=True) if _need(ctx, 8) else None
+        dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+        kv5, dkv5 = kv.view(G, S, 2, heads, dh), dkv.view(G, S, 2, heads, dh)
+        ops.attn_bwd(q.view(G, n2, heads, dh), kv5[:, :, 0], kv5[:, :, 1], o, lse, do, dq.view(G, n2, heads, dh),
+                     dkv5[:, :, 0], dkv5[:, :, 1], dh ** -0.5, ops.MASK_NONE)
+        dwq = ops.gemm(dq, hl, a_ks=True, b_ks=True) if _need(ctx, 6) else None
+        dhl = ops.gemm(dq, wq, b_ks=True)
+        dwkv = ops.gemm(dkv, kvin, a_ks=True, b_ks=True) if _need(ctx, 7) else None
+        dkvin = ops.gemm(dkv, wkv, b_ks=True)                                   # [G*S, D]
+        dxm = dgm = dbm = None
+        if _need(ctx, 0) or _need(ctx, 2) or _need(ctx, 3):
+            dxm, dgm, dbm = ops.layernorm_bwd(dkvin, x2, nm_w, mean_m, rstd_m, want_wgrad=_need(ctx, 2) or _need(ctx, 3),
+                                              grp=n1, grp_stride=S, grp_off=0)
+            dxm = dxm.view(G, n1, D) if _need(ctx, 0) else None
+        dl, dgl, dbl = ops.layernorm_bwd(dkvin, l2, nl_w, mean_l, rstd_l, dres=dy2, dy2=dhl,
+                                         want_wgrad=_need(ctx, 4) or _need(ctx, 5), grp=n2, grp_stride=S, grp_off=n1)
+        return dxm, dl.view(G, n2, D), dgm, dbm, dgl, dbl, dwq, dwkv, dwo, None, None
+
+
+def perceiver_attn(x, lat, nm_w, nm_b, nl_w, nl_b, wq, wkv, wo, heads, eps=1e-5):
+    return PerceiverAttnFn.apply(x, lat, nm_w, nm_b, nl_w, nl_b, wq, wkv, wo, heads, eps)
+
+
+class BcastRowsFn(Function):
+    """latents "n d -> (G n) d" repeat and its adjoint."""
+
+    @staticmethod
+    def forward(ctx, lat, G):
+        ctx.n = lat.shape[0]
+        return ops.bcast_rows(lat, G * lat.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.reduce_rows_periodic(dy.contiguous(), ctx.n), None
+
+
+# ----------------------------------------------------------------------------------------------- embedding
+class EmbeddingFn(Function):
+    @staticmethod
+    def forward(ctx, ids, w, pos, pw):
+        ctx.save_for_backward(ids, pos)
+        ctx.vocab, ctx.npos = w.shape[0], (pw.shape[0] if pw is not None else 0)
+        out = ops.embedding_fwd(ids.reshape(-1), w, pos.reshape(-1) if pos is not None else None, pw)
+        return out.view(*ids.shape, w.shape[1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        ids, pos = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        dw = ops.embedding_bwd(ids.reshape(-1), dy2, ctx.vocab) if _need(ctx, 1) else None
+        dp = ops.embedding_bwd(pos.reshape(-1), dy2, ctx.npos) if (pos is not None and _need(ctx, 3)) else None
+        return None, dw, None, dp
+
+
+def embedding(ids, w, pos=None, pw=None):
+    return EmbeddingFn.apply(ids, w, pos, pw)
+
+
+# ----------------------------------------------------------------------------------------------- weighted focal CE
+class FocalCEFn(Function):
+    """loss = sum_rows w_b * ce * (1 - p_y)^gamma / #labeled   (UniMP/mmrec.py:190-213; focal term NOT detached).
+    Also yields the HF-style unweighted mean CE (logged only, mmrec.py:182)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, weights, gamma, use_reweight):
+        B, L, V = logits.shape
+        assert logits.stride(2) == 1 and logits.stride(0) == L * logits.stride(1)
+        lse, zy, out3 = ops.focal_ce_fwd(logits, V, labels, weights, gamma, use_reweight)
+        ctx.save_for_backward(logits, labels, weights, lse, zy, out3)
+        ctx.cfg = (gamma, use_reweight)
+        loss = out3[0] / out3[1]
+        ctx.mark_non_differentiable(out3)
+        return loss, out3
+
+    @staticmethod
+    def backward(ctx, dloss, _):
+        logits, labels, weights, lse, zy, out3 = ctx.saved_tensors
+        gamma, rw = ctx.cfg
+        B, L, V = logits.shape
+        ldv = logits.stride(1)
+        buf = torch.empty((B, L, ldv), dtype=bf16, device=logits.device)
+        dl = buf[..., :V]
+        ops.focal_ce_bwd(logits, V, labels, weights, gamma, rw, lse, zy, out3, dloss.float().reshape(1), dl)
+        return dl, None, None, None, None
+
+
+def focal_ce(logits, labels, weights, gamma, use_reweight=True):
+    """returns (loss, stats) with stats = [loss_sum, n_labeled, ce_sum] (fp32 device tensor)."""
+    return FocalCEFn.apply(logits, labels, weights, float(gamma), bool(use_reweight))

@@ -1,0 +1,292 @@
+"""Causal-LM towers behind Flamingo, on the HIP kernels.
+
+GPT-NeoX (RedPajama-INCITE-3B = UniMP ``4b-instruct``, UniMP/mmrec.py:505-514) and OPT (plumbing config).
+Module tree / parameter names are those of transformers 4.29 (``gpt_neox.embed_in``, ``embed_out``,
+``model.decoder.layers`` ...), which OpenFlamingo's mixin and checkpoints address;
+arithmetic follows transformers' gpt_neox / opt modelling files (RoPE half-split on the first rotary_ndims,
+per-head interleaved QKV, sequential or parallel residual, GELU / ReLU MLP, OPT positions = cumsum(mask)+1).
+The towers own their layers (they do not wrap HF modules), so the HF-version drift noted in SURVEY.md §7 is moot.
+"""
+import math
+import torch
+import torch.nn as nn
+
+from . import functional as F_
+from . import ops
+
+bf16 = torch.bfloat16
+
+
+class LMOutput:
+    """``out[0]`` = loss when labels were passed (else logits); ``out["logits"]`` (UniMP/mmrec.py:182,190)."""
+
+    def __init__(self, loss, logits, stats=None):
+        self.loss, self.logits, self.stats = loss, logits, stats
+
+    def __getitem__(self, k):
+        if isinstance(k, str):
+            return getattr(self, k)
+        return [f for f in (self.loss, self.logits) if f is not None][k]
+
+
+class _Cfg:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def NeoXConfig(vocab_size=50432, hidden_size=2560, num_hidden_layers=32, num_attention_heads=32,
+               intermediate_size=10240, rotary_pct=1.0, rotary_emb_base=10000.0, layer_norm_eps=1e-5,
+               use_parallel_residual=False, max_position_embeddings=2048):
+    return _Cfg(model_type="gpt_neox", **{k: v for k, v in locals().items()})
+
+
+def OPTConfig(vocab_size=50272, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, ffn_dim=3072,
+              max_position_embeddings=2048):
+    return _Cfg(model_type="opt", **{k: v for k, v in locals().items()})
+
+
+LM_CONFIGS = {
+    # name fragments -> config factory (no network: weights are random-init or loaded from a local state_dict)
+    "RedPajama-INCITE-Instruct-3B-v1": lambda: NeoXConfig(),
+    "RedPajama-INCITE-Base-3B-v1": lambda: NeoXConfig(),
+    "pythia-160m": lambda: NeoXConfig(vocab_size=50304, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
+                                      intermediate_size=3072, rotary_pct=0.25, use_parallel_residual=True),
+    "opt-125m": lambda: OPTConfig(),
+    "opt-1.3b": lambda: OPTConfig(hidden_size=2048, num_hidden_layers=24, num_attention_heads=32, ffn_dim=8192),
+}
+
+
+def _pad8(n):
+    return (n + 7) // 8 * 8
+
+
+class _TowerBase(nn.Module):
+    """shared: resize_token_embeddings (HF semantics), kv_len from the attention mask, head + loss."""
+    tied = False
+
+    def resize_token_embeddings(self, n):
+        old = self.get_input_embeddings()
+        if n == old.weight.shape[0]:
+            return old
+        new = nn.Embedding(n, old.weight.shape[1], device=old.weight.device, dtype=old.weight.dtype)
+        new.weight.data.normal_(0, 0.02)
+        k = min(n, old.weight.shape[0])
+        new.weight.data[:k] = old.weight.data[:k]
+        self.set_input_embeddings(new)
+        head = self.get_output_embeddings()
+        if self.tied:
+            head.weight = new.weight
+        else:
+            nh = nn.Linear(head.weight.shape[1], n, bias=False, device=head.weight.device, dtype=head.weight.dtype)
+            nh.weight.data.normal_(0, 0.02)
+            nh.weight.data[:k] = head.weight.data[:k]
+            self.set_output_embeddings(nh)
+        self.config.vocab_size = n
+        return new
+
+    def _get_decoder_layers(self):
+        o = self
+        for part in self.decoder_layers_attr.split("."):
+            o = getattr(o, part)
+        return o
+
+    def is_conditioned(self):
+        return all(l.is_conditioned() for l in self._get_decoder_layers())
+
+    def clear_conditioned_layers(self):
+        for l in self._get_decoder_layers():
+            l.condition_vis_x(None)
+            l.condition_media_locations(None)
+            l.condition_media_time(None)
+            l.condition_use_cached_media(None)
+
+    @staticmethod
+    def _kv_len(attention_mask):
+        if attention_mask is None:
+            return None
+        return attention_mask.sum(1).to(torch.int32)          # right padding (collate_rec.py:38-74)
+
+    def _head(self, h, labels):
+        w = self.get_output_embeddings().weight
+        V = w.shape[0]
+        logits = F_.linear(h, w, None, _pad8(V) if V % 8 else None)
+        loss = stats = None
+        if labels is not None:
+            ones = torch.ones(h.shape[0], dtype=torch.float32, device=h.device)
+            loss, stats = F_.focal_ce(logits, labels.to(h.device), ones, 0.0, False)   # HF mean CE (mmrec.py:182)
+        return LMOutput(loss, logits, stats)
+
+
+# --------------------------------------------------------------------------- GPT-NeoX
+class _NeoXAttnParams(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.query_key_value = nn.Linear(c.hidden_size, 3 * c.hidden_size)
+        self.dense = nn.Linear(c.hidden_size, c.hidden_size)
+
+
+class _NeoXMLPParams(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.dense_h_to_4h = nn.Linear(c.hidden_size, c.intermediate_size)
+        self.dense_4h_to_h = nn.Linear(c.intermediate_size, c.hidden_size)
+
+
+class GPTNeoXLayer(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.c = c
+        self.input_layernorm = nn.LayerNorm(c.hidden_size, eps=c.layer_norm_eps)
+        self.post_attention_layernorm = nn.LayerNorm(c.hidden_size, eps=c.layer_norm_eps)
+        self.attention = _NeoXAttnParams(c)
+        self.mlp = _NeoXMLPParams(c)
+
+    def forward(self, x, attention_mask=None, rope=None, **kw):
+        c, a, m = self.c, self.attention, self.mlp
+        l1, l2 = self.input_layernorm, self.post_attention_layernorm
+        att = F_.self_attn_block(x, l1.weight, l1.bias, a.query_key_value.weight, a.query_key_value.bias, a.dense.weight,
+                                 a.dense.bias, c.num_attention_heads, rope=rope, kv_len=attention_mask, interleaved=True,
+                                 causal=True, eps=l1.eps)
+        if c.use_parallel_residual:      # x + attn(ln1(x)) + mlp(ln2(x))
+            return F_.mlp_block(x, l2.weight, l2.bias, m.dense_h_to_4h.weight, m.dense_h_to_4h.bias, m.dense_4h_to_h.weight,
+                                m.dense_4h_to_h.bias, "gelu", res=att, eps=l2.eps)
+        return F_.mlp_block(att, l2.weight, l2.bias, m.dense_h_to_4h.weight, m.dense_h_to_4h.bias, m.dense_4h_to_h.weight,
+                            m.dense_4h_to_h.bias, "gelu", eps=l2.eps)
+
+
+class _NeoXBody(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.embed_in = nn.Embedding(c.vocab_size, c.hidden_size)
+        self.layers = nn.ModuleList([GPTNeoXLayer(c) for _ in range(c.num_hidden_layers)])
+        self.final_layer_norm = nn.LayerNorm(c.hidden_size, eps=c.layer_norm_eps)
+
+
+class GPTNeoXForCausalLM(_TowerBase):
+    decoder_layers_attr = "gpt_neox.layers"
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.gpt_neox = _NeoXBody(config)
+        self.embed_out = nn.Linear(config.hidden_size, config.vocab_size, bias=False)
+        self._rope = None
+
+    def get_input_embeddings(self): return self.gpt_neox.embed_in
+    def set_input_embeddings(self, m): self.gpt_neox.embed_in = m
+    def get_output_embeddings(self): return self.embed_out
+    def set_output_embeddings(self, m): self.embed_out = m
+
+    def _rope_tables(self, L, device):
+        c = self.config
+        rot = int((c.hidden_size // c.num_attention_heads) * c.rotary_pct)
+        if self._rope is None or self._rope[0].shape[0] < L or self._rope[0].device != device:
+            n = max(L, 512)
+            inv = 1.0 / (c.rotary_emb_base ** (torch.arange(0, rot, 2, dtype=torch.float32) / rot))
+            fr = torch.arange(n, dtype=torch.float32)[:, None] * inv[None]
+            self._rope = (fr.cos().contiguous().to(device), fr.sin().contiguous().to(device), rot)
+        return self._rope
+
+    def forward(self, input_ids, attention_mask=None, labels=None, **kw):
+        B, L = input_ids.shape
+        x = F_.embedding(input_ids, self.gpt_neox.embed_in.weight)
+        kv_len = self._kv_len(attention_mask)
+        rope = self._rope_tables(L, x.device)
+        for layer in self.gpt_neox.layers:
+            x = layer(x, attention_mask=kv_len, rope=rope)
+        f = self.gpt_neox.final_layer_norm
+        h = F_.layer_norm(x, f.weight, f.bias, f.eps)
+        return self._head(h, labels)
+
+
+# --------------------------------------------------------------------------- OPT
+class _OPTAttnParams(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.k_proj, self.v_proj = nn.Linear(d, d), nn.Linear(d, d)
+        self.q_proj, self.out_proj = nn.Linear(d, d), nn.Linear(d, d)
+        self._fused = None
+
+    def fused_qkv(self):
+        """blocked [q;k;v] copy of the three frozen projections (rebuilt when any of them changes)."""
+        ps = [self.q_proj.weight, self.k_proj.weight, self.v_proj.weight, self.q_proj.bias, self.k_proj.bias, self.v_proj.bias]
+        if torch.is_grad_enabled() and any(p.requires_grad for p in ps):
+            raise NotImplementedError("training OPT q/k/v projections is not supported (the LM tower is frozen in UniMP)")
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        if self._fused is None or self._fused[0] != key:
+            self._fused = (key, torch.cat([p.detach() for p in ps[:3]]).contiguous(), torch.cat([p.detach() for p in ps[3:]]).contiguous())
+        return self._fused[1], self._fused[2]
+
+
+class OPTDecoderLayer(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.c = c
+        self.self_attn = _OPTAttnParams(c.hidden_size)
+        self.self_attn_layer_norm = nn.LayerNorm(c.hidden_size)
+        self.fc1 = nn.Linear(c.hidden_size, c.ffn_dim)
+        self.fc2 = nn.Linear(c.ffn_dim, c.hidden_size)
+        self.final_layer_norm = nn.LayerNorm(c.hidden_size)
+
+    def forward(self, x, attention_mask=None, **kw):
+        a, l1, l2 = self.self_attn, self.self_attn_layer_norm, self.final_layer_norm
+        wqkv, bqkv = a.fused_qkv()
+        x = F_.self_attn_block(x, l1.weight, l1.bias, wqkv, bqkv, a.out_proj.weight, a.out_proj.bias,
+                               self.c.num_attention_heads, kv_len=attention_mask, interleaved=False, causal=True, eps=l1.eps)
+        return F_.mlp_block(x, l2.weight, l2.bias, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, "relu", eps=l2.eps)
+
+
+class _OPTDecoder(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.embed_tokens = nn.Embedding(c.vocab_size, c.hidden_size)
+        self.embed_positions = nn.Embedding(c.max_position_embeddings + 2, c.hidden_size)
+        self.final_layer_norm = nn.LayerNorm(c.hidden_size)
+        self.layers = nn.ModuleList([OPTDecoderLayer(c) for _ in range(c.num_hidden_layers)])
+
+
+class _OPTModel(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.decoder = _OPTDecoder(c)
+
+
+class OPTForCausalLM(_TowerBase):
+    decoder_layers_attr = "model.decoder.layers"
+    tied = True
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.model = _OPTModel(config)
+        self.lm_head = nn.Linear(config.hidden_size, config.vocab_size, bias=False)
+        self.lm_head.weight = self.model.decoder.embed_tokens.weight
+
+    def get_input_embeddings(self): return self.model.decoder.embed_tokens
+    def set_input_embeddings(self, m): self.model.decoder.embed_tokens = m
+    def get_output_embeddings(self): return self.lm_head
+    def set_output_embeddings(self, m): self.lm_head = m
+
+    def forward(self, input_ids, attention_mask=None, labels=None, **kw):
+        d = self.model.decoder
+        B, L = input_ids.shape
+        am = attention_mask if attention_mask is not None else torch.ones_like(input_ids)
+        pos = (torch.cumsum(am, 1) * am).long() + 1                      # OPTLearnedPositionalEmbedding (offset 2)
+        x = F_.embedding(input_ids, d.embed_tokens.weight, pos, d.embed_positions.weight)
+        kv_len = self._kv_len(attention_mask)
+        for layer in d.layers:
+            x = layer(x, attention_mask=kv_len)
+        f = d.final_layer_norm
+        h = F_.layer_norm(x, f.weight, f.bias, f.eps)
+        return self._head(h, labels)
+
+
+def build_lm(name_or_config):
+    if isinstance(name_or_config, _Cfg):
+        c = name_or_config
+    else:
+        key = [k for k in LM_CONFIGS if k.lower() in str(name_or_config).lower()]
+        if not key:
+            raise ValueError(f"unknown lang_encoder_path {name_or_config!r}; known: {sorted(LM_CONFIGS)} (or pass a config object)")
+        c = LM_CONFIGS[key[0]]()
+    return {"gpt_neox": GPTNeoXForCausalLM, "opt": OPTForCausalLM}[c.model_type](c)

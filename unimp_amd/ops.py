@@ -13,6 +13,9 @@ MASK_NONE, MASK_CAUSAL, MASK_SEGMENT = 0, 1, 2
 bf16 = torch.bfloat16
 
 
+GEMM_PROFILE = None      # bench.py sets this to a list: (start_event, end_event, flops) per GEMM launch
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -70,6 +73,13 @@ def gemm(a, b, *, a_ks=False, b_ks=False, bias=None, act=None, res=None, aux=Non
     d.alpha = alpha
     d.act, d.dact = ACT[act], ACT[dact]
     d.out_f32, d.accumulate = int(out.dtype == torch.float32), int(accumulate)
+    if GEMM_PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(_lib.lib().unimp_gemm_bf16(C.byref(d), _stream()), "gemm")
+        e1.record()
+        GEMM_PROFILE.append((e0, e1, 2.0 * M * N * K))
+        return out
     check(_lib.lib().unimp_gemm_bf16(C.byref(d), _stream()), "gemm")
     return out
 
@@ -90,7 +100,7 @@ def layernorm_fwd(x, gamma, beta, eps, *, rms=False, out=None, grp=0, grp_stride
 _PARTIAL_BLOCKS = 256
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, *, dres=None, want_wgrad=False, has_beta=True, rms=False, grp=0,
+def layernorm_bwd(dy, x, gamma, mean, rstd, *, dres=None, dy2=None, want_wgrad=False, has_beta=True, rms=False, grp=0,
                   grp_stride=0, grp_off=0):
     """returns dx, dgamma, dbeta (bf16; None when not wanted).  dy may be the grouped (concat) buffer."""
     x, ldx = _mat(x)
@@ -102,7 +112,8 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, *, dres=None, want_wgrad=False, has_
         dg = torch.empty(D, dtype=bf16, device=x.device)
         db = torch.empty(D, dtype=bf16, device=x.device) if has_beta else None
         part = torch.empty(_PARTIAL_BLOCKS * 2 * D, dtype=torch.float32, device=x.device)
-    check(_lib.lib().unimp_layernorm_bwd(dy.data_ptr(), dy.stride(-2), x.data_ptr(), ldx, _p(gamma), _p(mean), _p(rstd),
+    check(_lib.lib().unimp_layernorm_bwd(dy.data_ptr(), dy.stride(-2), _p(dy2), dy2.stride(0) if dy2 is not None else 0,
+                                          x.data_ptr(), ldx, _p(gamma), _p(mean), _p(rstd),
                                           _p(dres), dres.stride(0) if dres is not None else 0, dx.data_ptr(), D,
                                           _p(dg), _p(db), _p(part), _PARTIAL_BLOCKS, rows, D, int(rms), grp, grp_stride,
                                           grp_off, _stream()), "layernorm_bwd")

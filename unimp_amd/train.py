@@ -1,0 +1,83 @@
+"""One optimizer step with train_one_epoch's semantics (UniMP/mmrec.py:65-302), every stage on the HIP kernels:
+
+  labels   = label-mask kernel                      (mmrec.py:143-168, Python double loop in the reference)
+  output   = model(vision_x, lang_x, mask, labels)   (mmrec.py:177-181)
+  loss     = weighted focal CE on output["logits"]   (mmrec.py:190-213)
+  backward + bucketed RCCL all-reduce                (mmrec.py:215; dp.py)
+  clip 1.0 + AdamW + LR schedule                     (mmrec.py:247-256; optim.py)
+
+Loss normalisation is per rank and gradients are averaged across ranks (mean of per-rank token means), as
+in the reference.  Samples/s accounting = GA * batch * world / step_time (mmrec.py:267-272).
+"""
+import time
+import torch
+
+from . import functional as F_
+from . import ops
+from .optim import FlatAdamW, cosine_lr, linear_lr
+from .dp import GradBucketer
+
+
+class AverageMeter:
+    """UniMP/pipeline/train/train_utils.py:268-284"""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.val = self.avg = self.sum = self.count = 0
+
+    def update(self, val, n=1):
+        self.val = val
+        self.sum += val * n
+        self.count += n
+        self.avg = self.sum / self.count
+
+
+def get_checkpoint(model):
+    """trainable-only state dict (train_utils.py:258-265)."""
+    sd = model.state_dict()
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            del sd[name]
+    return sd
+
+
+class Trainer:
+    def __init__(self, model, special_ids, lr=2e-4, weight_decay=0.1, gamma=2.0, use_reweight=True, max_grad_norm=1.0,
+                 lr_scheduler="cosine", warmup_steps=0, total_steps=1000, bucket_bytes=256 << 20, process_group=None):
+        self.model = model
+        self.ids = special_ids                   # dict(answer_id, eoc_id, pad_id, media_id)
+        self.gamma, self.use_reweight = gamma, use_reweight
+        self.opt = FlatAdamW(model.named_parameters(), lr=lr, weight_decay=weight_decay, max_grad_norm=max_grad_norm)
+        le = model.lang_encoder
+        late = [le.get_input_embeddings().weight] if getattr(le, "tied", False) else []
+        self.dp = GradBucketer(self.opt, bucket_bytes=bucket_bytes, process_group=process_group, late_params=late)
+        self.sched, self.base_lr, self.warmup, self.total = lr_scheduler, lr, warmup_steps, total_steps
+        self.sched_step = 0
+
+    def current_lr(self):
+        if self.sched == "cosine":
+            return cosine_lr(self.sched_step, self.base_lr, self.warmup, self.total)
+        if self.sched == "linear":
+            return linear_lr(self.sched_step, self.base_lr, self.warmup, self.total)
+        return self.base_lr if self.sched_step >= self.warmup else self.base_lr * self.sched_step / max(1, self.warmup)
+
+    def forward_loss(self, batch):
+        ids = batch["lang_x"]
+        labels, _ = ops.label_mask(ids, self.ids["answer_id"], self.ids["eoc_id"], self.ids["pad_id"], self.ids["media_id"],
+                                   want_media_time=False)
+        out = self.model(vision_x=batch["vision_x"].unsqueeze(2) if batch["vision_x"].ndim == 5 else batch["vision_x"],
+                         lang_x=ids, attention_mask=batch["attention_mask"], labels=None)
+        loss, stats = F_.focal_ce(out["logits"], labels, batch["weights"], self.gamma, self.use_reweight)
+        return loss, stats, out, labels
+
+    def step(self, batch):
+        """returns (loss, stats) device tensors; no host synchronisation."""
+        self.model.train()
+        loss, stats, out, _ = self.forward_loss(batch)
+        loss.backward()
+        gscale = self.dp.finish()
+        self.opt.step(lr=self.current_lr(), grad_scale=gscale)
+        self.sched_step += 1
+        return loss.detach(), stats
