@@ -88,3 +88,14 @@ def oracle_step(m, layout, batch, gamma=2.0, use_reweight=True):
 def rel_l2(got, want):
     got, want = got.float().cpu(), want.float().cpu()
     return ((got - want).norm() / (want.norm() + 1e-12)).item()
+
+
+def bf16_noise_floor(m, layout, batch, labels, ref_grads, gamma=2.0, use_reweight=True):
+    """per-parameter rel-L2 deviation of the oracle's own gradients when the oracle is re-run under bf16 autocast."""
+    m.zero_grad()
+    with torch.autocast("cpu", dtype=bf16):
+        out = m(batch["vision_x"], batch["lang_x"], batch["attention_mask"])
+        loss = ots.weighted_focal_ce(out["logits"].float(), labels, batch["weights"], gamma, use_reweight)
+    loss.backward()
+    return {n: (rel_l2(p.grad, ref_grads[n]) if ref_grads[n].norm() > 0 else 0.0)
+            for n, p in m.named_parameters() if p.grad is not None and n in ref_grads}

@@ -73,6 +73,8 @@ def lib():
             raise ImportError(
                 f"{LIB_PATH} not found: the HIP extension is not built. Run "
                 "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C unimp_amd/csrc`).")
+        import torch  # noqa: F401  -- load PyTorch's bundled HIP runtime FIRST so libunimp_hip.so binds to the same
+        #                          libamdhip64 (a second runtime from /opt/rocm would see no device and other streams)
         L = C.CDLL(LIB_PATH)
         L.unimp_last_error.restype = C.c_char_p
         L.unimp_abi_version.restype = c_i

@@ -73,6 +73,65 @@ __device__ __forceinline__ void r2s(char* tile, const u32x4 (&v)[4]) {
   }
 }
 
+// one 16x16 accumulator tile: 4 consecutive n of row m per lane.  FAST: N % 4 == 0 and every ld % 4 == 0, so the
+// 4 columns are all valid and 8-byte (bf16) / 16-byte (f32) aligned; otherwise per-element with bounds checks.
+template <bool FAST>
+__device__ __forceinline__ void epi_tile(const GemmParams& p, f32x4 a, int m, int n, float gate) {
+  if (m >= p.M || n >= p.N) return;
+  int nv = FAST ? 4 : min(4, p.N - n);
+  float v[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = a[r] * p.alpha;
+  if (p.bias) {
+    if (FAST) { bf16x4 b = *(const bf16x4*)(p.bias + n);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] += bf2f(b[r]); }
+    else { for (int r = 0; r < nv; ++r) v[r] += bf2f(p.bias[n + r]); }
+  }
+  if (p.pre) {
+    bf16* d = p.pre + (long)m * p.ldpre + n;
+    if (FAST) { bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])}; *(bf16x4*)d = o; }
+    else { for (int r = 0; r < nv; ++r) d[r] = f2bf(v[r]); }
+  }
+  if (p.act) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = act_fwd(p.act, v[r]);
+  }
+  if (p.aux) {
+    const bf16* s = p.aux + (long)m * p.ldaux + n;
+    if (FAST) { bf16x4 x = *(const bf16x4*)s;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] *= act_bwd(p.dact, bf2f(x[r])); }
+    else { for (int r = 0; r < nv; ++r) v[r] *= act_bwd(p.dact, bf2f(s[r])); }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] *= gate;
+  if (p.res) {
+    const bf16* s = p.res + (long)m * p.ldres + n;
+    if (FAST) { bf16x4 x = *(const bf16x4*)s;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] += bf2f(x[r]); }
+    else { for (int r = 0; r < nv; ++r) v[r] += bf2f(s[r]); }
+  }
+  if (p.out_f32) {
+    float* d = (float*)p.C + (long)m * p.ldc + n;
+    if (FAST) {
+      f32x4 o = {v[0], v[1], v[2], v[3]};
+      if (p.accumulate) o += *(const f32x4*)d;
+      *(f32x4*)d = o;
+    } else { for (int r = 0; r < nv; ++r) d[r] = p.accumulate ? d[r] + v[r] : v[r]; }
+  } else {
+    bf16* d = (bf16*)p.C + (long)m * p.ldc + n;
+    if (FAST) {
+      if (p.accumulate) { bf16x4 c = *(const bf16x4*)d;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += bf2f(c[r]); }
+      bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+      *(bf16x4*)d = o;
+    } else { for (int r = 0; r < nv; ++r) d[r] = f2bf(p.accumulate ? bf2f(d[r]) + v[r] : v[r]); }
+  }
+}
+
 template <bool AKS, bool BKS>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -136,76 +195,19 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
   }
 
   // ---- epilogue: lane holds C[m = .. + (lane&15)][n = .. + (lane>>4)*4 + r], r = 0..3
+  // Every acc[i][j] is named with literal indices (a runtime-indexed accumulator array is demoted to scratch
+  // and then spilled on every K-step: cdna guide rule 20).
   float gate = 1.f;
   if (p.gate) gate = tanhf(bf2f(*p.gate));
-  bool n_vec_ok = (p.N & 3) == 0;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int m = m0 + wm * 64 + i * 16 + (lane & 15);
-    if (m >= p.M) continue;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
-      if (n >= p.N) continue;
-      float v[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * p.alpha;
-      bool full = n_vec_ok || (n + 4 <= p.N);        // all 4 columns valid & (when N%4==0) aligned rows
-      int nv = min(4, p.N - n);
-      if (p.bias) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) if (r < nv) v[r] += bf2f(p.bias[n + r]);
-      }
-      if (p.pre) {
-        bf16* d = p.pre + (long)m * p.ldpre + n;
-        if (full && (p.ldpre & 3) == 0) { bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])}; *(bf16x4*)d = o; }
-        else { for (int r = 0; r < nv; ++r) d[r] = f2bf(v[r]); }
-      }
-      if (p.act) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = act_fwd(p.act, v[r]);
-      }
-      if (p.aux) {
-        const bf16* s = p.aux + (long)m * p.ldaux + n;
-        if (full && (p.ldaux & 3) == 0) { bf16x4 a = *(const bf16x4*)s;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] *= act_bwd(p.dact, bf2f(a[r])); }
-        else { for (int r = 0; r < nv; ++r) v[r] *= act_bwd(p.dact, bf2f(s[r])); }
-      }
-      if (p.gate) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] *= gate;
-      }
-      if (p.res) {
-        const bf16* s = p.res + (long)m * p.ldres + n;
-        if (full && (p.ldres & 3) == 0) { bf16x4 a = *(const bf16x4*)s;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += bf2f(a[r]); }
-        else { for (int r = 0; r < nv; ++r) v[r] += bf2f(s[r]); }
-      }
-      if (p.out_f32) {
-        float* d = (float*)p.C + (long)m * p.ldc + n;
-        if (full && (p.ldc & 3) == 0) {
-          f32x4 o = {v[0], v[1], v[2], v[3]};
-          if (p.accumulate) { f32x4 c = *(f32x4*)d; o += c; }
-          *(f32x4*)d = o;
-        } else {
-          for (int r = 0; r < nv; ++r) d[r] = p.accumulate ? d[r] + v[r] : v[r];
-        }
-      } else {
-        bf16* d = (bf16*)p.C + (long)m * p.ldc + n;
-        if (full && (p.ldc & 3) == 0) {
-          if (p.accumulate) { bf16x4 c = *(bf16x4*)d;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += bf2f(c[r]); }
-          bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-          *(bf16x4*)d = o;
-        } else {
-          for (int r = 0; r < nv; ++r) d[r] = f2bf(p.accumulate ? bf2f(d[r]) + v[r] : v[r]);
-        }
-      }
-    }
-  }
+  bool fast = ((p.N & 3) == 0) && (((p.ldc | p.ldres | p.ldaux | p.ldpre) & 3) == 0);
+  int mb = m0 + wm * 64 + (lane & 15), nb = n0 + wn * 64 + (lane >> 4) * 4;
+#define EPI_TILE(F, i, j) epi_tile<F>(p, acc[i][j], mb + (i) * 16, nb + (j) * 16, gate);
+#define EPI_ROW(F, i) EPI_TILE(F, i, 0) EPI_TILE(F, i, 1) EPI_TILE(F, i, 2) EPI_TILE(F, i, 3)
+#define EPI_ALL(F) EPI_ROW(F, 0) EPI_ROW(F, 1) EPI_ROW(F, 2) EPI_ROW(F, 3)
+  if (fast) { EPI_ALL(true) } else { EPI_ALL(false) }
+#undef EPI_ALL
+#undef EPI_ROW
+#undef EPI_TILE
 }
 
 static int check_operand(const void* p, long ld, int ks, int rows) {
