@@ -1,0 +1,108 @@
+"""world_size-2 gloo test of the data-parallel gradient path (dp.GradBucketer over the flat gradient buffer):
+bucket boundaries, hook-driven launches, unused-parameter flush, 1/W scaling and bit-identical replicas.
+Plumbing only (torch.distributed over CPU tensors): the arithmetic kernels are exercised by the -m gpu tests."""
+import os
+import socket
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _FakeOpt:
+    """the slice of FlatAdamW's interface GradBucketer uses, on CPU tensors (no kernels involved)."""
+    ALIGN = 64
+
+    def __init__(self, params):
+        self.layout, off = [], 0
+        for n, p in params:
+            self.layout.append((n, p, off, p.numel()))
+            off += (p.numel() + 63) // 64 * 64
+        self.flat_g = torch.zeros(off, dtype=torch.bfloat16)
+        for n, p, o, k in self.layout:
+            p.grad = self.flat_g[o:o + k].view(p.shape)
+
+    def _reattach(self):
+        pass
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from unimp_amd.dp import GradBucketer
+    torch.manual_seed(0)
+    ps = [(f"p{i}", torch.nn.Parameter(torch.randn(sz).to(torch.bfloat16))) for i, sz in enumerate([(300,), (64, 70), (1000,), (5,), (2048,)])]
+    opt = _FakeOpt(ps)
+    dp = GradBucketer(opt, bucket_bytes=4096)          # 2048 bf16 elements per bucket -> several buckets
+    assert len(dp.buckets) >= 3 and dp.buckets[0][0] == 0 and dp.buckets[-1][1] == opt.flat_g.numel()
+    for a, b in zip(dp.buckets[:-1], dp.buckets[1:]):
+        assert a[1] == b[0]
+    # rank-dependent loss; p3 (size 5) gets no gradient at all -> must be flushed by finish()
+    x = torch.full((), float(rank + 1))
+    loss = sum((p.float() * x).sum() * (i + 1) for i, (n, p) in enumerate(ps) if n != "p3")
+    loss.backward()
+    scale = dp.finish()
+    assert scale == 1.0 / world
+    want = {n: torch.full(p.shape, float(i + 1) * sum(r + 1 for r in range(world))) for i, (n, p) in enumerate(ps)}
+    for n, p in ps:
+        if n == "p3":
+            assert (p.grad == 0).all()
+        else:
+            assert torch.equal(p.grad.float(), want[n]), n
+    # second step works after finish() reset
+    opt.flat_g.zero_()
+    loss = sum((p.float() * x).sum() for n, p in ps)
+    loss.backward()
+    dp.finish()
+    assert torch.equal(ps[3][1].grad.float(), torch.full((5,), float(sum(r + 1 for r in range(world)))))
+    # replicas hold bit-identical reduced gradients
+    g = [torch.empty_like(opt.flat_g) for _ in range(world)]
+    dist.all_gather(g, opt.flat_g)
+    assert all(torch.equal(g[0], t) for t in g)
+    q.put((rank, "ok"))
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    got = sorted(q.get(timeout=5) for _ in range(world))
+    assert got == [(0, "ok"), (1, "ok")]
+
+
+def test_host_logic_cpu():
+    """optimizer grouping / schedules / synthetic layout (host logic, no kernels)."""
+    from unimp_amd.optim import apply_decay, cosine_lr
+    from unimp_amd.synthetic import TokenLayout, make_batch
+    from oracle import train_step as ots
+    names = ["lang_encoder.gpt_neox.layers.1.gated_cross_attn_layer.ff.0.weight", "lang_encoder.gpt_neox.layers.1.gated_cross_attn_layer.ff.0.bias",
+             "lang_encoder.gpt_neox.layers.1.gated_cross_attn_layer.attn.norm.weight", "lang_encoder.gpt_neox.layers.1.gated_cross_attn_layer.attn_gate",
+             "lang_encoder.gpt_neox.layers.1.gated_cross_attn_layer.attn.to_q.weight", "perceiver.layers.0.0.to_q.weight",
+             "lang_encoder.gpt_neox.embed_in.weight", "lang_encoder.gated_cross_attn_layers.1.ff.1.weight"]
+    groups = ots.grouped_params([(n, None) for n in names], 0.1)
+    decayed = {n for n, _ in groups[0]["params"]}
+    assert decayed == {n for n in names if apply_decay(n)} == {names[0], names[4], names[7]}     # incl. the ff.0.weight quirk
+    for s in (0, 3, 10, 500, 999):
+        assert abs(cosine_lr(s, 2e-4, 10, 1000) - ots.cosine_lr(s, 2e-4, 10, 1000)) < 1e-12
+    lay = TokenLayout()
+    assert lay.vocab == 74053 and lay.answer == 50280
+    b = make_batch(lay, 3, 8, 512, image_size=16)
+    ids = b["lang_x"]
+    assert ids.shape == (3, 512) and (ids == lay.media).sum(1).tolist() == [8, 8, 8]
+    assert ((ids != lay.pad).long() == b["attention_mask"]).all()
+    lab = ots.label_mask(ids.numpy(), lay.answer, lay.eoc, lay.pad, lay.media)
+    assert ((lab != -100).sum(1) == 9 + 1).all()        # 9 item answers + EOS after the last answer
