@@ -168,8 +168,16 @@ def main():
     if rank == 0:
         roofline = None
         if prof:
-            tot_ms = sum(s.elapsed_time(e) for s, e, _ in prof)
-            tot_fl = sum(f for _, _, f in prof)
+            tot_ms = sum(r[0].elapsed_time(r[1]) for r in prof)
+            tot_fl = sum(r[2] for r in prof)
+            if os.environ.get("UNIMP_BENCH_SHAPES"):
+                agg = {}
+                for r in prof:
+                    a = agg.setdefault(r[3], [0, 0.0, 0.0])
+                    a[0] += 1; a[1] += r[0].elapsed_time(r[1]); a[2] += r[2]
+                for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                    print(f"  gemm M={k[0]:6d} N={k[1]:6d} K={k[2]:6d} aks={k[3]} bks={k[4]}  calls/step {a[0] // args.steps:4d}  "
+                          f"{a[1] / args.steps:8.2f} ms/step  {a[2] / a[1] / 1e9:7.1f} TFLOP/s", file=sys.stderr)
             ach = tot_fl / (tot_ms * 1e-3) / 1e12
             roofline = {"bound": "mfma", "kernel": "gemm_bf16_kernel", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,

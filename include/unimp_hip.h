@@ -55,6 +55,14 @@ typedef struct {
   int out_f32, accumulate;
 } unimp_gemm_desc;
 int unimp_gemm_bf16(const unimp_gemm_desc* d, void* stream);
+/* same, with an explicit kernel variant (all compute identical results up to fp32 summation order):
+ *   V1      128x128x64 tiles, 4 waves, register-staged double buffer, 2 workgroups / CU (small or ragged problems)
+ *   DMA256/128  256 x {256,128} tiles, 8 waves, LDS-DMA staging, 2-stage ring
+ *   PP256/128   256 x {256,128} tiles, 8 waves, LDS-DMA, 4-deep ring of 32-k half-stages, SIMD partners ping-ponged
+ * AUTO picks by shape; the Python layer autotunes per (shape, layout) on first use. */
+enum { UNIMP_GEMM_AUTO = 0, UNIMP_GEMM_V1 = 1, UNIMP_GEMM_DMA256 = 2, UNIMP_GEMM_DMA128 = 3, UNIMP_GEMM_PP256 = 4,
+       UNIMP_GEMM_PP128 = 5 };
+int unimp_gemm_bf16_variant(const unimp_gemm_desc* d, int variant, void* stream);
 
 /* ---- LayerNorm / RMSNorm ---------------------------------------------------------------------------------
  * replaces nn.LayerNorm (clip.py:164-166,423; gpt_neox input/post_attention/final LN; open_flamingo norms)

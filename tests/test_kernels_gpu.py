@@ -49,7 +49,9 @@ def act_ref(name, x):
 
 # ------------------------------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (300, 200, 72), (1, 8, 8), (1024, 2560, 2560),
-                                   (77, 1000, 600), (513, 136, 1032)])
+                                   (77, 1000, 600), (513, 136, 1032),
+                                   # >= 1024 rows: the 256-row LDS-DMA kernel (gemm2), incl. ragged M/N/K edges and both tile widths
+                                   (1536, 1000, 600), (1304, 384, 192), (4096, 264, 128), (2048, 512, 1024), (1032, 136, 72)])
 @pytest.mark.parametrize("a_ks,b_ks", [(False, False), (False, True), (True, True), (True, False)])
 def test_gemm_layouts(ops, M, N, K, a_ks, b_ks):
     if (a_ks and M % 8) or (b_ks and N % 8):
@@ -58,10 +60,29 @@ def test_gemm_layouts(ops, M, N, K, a_ks, b_ks):
     want = a.float() @ b.float().t()
     ad = (a.t().contiguous() if a_ks else a).cuda()
     bd = (b.t().contiguous() if b_ks else b).cuda()
-    got = ops.gemm(ad, bd, a_ks=a_ks, b_ks=b_ks)
+    got = ops.gemm(ad, bd, a_ks=a_ks, b_ks=b_ks)                  # autotuned choice
     close(got, want, name=f"gemm {M}x{N}x{K} {a_ks}{b_ks}")
-    got32 = ops.gemm(ad, bd, a_ks=a_ks, b_ks=b_ks, out_f32=True)
+    for variant in (["v1"] if M < 256 else ["v1", "dma256", "dma128", "pp256", "pp128"]):   # every kernel, explicitly
+        got = ops.gemm(ad, bd, a_ks=a_ks, b_ks=b_ks, variant=variant)
+        close(got, want, name=f"gemm[{variant}] {M}x{N}x{K} {a_ks}{b_ks}")
+    got32 = ops.gemm(ad, bd, a_ks=a_ks, b_ks=b_ks, out_f32=True, variant="pp256" if M >= 256 else "v1")
     close(got32, want, rel=1e-5, name="gemm f32 out")
+
+
+def test_gemm_pingpong_long_k_race_screen(ops):
+    """many K half-steps, odd half-step count, repeated launches: screens the ping-pong kernel's LDS ring hazards."""
+    M, N = 2048, 768
+    for K in (32 * 37, 32 * 128, 2560 + 8):
+        a, b = rnd(M, K, seed=K), rnd(N, K, seed=K + 1)
+        want = a.float() @ b.float().t()
+        ad, bd = a.cuda(), b.cuda()
+        ref = ops.gemm(ad, bd, variant="v1")
+        close(ref, want, name="v1 long k")
+        for variant in ("pp256", "pp128", "dma256"):
+            outs = [ops.gemm(ad, bd, variant=variant) for _ in range(6)]
+            for o in outs:
+                assert torch.equal(o, outs[0]), f"{variant}: run-to-run mismatch at K={K}"
+            close(outs[0], want, name=f"{variant} long k")
 
 
 def test_gemm_asymmetric_identity(ops):
@@ -73,19 +94,22 @@ def test_gemm_asymmetric_identity(ops):
     assert torch.equal(got.float().cpu(), b.float().t())
 
 
+@pytest.mark.parametrize("M", [200, 1100])
 @pytest.mark.parametrize("act", [None, "gelu", "quick_gelu", "relu"])
-def test_gemm_epilogue_bias_act_pre(ops, act):
-    M, N, K = 200, 264, 136
+def test_gemm_epilogue_bias_act_pre(ops, act, M):
+    N, K = 264, 136
     a, b, bias = rnd(M, K, seed=3), rnd(N, K, seed=4, scale=0.2), rnd(N, seed=5)
     z = a.float() @ b.float().t() + bias.float()
-    pre = torch.empty(M, N, dtype=bf16, device="cuda")
-    got = ops.gemm(a.cuda(), b.cuda(), bias=bias.cuda(), act=act, pre=pre)
-    close(pre, z, name="pre")
-    close(got, act_ref(act, z), name=f"act {act}")
+    for variant in (["v1"] if M < 256 else ["v1", "dma128", "pp256", "pp128"]):
+        pre = torch.empty(M, N, dtype=bf16, device="cuda")
+        got = ops.gemm(a.cuda(), b.cuda(), bias=bias.cuda(), act=act, pre=pre, variant=variant)
+        close(pre, z, name="pre")
+        close(got, act_ref(act, z), name=f"act {act} [{variant}]")
 
 
-def test_gemm_epilogue_gate_res_dact_accum(ops):
-    M, N, K = 136, 200, 264
+@pytest.mark.parametrize("M", [136, 1160])
+def test_gemm_epilogue_gate_res_dact_accum(ops, M):
+    N, K = 200, 264
     a, b = rnd(M, K, seed=6), rnd(N, K, seed=7, scale=0.2)
     res, aux = rnd(M, N, seed=8), rnd(M, N, seed=9)
     gate = torch.tensor([0.7]).to(bf16)
@@ -106,9 +130,10 @@ def test_gemm_epilogue_gate_res_dact_accum(ops):
     close(acc, 0.5 * z + 3.0, rel=1e-5, name="accumulate f32")
 
 
-def test_gemm_padded_vocab_like(ops):
+@pytest.mark.parametrize("M", [96, 1024])
+def test_gemm_padded_vocab_like(ops, M):
     """lm-head shape class: N odd (74053-like), padded ldc; dX/dW read the padded dlogits."""
-    M, V, H = 96, 1005, 128
+    V, H = 1005, 128
     ldv = 1008
     h, w = rnd(M, H, seed=10), rnd(V, H, seed=11, scale=0.3)
     logits = ops.gemm(h.cuda(), w.cuda(), ldc=ldv)

@@ -34,9 +34,20 @@ __device__ __forceinline__ float wave_max(float v) {
 // ---- activations (fp32 math) -------------------------------------------------------------
 enum { ACT_NONE = 0, ACT_GELU = 1, ACT_QUICKGELU = 2, ACT_RELU = 3, ACT_SILU = 4 };
 
+// erf-GELU with ONE exponential: Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below bf16 resolution);
+// e = exp(-x^2/2) serves both erf(x/sqrt2) and the Gaussian density of the derivative.
+__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& e) {
+  float z = fabsf(x) * 0.70710678118654752f;
+  float t = __frcp_rn(1.0f + 0.3275911f * z);
+  e = __expf(-z * z);
+  float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  float erf_abs = 1.0f - poly * e;
+  cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
+}
+
 __device__ __forceinline__ float act_fwd(int act, float x) {
   switch (act) {
-    case ACT_GELU: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+    case ACT_GELU: { float cdf, e; gelu_parts(x, cdf, e); return x * cdf; }
     case ACT_QUICKGELU: return x / (1.0f + __expf(-1.702f * x));
     case ACT_RELU: return x > 0.f ? x : 0.f;
     case ACT_SILU: return x / (1.0f + __expf(-x));
@@ -45,10 +56,7 @@ __device__ __forceinline__ float act_fwd(int act, float x) {
 }
 __device__ __forceinline__ float act_bwd(int act, float x) {   // d act(x) / dx
   switch (act) {
-    case ACT_GELU: {
-      float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-      return cdf + x * 0.3989422804014327f * __expf(-0.5f * x * x);
-    }
+    case ACT_GELU: { float cdf, e; gelu_parts(x, cdf, e); return cdf + x * 0.3989422804014327f * e; }
     case ACT_QUICKGELU: {
       float s = 1.0f / (1.0f + __expf(-1.702f * x));
       return s * (1.0f + 1.702f * x * (1.0f - s));

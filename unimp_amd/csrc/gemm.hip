@@ -16,6 +16,7 @@
 // conflict-free (see common.h).  The MFMA is issued with the operands swapped (D = B_frag x A_frag)
 // so each lane ends up with 4 CONSECUTIVE n of one m: 8-byte bf16 / 16-byte f32 epilogue accesses.
 // Block ids are remapped XCD-contiguously and then swept in GROUP_M-row groups for L2 reuse.
+#include <stdlib.h>
 #include "common.h"
 #include "unimp_hip.h"
 
@@ -210,6 +211,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
 #undef EPI_TILE
 }
 
+extern "C" int unimp_gemm2_launch(const unimp_gemm_desc* d, int bn, void* stream);   // gemm2.hip: 256-row tiles, LDS-DMA, 2-stage
+extern "C" int unimp_gemm3_launch(const unimp_gemm_desc* d, int bn, void* stream);   // gemm3.hip: 256-row tiles, LDS-DMA, ping-pong
+
 static int check_operand(const void* p, long ld, int ks, int rows) {
   if (((uintptr_t)p & 15) != 0) return UNIMP_ERR_ALIGN;
   if ((ld & 7) != 0) return UNIMP_ERR_ALIGN;
@@ -217,7 +221,7 @@ static int check_operand(const void* p, long ld, int ks, int rows) {
   return 0;
 }
 
-extern "C" int unimp_gemm_bf16(const unimp_gemm_desc* d, void* stream) {
+static int validate(const unimp_gemm_desc* d) {
   if (!d || !d->A || !d->B || !d->C) return unimp_set_error(UNIMP_ERR_ARG, "gemm: null pointer");
   if (d->M <= 0 || d->N <= 0 || d->K <= 0) return unimp_set_error(UNIMP_ERR_SHAPE, "gemm: empty shape");
   int e;
@@ -225,6 +229,10 @@ extern "C" int unimp_gemm_bf16(const unimp_gemm_desc* d, void* stream) {
     return unimp_set_error(e, "gemm: operand base must be 16-B aligned, ld %% 8 == 0, k-strided ld >= roundup8(rows)");
   if (!d->a_kstrided && d->lda < ((d->K + 7) & ~7)) return unimp_set_error(UNIMP_ERR_SHAPE, "gemm: lda < roundup8(K)");
   if (!d->b_kstrided && d->ldb < ((d->K + 7) & ~7)) return unimp_set_error(UNIMP_ERR_SHAPE, "gemm: ldb < roundup8(K)");
+  return 0;
+}
+
+static void launch_v1(const unimp_gemm_desc* d, void* stream) {
   GemmParams p;
   p.A = (const bf16*)d->A; p.B = (const bf16*)d->B; p.C = d->C;
   p.M = d->M; p.N = d->N; p.K = d->K; p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;
@@ -240,5 +248,34 @@ extern "C" int unimp_gemm_bf16(const unimp_gemm_desc* d, void* stream) {
   else if (!d->a_kstrided && d->b_kstrided) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, lds, s, p);
   else if (d->a_kstrided && d->b_kstrided) hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, lds, s, p);
   else hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, lds, s, p);
+}
+
+// default choice when the caller does not autotune: the ping-pong kernel once there are enough rows for 256-row tiles,
+// tile width by round quantisation over the 256 CUs; the 128x128 kernel otherwise.
+static int auto_variant(const unimp_gemm_desc* d) {
+  if (d->M < 1024 || d->N < 128 || d->K < 128) return UNIMP_GEMM_V1;
+  long nbm = (d->M + 255) / 256;
+  long t256 = nbm * ((d->N + 255) / 256), t128 = nbm * ((d->N + 127) / 128);
+  auto eff = [](long tiles) { long rounds = (tiles + 255) / 256; return (double)tiles / (double)(rounds * 256); };
+  bool wide = d->N >= 256 && eff(t256) >= eff(t128) * 0.88;
+  return wide ? UNIMP_GEMM_PP256 : UNIMP_GEMM_PP128;
+}
+
+extern "C" int unimp_gemm_bf16_variant(const unimp_gemm_desc* d, int variant, void* stream) {
+  int e = validate(d);
+  if (e) return e;
+  if (variant == UNIMP_GEMM_AUTO) variant = auto_variant(d);
+  switch (variant) {
+    case UNIMP_GEMM_V1: launch_v1(d, stream); break;
+    case UNIMP_GEMM_DMA256: unimp_gemm2_launch(d, 256, stream); break;
+    case UNIMP_GEMM_DMA128: unimp_gemm2_launch(d, 128, stream); break;
+    case UNIMP_GEMM_PP256: unimp_gemm3_launch(d, 256, stream); break;
+    case UNIMP_GEMM_PP128: unimp_gemm3_launch(d, 128, stream); break;
+    default: return unimp_set_error(UNIMP_ERR_ARG, "gemm: unknown variant");
+  }
   return unimp_check_launch("gemm");
+}
+
+extern "C" int unimp_gemm_bf16(const unimp_gemm_desc* d, void* stream) {
+  return unimp_gemm_bf16_variant(d, UNIMP_GEMM_AUTO, stream);
 }

@@ -1,0 +1,248 @@
+// Ping-pong bf16 MFMA GEMM for gfx950: 256 x BN tiles (BN = 256 / 128), 512 threads = 8 waves, one workgroup per CU.
+//
+// The two waves that share a SIMD (wave w and w+4) run the same program ONE PHASE APART, so the matrix pipe always has
+// a wave issuing MFMAs while its partner does the memory-side work (MI355X_MICROARCH "Two waves per SIMD", item 9 and
+// the 8-phase idea of the cdna guide §5): K is consumed in half-steps of 32, each half-step being
+//     L phase: issue the LDS-DMA of half-step h+3, ds_read the fragments of half-step h+1, wait for them, s_barrier
+//     C phase: 8 x NJ MFMAs on the fragments of half-step h (register set R[h&1]),                       s_barrier
+// Group A (waves 0-3) is in its C phase while group B (waves 4-7) is in its L phase and vice versa (B passes one
+// extra barrier up front, A one at the end).  Raw s_barrier + counted s_waitcnt vmcnt keep 1-2 DMA half-stages in
+// flight across barriers (a __syncthreads() would drain them).
+//
+// LDS: ring of 4 half-stages (A [256][32] + B [BN][32] bf16 = 32 / 24 KiB each).  Hazards, with A's phases at intervals
+// 2h (L) / 2h+1 (C) and B's at 2h+1 / 2h+2:
+//   * DMA(h+3) overwrites the buffer of half-step h-1: its last readers ran L(h-2) (intervals 2h-4 / 2h-3) and every
+//     L phase ends with lgkmcnt(0) + barrier, so all reads are complete before interval 2h.
+//   * half-step h+1 is read in L(h): its DMA was issued in L(h-2) and each wave waits for it (vmcnt(newest only)) at the
+//     end of L(h-1), i.e. before the barriers that precede both groups' L(h).
+// Images: k-contiguous operands as [rows][32] with 64-B rows, 16-B chunk XOR ((row>>3)&1)*3 (conflict-free
+// ds_read_b128); k-strided operands as [32][rows] read by ds_read_b64_tr_b16 (granule swizzle of common.h).  The DMA
+// destination is lane-linear, so both swizzles are applied to the per-lane SOURCE address; out-of-range chunks come
+// from a zero constant (no predication).  Epilogue: gemm_tile.h (through LDS, 16-byte row-major accesses).
+#include "gemm_tile.h"
+
+#define G3_BM 256
+
+__device__ __forceinline__ int kc32_off(int row, int chunk) { return row * 64 + ((chunk ^ (((row >> 3) & 1) * 3)) << 4); }
+
+__device__ __forceinline__ bf16x8 frag_kc32(const char* tile, int r0) {
+  int l = lane_id();
+  return *(const bf16x8*)(tile + kc32_off(r0 + (l & 15), l >> 4));
+}
+template <int ROWS>
+__device__ __forceinline__ int ks32_off(int krow, int col) {
+  return krow * (ROWS * 2) + ((((col >> 4) ^ ks_h(krow)) << 5) | ((col & 15) << 1));
+}
+// Transposed fragment of a k-strided image, issued as INLINE ASM: with the builtin, hipcc puts `s_waitcnt vmcnt(0)` in
+// front of every ds_read_b64_tr_b16 while an LDS-DMA is in flight (it cannot tell the DMA's LDS destination from the
+// read), which drains the prefetch ring every half-step.  The two 64-bit halves stay separate values until the C phase
+// (after the explicit lgkmcnt(0) + barrier of G3_BARRIER), so the compiler never touches the destination registers
+// before the data has landed (cdna guide §5.7 item 1, form iii).
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+template <int ROWS>
+__device__ __forceinline__ void frag_ks32_asm(const char* tile, int r0, s16x4& lo, s16x4& hi) {
+  int l = lane_id();
+  int g = l >> 4, q = (l >> 2) & 3, p = l & 3;
+  int kr = g * 8 + q, col = r0 + 4 * p;
+  uint32_t addr = (uint32_t)(uintptr_t)LDS_PTR(char, tile + ks32_off<ROWS>(kr, col));
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(addr) : "memory");
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "n"(4 * ROWS * 2) : "memory");
+}
+__device__ __forceinline__ bf16x8 join_halves(s16x4 lo, s16x4 hi) {
+  s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// LDS-DMA of one operand's [ROWS x 32] half-stage: ROWS/128 wave-instructions per wave.
+// dma_setup() computes, once, each lane's byte offset of its chunk at half-step 0.  Rows / columns beyond the matrix are
+// CLAMPED to the last valid chunk instead of predicated: they only feed output rows / columns that are never stored, so
+// the steady-state issue is  `scalar base of the half-step + per-lane constant`  with no VALU work and no branches.
+// Only a ragged K tail (K % 32 != 0) takes the predicated path, where chunks with k >= K must read as zeros.
+template <bool KS, int ROWS>
+__device__ __forceinline__ void dma_setup(long ld, int r0, int R, int wave, uint32_t (&off)[ROWS / 128]) {
+  constexpr int NI = ROWS / 128;
+  int l = lane_id();
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    int slot0 = (wave * NI + i) * 64;
+    if (!KS) {
+      int row = (slot0 >> 2) + (l >> 2), s = l & 3;
+      int c = s ^ (((row >> 3) & 1) * 3);
+      int gr = min(r0 + row, R - 1);
+      off[i] = (uint32_t)(((long)gr * ld + c * 8) * 2);
+    } else {
+      constexpr int SPR = ROWS / 8;
+      int krow = (slot0 + l) / SPR, s = (slot0 + l) % SPR;
+      int col = (((s >> 1) ^ ks_h(krow)) << 4) | ((s & 1) << 3);
+      int gr = min(r0 + col, ((R + 7) & ~7) - 8);
+      off[i] = (uint32_t)(((long)krow * ld + gr) * 2);
+    }
+  }
+}
+template <bool KS, int ROWS>
+__device__ __forceinline__ void dma_issue(const bf16* __restrict__ X, long ld, int h, int K, char* img, int wave,
+                                          const uint32_t (&off)[ROWS / 128]) {
+  constexpr int NI = ROWS / 128;
+  const char* ub = (const char*)X + (KS ? (long)h * 32 * ld * 2 : (long)h * 64);       // wave-uniform
+  if (h * 32 + 32 <= K) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) glds16(ub + off[i], img + (wave * NI + i) * 1024);
+  } else {                                                                                // ragged K tail
+    int l = lane_id();
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      int slot0 = (wave * NI + i) * 64;
+      int gk;
+      if (!KS) { int row = (slot0 >> 2) + (l >> 2); gk = h * 32 + (((l & 3) ^ (((row >> 3) & 1) * 3)) << 3); }
+      else gk = h * 32 + (slot0 + l) / (ROWS / 8);
+      const char* src = gk < K ? ub + off[i] : (const char*)g_zero16;
+      glds16(src, img + slot0 * 16);
+    }
+  }
+}
+
+#ifdef G3_NO_PRIO
+#define G3_PRIO(x) do {} while (0)
+#else
+#define G3_PRIO(x) __builtin_amdgcn_s_setprio(x)
+#endif
+#define G3_FENCE() do { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); } while (0)
+#define G3_BARRIER() do { G3_FENCE(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); G3_FENCE(); } while (0)
+
+template <bool AKS, bool BKS, int BN>
+__global__ __launch_bounds__(512, 2) void gemm3_bf16_kernel(Gemm2Params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NJ = BN / 64, WN = BN / 4;
+  constexpr int A_SUB = G3_BM * 64, B_SUB = BN * 64, SUB = A_SUB + B_SUB;
+  constexpr int NEW = G3_BM / 128 + BN / 128;          // LDS-DMA instructions a wave issues per half-step
+
+  int nwg = p.nbm * p.nbn;
+  int id = xcd_remap(blockIdx.x, nwg);
+  constexpr int GM = 4;
+  int per_group = GM * p.nbn;
+  int grp_ = id / per_group;
+  int first_m = grp_ * GM;
+  int gsz = min(p.nbm - first_m, GM);
+  int in_g = id - grp_ * per_group;
+  int tm = first_m + in_g % gsz, tn = in_g / gsz;
+  int m0 = tm * G3_BM, n0 = tn * BN;
+
+  int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
+  int wm = wave >> 2, wn = wave & 3;                    // wm doubles as the ping-pong group
+
+  f32x4 acc[8][NJ];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 ra0[8], rb0[NJ], ra1[8], rb1[NJ];                  // k-contiguous operands: whole fragments
+  s16x4 la0[8], ha0[8], lb0[NJ], hb0[NJ], la1[8], ha1[8], lb1[NJ], hb1[NJ];   // k-strided operands: two tr halves
+
+  int nh = (p.K + 31) >> 5;
+
+  uint32_t aoff[G3_BM / 128], boff[BN / 128];
+  dma_setup<AKS, G3_BM>(p.lda, m0, p.M, wave, aoff);
+  dma_setup<BKS, BN>(p.ldb, n0, p.N, wave, boff);
+#define DMA(H) do { char* b_ = smem + ((H) & 3) * SUB;                                                             \
+    dma_issue<AKS, G3_BM>(p.A, p.lda, (H), p.K, b_, wave, aoff);                                                   \
+    dma_issue<BKS, BN>(p.B, p.ldb, (H), p.K, b_ + A_SUB, wave, boff); } while (0)
+#define LOADF(S, H) do { const char* b_ = smem + ((H) & 3) * SUB;                                                  \
+    _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                               \
+      if (BKS) frag_ks32_asm<BN>(b_ + A_SUB, wn * WN + j * 16, lb##S[j], hb##S[j]);                                \
+      else rb##S[j] = frag_kc32(b_ + A_SUB, wn * WN + j * 16); }                                                   \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                \
+      if (AKS) frag_ks32_asm<G3_BM>(b_, wm * 128 + i * 16, la##S[i], ha##S[i]);                                    \
+      else ra##S[i] = frag_kc32(b_, wm * 128 + i * 16); } } while (0)
+#define MFMAS(S) do { G3_PRIO(1);                                                                                  \
+    bf16x8 fb_[NJ];                                                                                                \
+    _Pragma("unroll") for (int j = 0; j < NJ; ++j) fb_[j] = BKS ? join_halves(lb##S[j], hb##S[j]) : rb##S[j];      \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                \
+      bf16x8 fa_ = AKS ? join_halves(la##S[i], ha##S[i]) : ra##S[i];                                               \
+      _Pragma("unroll") for (int j = 0; j < NJ; ++j) acc[i][j] = MFMA16(fb_[j], fa_, acc[i][j]); }                 \
+    G3_PRIO(0); } while (0)
+// one half-step: L phase (prefetch h+3, fragments of h+1 -> RN), barrier, C phase (MFMA on RC), barrier
+#define HALF_STEP(H, SC, SN) do {                                                                                  \
+    if ((H) + 3 < nh) DMA((H) + 3);                                                                                \
+    if ((H) + 1 < nh) LOADF(SN, (H) + 1);                                                                          \
+    if ((H) + 3 < nh) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NEW) : "memory");                                  \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                          \
+    G3_BARRIER();                                                                                                  \
+    MFMAS(SC);                                                                                                     \
+    G3_BARRIER(); } while (0)
+
+  DMA(0);
+  if (nh > 1) DMA(1);
+  if (nh > 2) DMA(2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  G3_BARRIER();
+  LOADF(0, 0);
+  if (wm == 1) G3_BARRIER();                            // group B runs one phase behind group A
+  for (int h = 0; h < nh; h += 2) {
+    HALF_STEP(h, 0, 1);
+    if (h + 1 < nh) HALF_STEP(h + 1, 1, 0);
+  }
+  if (wm == 0) G3_BARRIER();                            // equalise the barrier count; all LDS reads are complete
+#undef DMA
+#undef LOADF
+#undef MFMAS
+#undef HALF_STEP
+
+  // ---- epilogue through LDS (see gemm2.hip): wave-private [64][WN] f32 region, 16-B units XOR-swizzled by row
+  constexpr int ESTR = WN * 4, UNITS = WN / 4;
+  char* er = smem + wave * (64 * ESTR);
+  float gate = 1.f;
+  if (p.gate) gate = tanhf(bf2f(*p.gate));
+  bool fast = ((p.N & 7) == 0) && (((p.ldc | p.ldres | p.ldaux | p.ldpre) & 7) == 0);
+  constexpr int LPR = WN / 8, RPI = 64 / LPR;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+    for (int i2 = 0; i2 < 4; ++i2)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        int row = i2 * 16 + (lane & 15), u = j * 4 + (lane >> 4);
+        *(f32x4*)(er + row * ESTR + ((u ^ (row & (UNITS - 1))) << 4)) = acc[pass * 4 + i2][j];
+      }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    for (int it = 0; it < 64 / RPI; ++it) {
+      int row = it * RPI + lane / LPR, cg = lane % LPR;
+      int m = m0 + wm * 128 + pass * 64 + row, n = n0 + wn * WN + cg * 8;
+      int sw = row & (UNITS - 1);
+      f32x4 x0 = *(const f32x4*)(er + row * ESTR + (((2 * cg) ^ sw) << 4));
+      f32x4 x1 = *(const f32x4*)(er + row * ESTR + (((2 * cg + 1) ^ sw) << 4));
+      if (m < p.M && n < p.N) {
+        float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+        if (fast) epi8<true>(p, v, m, n, gate); else epi8<false>(p, v, m, n, gate);
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+  }
+}
+
+template <bool AKS, bool BKS, int BN>
+static void launch3(const Gemm2Params& p, hipStream_t s) {
+  static bool attr_set = false;
+  constexpr size_t lds = 4 * (G3_BM * 64 + BN * 64);
+  auto kern = gemm3_bf16_kernel<AKS, BKS, BN>;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+  hipLaunchKernelGGL(kern, dim3(p.nbm * p.nbn), dim3(512), lds, s, p);
+}
+
+// variant: 256 or 128 = tile width.  Returns 1 if launched.
+extern "C" int unimp_gemm3_launch(const unimp_gemm_desc* d, int bn, void* stream) {
+  Gemm2Params p;
+  p.A = (const bf16*)d->A; p.B = (const bf16*)d->B; p.C = d->C;
+  p.M = d->M; p.N = d->N; p.K = d->K; p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;
+  p.bias = (const bf16*)d->bias; p.res = (const bf16*)d->res; p.ldres = d->ldres;
+  p.aux = (const bf16*)d->aux; p.ldaux = d->ldaux; p.pre = (bf16*)d->pre; p.ldpre = d->ldpre;
+  p.gate = (const bf16*)d->gate; p.alpha = d->alpha; p.act = d->act; p.dact = d->dact;
+  p.out_f32 = d->out_f32; p.accumulate = d->accumulate;
+  p.nbm = (d->M + G3_BM - 1) / G3_BM;
+  p.nbn = (d->N + bn - 1) / bn;
+  hipStream_t s = (hipStream_t)stream;
+  int a = d->a_kstrided, b = d->b_kstrided;
+#define L3(AK, BK_) do { if (bn == 256) launch3<AK, BK_, 256>(p, s); else launch3<AK, BK_, 128>(p, s); } while (0)
+  if (!a && !b) L3(false, false); else if (!a && b) L3(false, true); else if (a && b) L3(true, true); else L3(true, false);
+#undef L3
+  return 1;
+}

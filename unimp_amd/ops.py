@@ -14,6 +14,50 @@ bf16 = torch.bfloat16
 
 
 GEMM_PROFILE = None      # bench.py sets this to a list: (start_event, end_event, flops) per GEMM launch
+GEMM_AUTOTUNE = True     # time the kernel variants once per (M, N, K, layout) on scratch operands and keep the fastest
+GEMM_VARIANTS = {"auto": 0, "v1": 1, "dma256": 2, "dma128": 3, "pp256": 4, "pp128": 5}
+_GEMM_CHOICE = {}
+
+
+def _launch_gemm(d, variant):
+    check(_lib.lib().unimp_gemm_bf16_variant(C.byref(d), variant, _stream()), "gemm")
+
+
+def _tune_gemm(M, N, K, a_ks, b_ks, device):
+    """pick the fastest variant for this problem class (plain GEMM on scratch data; the choice is reused for every
+    epilogue flavour of the same shape).  Runs once per key, outside graph capture."""
+    key = (M, N, K, a_ks, b_ks)
+    v = _GEMM_CHOICE.get(key)
+    if v is not None:
+        return v
+    if not GEMM_AUTOTUNE or torch.cuda.is_current_stream_capturing():
+        return 0
+    cands = [1] if (M < 512 or N < 128 or K < 128) else [1, 4, 5, 2, 3]
+    if len(cands) == 1:
+        _GEMM_CHOICE[key] = cands[0]
+        return cands[0]
+    r8 = lambda n: (n + 7) // 8 * 8
+    a = torch.randn((K, r8(M)) if a_ks else (M, r8(K)), device=device, dtype=torch.float32).to(bf16)
+    b = torch.randn((K, r8(N)) if b_ks else (N, r8(K)), device=device, dtype=torch.float32).to(bf16)
+    ldc = r8(N)
+    c = torch.empty((M, ldc), dtype=bf16, device=device)
+    d = GemmDesc()
+    d.A, d.B, d.C, d.M, d.N, d.K = a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K
+    d.lda, d.ldb, d.ldc, d.a_kstrided, d.b_kstrided, d.alpha = a.stride(0), b.stride(0), ldc, int(a_ks), int(b_ks), 1.0
+    best, best_t = 0, float("inf")
+    for v in cands:
+        _launch_gemm(d, v)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            _launch_gemm(d, v)
+        e1.record()
+        e1.synchronize()
+        t = e0.elapsed_time(e1)
+        if t < best_t:
+            best, best_t = v, t
+    _GEMM_CHOICE[key] = best
+    return best
 
 
 def _stream():
@@ -39,7 +83,7 @@ def _mat(t):
 
 
 def gemm(a, b, *, a_ks=False, b_ks=False, bias=None, act=None, res=None, aux=None, dact=None, pre=None,
-         gate=None, alpha=1.0, out=None, out_f32=False, accumulate=False, ldc=None):
+         gate=None, alpha=1.0, out=None, out_f32=False, accumulate=False, ldc=None, variant=None):
     """C[M,N] = epi(alpha * A B^T).  a: [M,K] (or [K,M] if a_ks); b: [N,K] (or [K,N] if b_ks)."""
     a, lda = _mat(a)
     b, ldb = _mat(b)
@@ -73,14 +117,16 @@ def gemm(a, b, *, a_ks=False, b_ks=False, bias=None, act=None, res=None, aux=Non
     d.alpha = alpha
     d.act, d.dact = ACT[act], ACT[dact]
     d.out_f32, d.accumulate = int(out.dtype == torch.float32), int(accumulate)
+    v = GEMM_VARIANTS[variant] if isinstance(variant, str) else (variant if variant is not None else
+                                                                  _tune_gemm(M, N, K, bool(a_ks), bool(b_ks), a.device))
     if GEMM_PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        check(_lib.lib().unimp_gemm_bf16(C.byref(d), _stream()), "gemm")
+        _launch_gemm(d, v)
         e1.record()
-        GEMM_PROFILE.append((e0, e1, 2.0 * M * N * K))
+        GEMM_PROFILE.append((e0, e1, 2.0 * M * N * K, (M, N, K, int(a_ks), int(b_ks), v)))
         return out
-    check(_lib.lib().unimp_gemm_bf16(C.byref(d), _stream()), "gemm")
+    _launch_gemm(d, v)
     return out
 
 
