@@ -63,6 +63,10 @@ int unimp_gemm_bf16(const unimp_gemm_desc* d, void* stream);
 enum { UNIMP_GEMM_AUTO = 0, UNIMP_GEMM_V1 = 1, UNIMP_GEMM_DMA256 = 2, UNIMP_GEMM_DMA128 = 3, UNIMP_GEMM_PP256 = 4,
        UNIMP_GEMM_PP128 = 5 };
 int unimp_gemm_bf16_variant(const unimp_gemm_desc* d, int variant, void* stream);
+/* split-K form for outputs much smaller than the chip (weight gradients of narrow projections): `splits` K slices into
+ * f32 slabs [splits][M][N] (caller-provided workspace), then an ordered reduction applying alpha*tanh(gate).  Only the
+ * alpha / gate epilogue is allowed. */
+int unimp_gemm_bf16_splitk(const unimp_gemm_desc* d, int splits, float* slabs, void* stream);
 
 /* ---- LayerNorm / RMSNorm ---------------------------------------------------------------------------------
  * replaces nn.LayerNorm (clip.py:164-166,423; gpt_neox input/post_attention/final LN; open_flamingo norms)

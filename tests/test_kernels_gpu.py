@@ -148,6 +148,19 @@ def test_gemm_padded_vocab_like(ops, M):
     close(dw, dl[:, :V].float().t() @ h.float(), name="head dW")
 
 
+@pytest.mark.parametrize("M,N,K,gate", [(512, 1024, 4096, False), (256, 264, 8192 + 72, True), (1024, 512, 2048, False)])
+def test_gemm_splitk_weight_grad(ops, M, N, K, gate):
+    """dW-shaped problem (both operands k-strided, tiny output, deep K): the split-K path is picked automatically."""
+    dy, x = rnd(K, M, seed=1, scale=0.1), rnd(K, N, seed=2)
+    g = torch.tensor([0.4]).to(bf16) if gate else None
+    want = dy.float().t() @ x.float() * (math.tanh(0.4) if gate else 1.0)
+    got = ops.gemm(dy.cuda(), x.cuda(), a_ks=True, b_ks=True, gate=g.cuda() if gate else None)
+    close(got, want, name="splitk dW")
+    ref = ops.gemm(dy.cuda(), x.cuda(), a_ks=True, b_ks=True, gate=g.cuda() if gate else None, variant="v1")
+    close(ref, want, name="v1 dW")
+    assert torch.equal(got, ops.gemm(dy.cuda(), x.cuda(), a_ks=True, b_ks=True, gate=g.cuda() if gate else None))   # reproducible
+
+
 def test_gemm_rejects_bad_args(ops):
     from unimp_amd._lib import UnimpHipError
     a = rnd(16, 12).cuda()      # K = 12: ld not a multiple of 8

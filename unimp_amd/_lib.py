@@ -35,6 +35,7 @@ class AttnDesc(C.Structure):
 _SIGS = {
     "unimp_gemm_bf16": [C.POINTER(GemmDesc), c_p],
     "unimp_gemm_bf16_variant": [C.POINTER(GemmDesc), c_i, c_p],
+    "unimp_gemm_bf16_splitk": [C.POINTER(GemmDesc), c_i, c_p, c_p],
     "unimp_layernorm_fwd": [c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_p, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_p],
     "unimp_layernorm_bwd": [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_i,
                             c_i, c_i, c_i, c_i, c_i, c_i, c_p],

@@ -32,6 +32,7 @@ struct GemmParams {
   float alpha;
   int act, dact, out_f32, accumulate;
   int nbm, nbn;
+  int ksplit;                       // > 0: blockIdx.y handles k in [y*ksplit, (y+1)*ksplit) and writes f32 slab y of C
 };
 
 #define BM 128
@@ -151,6 +152,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
   int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   int wm = wave >> 1, wn = wave & 1;
 
+  if (p.ksplit > 0) {               // split-K: this block reduces one K slice into its own f32 slab (summed by splitk_reduce)
+    int k_off = blockIdx.y * p.ksplit;
+    p.A += AKS ? (long)k_off * p.lda : (long)k_off;
+    p.B += BKS ? (long)k_off * p.ldb : (long)k_off;
+    p.K = min(p.K - k_off, p.ksplit);
+    p.C = (float*)p.C + (long)blockIdx.y * p.M * p.ldc;
+  }
+
   f32x4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -232,7 +241,7 @@ static int validate(const unimp_gemm_desc* d) {
   return 0;
 }
 
-static void launch_v1(const unimp_gemm_desc* d, void* stream) {
+static void launch_v1(const unimp_gemm_desc* d, void* stream, int splits = 1, float* slabs = nullptr) {
   GemmParams p;
   p.A = (const bf16*)d->A; p.B = (const bf16*)d->B; p.C = d->C;
   p.M = d->M; p.N = d->N; p.K = d->K; p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;
@@ -241,7 +250,13 @@ static void launch_v1(const unimp_gemm_desc* d, void* stream) {
   p.gate = (const bf16*)d->gate; p.alpha = d->alpha; p.act = d->act; p.dact = d->dact;
   p.out_f32 = d->out_f32; p.accumulate = d->accumulate;
   p.nbm = (d->M + BM - 1) / BM; p.nbn = (d->N + BN - 1) / BN;
-  dim3 grid(p.nbm * p.nbn), block(256);
+  p.ksplit = 0;
+  if (splits > 1) {
+    p.ksplit = ((d->K + splits - 1) / splits + 63) & ~63;
+    p.C = slabs; p.ldc = d->N; p.out_f32 = 1; p.accumulate = 0; p.alpha = 1.f;
+    p.bias = nullptr; p.res = nullptr; p.aux = nullptr; p.pre = nullptr; p.gate = nullptr; p.act = 0; p.dact = 0;
+  }
+  dim3 grid(p.nbm * p.nbn, splits > 1 ? (d->K + p.ksplit - 1) / p.ksplit : 1), block(256);
   size_t lds = 2 * STAGE_BYTES;
   hipStream_t s = (hipStream_t)stream;
   if (!d->a_kstrided && !d->b_kstrided) hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, lds, s, p);
@@ -274,6 +289,37 @@ extern "C" int unimp_gemm_bf16_variant(const unimp_gemm_desc* d, int variant, vo
     default: return unimp_set_error(UNIMP_ERR_ARG, "gemm: unknown variant");
   }
   return unimp_check_launch("gemm");
+}
+
+// ---- split-K for weight-gradient GEMMs whose output is far smaller than the chip (e.g. dW of a 512 x 2560 projection
+// with K = all tokens): K slices -> f32 slabs [S][M][N] (plain stores), then one ordered reduction pass (reproducible,
+// no atomics) that applies alpha * tanh(gate) and writes bf16 / f32.
+__global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int S, long MN, int N, void* __restrict__ C, long ldc,
+                                     int out_f32, float alpha, const bf16* __restrict__ gate) {
+  long i4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i4 >= MN) return;
+  float g = alpha * (gate ? tanhf(bf2f(*gate)) : 1.f);
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < S; ++s) a += *(const f32x4*)(slabs + (long)s * MN + i4);
+  long m = i4 / N; int n = (int)(i4 - m * N);
+  if (out_f32) { *(f32x4*)((float*)C + m * ldc + n) = a * g; }
+  else { bf16x4 o = {f2bf(a[0] * g), f2bf(a[1] * g), f2bf(a[2] * g), f2bf(a[3] * g)}; *(bf16x4*)((bf16*)C + m * ldc + n) = o; }
+}
+
+extern "C" int unimp_gemm_bf16_splitk(const unimp_gemm_desc* d, int splits, float* slabs, void* stream) {
+  int e = validate(d);
+  if (e) return e;
+  if (splits < 2 || !slabs) return unimp_set_error(UNIMP_ERR_ARG, "gemm_splitk: need splits >= 2 and a slab workspace");
+  if (d->bias || d->res || d->aux || d->pre || d->act || d->dact || d->accumulate)
+    return unimp_set_error(UNIMP_ERR_UNSUPPORTED, "gemm_splitk: only alpha / gate epilogues");
+  if ((d->N & 3) || (d->ldc & 3)) return unimp_set_error(UNIMP_ERR_SHAPE, "gemm_splitk: N and ldc must be multiples of 4");
+  launch_v1(d, stream, splits, slabs);
+  int ks = ((d->K + splits - 1) / splits + 63) & ~63;
+  int S = (d->K + ks - 1) / ks;
+  long MN = (long)d->M * d->N;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((MN / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, slabs, S, MN, d->N,
+                     d->C, (long)d->ldc, d->out_f32, d->alpha, (const bf16*)d->gate);
+  return unimp_check_launch("gemm_splitk");
 }
 
 extern "C" int unimp_gemm_bf16(const unimp_gemm_desc* d, void* stream) {

@@ -117,6 +117,20 @@ def gemm(a, b, *, a_ks=False, b_ks=False, bias=None, act=None, res=None, aux=Non
     d.alpha = alpha
     d.act, d.dact = ACT[act], ACT[dact]
     d.out_f32, d.accumulate = int(out.dtype == torch.float32), int(accumulate)
+    plain = bias is None and res is None and aux is None and pre is None and act is None and dact is None and not accumulate
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    if variant is None and plain and tiles <= 96 and K >= 2048 and N % 4 == 0 and out.stride(0) % 4 == 0:
+        # weight gradient of a narrow projection: far fewer tiles than CUs, very deep K -> split-K over the chip
+        splits = max(2, min(32, 320 // tiles, K // 512))
+        slabs = torch.empty((splits, M, N), dtype=torch.float32, device=a.device)
+        if GEMM_PROFILE is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        check(_lib.lib().unimp_gemm_bf16_splitk(C.byref(d), splits, slabs.data_ptr(), _stream()), "gemm_splitk")
+        if GEMM_PROFILE is not None:
+            e1.record()
+            GEMM_PROFILE.append((e0, e1, 2.0 * M * N * K, (M, N, K, int(a_ks), int(b_ks), -splits)))
+        return out
     v = GEMM_VARIANTS[variant] if isinstance(variant, str) else (variant if variant is not None else
                                                                   _tune_gemm(M, N, K, bool(a_ks), bool(b_ks), a.device))
     if GEMM_PROFILE is not None:
