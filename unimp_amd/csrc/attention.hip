@@ -19,6 +19,7 @@
 
 #define LOG2E 1.4426950408889634f
 #define LN2 0.6931471805599453f
+#define EXP2(x) __builtin_amdgcn_exp2f(x)
 
 struct AttnP {
   const bf16* q; const bf16* k; const bf16* v; bf16* o; float* lse;
@@ -137,25 +138,34 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
       for (int ks = 0; ks < NKS; ++ks) s[nt] = MFMA16(lfrag_kc<KSTR>(ks_t, nt * 16, ks), qf[ks], s[nt]);
     }
     float mloc = -INFINITY;
+    // wave-uniform fast path: every key of this tile is visible to every row of the wave (interior tiles)
+    bool full = __all(kt * 64 >= lo && kt * 64 + 64 <= hi);
+    if (full) {
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+      for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int key = kt * 64 + nt * 16 + g * 4 + r;
-        float v = (key >= lo && key < hi) ? s[nt][r] * sc2 : -INFINITY;
-        s[nt][r] = v;
-        mloc = fmaxf(mloc, v);
-      }
+        for (int r = 0; r < 4; ++r) { float v = s[nt][r] * sc2; s[nt][r] = v; mloc = fmaxf(mloc, v); }
+    } else {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int key = kt * 64 + nt * 16 + g * 4 + r;
+          float v = (key >= lo && key < hi) ? s[nt][r] * sc2 : -INFINITY;
+          s[nt][r] = v;
+          mloc = fmaxf(mloc, v);
+        }
+    }
     mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
     float mnew = fmaxf(m, mloc);
     float muse = (mnew == -INFINITY) ? 0.f : mnew;
-    float alpha = exp2f(m - muse);
+    float alpha = EXP2(m - muse);
     float rs = 0.f;
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { float e = exp2f(s[nt][r] - muse); s[nt][r] = e; rs += e; }
+      for (int r = 0; r < 4; ++r) { float e = EXP2(s[nt][r] - muse); s[nt][r] = e; rs += e; }
     rs += __shfl_xor(rs, 16, 64);
     rs += __shfl_xor(rs, 32, 64);
     lsum = lsum * alpha + rs;
@@ -245,7 +255,7 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(AttnP p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int key = kt * 64 + nt * 16 + g * 4 + r;
-        float pr = (key >= lo && key < hi) ? exp2f(s[nt][r] * sc2 - lse2) : 0.f;
+        float pr = (key >= lo && key < hi) ? EXP2(s[nt][r] * sc2 - lse2) : 0.f;
         s[nt][r] = pr * (dp[nt][r] - dl) * p.scale;
       }
     bf16x8 dsf[2] = {pack8(s[0], s[1]), pack8(s[2], s[3])};
@@ -327,7 +337,7 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int ql = qb2 * 16 + g * 4 + r;
-        float pr = (key >= st_lo[ql] && key < st_hi[ql]) ? exp2f(s[qb2][r] * sc2 - st_lse[ql]) : 0.f;
+        float pr = (key >= st_lo[ql] && key < st_hi[ql]) ? EXP2(s[qb2][r] * sc2 - st_lse[ql]) : 0.f;
         s[qb2][r] = pr;
         dp[qb2][r] = pr * (dp[qb2][r] - st_dl[ql]) * p.scale;
       }

@@ -39,12 +39,18 @@ __device__ __forceinline__ int ks32_off(int krow, int col) {
 // (after the explicit lgkmcnt(0) + barrier of G3_BARRIER), so the compiler never touches the destination registers
 // before the data has landed (cdna guide §5.7 item 1, form iii).
 typedef __attribute__((ext_vector_type(8))) short s16x8;
+// per-lane LDS byte offset of fragment 0 of a wave's column range starting at c0 (multiple of 64, or of 32 for WN = 32):
+// fragment i (columns c0 + 16 i ..) is then at  (lane_base + buffer_base) ^ (i << 5)  because the granule XOR only
+// touches bits 5..7 -- ONE live address register per operand instead of one per fragment.
 template <int ROWS>
-__device__ __forceinline__ void frag_ks32_asm(const char* tile, int r0, s16x4& lo, s16x4& hi) {
+__device__ __forceinline__ uint32_t ks32_lane_base(int c0) {
   int l = lane_id();
   int g = l >> 4, q = (l >> 2) & 3, p = l & 3;
-  int kr = g * 8 + q, col = r0 + 4 * p;
-  uint32_t addr = (uint32_t)(uintptr_t)LDS_PTR(char, tile + ks32_off<ROWS>(kr, col));
+  return (uint32_t)ks32_off<ROWS>(g * 8 + q, c0 + 4 * p);
+}
+template <int ROWS>
+__device__ __forceinline__ void frag_ks32_asm(uint32_t a0, int i, s16x4& lo, s16x4& hi) {
+  uint32_t addr = a0 ^ ((uint32_t)i << 5);
   asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(addr) : "memory");
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "n"(4 * ROWS * 2) : "memory");
 }
@@ -146,12 +152,15 @@ __global__ __launch_bounds__(512, 2) void gemm3_bf16_kernel(Gemm2Params p) {
 #define DMA(H) do { char* b_ = smem + ((H) & 3) * SUB;                                                             \
     dma_issue<AKS, G3_BM>(p.A, p.lda, (H), p.K, b_, wave, aoff);                                                   \
     dma_issue<BKS, BN>(p.B, p.ldb, (H), p.K, b_ + A_SUB, wave, boff); } while (0)
+  const uint32_t smem_lds = (uint32_t)(uintptr_t)LDS_PTR(char, smem);
+  const uint32_t lbA = AKS ? ks32_lane_base<G3_BM>(wm * 128) : 0u, lbB = BKS ? ks32_lane_base<BN>(wn * WN) : 0u;
 #define LOADF(S, H) do { const char* b_ = smem + ((H) & 3) * SUB;                                                  \
+    uint32_t ub_ = smem_lds + ((H) & 3) * SUB;                                                                     \
     _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                               \
-      if (BKS) frag_ks32_asm<BN>(b_ + A_SUB, wn * WN + j * 16, lb##S[j], hb##S[j]);                                \
+      if (BKS) frag_ks32_asm<BN>(lbB + ub_ + A_SUB, j, lb##S[j], hb##S[j]);                                        \
       else rb##S[j] = frag_kc32(b_ + A_SUB, wn * WN + j * 16); }                                                   \
     _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                \
-      if (AKS) frag_ks32_asm<G3_BM>(b_, wm * 128 + i * 16, la##S[i], ha##S[i]);                                    \
+      if (AKS) frag_ks32_asm<G3_BM>(lbA + ub_, i, la##S[i], ha##S[i]);                                             \
       else ra##S[i] = frag_kc32(b_, wm * 128 + i * 16); } } while (0)
 #define MFMAS(S) do { G3_PRIO(1);                                                                                  \
     bf16x8 fb_[NJ];                                                                                                \

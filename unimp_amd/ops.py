@@ -3,6 +3,8 @@
 Every tensor must live on a HIP device; nothing here has a CPU or eager-PyTorch fallback.
 """
 import ctypes as C
+import json
+import os
 import torch
 
 from . import _lib
@@ -17,6 +19,10 @@ GEMM_PROFILE = None      # bench.py sets this to a list: (start_event, end_event
 GEMM_AUTOTUNE = True     # time the kernel variants once per (M, N, K, layout) on scratch operands and keep the fastest
 GEMM_VARIANTS = {"auto": 0, "v1": 1, "dma256": 2, "dma128": 3, "pp256": 4, "pp128": 5}
 _GEMM_CHOICE = {}
+_TUNE_FILE = os.environ.get("UNIMP_GEMM_TUNE_FILE")       # optional JSON cache of the autotune table (profiling runs reuse it)
+if _TUNE_FILE and os.path.exists(_TUNE_FILE):
+    with open(_TUNE_FILE) as _f:
+        _GEMM_CHOICE.update({tuple(json.loads(k)): v for k, v in json.load(_f).items()})
 
 
 def _launch_gemm(d, variant):
@@ -57,6 +63,9 @@ def _tune_gemm(M, N, K, a_ks, b_ks, device):
         if t < best_t:
             best, best_t = v, t
     _GEMM_CHOICE[key] = best
+    if _TUNE_FILE:
+        with open(_TUNE_FILE, "w") as f:
+            json.dump({json.dumps([int(k[0]), int(k[1]), int(k[2]), bool(k[3]), bool(k[4])]): v for k, v in _GEMM_CHOICE.items()}, f)
     return best
 
 
