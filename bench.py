@@ -113,7 +113,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("UNIMP_BENCH_BATCH", 24)), help="samples per GPU per step")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("UNIMP_BENCH_BATCH", 48)), help="samples per GPU per step")
     ap.add_argument("--images", type=int, default=8)
     ap.add_argument("--seq", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -23,7 +23,8 @@ extern "C" {
 #define UNIMP_ABI_VERSION 1
 enum { UNIMP_OK = 0, UNIMP_ERR_ARG = 1, UNIMP_ERR_SHAPE = 2, UNIMP_ERR_ALIGN = 3, UNIMP_ERR_LAUNCH = 4,
        UNIMP_ERR_UNSUPPORTED = 5 };
-enum { UNIMP_ACT_NONE = 0, UNIMP_ACT_GELU = 1, UNIMP_ACT_QUICKGELU = 2, UNIMP_ACT_RELU = 3, UNIMP_ACT_SILU = 4 };
+enum { UNIMP_ACT_NONE = 0, UNIMP_ACT_GELU = 1, UNIMP_ACT_QUICKGELU = 2, UNIMP_ACT_RELU = 3, UNIMP_ACT_SILU = 4,
+       UNIMP_ACT_DERIV = 5 /* dact only: aux already holds act'(z) */ };
 enum { UNIMP_MASK_NONE = 0, UNIMP_MASK_CAUSAL = 1, UNIMP_MASK_SEGMENT = 2 };
 
 int unimp_abi_version(void);
@@ -37,7 +38,7 @@ int unimp_check_launch(const char* what);
  * helpers to_q/to_kv/to_out/ff), their autograd backward, and the lm-head GEMM (mmrec.py:177-190).
  *   C[M,N] = epi( alpha * sum_k A(m,k) B(n,k) )
  *   a_kstrided=0: A(m,k)=A[m*lda+k]   a_kstrided=1: A(m,k)=A[k*lda+m]      (same for B with n)
- *   epi: v += bias[n]; pre[m,n] = v; v = act(v); v *= act'(aux[m,n]) (dact); v *= tanh(*gate);
+ *   epi: v += bias[n]; pre[m,n] = v (or act'(v) if pre_deriv); v = act(v); v *= act'(aux[m,n]) (dact); v *= tanh(*gate);
  *        v += res[m,n]; if accumulate v += C[m,n]; C = bf16(v) or f32(v)
  */
 typedef struct {
@@ -53,6 +54,7 @@ typedef struct {
   float alpha;
   int act, dact;
   int out_f32, accumulate;
+  int pre_deriv;   /* pre receives act'(v) instead of v: the backward multiply then needs no transcendental (dact = DERIV) */
 } unimp_gemm_desc;
 int unimp_gemm_bf16(const unimp_gemm_desc* d, void* stream);
 /* same, with an explicit kernel variant (all compute identical results up to fp32 summation order):

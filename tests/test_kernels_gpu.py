@@ -105,6 +105,17 @@ def test_gemm_epilogue_bias_act_pre(ops, act, M):
         got = ops.gemm(a.cuda(), b.cuda(), bias=bias.cuda(), act=act, pre=pre, variant=variant)
         close(pre, z, name="pre")
         close(got, act_ref(act, z), name=f"act {act} [{variant}]")
+        if act is not None:                         # forward epilogue that stores act'(z) instead of z, consumed by dact="deriv"
+            dz = torch.empty(M, N, dtype=bf16, device="cuda")
+            got = ops.gemm(a.cuda(), b.cuda(), bias=bias.cuda(), act=act, pre=dz, pre_deriv=True, variant=variant)
+            close(got, act_ref(act, z), name=f"act {act} [{variant}] with deriv")
+            zz = z.clone().requires_grad_(True)
+            act_ref(act, zz).sum().backward()
+            close(dz, zz.grad, name=f"stored act'(z) {act} [{variant}]")
+            up = rnd(M, N, seed=9)
+            w2 = rnd(N, N, seed=10, scale=0.1)
+            got = ops.gemm(up.cuda(), w2.cuda(), b_ks=True, aux=dz, dact="deriv", variant=variant)
+            close(got, (up.float() @ w2.float()) * dz.float().cpu(), name="dact=deriv")
 
 
 @pytest.mark.parametrize("M", [136, 1160])

@@ -5,7 +5,7 @@ kernels with fp32 accumulation inside them; against the fp32 oracle we require
   logits   relative L2 error <= 1e-2   (per-element bf16 rounding is 4e-3; north_star's 1e-3 is met on the loss)
   loss     relative error    <= 2e-3
   argmax   identical wherever the oracle's top-2 margin exceeds 2% of the logit scale
-  grads    relative L2 error per parameter tensor <= max(3e-2, 4 x the bf16 noise floor of that tensor), the noise
+  grads    relative L2 error per parameter tensor <= max(3e-2, 5 x the bf16 noise floor of that tensor), the noise
            floor being the deviation of the SAME fp32 oracle re-run under bf16 autocast (tiny, ill-conditioned towers
            amplify bf16 rounding: e.g. 5% on the 128-wide OPT case even for the reference arithmetic itself)
   labels   bit-exact (integer work)
@@ -58,7 +58,7 @@ def test_forward_backward_parity(P, cfgname):
             assert p.grad.float().abs().max() == 0, n
             continue
         e = P.rel_l2(p.grad, g)
-        assert e <= max(3e-2, 4 * noise[n]), f"grad {n}: rel L2 {e} (bf16 noise floor {noise[n]})"
+        assert e <= max(3e-2, 5 * noise[n]), f"grad {n}: rel L2 {e} (bf16 noise floor {noise[n]})"
         checked += 1
     assert checked >= 20
     for n, p in named.items():

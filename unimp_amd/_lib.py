@@ -17,7 +17,7 @@ class GemmDesc(C.Structure):
                 ("lda", c_l), ("ldb", c_l), ("ldc", c_l), ("a_kstrided", c_i), ("b_kstrided", c_i),
                 ("bias", c_p), ("res", c_p), ("ldres", c_l), ("aux", c_p), ("ldaux", c_l),
                 ("pre", c_p), ("ldpre", c_l), ("gate", c_p), ("alpha", c_f), ("act", c_i), ("dact", c_i),
-                ("out_f32", c_i), ("accumulate", c_i)]
+                ("out_f32", c_i), ("accumulate", c_i), ("pre_deriv", c_i)]
 
 
 class AttnDesc(C.Structure):

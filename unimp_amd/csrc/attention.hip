@@ -193,19 +193,27 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
 
 // ------------------------------------------------------------------------------------------- delta = rowsum(dO * O)
 __global__ void attn_delta_kernel(AttnP p) {
-  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  // 16 lanes per (b, h, q) row: lane c reads the 16-byte chunk c of O and dO (coalesced 160..256-byte rows), then a
+  // 16-lane butterfly; 4 rows per wave-instruction.
+  long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  int c = threadIdx.x & 15;
   long n = (long)p.B * p.H * p.Sq;
-  if (i >= n) return;
-  int qr = i % p.Sq; long t = i / p.Sq; int h = t % p.H; int b = t / p.H;
-  const bf16* o = p.o + b * p.o_bs + (long)qr * p.o_ss + h * p.o_hs;
-  const bf16* d = p.d_o + b * p.do_bs + (long)qr * p.do_ss + h * p.do_hs;
   float acc = 0.f;
-  for (int c = 0; c < p.D; c += 8) {
-    bf16x8 a = *(const bf16x8*)(o + c), bb = *(const bf16x8*)(d + c);
+  if (i < n) {
+    int h = i % p.H; long t = i / p.H; int qr = t % p.Sq; int b = t / p.Sq;          // heads fastest: adjacent rows are adjacent in memory
+    if (c * 8 < p.D) {
+      bf16x8 a = *(const bf16x8*)(p.o + b * p.o_bs + (long)qr * p.o_ss + h * p.o_hs + c * 8);
+      bf16x8 d = *(const bf16x8*)(p.d_o + b * p.do_bs + (long)qr * p.do_ss + h * p.do_hs + c * 8);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc += bf2f(a[j]) * bf2f(bb[j]);
+      for (int j = 0; j < 8; ++j) acc += bf2f(a[j]) * bf2f(d[j]);
+    }
   }
-  p.delta[i] = acc;
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (i < n && c == 0) {
+    int h = i % p.H; long t = i / p.H; int qr = t % p.Sq; int b = t / p.Sq;
+    p.delta[((long)b * p.H + h) * p.Sq + qr] = acc;
+  }
 }
 
 // ------------------------------------------------------------------------------------------- dQ
@@ -410,7 +418,7 @@ extern "C" int unimp_attn_bwd(const unimp_attn_desc* d, void* stream) {
   if (p.B <= 0 || p.H <= 0 || p.Sq <= 0) return UNIMP_OK;
   hipStream_t s = (hipStream_t)stream;
   long n = (long)p.B * p.H * p.Sq;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((n * 16 + 255) / 256)), dim3(256), 0, s, p);
   dim3 gq((p.Sq + 63) / 64, p.H, p.B), gk((p.Sk + 63) / 64, p.H, p.B), block(256);
   if (p.D == 64) { hipLaunchKernelGGL((attn_dq_kernel<64, 64>), gq, block, 0, s, p); hipLaunchKernelGGL((attn_dkv_kernel<64, 64>), gk, block, 0, s, p); }
   else if (p.D == 80) { hipLaunchKernelGGL((attn_dq_kernel<96, 80>), gq, block, 0, s, p); hipLaunchKernelGGL((attn_dkv_kernel<96, 80>), gk, block, 0, s, p); }

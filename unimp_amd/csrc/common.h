@@ -32,7 +32,7 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // ---- activations (fp32 math) -------------------------------------------------------------
-enum { ACT_NONE = 0, ACT_GELU = 1, ACT_QUICKGELU = 2, ACT_RELU = 3, ACT_SILU = 4 };
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_QUICKGELU = 2, ACT_RELU = 3, ACT_SILU = 4, ACT_DERIV = 5 };   // DERIV: aux IS act'(z)
 
 // erf-GELU with ONE exponential: Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below bf16 resolution);
 // e = exp(-x^2/2) serves both erf(x/sqrt2) and the Gaussian density of the derivative.
@@ -54,8 +54,19 @@ __device__ __forceinline__ float act_fwd(int act, float x) {
     default: return x;
   }
 }
-__device__ __forceinline__ float act_bwd(int act, float x) {   // d act(x) / dx
+// y = act(x) and d = act'(x) together (one exponential for GELU): the forward epilogue can store d instead of x
+__device__ __forceinline__ void act_fwd_deriv(int act, float x, float& y, float& d) {
   switch (act) {
+    case ACT_GELU: { float cdf, e; gelu_parts(x, cdf, e); y = x * cdf; d = cdf + x * 0.3989422804014327f * e; break; }
+    case ACT_QUICKGELU: { float s = 1.0f / (1.0f + __expf(-1.702f * x)); y = x * s; d = s * (1.0f + 1.702f * x * (1.0f - s)); break; }
+    case ACT_RELU: y = x > 0.f ? x : 0.f; d = x > 0.f ? 1.f : 0.f; break;
+    case ACT_SILU: { float s = 1.0f / (1.0f + __expf(-x)); y = x * s; d = s * (1.0f + x * (1.0f - s)); break; }
+    default: y = x; d = 1.f;
+  }
+}
+__device__ __forceinline__ float act_bwd(int act, float x) {   // d act(x) / dx   (ACT_DERIV: x already is the derivative)
+  switch (act) {
+    case ACT_DERIV: return x;
     case ACT_GELU: { float cdf, e; gelu_parts(x, cdf, e); return cdf + x * 0.3989422804014327f * e; }
     case ACT_QUICKGELU: {
       float s = 1.0f / (1.0f + __expf(-1.702f * x));

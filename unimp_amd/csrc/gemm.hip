@@ -30,7 +30,7 @@ struct GemmParams {
   bf16* pre;        long ldpre;     // [M,N] or null: receives v before act/gate/res
   const bf16* gate;                 // device scalar or null: v *= tanh(*gate)
   float alpha;
-  int act, dact, out_f32, accumulate;
+  int act, dact, out_f32, accumulate, pre_deriv;
   int nbm, nbn;
   int ksplit;                       // > 0: blockIdx.y handles k in [y*ksplit, (y+1)*ksplit) and writes f32 slab y of C
 };
@@ -90,14 +90,23 @@ __device__ __forceinline__ void epi_tile(const GemmParams& p, f32x4 a, int m, in
       for (int r = 0; r < 4; ++r) v[r] += bf2f(b[r]); }
     else { for (int r = 0; r < nv; ++r) v[r] += bf2f(p.bias[n + r]); }
   }
-  if (p.pre) {
-    bf16* d = p.pre + (long)m * p.ldpre + n;
-    if (FAST) { bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])}; *(bf16x4*)d = o; }
-    else { for (int r = 0; r < nv; ++r) d[r] = f2bf(v[r]); }
-  }
-  if (p.act) {
+  if (p.pre && p.pre_deriv) {
+    float dv[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = act_fwd(p.act, v[r]);
+    for (int r = 0; r < 4; ++r) act_fwd_deriv(p.act, v[r], v[r], dv[r]);
+    bf16* d = p.pre + (long)m * p.ldpre + n;
+    if (FAST) { bf16x4 o = {f2bf(dv[0]), f2bf(dv[1]), f2bf(dv[2]), f2bf(dv[3])}; *(bf16x4*)d = o; }
+    else { for (int r = 0; r < nv; ++r) d[r] = f2bf(dv[r]); }
+  } else {
+    if (p.pre) {
+      bf16* d = p.pre + (long)m * p.ldpre + n;
+      if (FAST) { bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])}; *(bf16x4*)d = o; }
+      else { for (int r = 0; r < nv; ++r) d[r] = f2bf(v[r]); }
+    }
+    if (p.act) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = act_fwd(p.act, v[r]);
+    }
   }
   if (p.aux) {
     const bf16* s = p.aux + (long)m * p.ldaux + n;
@@ -248,13 +257,13 @@ static void launch_v1(const unimp_gemm_desc* d, void* stream, int splits = 1, fl
   p.bias = (const bf16*)d->bias; p.res = (const bf16*)d->res; p.ldres = d->ldres;
   p.aux = (const bf16*)d->aux; p.ldaux = d->ldaux; p.pre = (bf16*)d->pre; p.ldpre = d->ldpre;
   p.gate = (const bf16*)d->gate; p.alpha = d->alpha; p.act = d->act; p.dact = d->dact;
-  p.out_f32 = d->out_f32; p.accumulate = d->accumulate;
+  p.out_f32 = d->out_f32; p.accumulate = d->accumulate; p.pre_deriv = d->pre_deriv;
   p.nbm = (d->M + BM - 1) / BM; p.nbn = (d->N + BN - 1) / BN;
   p.ksplit = 0;
   if (splits > 1) {
     p.ksplit = ((d->K + splits - 1) / splits + 63) & ~63;
     p.C = slabs; p.ldc = d->N; p.out_f32 = 1; p.accumulate = 0; p.alpha = 1.f;
-    p.bias = nullptr; p.res = nullptr; p.aux = nullptr; p.pre = nullptr; p.gate = nullptr; p.act = 0; p.dact = 0;
+    p.bias = nullptr; p.res = nullptr; p.aux = nullptr; p.pre = nullptr; p.gate = nullptr; p.act = 0; p.dact = 0; p.pre_deriv = 0;
   }
   dim3 grid(p.nbm * p.nbn, splits > 1 ? (d->K + p.ksplit - 1) / p.ksplit : 1), block(256);
   size_t lds = 2 * STAGE_BYTES;

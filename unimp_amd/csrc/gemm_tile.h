@@ -13,7 +13,7 @@ struct Gemm2Params {
   bf16* pre;        long ldpre;
   const bf16* gate;
   float alpha;
-  int act, dact, out_f32, accumulate;
+  int act, dact, out_f32, accumulate, pre_deriv;
   int nbm, nbn;
 };
 
@@ -36,17 +36,29 @@ __device__ __forceinline__ void epi8(const Gemm2Params& p, float (&v)[8], int m,
       for (int r = 0; r < 8; ++r) v[r] += bf2f(b[r]); }
     else { for (int r = 0; r < nv; ++r) v[r] += bf2f(p.bias[n + r]); }
   }
-  if (p.pre) {
+  if (p.pre && p.pre_deriv) {                 // y = act(v) and act'(v) from one exponential; store the derivative
+    float dv[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) act_fwd_deriv(p.act, v[r], v[r], dv[r]);
     bf16* d = p.pre + (long)m * p.ldpre + n;
     if (FAST) { bf16x8 o;
 #pragma unroll
-      for (int r = 0; r < 8; ++r) o[r] = f2bf(v[r]);
+      for (int r = 0; r < 8; ++r) o[r] = f2bf(dv[r]);
       *(bf16x8*)d = o; }
-    else { for (int r = 0; r < nv; ++r) d[r] = f2bf(v[r]); }
-  }
-  if (p.act) {
+    else { for (int r = 0; r < nv; ++r) d[r] = f2bf(dv[r]); }
+  } else {
+    if (p.pre) {
+      bf16* d = p.pre + (long)m * p.ldpre + n;
+      if (FAST) { bf16x8 o;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) v[r] = act_fwd(p.act, v[r]);
+        for (int r = 0; r < 8; ++r) o[r] = f2bf(v[r]);
+        *(bf16x8*)d = o; }
+      else { for (int r = 0; r < nv; ++r) d[r] = f2bf(v[r]); }
+    }
+    if (p.act) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] = act_fwd(p.act, v[r]);
+    }
   }
   if (p.aux) {
     const bf16* s = p.aux + (long)m * p.ldaux + n;

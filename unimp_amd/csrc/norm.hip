@@ -175,15 +175,26 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
   }
 }
 
-__global__ void ln_wgrad_reduce_kernel(const float* __restrict__ partial, int nblk, int D, bf16* __restrict__ dgamma,
-                                       bf16* __restrict__ dbeta) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 2 * D) return;
-  int which = i / D, col = i - which * D;
+// column sums of the per-block partials [nblk][2][D]: a block owns 32 columns of dgamma or dbeta, 8 row groups x 32 lanes
+// read 128 contiguous bytes per partial row, LDS combines the 8 groups.
+__global__ __launch_bounds__(256) void ln_wgrad_reduce_kernel(const float* __restrict__ partial, int nblk, int D, bf16* __restrict__ dgamma,
+                                                              bf16* __restrict__ dbeta) {
+  __shared__ float sh[8][32];
+  int cb = blockIdx.x * 32, which = blockIdx.y;
+  int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  int col = cb + cl;
   float t = 0.f;
-  for (int b = 0; b < nblk; ++b) t += partial[((long)b * 2 + which) * D + col];
-  if (which == 0) dgamma[col] = f2bf(t);
-  else if (dbeta) dbeta[col] = f2bf(t);
+  if (col < D)
+    for (int b = rg; b < nblk; b += 8) t += partial[((long)b * 2 + which) * D + col];
+  sh[rg][cl] = t;
+  __syncthreads();
+  if (rg == 0 && col < D) {
+    float a = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) a += sh[g][cl];
+    if (which == 0) dgamma[col] = f2bf(a);
+    else if (dbeta) dbeta[col] = f2bf(a);
+  }
 }
 
 static inline int ln_grid(int rows) {
@@ -230,7 +241,7 @@ extern "C" int unimp_layernorm_bwd(const void* dy, int64_t lddy, const void* dy2
   int e = unimp_check_launch("layernorm_bwd");
   if (e) return e;
   if (wg) {
-    hipLaunchKernelGGL(ln_wgrad_reduce_kernel, dim3((2 * D + 255) / 256), dim3(256), 0, s, partial, nb, D, (bf16*)dgamma, (bf16*)dbeta);
+    hipLaunchKernelGGL(ln_wgrad_reduce_kernel, dim3((D + 31) / 32, 2), dim3(256), 0, s, partial, nb, D, (bf16*)dgamma, (bf16*)dbeta);
     return unimp_check_launch("layernorm_wgrad_reduce");
   }
   return UNIMP_OK;

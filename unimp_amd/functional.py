@@ -131,7 +131,7 @@ class MLPBlockFn(Function):
         h, mean, rstd = ops.layernorm_fwd(x2, ln_w, ln_b, eps)
         M, F = x2.shape[0], w1.shape[0]
         pre = torch.empty((M, F), dtype=bf16, device=x.device)
-        a = ops.gemm(h, w1, bias=b1, act=act, pre=pre)
+        a = ops.gemm(h, w1, bias=b1, act=act, pre=pre, pre_deriv=True)           # pre <- act'(z): backward needs no transcendental
         raw = torch.empty_like(x2) if gate is not None else None
         out = ops.gemm(a, w2, bias=b2, gate=gate, res=r2, pre=raw)
         w1g, w2g = w1.requires_grad, w2.requires_grad
@@ -148,7 +148,7 @@ class MLPBlockFn(Function):
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
         dgate = _gate_grad(dy2, raw, gate) if gate is not None and _need(ctx, 8) else None
-        dpre = ops.gemm(dy2, w2, b_ks=True, gate=gate, aux=pre, dact=ctx.act)           # [M,F]
+        dpre = ops.gemm(dy2, w2, b_ks=True, gate=gate, aux=pre, dact="deriv")          # [M,F]  (dy tanh(g) W2) * act'(z)
         dw2 = ops.gemm(dy2, a, a_ks=True, b_ks=True, gate=gate) if _need(ctx, 6) else None
         dw1 = ops.gemm(dpre, h, a_ks=True, b_ks=True) if _need(ctx, 4) else None
         dh = ops.gemm(dpre, w1, b_ks=True)

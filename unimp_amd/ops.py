@@ -10,7 +10,7 @@ import torch
 from . import _lib
 from ._lib import GemmDesc, AttnDesc, check
 
-ACT = {None: 0, "none": 0, "gelu": 1, "quick_gelu": 2, "relu": 3, "silu": 4}
+ACT = {None: 0, "none": 0, "gelu": 1, "quick_gelu": 2, "relu": 3, "silu": 4, "deriv": 5}
 MASK_NONE, MASK_CAUSAL, MASK_SEGMENT = 0, 1, 2
 bf16 = torch.bfloat16
 
@@ -92,7 +92,7 @@ def _mat(t):
 
 
 def gemm(a, b, *, a_ks=False, b_ks=False, bias=None, act=None, res=None, aux=None, dact=None, pre=None,
-         gate=None, alpha=1.0, out=None, out_f32=False, accumulate=False, ldc=None, variant=None):
+         gate=None, alpha=1.0, out=None, out_f32=False, accumulate=False, ldc=None, variant=None, pre_deriv=False):
     """C[M,N] = epi(alpha * A B^T).  a: [M,K] (or [K,M] if a_ks); b: [N,K] (or [K,N] if b_ks)."""
     a, lda = _mat(a)
     b, ldb = _mat(b)
@@ -126,6 +126,7 @@ def gemm(a, b, *, a_ks=False, b_ks=False, bias=None, act=None, res=None, aux=Non
     d.alpha = alpha
     d.act, d.dact = ACT[act], ACT[dact]
     d.out_f32, d.accumulate = int(out.dtype == torch.float32), int(accumulate)
+    d.pre_deriv = int(pre_deriv)
     plain = bias is None and res is None and aux is None and pre is None and act is None and dact is None and not accumulate
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     if variant is None and plain and tiles <= 96 and K >= 2048 and N % 4 == 0 and out.stride(0) % 4 == 0:
