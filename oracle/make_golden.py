@@ -175,6 +175,26 @@ def gen_intree():
                         **{"grad." + n: p.grad.numpy() for n, p in lm.named_parameters()})
     print("llama_tiny loss", float(out.loss))
 
+    # head dim 64 variant (the HIP attention kernels support head dims 64 / 80 / 128), bf16-representable weights
+    torch.manual_seed(6)
+    lc = LlamaConfig(vocab_size=200, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                     num_attention_heads=2, max_position_embeddings=64, rms_norm_eps=1e-6, pad_token_id=0)
+    lm = LlamaForCausalLM(lc).train()
+    for n, p in lm.named_parameters():
+        p.data.normal_(0, 0.08)
+        if "norm" in n:
+            p.data.add_(1.0)
+        p.data = p.data.to(torch.bfloat16).float()
+    ids = torch.randint(1, 200, (2, 40))
+    out = lm(input_ids=ids, attention_mask=torch.ones_like(ids), labels=ids)
+    out.loss.backward()
+    sd = {k: v for k, v in lm.state_dict().items() if "inv_freq" not in k}
+    np.savez_compressed(os.path.join(OUT, "llama_hd64.npz"), ids=ids.numpy(), logits=out.logits.detach().numpy(),
+                        loss=out.loss.detach().numpy(),
+                        **{"sd." + k: v for k, v in _np(sd).items()},
+                        **{"grad." + n: p.grad.numpy() for n, p in lm.named_parameters()})
+    print("llama_hd64 loss", float(out.loss))
+
 
 # ------------------------------------------------------------------ 4. HF towers
 def gen_hf_towers():

@@ -9,8 +9,8 @@ bf16 = torch.bfloat16
 TINY = dict(vit=dict(image_size=32, patch_size=8, width=128, layers=2, heads=2, mlp_dim=256, output_dim=64),
             lm=dict(kind="neox", vocab_size=512, hidden_size=160, num_hidden_layers=4, num_attention_heads=2,
                     intermediate_size=320), every=2, T=3, L=48, B=2, n_items=40, base_vocab=300)
-TINY_OPT = dict(vit=dict(image_size=32, patch_size=16, width=128, layers=1, heads=2, mlp_dim=256, output_dim=32),
-                lm=dict(kind="opt", vocab_size=512, hidden_size=256, num_hidden_layers=2, num_attention_heads=4, ffn_dim=512,
+TINY_OPT = dict(vit=dict(image_size=32, patch_size=16, width=64, layers=1, heads=1, mlp_dim=128, output_dim=32),
+                lm=dict(kind="opt", vocab_size=512, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, ffn_dim=256,
                         max_position_embeddings=128), every=1, T=2, L=40, B=2, n_items=40, base_vocab=300)
 TINY_PAR = dict(vit=dict(image_size=32, patch_size=8, width=128, layers=1, heads=2, mlp_dim=256, output_dim=64),
                 lm=dict(kind="neox", vocab_size=512, hidden_size=256, num_hidden_layers=2, num_attention_heads=2,

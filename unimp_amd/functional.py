@@ -164,6 +164,42 @@ def mlp_block(x, ln_w, ln_b, w1, b1, w2, b2, act, gate=None, res=None, eps=1e-5)
     return MLPBlockFn.apply(x, res, ln_w, ln_b, w1, b1, w2, b2, gate, act, eps)
 
 
+class SwiGLUBlockFn(Function):
+    """out = x + down( silu(gate(RMSNorm(x))) * up(RMSNorm(x)) )   (UniMP/xformers_model/llama.py:185-199,311-380).
+    w_gu is the row-concatenation [gate_proj; up_proj] so one GEMM yields [gate | up]."""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, w_gu, w_down, eps):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        F = w_gu.shape[0] // 2
+        h, _, rstd = ops.layernorm_fwd(x2, ln_w, None, eps, rms=True)
+        gu = ops.gemm(h, w_gu)
+        a = ops.swiglu_fwd(gu, F)
+        out = ops.gemm(a, w_down, res=x2)
+        ctx.save_for_backward(x2, ln_w, rstd, w_gu, w_down, gu, h if w_gu.requires_grad else None, a if w_down.requires_grad else None)
+        ctx.shp, ctx.F = shp, F
+        return out.view(shp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, ln_w, rstd, w_gu, w_down, gu, h, a = ctx.saved_tensors
+        dy2 = dy.reshape(-1, ctx.shp[-1])
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        da = ops.gemm(dy2, w_down, b_ks=True)
+        dwd = ops.gemm(dy2, a, a_ks=True, b_ks=True) if _need(ctx, 3) else None
+        dgu = ops.swiglu_bwd(gu, da, ctx.F)
+        dwgu = ops.gemm(dgu, h, a_ks=True, b_ks=True) if _need(ctx, 2) else None
+        dh = ops.gemm(dgu, w_gu, b_ks=True)
+        dx, dg, _ = ops.layernorm_bwd(dh, x2, ln_w, None, rstd, dres=dy2, want_wgrad=_need(ctx, 1), has_beta=False, rms=True)
+        return dx.view(ctx.shp), dg, dwgu, dwd, None
+
+
+def swiglu_block(x, ln_w, w_gu, w_down, eps=1e-6):
+    return SwiGLUBlockFn.apply(x, ln_w, w_gu, w_down, eps)
+
+
 # ----------------------------------------------------------------------------------------------- GPT-NeoX / OPT / Llama self-attention sub-block
 class SelfAttnBlockFn(Function):
     """out = res + dense(causal_attn(rope(qkv(LN(x)))));  qkv layout [B, L, nh, 3*hd] (GPT-NeoX per-head interleave)

@@ -281,6 +281,115 @@ class OPTForCausalLM(_TowerBase):
         return self._head(h, labels)
 
 
+# --------------------------------------------------------------------------- Llama (in-tree UniMP/xformers_model/llama.py)
+def LlamaConfig(vocab_size=32000, hidden_size=4096, intermediate_size=11008, num_hidden_layers=32, num_attention_heads=32,
+                rms_norm_eps=1e-6, max_position_embeddings=2048, rope_base=10000.0):
+    return _Cfg(model_type="llama", **{k: v for k, v in locals().items()})
+
+
+class _Frozen:
+    """cache of a fused copy of several frozen parameters (rebuilt when any of them changes)."""
+
+    def __init__(self):
+        self._c = None
+
+    def get(self, params, what):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            raise NotImplementedError(f"training the {what} projections is not supported (the LM tower is frozen in UniMP)")
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if self._c is None or self._c[0] != key:
+            self._c = (key, torch.cat([p.detach() for p in params]).contiguous())
+        return self._c[1]
+
+
+class _LlamaAttnParams(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.q_proj = nn.Linear(d, d, bias=False)
+        self.k_proj = nn.Linear(d, d, bias=False)
+        self.v_proj = nn.Linear(d, d, bias=False)
+        self.o_proj = nn.Linear(d, d, bias=False)
+
+
+class _LlamaMLPParams(nn.Module):
+    def __init__(self, d, m):
+        super().__init__()
+        self.gate_proj = nn.Linear(d, m, bias=False)
+        self.down_proj = nn.Linear(m, d, bias=False)
+        self.up_proj = nn.Linear(d, m, bias=False)
+
+
+class _RMSNormParams(nn.Module):
+    def __init__(self, d, eps):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(d))
+        self.variance_epsilon = eps
+
+
+class LlamaDecoderLayer(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.c = c
+        self.self_attn = _LlamaAttnParams(c.hidden_size)
+        self.mlp = _LlamaMLPParams(c.hidden_size, c.intermediate_size)
+        self.input_layernorm = _RMSNormParams(c.hidden_size, c.rms_norm_eps)
+        self.post_attention_layernorm = _RMSNormParams(c.hidden_size, c.rms_norm_eps)
+        self._fqkv, self._fgu = _Frozen(), _Frozen()
+
+    def forward(self, x, attention_mask=None, rope=None, **kw):
+        a, m, c = self.self_attn, self.mlp, self.c
+        wqkv = self._fqkv.get([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], "Llama q/k/v")
+        wgu = self._fgu.get([m.gate_proj.weight, m.up_proj.weight], "Llama gate/up")
+        # training path of the in-tree model: LowerTriangularMask only, padding masks are ignored (llama.py:287-293)
+        x = F_.self_attn_block(x, self.input_layernorm.weight, None, wqkv, None, a.o_proj.weight, None, c.num_attention_heads,
+                               rope=rope, kv_len=None, interleaved=False, causal=True, eps=c.rms_norm_eps, rms=True)
+        return F_.swiglu_block(x, self.post_attention_layernorm.weight, wgu, m.down_proj.weight, c.rms_norm_eps)
+
+
+class _LlamaModel(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.embed_tokens = nn.Embedding(c.vocab_size, c.hidden_size)
+        self.layers = nn.ModuleList([LlamaDecoderLayer(c) for _ in range(c.num_hidden_layers)])
+        self.norm = _RMSNormParams(c.hidden_size, c.rms_norm_eps)
+
+
+class LlamaForCausalLM(_TowerBase):
+    decoder_layers_attr = "model.layers"
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.model = _LlamaModel(config)
+        self.lm_head = nn.Linear(config.hidden_size, config.vocab_size, bias=False)
+        self._rope = None
+
+    def get_input_embeddings(self): return self.model.embed_tokens
+    def set_input_embeddings(self, m): self.model.embed_tokens = m
+    def get_output_embeddings(self): return self.lm_head
+    def set_output_embeddings(self, m): self.lm_head = m
+
+    def _rope_tables(self, L, device):
+        c = self.config
+        hd = c.hidden_size // c.num_attention_heads
+        if self._rope is None or self._rope[0].shape[0] < L or self._rope[0].device != device:
+            n = max(L, 512)
+            inv = 1.0 / (c.rope_base ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
+            fr = torch.arange(n, dtype=torch.float32)[:, None] * inv[None]
+            self._rope = (fr.cos().contiguous().to(device), fr.sin().contiguous().to(device), hd)
+        return self._rope
+
+    def forward(self, input_ids, attention_mask=None, labels=None, **kw):
+        B, L = input_ids.shape
+        x = F_.embedding(input_ids, self.model.embed_tokens.weight)
+        rope = self._rope_tables(L, x.device)
+        for layer in self.model.layers:
+            x = layer(x, attention_mask=None, rope=rope)
+        n = self.model.norm
+        h = F_.layer_norm(x, n.weight, None, n.variance_epsilon, rms=True)
+        return self._head(h, labels)
+
+
 def build_lm(name_or_config):
     if isinstance(name_or_config, _Cfg):
         c = name_or_config
@@ -289,4 +398,4 @@ def build_lm(name_or_config):
         if not key:
             raise ValueError(f"unknown lang_encoder_path {name_or_config!r}; known: {sorted(LM_CONFIGS)} (or pass a config object)")
         c = LM_CONFIGS[key[0]]()
-    return {"gpt_neox": GPTNeoXForCausalLM, "opt": OPTForCausalLM}[c.model_type](c)
+    return {"gpt_neox": GPTNeoXForCausalLM, "opt": OPTForCausalLM, "llama": LlamaForCausalLM}[c.model_type](c)
