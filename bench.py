@@ -181,8 +181,18 @@ def main():
                     print(f"  gemm M={k[0]:6d} N={k[1]:6d} K={k[2]:6d} aks={k[3]} bks={k[4]}  calls/step {a[0] // args.steps:4d}  "
                           f"{a[1] / args.steps:8.2f} ms/step  {a[2] / a[1] / 1e9:7.1f} TFLOP/s", file=sys.stderr)
             ach = tot_fl / (tot_ms * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": "gemm_bf16_kernel", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            traffic, note = None, None
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_gemm.json")
+            if os.path.exists(pmc):                      # PMC passes cannot run inside the timed bench: committed measurement
+                with open(pmc) as f:
+                    j = json.load(f)
+                traffic = j["traffic_bytes_per_launch"]
+                note = (f"rocprofv3 --pmc FETCH_SIZE(x2, gfx950 correction)+WRITE_SIZE per launch of {j['kernel']} at M,N,K={j['shape']} "
+                        f"(algorithmic {(j['shape'][0] * j['shape'][2] + j['shape'][1] * j['shape'][2] + j['shape'][0] * j['shape'][1]) * 2} B; "
+                        f"L2-to-fabric requests incl. Infinity-Cache hits); MFMA pipe busy {j['mfma_util']:.3f} of SIMD cycles; {j['source']}")
+            roofline = {"bound": "mfma", "kernel": "gemm3_bf16_kernel (256-row ping-pong) + variants, all GEMM launches of the step",
+                        "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_note": note,
                         "launches_per_step": len(prof) // args.steps, "gemm_ms_per_step": round(tot_ms / args.steps, 2),
                         "gemm_flop_per_step": tot_fl / args.steps}
         cpu = None

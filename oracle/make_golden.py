@@ -157,6 +157,23 @@ def gen_intree():
                         **{"sd." + k: v for k, v in _np(sd).items()})
     print("clip_tiny", tuple(out.last_hidden_state.shape))
 
+    # head dim 64 variant for the HIP ViT (attention kernels: head dims 64 / 80 / 128), bf16-representable weights / pixels
+    torch.manual_seed(8)
+    cfg = CLIPVisionConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+                           image_size=32, patch_size=8, hidden_act="quick_gelu")
+    m = CLIPVisionModel(cfg).eval()
+    for p in m.parameters():
+        p.data.normal_(0, 0.1)
+        p.data = p.data.to(torch.bfloat16).float()
+    x = torch.randn(3, 3, 32, 32).to(torch.bfloat16).float()
+    with torch.no_grad():
+        out = m(pixel_values=x)
+    sd = {k: v for k, v in m.state_dict().items() if "position_ids" not in k}
+    np.savez_compressed(os.path.join(OUT, "clip_hd64.npz"), pixels=x.numpy(),
+                        last_hidden_state=out.last_hidden_state.numpy(), pooler_output=out.pooler_output.numpy(),
+                        **{"sd." + k: v for k, v in _np(sd).items()})
+    print("clip_hd64", tuple(out.last_hidden_state.shape))
+
     torch.manual_seed(4)
     lc = LlamaConfig(vocab_size=97, hidden_size=64, intermediate_size=112, num_hidden_layers=2,
                      num_attention_heads=4, max_position_embeddings=64, rms_norm_eps=1e-6, pad_token_id=0)

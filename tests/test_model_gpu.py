@@ -157,3 +157,40 @@ def test_llama_tower_vs_intree_reference(P, golden_dir):
         g = dict(m.named_parameters())[n].grad
         e = P.rel_l2(g, torch.from_numpy(z["grad." + n]))
         assert e <= 3e-2, f"grad {n}: rel L2 {e}"
+
+
+def test_vit_vs_intree_clip_reference(P, golden_dir):
+    """§8 a-3/4/5: the HIP ViT (conv1-as-GEMM, fused in_proj, QuickGELU MLP, pre-LN) against the in-tree
+    UniMP/xformers_model/clip.py (fixture tests/golden/clip_hd64.npz captured from the reference)."""
+    import os
+    import numpy as np
+    from unimp_amd.vit import VisionTransformer
+    z = np.load(os.path.join(golden_dir, "clip_hd64.npz"))
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd.")}
+    e_ = "vision_model.embeddings."
+    new = {"conv1.weight": sd[e_ + "patch_embedding.weight"], "class_embedding": sd[e_ + "class_embedding"],
+           "positional_embedding": sd[e_ + "position_embedding.weight"],
+           "ln_pre.weight": sd["vision_model.pre_layrnorm.weight"], "ln_pre.bias": sd["vision_model.pre_layrnorm.bias"],
+           "ln_post.weight": sd["vision_model.post_layernorm.weight"], "ln_post.bias": sd["vision_model.post_layernorm.bias"],
+           "proj": torch.eye(128)[:, :8].contiguous()}
+    for i in range(2):
+        s_, d_ = f"vision_model.encoder.layers.{i}.", f"transformer.resblocks.{i}."
+        new[d_ + "attn.in_proj_weight"] = torch.cat([sd[s_ + f"self_attn.{n}_proj.weight"] for n in "qkv"])
+        new[d_ + "attn.in_proj_bias"] = torch.cat([sd[s_ + f"self_attn.{n}_proj.bias"] for n in "qkv"])
+        for a, b in [("attn.out_proj", "self_attn.out_proj"), ("ln_1", "layer_norm1"), ("ln_2", "layer_norm2"),
+                     ("mlp.c_fc", "mlp.fc1"), ("mlp.c_proj", "mlp.fc2")]:
+            for w in ("weight", "bias"):
+                new[d_ + a + "." + w] = sd[s_ + b + "." + w]
+    with torch.device("cuda"):
+        v = VisionTransformer(image_size=32, patch_size=8, width=128, layers=2, heads=2, mlp_dim=256, output_dim=8)
+    v.to(dtype=bf16)
+    v.load_state_dict(new)
+    v.output_tokens = True
+    v.requires_grad_(False)
+    with torch.no_grad():
+        pooled, tokens = v(torch.from_numpy(z["pixels"]).cuda())
+    want = torch.from_numpy(z["last_hidden_state"])
+    e = P.rel_l2(tokens, want[:, 1:])
+    assert e <= 1e-2, f"tokens rel L2 {e}"
+    e = P.rel_l2(pooled, torch.from_numpy(z["pooler_output"])[:, :8])
+    assert e <= 1e-2, f"pooled rel L2 {e}"
