@@ -100,94 +100,182 @@ __device__ __forceinline__ void block_key_tiles(const AttnP& p, int b, int q_fir
   }
 }
 
+// Register-staged tile copy, split so the global loads of tile t+1 fly under the MFMAs of tile t (T14), with all the
+// index / bounds arithmetic hoisted out of the tile loop:
+//   init(): per-thread byte offsets of its 16-byte chunks inside a tile (global and LDS side), computed once;
+//   g2r(tile_base, rows_left): the steady state is `scalar tile base + per-lane constant`; rows beyond the tensor are
+//        CLAMPED to the last valid row (they only meet masked probabilities, never garbage: 0 * finite = 0);
+//   r2s(lds): plain 16-byte LDS stores.  Pad columns d in [D, DPAD) are never written: the caller zero-fills LDS once.
+template <int ROWS, int DPAD, int STR>
+struct TileCopy {
+  static constexpr int CPR = DPAD / 8, N = (ROWS * CPR + 255) / 256;
+  uint32_t goff[N], loff[N];
+  int row[N];
+  u32x4 v[N];
+  long stride_b;
+  __device__ __forceinline__ void init(long row_stride, int D) {
+    stride_b = row_stride * 2;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      int q = threadIdx.x + 256 * i;
+      int r = q / CPR, c = q - r * CPR;
+      bool ok = q < ROWS * CPR && c * 8 < D;
+      row[i] = ok ? r : -1;
+      goff[i] = (uint32_t)(r * stride_b + c * 16);
+      loff[i] = (uint32_t)(r * STR + c * 16);
+    }
+  }
+  __device__ __forceinline__ void g2r(const bf16* __restrict__ tile_base, int rows_left) {
+    const char* tb = (const char*)tile_base;
+    if (rows_left >= ROWS) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) if (row[i] >= 0) v[i] = *(const u32x4*)(tb + goff[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < N; ++i)
+        if (row[i] >= 0) { int over = max(row[i] - (rows_left - 1), 0); v[i] = *(const u32x4*)(tb + goff[i] - over * stride_b); }
+    }
+  }
+  __device__ __forceinline__ void r2s(char* lds) const {
+#pragma unroll
+    for (int i = 0; i < N; ++i) if (row[i] >= 0) *(u32x4*)(lds + loff[i]) = v[i];
+  }
+};
+
+__device__ __forceinline__ void lds_zero(char* smem, int bytes) {
+  for (int i = threadIdx.x * 16; i < bytes; i += 256 * 16) *(u32x4*)(smem + i) = u32x4{0, 0, 0, 0};
+  __syncthreads();
+}
+
 // ------------------------------------------------------------------------------------------- forward
+// block = 4 waves x 32 query rows (two 16-row MFMA blocks per wave share every K / V fragment read); 64-key tiles,
+// two LDS stages, one barrier per tile.
 template <int DQK, int DV>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
   constexpr int KSTR = DQK * 2 + 16, VSTR = DV * 2 + 16, NKS = DQK / 32, ND = DV / 16;
-  __shared__ __attribute__((aligned(16))) char smem[64 * KSTR + 64 * VSTR];
-  char* ks_t = smem; char* vs_t = smem + 64 * KSTR;
+  constexpr int STAGE = 64 * KSTR + 64 * VSTR;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
   int b = blockIdx.z, h = blockIdx.y;
   int wave = threadIdx.x >> 6, l = lane_id(), g = l >> 4;
-  int q0 = blockIdx.x * 64 + wave * 16;
-  int qr = q0 + (l & 15);
+  int q0 = blockIdx.x * 128 + wave * 32;
   const bf16* qb = p.q + b * p.q_bs + h * p.q_hs;
   const bf16* kb = p.k + b * p.k_bs + h * p.k_hs;
   const bf16* vb = p.v + b * p.v_bs + h * p.v_hs;
-  bf16x8 qf[NKS];
+  bf16x8 qf[2][NKS];
+  int lo[2], hi[2];
 #pragma unroll
-  for (int ks = 0; ks < NKS; ++ks) qf[ks] = gfrag(qb, p.q_ss, qr, p.Sq, ks, p.D);
-  int lo, hi;
-  key_range(p, b, qr, lo, hi);
+  for (int u = 0; u < 2; ++u) {
+    int qr = q0 + u * 16 + (l & 15);
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) qf[u][ks] = gfrag(qb, p.q_ss, qr, p.Sq, ks, p.D);
+    key_range(p, b, qr, lo[u], hi[u]);
+  }
   int kt_lo, kt_hi;
-  block_key_tiles(p, b, blockIdx.x * 64, blockIdx.x * 64 + 63, kt_lo, kt_hi);
+  block_key_tiles(p, b, blockIdx.x * 128, blockIdx.x * 128 + 127, kt_lo, kt_hi);
   float sc2 = p.scale * LOG2E;
-  float m = -INFINITY, lsum = 0.f;
-  f32x4 o[ND];
+  float m[2] = {-INFINITY, -INFINITY}, lsum[2] = {0.f, 0.f};
+  f32x4 o[2][ND];
 #pragma unroll
-  for (int nd = 0; nd < ND; ++nd) o[nd] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int nd = 0; nd < ND; ++nd) o[u][nd] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  TileCopy<64, DQK, KSTR> rk; TileCopy<64, DV, VSTR> rv;
+  rk.init(p.k_ss, p.D); rv.init(p.v_ss, p.D);
+  if (DQK != DV) lds_zero(smem, 2 * STAGE);              // pad columns [D, DQK) of the K images must read as zeros
+  if (kt_lo < kt_hi) {
+    rk.g2r(kb + (long)kt_lo * 64 * p.k_ss, p.Sk - kt_lo * 64);
+    rv.g2r(vb + (long)kt_lo * 64 * p.v_ss, p.Sk - kt_lo * 64);
+    rk.r2s(smem);
+    rv.r2s(smem + 64 * KSTR);
+  }
+  __syncthreads();
   for (int kt = kt_lo; kt < kt_hi; ++kt) {
-    load_tile<64, DQK, KSTR>(ks_t, kb, p.k_ss, kt * 64, p.Sk, p.D);
-    load_tile<64, DV, VSTR>(vs_t, vb, p.v_ss, kt * 64, p.Sk, p.D);
-    __syncthreads();
-    f32x4 s[4];
+    char* ks_t = smem + ((kt - kt_lo) & 1) * STAGE;
+    char* vs_t = ks_t + 64 * KSTR;
+    char* nx = smem + ((kt - kt_lo + 1) & 1) * STAGE;
+    bool more = kt + 1 < kt_hi;
+    if (more) {
+      rk.g2r(kb + (long)(kt + 1) * 64 * p.k_ss, p.Sk - (kt + 1) * 64);
+      rv.g2r(vb + (long)(kt + 1) * 64 * p.v_ss, p.Sk - (kt + 1) * 64);
+    }
+    f32x4 s[2][4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
-      s[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      s[0][nt] = f32x4{0.f, 0.f, 0.f, 0.f}; s[1][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) s[nt] = MFMA16(lfrag_kc<KSTR>(ks_t, nt * 16, ks), qf[ks], s[nt]);
+      for (int ks = 0; ks < NKS; ++ks) {
+        bf16x8 kf = lfrag_kc<KSTR>(ks_t, nt * 16, ks);
+        s[0][nt] = MFMA16(kf, qf[0][ks], s[0][nt]);
+        s[1][nt] = MFMA16(kf, qf[1][ks], s[1][nt]);
+      }
     }
-    float mloc = -INFINITY;
-    // wave-uniform fast path: every key of this tile is visible to every row of the wave (interior tiles)
-    bool full = __all(kt * 64 >= lo && kt * 64 + 64 <= hi);
-    if (full) {
+    bf16x8 pf[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      float mloc = -INFINITY;
+      bool full = __all(kt * 64 >= lo[u] && kt * 64 + 64 <= hi[u]);      // interior tile: no masking work
+      if (full) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mloc = fmaxf(mloc, s[u][nt][r]);
+      } else {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            int key = kt * 64 + nt * 16 + g * 4 + r;
+            float v = (key >= lo[u] && key < hi[u]) ? s[u][nt][r] : -INFINITY;
+            s[u][nt][r] = v;
+            mloc = fmaxf(mloc, v);
+          }
+      }
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+      float mnew = fmaxf(m[u], mloc * sc2);                 // running max in the scaled (log2) domain; sc2 > 0
+      float muse = (mnew == -INFINITY) ? 0.f : mnew;
+      float alpha = EXP2(m[u] - muse);
+      float rs = 0.f;
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { float v = s[nt][r] * sc2; s[nt][r] = v; mloc = fmaxf(mloc, v); }
-    } else {
+        for (int r = 0; r < 4; ++r) { float e = EXP2(fmaf(s[u][nt][r], sc2, -muse)); s[u][nt][r] = e; rs += e; }
+      rs += __shfl_xor(rs, 16, 64);
+      rs += __shfl_xor(rs, 32, 64);
+      lsum[u] = lsum[u] * alpha + rs;
+      m[u] = mnew;
+      pf[u][0] = pack8(s[u][0], s[u][1]); pf[u][1] = pack8(s[u][2], s[u][3]);
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          int key = kt * 64 + nt * 16 + g * 4 + r;
-          float v = (key >= lo && key < hi) ? s[nt][r] * sc2 : -INFINITY;
-          s[nt][r] = v;
-          mloc = fmaxf(mloc, v);
-        }
+      for (int nd = 0; nd < ND; ++nd) o[u][nd] *= alpha;
     }
-    mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
-    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-    float mnew = fmaxf(m, mloc);
-    float muse = (mnew == -INFINITY) ? 0.f : mnew;
-    float alpha = EXP2(m - muse);
-    float rs = 0.f;
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+    for (int nd = 0; nd < ND; ++nd)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { float e = EXP2(s[nt][r] - muse); s[nt][r] = e; rs += e; }
-    rs += __shfl_xor(rs, 16, 64);
-    rs += __shfl_xor(rs, 32, 64);
-    lsum = lsum * alpha + rs;
-    m = mnew;
-    bf16x8 pf[2] = {pack8(s[0], s[1]), pack8(s[2], s[3])};
-#pragma unroll
-    for (int nd = 0; nd < ND; ++nd) {
-      o[nd] *= alpha;
-#pragma unroll
-      for (int k2 = 0; k2 < 2; ++k2) o[nd] = MFMA16(lfrag_tr_perm<VSTR>(vs_t, k2 * 32, nd * 16), pf[k2], o[nd]);
+      for (int k2 = 0; k2 < 2; ++k2) {
+        bf16x8 vf = lfrag_tr_perm<VSTR>(vs_t, k2 * 32, nd * 16);
+        o[0][nd] = MFMA16(vf, pf[0][k2], o[0][nd]);
+        o[1][nd] = MFMA16(vf, pf[1][k2], o[1][nd]);
+      }
+    if (more) {
+      rk.r2s(nx);
+      rv.r2s(nx + 64 * KSTR);
     }
     __syncthreads();
   }
-  if (qr < p.Sq) {
-    float inv = lsum > 0.f ? 1.f / lsum : 0.f;
-    bf16* ob = p.o + b * p.o_bs + (long)qr * p.o_ss + h * p.o_hs;
 #pragma unroll
-    for (int nd = 0; nd < ND; ++nd) {
-      bf16x4 w = {f2bf(o[nd][0] * inv), f2bf(o[nd][1] * inv), f2bf(o[nd][2] * inv), f2bf(o[nd][3] * inv)};
-      *(bf16x4*)(ob + nd * 16 + g * 4) = w;
+  for (int u = 0; u < 2; ++u) {
+    int qr = q0 + u * 16 + (l & 15);
+    if (qr < p.Sq) {
+      float inv = lsum[u] > 0.f ? 1.f / lsum[u] : 0.f;
+      bf16* ob = p.o + b * p.o_bs + (long)qr * p.o_ss + h * p.o_hs;
+#pragma unroll
+      for (int nd = 0; nd < ND; ++nd) {
+        bf16x4 w = {f2bf(o[u][nd][0] * inv), f2bf(o[u][nd][1] * inv), f2bf(o[u][nd][2] * inv), f2bf(o[u][nd][3] * inv)};
+        *(bf16x4*)(ob + nd * 16 + g * 4) = w;
+      }
+      if (g == 0 && p.lse) p.lse[((long)b * p.H + h) * p.Sq + qr] = lsum[u] > 0.f ? (m[u] + log2f(lsum[u])) * LN2 : -INFINITY;
     }
-    if (g == 0 && p.lse) p.lse[((long)b * p.H + h) * p.Sq + qr] = lsum > 0.f ? (m + log2f(lsum)) * LN2 : -INFINITY;
   }
 }
 
@@ -217,155 +305,237 @@ __global__ void attn_delta_kernel(AttnP p) {
 }
 
 // ------------------------------------------------------------------------------------------- dQ
+// same geometry as the forward: 4 waves x 32 query rows, 64-key tiles double-buffered; K and V tiles share one image
+// layout (row reads for S and dP, transposed K reads for dQ).
 template <int DQK, int DV>
 __global__ __launch_bounds__(256) void attn_dq_kernel(AttnP p) {
   constexpr int STR = DQK * 2 + 16, NKS = DQK / 32, ND = DV / 16;
-  __shared__ __attribute__((aligned(16))) char smem[2 * 64 * STR];
-  char* ks_t = smem; char* vs_t = smem + 64 * STR;
+  constexpr int STAGE = 2 * 64 * STR;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
   int b = blockIdx.z, h = blockIdx.y;
   int wave = threadIdx.x >> 6, l = lane_id(), g = l >> 4;
-  int q0 = blockIdx.x * 64 + wave * 16;
-  int qr = q0 + (l & 15);
+  int q0 = blockIdx.x * 128 + wave * 32;
   const bf16* qb = p.q + b * p.q_bs + h * p.q_hs;
   const bf16* kb = p.k + b * p.k_bs + h * p.k_hs;
   const bf16* vb = p.v + b * p.v_bs + h * p.v_hs;
   const bf16* dob = p.d_o + b * p.do_bs + h * p.do_hs;
-  bf16x8 qf[NKS], dof[NKS];
+  bf16x8 qf[2][NKS], dof[2][NKS];
+  int lo[2], hi[2];
+  float lse2[2], dl[2];
 #pragma unroll
-  for (int ks = 0; ks < NKS; ++ks) { qf[ks] = gfrag(qb, p.q_ss, qr, p.Sq, ks, p.D); dof[ks] = gfrag(dob, p.do_ss, qr, p.Sq, ks, p.D); }
-  int lo, hi;
-  key_range(p, b, qr, lo, hi);
+  for (int u = 0; u < 2; ++u) {
+    int qr = q0 + u * 16 + (l & 15);
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) { qf[u][ks] = gfrag(qb, p.q_ss, qr, p.Sq, ks, p.D); dof[u][ks] = gfrag(dob, p.do_ss, qr, p.Sq, ks, p.D); }
+    key_range(p, b, qr, lo[u], hi[u]);
+    long sidx = ((long)b * p.H + h) * p.Sq + min(qr, p.Sq - 1);
+    lse2[u] = p.lse[sidx] * LOG2E; dl[u] = p.delta[sidx];
+  }
   int kt_lo, kt_hi;
-  block_key_tiles(p, b, blockIdx.x * 64, blockIdx.x * 64 + 63, kt_lo, kt_hi);
+  block_key_tiles(p, b, blockIdx.x * 128, blockIdx.x * 128 + 127, kt_lo, kt_hi);
   float sc2 = p.scale * LOG2E;
-  long sidx = ((long)b * p.H + h) * p.Sq + min(qr, p.Sq - 1);
-  float lse2 = p.lse[sidx] * LOG2E, dl = p.delta[sidx];
-  f32x4 dq[ND];
+  f32x4 dq[2][ND];
 #pragma unroll
-  for (int nd = 0; nd < ND; ++nd) dq[nd] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int nd = 0; nd < ND; ++nd) dq[u][nd] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  TileCopy<64, DQK, STR> rk, rv;
+  rk.init(p.k_ss, p.D); rv.init(p.v_ss, p.D);
+  if (DQK != DV) lds_zero(smem, 2 * STAGE);
+  if (kt_lo < kt_hi) {
+    rk.g2r(kb + (long)kt_lo * 64 * p.k_ss, p.Sk - kt_lo * 64);
+    rv.g2r(vb + (long)kt_lo * 64 * p.v_ss, p.Sk - kt_lo * 64);
+    rk.r2s(smem);
+    rv.r2s(smem + 64 * STR);
+  }
+  __syncthreads();
   for (int kt = kt_lo; kt < kt_hi; ++kt) {
-    load_tile<64, DQK, STR>(ks_t, kb, p.k_ss, kt * 64, p.Sk, p.D);
-    load_tile<64, DQK, STR>(vs_t, vb, p.v_ss, kt * 64, p.Sk, p.D);
-    __syncthreads();
-    f32x4 s[4], dp[4];
+    char* ks_t = smem + ((kt - kt_lo) & 1) * STAGE;
+    char* vs_t = ks_t + 64 * STR;
+    char* nx = smem + ((kt - kt_lo + 1) & 1) * STAGE;
+    bool more = kt + 1 < kt_hi;
+    if (more) {
+      rk.g2r(kb + (long)(kt + 1) * 64 * p.k_ss, p.Sk - (kt + 1) * 64);
+      rv.g2r(vb + (long)(kt + 1) * 64 * p.v_ss, p.Sk - (kt + 1) * 64);
+    }
+    f32x4 s[2][4], dp[2][4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
-      s[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 2; ++u) { s[u][nt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[u][nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
-        s[nt] = MFMA16(lfrag_kc<STR>(ks_t, nt * 16, ks), qf[ks], s[nt]);
-        dp[nt] = MFMA16(lfrag_kc<STR>(vs_t, nt * 16, ks), dof[ks], dp[nt]);
+        bf16x8 kf = lfrag_kc<STR>(ks_t, nt * 16, ks), vf = lfrag_kc<STR>(vs_t, nt * 16, ks);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { s[u][nt] = MFMA16(kf, qf[u][ks], s[u][nt]); dp[u][nt] = MFMA16(vf, dof[u][ks], dp[u][nt]); }
       }
     }
+    bf16x8 dsf[2][2];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+    for (int u = 0; u < 2; ++u) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int key = kt * 64 + nt * 16 + g * 4 + r;
-        float pr = (key >= lo && key < hi) ? EXP2(s[nt][r] * sc2 - lse2) : 0.f;
-        s[nt][r] = pr * (dp[nt][r] - dl) * p.scale;
-      }
-    bf16x8 dsf[2] = {pack8(s[0], s[1]), pack8(s[2], s[3])};
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int key = kt * 64 + nt * 16 + g * 4 + r;
+          float pr = (key >= lo[u] && key < hi[u]) ? EXP2(fmaf(s[u][nt][r], sc2, -lse2[u])) : 0.f;
+          s[u][nt][r] = pr * (dp[u][nt][r] - dl[u]) * p.scale;
+        }
+      dsf[u][0] = pack8(s[u][0], s[u][1]); dsf[u][1] = pack8(s[u][2], s[u][3]);
+    }
 #pragma unroll
     for (int nd = 0; nd < ND; ++nd)
 #pragma unroll
-      for (int k2 = 0; k2 < 2; ++k2) dq[nd] = MFMA16(lfrag_tr_perm<STR>(ks_t, k2 * 32, nd * 16), dsf[k2], dq[nd]);
+      for (int k2 = 0; k2 < 2; ++k2) {
+        bf16x8 kt_f = lfrag_tr_perm<STR>(ks_t, k2 * 32, nd * 16);
+        dq[0][nd] = MFMA16(kt_f, dsf[0][k2], dq[0][nd]);
+        dq[1][nd] = MFMA16(kt_f, dsf[1][k2], dq[1][nd]);
+      }
+    if (more) {
+      rk.r2s(nx);
+      rv.r2s(nx + 64 * STR);
+    }
     __syncthreads();
   }
-  if (qr < p.Sq) {
-    bf16* ob = p.dq + b * p.dq_bs + (long)qr * p.dq_ss + h * p.dq_hs;
 #pragma unroll
-    for (int nd = 0; nd < ND; ++nd) {
-      bf16x4 w = {f2bf(dq[nd][0]), f2bf(dq[nd][1]), f2bf(dq[nd][2]), f2bf(dq[nd][3])};
-      *(bf16x4*)(ob + nd * 16 + g * 4) = w;
+  for (int u = 0; u < 2; ++u) {
+    int qr = q0 + u * 16 + (l & 15);
+    if (qr < p.Sq) {
+      bf16* ob = p.dq + b * p.dq_bs + (long)qr * p.dq_ss + h * p.dq_hs;
+#pragma unroll
+      for (int nd = 0; nd < ND; ++nd) {
+        bf16x4 w = {f2bf(dq[u][nd][0]), f2bf(dq[u][nd][1]), f2bf(dq[u][nd][2]), f2bf(dq[u][nd][3])};
+        *(bf16x4*)(ob + nd * 16 + g * 4) = w;
+      }
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------- dK, dV
+// block = 128 keys: each wave owns 32 keys (two 16-key blocks whose K / V fragments live in registers) and sweeps the
+// query tiles (32 rows, double-buffered Q / dO images + per-row lse / delta / key range); P and dS stay in registers.
 template <int DQK, int DV>
 __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p) {
   constexpr int STR = DQK * 2 + 16, NKS = DQK / 32, ND = DV / 16;
-  __shared__ __attribute__((aligned(16))) char smem[2 * 32 * STR + 32 * 16];
-  char* qs_t = smem; char* dos_t = smem + 32 * STR;
-  float* st_lse = (float*)(smem + 2 * 32 * STR);     // [32] lse*log2e
-  float* st_dl = st_lse + 32;                          // [32] delta
-  int* st_lo = (int*)(st_dl + 32);                     // [32]
-  int* st_hi = st_lo + 32;                             // [32]
-  int b = blockIdx.z, h = blockIdx.y, kt = blockIdx.x;
+  constexpr int STAGE = 2 * 32 * STR + 32 * 16;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  int b = blockIdx.z, h = blockIdx.y, kblk = blockIdx.x;
   int wave = threadIdx.x >> 6, l = lane_id(), g = l >> 4;
-  int key = kt * 64 + wave * 16 + (l & 15);
+  int key0 = kblk * 128 + wave * 32;
   const bf16* qb = p.q + b * p.q_bs + h * p.q_hs;
   const bf16* kb = p.k + b * p.k_bs + h * p.k_hs;
   const bf16* vb = p.v + b * p.v_bs + h * p.v_hs;
   const bf16* dob = p.d_o + b * p.do_bs + h * p.do_hs;
-  bf16x8 kf[NKS], vf[NKS];
+  bf16x8 kf[2][NKS], vf[2][NKS];
+  f32x4 dk[2][ND], dv[2][ND];
 #pragma unroll
-  for (int ks = 0; ks < NKS; ++ks) { kf[ks] = gfrag(kb, p.k_ss, key, p.Sk, ks, p.D); vf[ks] = gfrag(vb, p.v_ss, key, p.Sk, ks, p.D); }
-  f32x4 dk[ND], dv[ND];
+  for (int u = 0; u < 2; ++u) {
+    int key = key0 + u * 16 + (l & 15);
 #pragma unroll
-  for (int nd = 0; nd < ND; ++nd) { dk[nd] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[nd] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int ks = 0; ks < NKS; ++ks) { kf[u][ks] = gfrag(kb, p.k_ss, key, p.Sk, ks, p.D); vf[u][ks] = gfrag(vb, p.v_ss, key, p.Sk, ks, p.D); }
+#pragma unroll
+    for (int nd = 0; nd < ND; ++nd) { dk[u][nd] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[u][nd] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  }
   float sc2 = p.scale * LOG2E;
   int nqt = (p.Sq + 31) >> 5;
-  int qt0 = 0;
-  if (p.mask_mode == UNIMP_MASK_CAUSAL) qt0 = (kt * 64) >> 5;
-  int kfirst = kt * 64, klast = kt * 64 + 63;
-
-  for (int qt = qt0; qt < nqt; ++qt) {
-    if (p.mask_mode == UNIMP_MASK_SEGMENT) {   // block-uniform skip of query tiles that cannot see this key tile
-      int ta = p.seg[(long)b * p.Sq + qt * 32], tb = p.seg[(long)b * p.Sq + min(qt * 32 + 31, p.Sq - 1)];
-      if (tb == 0 || tb * p.seg_len <= kfirst || (max(ta, 1) - 1) * p.seg_len > klast) continue;
-    }
-    load_tile<32, DQK, STR>(qs_t, qb, p.q_ss, qt * 32, p.Sq, p.D);
-    load_tile<32, DQK, STR>(dos_t, dob, p.do_ss, qt * 32, p.Sq, p.D);
+  int kfirst = kblk * 128, klast = kblk * 128 + 127;
+  // block-uniform list of query tiles that can see this key block: [qt_a, qt_b)
+  int qt_a = 0, qt_b = nqt;
+  if (p.mask_mode == UNIMP_MASK_CAUSAL) qt_a = kfirst >> 5;
+  else if (p.mask_mode == UNIMP_MASK_SEGMENT) {
+    // media_time is non-decreasing along the sequence: first / last tile whose rows can attend [kfirst, klast]
+    while (qt_a < nqt) { int tb = p.seg[(long)b * p.Sq + min(qt_a * 32 + 31, p.Sq - 1)]; if (tb * p.seg_len > kfirst) break; ++qt_a; }
+    while (qt_b > qt_a) { int ta = p.seg[(long)b * p.Sq + (qt_b - 1) * 32]; if ((max(ta, 1) - 1) * p.seg_len <= klast) break; --qt_b; }
+  }
+  TileCopy<32, DQK, STR> rq, rdo;
+  rq.init(p.q_ss, p.D); rdo.init(p.do_ss, p.D);
+  if (DQK != DV) lds_zero(smem, 2 * STAGE);
+  auto stage_aux = [&](char* st, int qt) {
     if (threadIdx.x < 32) {
+      float* st_lse = (float*)(st + 2 * 32 * STR);
       int qr = qt * 32 + threadIdx.x;
       long sidx = ((long)b * p.H + h) * p.Sq + min(qr, p.Sq - 1);
       st_lse[threadIdx.x] = p.lse[sidx] * LOG2E;
-      st_dl[threadIdx.x] = p.delta[sidx];
+      st_lse[32 + threadIdx.x] = p.delta[sidx];
       int lo, hi;
       key_range(p, b, qr, lo, hi);
-      st_lo[threadIdx.x] = lo; st_hi[threadIdx.x] = hi;
+      ((int*)st_lse)[64 + threadIdx.x] = lo; ((int*)st_lse)[96 + threadIdx.x] = hi;
     }
-    __syncthreads();
-    f32x4 s[2], dp[2];
+  };
+  if (qt_a < qt_b) {
+    rq.g2r(qb + (long)qt_a * 32 * p.q_ss, p.Sq - qt_a * 32);
+    rdo.g2r(dob + (long)qt_a * 32 * p.do_ss, p.Sq - qt_a * 32);
+    rq.r2s(smem);
+    rdo.r2s(smem + 32 * STR);
+    stage_aux(smem, qt_a);
+  }
+  __syncthreads();
+  for (int qt = qt_a; qt < qt_b; ++qt) {
+    char* st = smem + ((qt - qt_a) & 1) * STAGE;
+    char* nx = smem + ((qt - qt_a + 1) & 1) * STAGE;
+    const char* qs_t = st; const char* dos_t = st + 32 * STR;
+    const float* st_lse = (const float*)(st + 2 * 32 * STR);
+    const float* st_dl = st_lse + 32;
+    const int* st_lo = (const int*)(st_lse + 64); const int* st_hi = st_lo + 32;
+    bool more = qt + 1 < qt_b;
+    if (more) {
+      rq.g2r(qb + (long)(qt + 1) * 32 * p.q_ss, p.Sq - (qt + 1) * 32);
+      rdo.g2r(dob + (long)(qt + 1) * 32 * p.do_ss, p.Sq - (qt + 1) * 32);
+    }
+    f32x4 s[2][2], dp[2][2];              // [key block u][query block qb2]: lane holds S[q = 16*qb2 + 4g + r][key = l&15]
 #pragma unroll
     for (int qb2 = 0; qb2 < 2; ++qb2) {
-      s[qb2] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[qb2] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 2; ++u) { s[u][qb2] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[u][qb2] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
-        s[qb2] = MFMA16(lfrag_kc<STR>(qs_t, qb2 * 16, ks), kf[ks], s[qb2]);       // D[q][key]
-        dp[qb2] = MFMA16(lfrag_kc<STR>(dos_t, qb2 * 16, ks), vf[ks], dp[qb2]);
+        bf16x8 qf_ = lfrag_kc<STR>(qs_t, qb2 * 16, ks), dof_ = lfrag_kc<STR>(dos_t, qb2 * 16, ks);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { s[u][qb2] = MFMA16(qf_, kf[u][ks], s[u][qb2]); dp[u][qb2] = MFMA16(dof_, vf[u][ks], dp[u][qb2]); }
       }
     }
-    // lane holds S[q = 16*qb2 + 4g + r][key = l&15]
+    bf16x8 pf[2], dsf[2];
 #pragma unroll
-    for (int qb2 = 0; qb2 < 2; ++qb2)
+    for (int u = 0; u < 2; ++u) {
+      int key = key0 + u * 16 + (l & 15);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int ql = qb2 * 16 + g * 4 + r;
-        float pr = (key >= st_lo[ql] && key < st_hi[ql]) ? EXP2(s[qb2][r] * sc2 - st_lse[ql]) : 0.f;
-        s[qb2][r] = pr;
-        dp[qb2][r] = pr * (dp[qb2][r] - st_dl[ql]) * p.scale;
-      }
-    bf16x8 pf = pack8(s[0], s[1]), dsf = pack8(dp[0], dp[1]);
+      for (int qb2 = 0; qb2 < 2; ++qb2)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int ql = qb2 * 16 + g * 4 + r;
+          float pr = (key >= st_lo[ql] && key < st_hi[ql]) ? EXP2(fmaf(s[u][qb2][r], sc2, -st_lse[ql])) : 0.f;
+          s[u][qb2][r] = pr;
+          dp[u][qb2][r] = pr * (dp[u][qb2][r] - st_dl[ql]) * p.scale;
+        }
+      pf[u] = pack8(s[u][0], s[u][1]); dsf[u] = pack8(dp[u][0], dp[u][1]);
+    }
 #pragma unroll
     for (int nd = 0; nd < ND; ++nd) {
-      dv[nd] = MFMA16(lfrag_tr_perm<STR>(dos_t, 0, nd * 16), pf, dv[nd]);     // D[d][key]
-      dk[nd] = MFMA16(lfrag_tr_perm<STR>(qs_t, 0, nd * 16), dsf, dk[nd]);
+      bf16x8 dot_f = lfrag_tr_perm<STR>(dos_t, 0, nd * 16), qt_f = lfrag_tr_perm<STR>(qs_t, 0, nd * 16);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) { dv[u][nd] = MFMA16(dot_f, pf[u], dv[u][nd]); dk[u][nd] = MFMA16(qt_f, dsf[u], dk[u][nd]); }
+    }
+    if (more) {
+      rq.r2s(nx);
+      rdo.r2s(nx + 32 * STR);
+      stage_aux(nx, qt + 1);
     }
     __syncthreads();
   }
-  if (key < p.Sk) {
-    bf16* okb = p.dk + b * p.dk_bs + (long)key * p.dk_ss + h * p.dk_hs;
-    bf16* ovb = p.dv + b * p.dv_bs + (long)key * p.dv_ss + h * p.dv_hs;
 #pragma unroll
-    for (int nd = 0; nd < ND; ++nd) {
-      bf16x4 a = {f2bf(dk[nd][0]), f2bf(dk[nd][1]), f2bf(dk[nd][2]), f2bf(dk[nd][3])};
-      bf16x4 c = {f2bf(dv[nd][0]), f2bf(dv[nd][1]), f2bf(dv[nd][2]), f2bf(dv[nd][3])};
-      *(bf16x4*)(okb + nd * 16 + g * 4) = a;
-      *(bf16x4*)(ovb + nd * 16 + g * 4) = c;
+  for (int u = 0; u < 2; ++u) {
+    int key = key0 + u * 16 + (l & 15);
+    if (key < p.Sk) {
+      bf16* okb = p.dk + b * p.dk_bs + (long)key * p.dk_ss + h * p.dk_hs;
+      bf16* ovb = p.dv + b * p.dv_bs + (long)key * p.dv_ss + h * p.dv_hs;
+#pragma unroll
+      for (int nd = 0; nd < ND; ++nd) {
+        bf16x4 a = {f2bf(dk[u][nd][0]), f2bf(dk[u][nd][1]), f2bf(dk[u][nd][2]), f2bf(dk[u][nd][3])};
+        bf16x4 c = {f2bf(dv[u][nd][0]), f2bf(dv[u][nd][1]), f2bf(dv[u][nd][2]), f2bf(dv[u][nd][3])};
+        *(bf16x4*)(okb + nd * 16 + g * 4) = a;
+        *(bf16x4*)(ovb + nd * 16 + g * 4) = c;
+      }
     }
   }
 }
@@ -403,7 +573,7 @@ extern "C" int unimp_attn_fwd(const unimp_attn_desc* d, void* stream) {
   int e = fill(p, d, false);
   if (e) return e;
   if (p.B <= 0 || p.H <= 0 || p.Sq <= 0) return UNIMP_OK;
-  dim3 grid((p.Sq + 63) / 64, p.H, p.B), block(256);
+  dim3 grid((p.Sq + 127) / 128, p.H, p.B), block(256);
   hipStream_t s = (hipStream_t)stream;
   if (p.D == 64) hipLaunchKernelGGL((attn_fwd_kernel<64, 64>), grid, block, 0, s, p);
   else if (p.D == 80) hipLaunchKernelGGL((attn_fwd_kernel<96, 80>), grid, block, 0, s, p);
@@ -419,7 +589,7 @@ extern "C" int unimp_attn_bwd(const unimp_attn_desc* d, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   long n = (long)p.B * p.H * p.Sq;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((n * 16 + 255) / 256)), dim3(256), 0, s, p);
-  dim3 gq((p.Sq + 63) / 64, p.H, p.B), gk((p.Sk + 63) / 64, p.H, p.B), block(256);
+  dim3 gq((p.Sq + 127) / 128, p.H, p.B), gk((p.Sk + 127) / 128, p.H, p.B), block(256);
   if (p.D == 64) { hipLaunchKernelGGL((attn_dq_kernel<64, 64>), gq, block, 0, s, p); hipLaunchKernelGGL((attn_dkv_kernel<64, 64>), gk, block, 0, s, p); }
   else if (p.D == 80) { hipLaunchKernelGGL((attn_dq_kernel<96, 80>), gq, block, 0, s, p); hipLaunchKernelGGL((attn_dkv_kernel<96, 80>), gk, block, 0, s, p); }
   else { hipLaunchKernelGGL((attn_dq_kernel<128, 128>), gq, block, 0, s, p); hipLaunchKernelGGL((attn_dkv_kernel<128, 128>), gk, block, 0, s, p); }
