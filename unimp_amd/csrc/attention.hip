@@ -374,14 +374,25 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(AttnP p) {
     bf16x8 dsf[2][2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
+      bool full = __all(kt * 64 >= lo[u] && kt * 64 + 64 <= hi[u]);      // interior tile: no masking work
+      if (full) {
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
+        for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          int key = kt * 64 + nt * 16 + g * 4 + r;
-          float pr = (key >= lo[u] && key < hi[u]) ? EXP2(fmaf(s[u][nt][r], sc2, -lse2[u])) : 0.f;
-          s[u][nt][r] = pr * (dp[u][nt][r] - dl[u]) * p.scale;
-        }
+          for (int r = 0; r < 4; ++r) {
+            float pr = EXP2(fmaf(s[u][nt][r], sc2, -lse2[u]));
+            s[u][nt][r] = pr * (dp[u][nt][r] - dl[u]) * p.scale;
+          }
+      } else {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            int key = kt * 64 + nt * 16 + g * 4 + r;
+            float pr = (key >= lo[u] && key < hi[u]) ? EXP2(fmaf(s[u][nt][r], sc2, -lse2[u])) : 0.f;
+            s[u][nt][r] = pr * (dp[u][nt][r] - dl[u]) * p.scale;
+          }
+      }
       dsf[u][0] = pack8(s[u][0], s[u][1]); dsf[u][1] = pack8(s[u][2], s[u][3]);
     }
 #pragma unroll
@@ -418,7 +429,7 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(AttnP p) {
 template <int DQK, int DV>
 __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p) {
   constexpr int STR = DQK * 2 + 16, NKS = DQK / 32, ND = DV / 16;
-  constexpr int STAGE = 2 * 32 * STR + 32 * 16;
+  constexpr int STAGE = 2 * 32 * STR + 32 * 16 + 16;
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
   int b = blockIdx.z, h = blockIdx.y, kblk = blockIdx.x;
   int wave = threadIdx.x >> 6, l = lane_id(), g = l >> 4;
@@ -461,6 +472,9 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p) {
       int lo, hi;
       key_range(p, b, qr, lo, hi);
       ((int*)st_lse)[64 + threadIdx.x] = lo; ((int*)st_lse)[96 + threadIdx.x] = hi;
+      // all 32 rows of this query tile see every key of the block -> the waves skip the per-element mask
+      unsigned long long okm = __ballot(lo <= kfirst && hi > klast);
+      if (threadIdx.x == 0) ((int*)st_lse)[128] = (okm & 0xffffffffull) == 0xffffffffull;
     }
   };
   if (qt_a < qt_b) {
@@ -496,18 +510,37 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p) {
       }
     }
     bf16x8 pf[2], dsf[2];
+    float lse_r[2][4], dl_r[2][4];
+#pragma unroll
+    for (int qb2 = 0; qb2 < 2; ++qb2) {
+      f32x4 a = *(const f32x4*)(st_lse + qb2 * 16 + g * 4), d = *(const f32x4*)(st_dl + qb2 * 16 + g * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { lse_r[qb2][r] = a[r]; dl_r[qb2][r] = d[r]; }
+    }
+    bool all_visible = st_lo[64] != 0;        // word 128 of the aux block
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       int key = key0 + u * 16 + (l & 15);
+      if (all_visible && key < p.Sk) {
 #pragma unroll
-      for (int qb2 = 0; qb2 < 2; ++qb2)
+        for (int qb2 = 0; qb2 < 2; ++qb2)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          int ql = qb2 * 16 + g * 4 + r;
-          float pr = (key >= st_lo[ql] && key < st_hi[ql]) ? EXP2(fmaf(s[u][qb2][r], sc2, -st_lse[ql])) : 0.f;
-          s[u][qb2][r] = pr;
-          dp[u][qb2][r] = pr * (dp[u][qb2][r] - st_dl[ql]) * p.scale;
-        }
+          for (int r = 0; r < 4; ++r) {
+            float pr = EXP2(fmaf(s[u][qb2][r], sc2, -lse_r[qb2][r]));
+            s[u][qb2][r] = pr;
+            dp[u][qb2][r] = pr * (dp[u][qb2][r] - dl_r[qb2][r]) * p.scale;
+          }
+      } else {
+#pragma unroll
+        for (int qb2 = 0; qb2 < 2; ++qb2)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            int ql = qb2 * 16 + g * 4 + r;
+            float pr = (key >= st_lo[ql] && key < st_hi[ql]) ? EXP2(fmaf(s[u][qb2][r], sc2, -lse_r[qb2][r])) : 0.f;
+            s[u][qb2][r] = pr;
+            dp[u][qb2][r] = pr * (dp[u][qb2][r] - dl_r[qb2][r]) * p.scale;
+          }
+      }
       pf[u] = pack8(s[u][0], s[u][1]); dsf[u] = pack8(dp[u][0], dp[u][1]);
     }
 #pragma unroll

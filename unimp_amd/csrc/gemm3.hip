@@ -22,6 +22,9 @@
 #include "gemm_tile.h"
 
 #define G3_BM 256
+#ifndef G3_NST
+#define G3_NST 4          // LDS ring depth in 32-k half-stages (4 x 32 KiB for 256 x 256 tiles; 5 = the whole 160 KiB LDS measured no faster)
+#endif
 
 __device__ __forceinline__ int kc32_off(int row, int chunk) { return row * 64 + ((chunk ^ (((row >> 3) & 1) * 3)) << 4); }
 
@@ -149,13 +152,13 @@ __global__ __launch_bounds__(512, 2) void gemm3_bf16_kernel(Gemm2Params p) {
   uint32_t aoff[G3_BM / 128], boff[BN / 128];
   dma_setup<AKS, G3_BM>(p.lda, m0, p.M, wave, aoff);
   dma_setup<BKS, BN>(p.ldb, n0, p.N, wave, boff);
-#define DMA(H) do { char* b_ = smem + ((H) & 3) * SUB;                                                             \
+#define DMA(H) do { char* b_ = smem + ((H) % G3_NST) * SUB;                                                             \
     dma_issue<AKS, G3_BM>(p.A, p.lda, (H), p.K, b_, wave, aoff);                                                   \
     dma_issue<BKS, BN>(p.B, p.ldb, (H), p.K, b_ + A_SUB, wave, boff); } while (0)
   const uint32_t smem_lds = (uint32_t)(uintptr_t)LDS_PTR(char, smem);
   const uint32_t lbA = AKS ? ks32_lane_base<G3_BM>(wm * 128) : 0u, lbB = BKS ? ks32_lane_base<BN>(wn * WN) : 0u;
-#define LOADF(S, H) do { const char* b_ = smem + ((H) & 3) * SUB;                                                  \
-    uint32_t ub_ = smem_lds + ((H) & 3) * SUB;                                                                     \
+#define LOADF(S, H) do { const char* b_ = smem + ((H) % G3_NST) * SUB;                                                  \
+    uint32_t ub_ = smem_lds + ((H) % G3_NST) * SUB;                                                                     \
     _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                               \
       if (BKS) frag_ks32_asm<BN>(lbB + ub_ + A_SUB, j, lb##S[j], hb##S[j]);                                        \
       else rb##S[j] = frag_kc32(b_ + A_SUB, wn * WN + j * 16); }                                                   \
@@ -171,17 +174,18 @@ __global__ __launch_bounds__(512, 2) void gemm3_bf16_kernel(Gemm2Params p) {
     G3_PRIO(0); } while (0)
 // one half-step: L phase (prefetch h+3, fragments of h+1 -> RN), barrier, C phase (MFMA on RC), barrier
 #define HALF_STEP(H, SC, SN) do {                                                                                  \
-    if ((H) + 3 < nh) DMA((H) + 3);                                                                                \
+    if ((H) + PD < nh) DMA((H) + PD);                                                                              \
     if ((H) + 1 < nh) LOADF(SN, (H) + 1);                                                                          \
-    if ((H) + 3 < nh) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NEW) : "memory");                                  \
+    /* half-step H+2 must have landed; the (PD-2) younger ones may stay in flight (fewer near the end of K) */     \
+    if ((H) + PD < nh) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((PD - 2) * NEW) : "memory");                      \
+    else if ((H) + PD - 1 < nh && PD >= 4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((PD - 3) * NEW) : "memory");  \
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                          \
     G3_BARRIER();                                                                                                  \
     MFMAS(SC);                                                                                                     \
     G3_BARRIER(); } while (0)
 
-  DMA(0);
-  if (nh > 1) DMA(1);
-  if (nh > 2) DMA(2);
+  constexpr int PD = G3_NST - 1;                        // prefetch distance in half-steps
+  for (int h0 = 0; h0 < PD && h0 < nh; ++h0) DMA(h0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   G3_BARRIER();
   LOADF(0, 0);
@@ -231,7 +235,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_bf16_kernel(Gemm2Params p) {
 template <bool AKS, bool BKS, int BN>
 static void launch3(const Gemm2Params& p, hipStream_t s) {
   static bool attr_set = false;
-  constexpr size_t lds = 4 * (G3_BM * 64 + BN * 64);
+  constexpr size_t lds = G3_NST * (G3_BM * 64 + BN * 64);
   auto kern = gemm3_bf16_kernel<AKS, BKS, BN>;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
   hipLaunchKernelGGL(kern, dim3(p.nbm * p.nbn), dim3(512), lds, s, p);
