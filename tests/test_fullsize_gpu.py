@@ -110,3 +110,30 @@ def test_ragged_batches_vs_oracle(case):
         with torch.no_grad():
             got2 = hm(vx.cuda(), batch["lang_x"].cuda(), batch["attention_mask"].cuda())["logits"]
         assert torch.equal(got[0], got2[0])        # no <image> token in the row: images cannot influence it
+
+
+def test_checkpoint_roundtrip_and_resume(tmp_path):
+    """trainable-only checkpoint (UniMP format) + resume side file: a resumed trainer continues bit-identically."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import _parity as P
+    from unimp_amd.train import Trainer, save_checkpoint, load_checkpoint, get_checkpoint
+    cfg = P.TINY
+    om, layout = P.build_oracle(cfg)
+    batches = [{k: v.cuda() for k, v in P.make_batch(cfg, layout, seed=50 + i).items()} for i in range(4)]
+    hm = P.build_hip(cfg, om, layout)
+    tr = Trainer(hm, layout.special(), lr=1e-3, lr_scheduler="cosine", warmup_steps=1, total_steps=10)
+    for b in batches[:2]:
+        tr.step(b)
+    ck = str(tmp_path / "weights_epoch_0.pt")
+    save_checkpoint(ck, hm, tr, epoch=0)
+    sd = torch.load(ck)
+    assert set(sd) == set(get_checkpoint(hm)) and all("vision_encoder" not in k for k in sd)
+    assert any("gated_cross_attn_layer" in k for k in sd) and "perceiver.latents" in sd
+    ref = [tr.step(b)[0].item() for b in batches[2:]]
+    hm2 = P.build_hip(cfg, om, layout)
+    tr2 = Trainer(hm2, layout.special(), lr=1e-3, lr_scheduler="cosine", warmup_steps=1, total_steps=10)
+    assert load_checkpoint(ck, hm2, tr2) == 1
+    got = [tr2.step(b)[0].item() for b in batches[2:]]
+    assert got == ref, (got, ref)
+    assert torch.equal(tr.opt.master, tr2.opt.master)

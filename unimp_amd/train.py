@@ -43,6 +43,42 @@ def get_checkpoint(model):
     return sd
 
 
+def save_checkpoint(path, model, trainer=None, epoch=0):
+    """UniMP writes only the trainable tensors (mmrec.py:873-892: ``get_checkpoint``) and never the optimizer, so its
+    resume path is broken.  Same file format for the weights -- a flat ``{name: tensor}`` dict that
+    ``model.load_state_dict(sd, strict=False)`` consumes -- plus, optionally, a side file with the fp32 optimizer state
+    and the scheduler position so a run can actually resume."""
+    sd = {k: v.detach().to("cpu") for k, v in get_checkpoint(model).items()}
+    torch.save(sd, path)
+    if trainer is not None:
+        o = trainer.opt.state_dict()
+        torch.save({"epoch": epoch, "sched_step": trainer.sched_step,
+                    "optimizer": {k: (v.detach().to("cpu") if torch.is_tensor(v) else v) for k, v in o.items()}},
+                   path + ".resume")
+
+
+def load_checkpoint(path, model, trainer=None):
+    """inverse of save_checkpoint; also accepts OpenFlamingo ``checkpoint.pt`` / UniMP ``weights_epoch_*.pt`` files
+    (same parameter names).  Returns the epoch to resume from (0 without a .resume side file)."""
+    import os
+    sd = torch.load(path, map_location="cpu")
+    if "model_state_dict" in sd:
+        sd = sd["model_state_dict"]
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    if unexpected:
+        raise KeyError(f"unexpected keys in checkpoint: {unexpected[:5]} ...")
+    epoch = 0
+    if trainer is not None:
+        # parameters are views of the flat bf16 buffer: refresh the fp32 master copy from what was just loaded
+        for n, p, o, k in trainer.opt.layout:
+            trainer.opt.master[o:o + k].copy_(p.detach().reshape(-1))
+        if os.path.exists(path + ".resume"):
+            r = torch.load(path + ".resume", map_location="cpu")
+            trainer.opt.load_state_dict(r["optimizer"])
+            trainer.sched_step, epoch = r["sched_step"], r["epoch"] + 1
+    return epoch
+
+
 class Trainer:
     def __init__(self, model, special_ids, lr=2e-4, weight_decay=0.1, gamma=2.0, use_reweight=True, max_grad_norm=1.0,
                  lr_scheduler="cosine", warmup_steps=0, total_steps=1000, bucket_bytes=256 << 20, process_group=None):
