@@ -137,3 +137,41 @@ def test_checkpoint_roundtrip_and_resume(tmp_path):
     got = [tr2.step(b)[0].item() for b in batches[2:]]
     assert got == ref, (got, ref)
     assert torch.equal(tr.opt.master, tr2.opt.master)
+
+
+def test_generate_greedy_and_beam_tiny():
+    """Flamingo.generate on the tiny model: greedy tokens follow the fp32 oracle's greedy decode while the
+    oracle's top-2 margin is clear of bf16 noise; beam search returns K hypotheses that extend the prompt."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import _parity as P
+    from unimp_amd.generate import greedy_search
+    cfg = P.TINY
+    om, layout = P.build_oracle(cfg)
+    for p_ in om.lang_encoder.embed_out.parameters():
+        p_.data.mul_(4.0)                     # peakier next-token distributions
+    hm = P.build_hip(cfg, om, layout).eval()
+    batch = P.make_batch(cfg, layout)
+    n = int(batch["attention_mask"][0].sum())
+    ids = batch["lang_x"][:1, :n - 2]           # one user, prompt ends right after "<answer>"
+    vx = batch["vision_x"][:1]
+    got = hm.generate(vx.cuda(), ids.cuda(), max_new_tokens=6, eos_token_id=layout.eos, pad_token_id=layout.eos).cpu()
+    assert got.shape[1] <= ids.shape[1] + 6 and torch.equal(got[:, :ids.shape[1]], ids)
+
+    om.eval()
+    margins = []
+    def oracle_logits(seqs):
+        with torch.no_grad():
+            lg = om(vx.expand(seqs.shape[0], *vx.shape[1:]), seqs, None)["logits"][:, -1]
+        t = lg.topk(2, -1).values
+        margins.append(float((t[0, 0] - t[0, 1]) / lg.abs().max()))
+        return lg
+    want = greedy_search(oracle_logits, ids, 6, layout.eos, layout.eos)
+    for j in range(ids.shape[1], min(got.shape[1], want.shape[1])):
+        if margins[j - ids.shape[1]] < 0.02:
+            break                                 # near-tie: bf16 may legitimately pick the other token
+        assert got[0, j] == want[0, j], (j, got.tolist(), want.tolist(), margins)
+    beams = hm.generate(vx.cuda(), ids.cuda(), num_beams=4, num_return_sequences=4, early_stopping=True, max_new_tokens=5,
+                        eos_token_id=layout.eos, pad_token_id=layout.eos).cpu()
+    assert beams.shape[0] == 4 and torch.equal(beams[:, :ids.shape[1]], ids.expand(4, -1))
+    assert len({tuple(r.tolist()) for r in beams}) == 4

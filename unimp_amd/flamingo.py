@@ -221,8 +221,43 @@ class Flamingo(nn.Module):
             layer.condition_media_time(None)
             layer.condition_use_cached_media(None)
 
+    @torch.no_grad()
     def generate(self, vision_x, lang_x, attention_mask=None, **kwargs):
-        raise NotImplementedError("generate() (beam search with cached media) is SURVEY.md §8(f) F1, not built yet")
+        """open_flamingo ``Flamingo.generate`` (eval_rec.py:100-110): vision encoded once (repeated per beam),
+        then greedy / beam search over the LM (generate.py: transformers' BeamSearchScorer semantics).  The decode loop has
+        no KV cache yet: every step re-scores the full sequences with the media kept conditioned."""
+        from .generate import beam_search, greedy_search
+        if attention_mask is not None and not bool(attention_mask.all()):
+            raise NotImplementedError("generate() with padded prompts (UniMP evaluates one user at a time, eval_rec.py:32-110)")
+        num_beams = kwargs.pop("num_beams", 1)
+        if num_beams > 1:
+            vision_x = vision_x.repeat_interleave(num_beams, dim=0)
+        eos_token_id = kwargs.pop("eos_token_id", self.eoc_token_id)
+        pad_token_id = kwargs.pop("pad_token_id", eos_token_id)
+        max_new_tokens = kwargs.pop("max_new_tokens", 20)
+        nret = kwargs.pop("num_return_sequences", 1)
+        early = kwargs.pop("early_stopping", False)
+        ngram = kwargs.pop("no_repeat_ngram_size", 0)
+        lp = kwargs.pop("length_penalty", 1.0)
+        if kwargs.pop("do_sample", False) or kwargs:
+            raise NotImplementedError(f"unsupported generate() arguments: do_sample / {sorted(kwargs)}")
+        was_training = self.training
+        self.eval()
+        self.lang_encoder._use_cached_vision_x = True
+        self._encode_vision_x(vision_x=vision_x)
+        try:
+            def logits_fn(seqs):
+                self._condition_media_locations(input_ids=seqs)
+                return self.lang_encoder(input_ids=seqs, attention_mask=None, logits_last_only=True)["logits"][:, -1]
+            if num_beams > 1:
+                out = beam_search(logits_fn, lang_x, num_beams, max_new_tokens, eos_token_id, pad_token_id, nret, early, lp, ngram)
+            else:
+                out = greedy_search(logits_fn, lang_x, max_new_tokens, eos_token_id, pad_token_id)
+        finally:
+            self.clear_conditioned_layers()
+            self.lang_encoder._use_cached_vision_x = False
+            self.train(was_training)
+        return out
 
 
 def freeze_like_factory(model, freeze_lm_embeddings=False):

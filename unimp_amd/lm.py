@@ -106,9 +106,11 @@ class _TowerBase(nn.Module):
             return None
         return attention_mask.sum(1).to(torch.int32)          # right padding (collate_rec.py:38-74)
 
-    def _head(self, h, labels):
+    def _head(self, h, labels, last_only=False):
         w = self.get_output_embeddings().weight
         V = w.shape[0]
+        if last_only:                      # decoding: score only the final position (generate.py)
+            h = h[:, -1:].contiguous()
         logits = F_.linear(h, w, None, _pad8(V) if V % 8 else None)
         loss = stats = None
         if labels is not None:
@@ -196,7 +198,7 @@ class GPTNeoXForCausalLM(_TowerBase):
             x = layer(x, attention_mask=kv_len, rope=rope)
         f = self.gpt_neox.final_layer_norm
         h = F_.layer_norm(x, f.weight, f.bias, f.eps)
-        return self._head(h, labels)
+        return self._head(h, labels, kw.get("logits_last_only", False))
 
 
 # --------------------------------------------------------------------------- OPT
@@ -278,7 +280,7 @@ class OPTForCausalLM(_TowerBase):
             x = layer(x, attention_mask=kv_len)
         f = d.final_layer_norm
         h = F_.layer_norm(x, f.weight, f.bias, f.eps)
-        return self._head(h, labels)
+        return self._head(h, labels, kw.get("logits_last_only", False))
 
 
 # --------------------------------------------------------------------------- Llama (in-tree UniMP/xformers_model/llama.py)
@@ -387,7 +389,7 @@ class LlamaForCausalLM(_TowerBase):
             x = layer(x, attention_mask=None, rope=rope)
         n = self.model.norm
         h = F_.layer_norm(x, n.weight, None, n.variance_epsilon, rms=True)
-        return self._head(h, labels)
+        return self._head(h, labels, kw.get("logits_last_only", False))
 
 
 def build_lm(name_or_config):
