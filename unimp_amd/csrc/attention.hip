@@ -199,6 +199,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
       rk.g2r(kb + (long)(kt + 1) * 64 * p.k_ss, p.Sk - (kt + 1) * 64);
       rv.g2r(vb + (long)(kt + 1) * 64 * p.v_ss, p.Sk - (kt + 1) * 64);
     }
+    if (q0 < p.Sq) {        // wave-uniform: a wave whose rows all lie beyond Sq (S = 257 -> 384 padded rows) only helps with the loads
     f32x4 s[2][4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
@@ -257,6 +258,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
         o[0][nd] = MFMA16(vf, pf[0][k2], o[0][nd]);
         o[1][nd] = MFMA16(vf, pf[1][k2], o[1][nd]);
       }
+    }
     if (more) {
       rk.r2s(nx);
       rv.r2s(nx + 64 * KSTR);
@@ -359,6 +361,7 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(AttnP p) {
       rk.g2r(kb + (long)(kt + 1) * 64 * p.k_ss, p.Sk - (kt + 1) * 64);
       rv.g2r(vb + (long)(kt + 1) * 64 * p.v_ss, p.Sk - (kt + 1) * 64);
     }
+    if (q0 < p.Sq) {
     f32x4 s[2][4], dp[2][4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
@@ -403,6 +406,7 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(AttnP p) {
         dq[0][nd] = MFMA16(kt_f, dsf[0][k2], dq[0][nd]);
         dq[1][nd] = MFMA16(kt_f, dsf[1][k2], dq[1][nd]);
       }
+    }
     if (more) {
       rk.r2s(nx);
       rv.r2s(nx + 64 * STR);
@@ -497,6 +501,7 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p) {
       rq.g2r(qb + (long)(qt + 1) * 32 * p.q_ss, p.Sq - (qt + 1) * 32);
       rdo.g2r(dob + (long)(qt + 1) * 32 * p.do_ss, p.Sq - (qt + 1) * 32);
     }
+    if (key0 < p.Sk) {
     f32x4 s[2][2], dp[2][2];              // [key block u][query block qb2]: lane holds S[q = 16*qb2 + 4g + r][key = l&15]
 #pragma unroll
     for (int qb2 = 0; qb2 < 2; ++qb2) {
@@ -548,6 +553,7 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p) {
       bf16x8 dot_f = lfrag_tr_perm<STR>(dos_t, 0, nd * 16), qt_f = lfrag_tr_perm<STR>(qs_t, 0, nd * 16);
 #pragma unroll
       for (int u = 0; u < 2; ++u) { dv[u][nd] = MFMA16(dot_f, pf[u], dv[u][nd]); dk[u][nd] = MFMA16(qt_f, dsf[u], dk[u][nd]); }
+    }
     }
     if (more) {
       rq.r2s(nx);
