@@ -63,7 +63,7 @@ int unimp_gemm_bf16(const unimp_gemm_desc* d, void* stream);
  *   PP256/128   256 x {256,128} tiles, 8 waves, LDS-DMA, 4-deep ring of 32-k half-stages, SIMD partners ping-ponged
  * AUTO picks by shape; the Python layer autotunes per (shape, layout) on first use. */
 enum { UNIMP_GEMM_AUTO = 0, UNIMP_GEMM_V1 = 1, UNIMP_GEMM_DMA256 = 2, UNIMP_GEMM_DMA128 = 3, UNIMP_GEMM_PP256 = 4,
-       UNIMP_GEMM_PP128 = 5 };
+       UNIMP_GEMM_PP128 = 5, UNIMP_GEMM_SKINNY = 6 /* M <= 64 (decode): W streamed once, no LDS staging */ };
 int unimp_gemm_bf16_variant(const unimp_gemm_desc* d, int variant, void* stream);
 /* split-K form for outputs much smaller than the chip (weight gradients of narrow projections): `splits` K slices into
  * f32 slabs [splits][M][N] (caller-provided workspace), then an ordered reduction applying alpha*tanh(gate).  Only the
@@ -100,7 +100,8 @@ int unimp_rope_halfsplit(void* x, int64_t row_stride, int64_t head_stride, int r
  * replaces xformers.ops.memory_efficient_attention (clip.py:130-136; llama.py:287-301), the GPT-NeoX causal
  * SDPA, open_flamingo PerceiverAttention and MaskedCrossAttention softmax(QK^T)V.
  * q/k/v/o are [B][S][H][D] views with element strides (batch, seq, head); D in {64, 80, 128}.
- *   MASK_NONE   : keys j < kv_len[b] (kv_len NULL: all Sk)
+ *   MASK_NONE   : keys j < kv_len[b] (kv_len NULL: all Sk).  K/V rows in [kv_len[b], Sk) are still loaded (whole 64-key
+ *                 tiles) and weighted with p = 0: they must hold finite values (a KV cache is zero-initialised)
  *   MASK_CAUSAL : keys j <= i and j < kv_len[b]
  *   MASK_SEGMENT: query i attends keys [(t-1)*seg_len, t*seg_len) with t = seg[b*Sq+i]; t == 0: output 0
  *                 (open_flamingo only_attend_immediate_media=True, rows before the first <image> zeroed)

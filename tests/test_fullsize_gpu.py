@@ -175,3 +175,78 @@ def test_generate_greedy_and_beam_tiny():
                         eos_token_id=layout.eos, pad_token_id=layout.eos).cpu()
     assert beams.shape[0] == 4 and torch.equal(beams[:, :ids.shape[1]], ids.expand(4, -1))
     assert len({tuple(r.tolist()) for r in beams}) == 4
+
+
+@pytest.mark.parametrize("cfg_name", ["TINY", "TINY_OPT", "TINY_PAR"])
+def test_kv_cache_decode_matches_full_rescoring(cfg_name):
+    """F1 KV-cache decode: prefill + one-token steps give the logits of a full forward over the grown sequence (same
+    kernels, different tiling of the same sums -> bf16-level agreement), and generate(use_cache=True) returns the tokens of
+    generate(use_cache=False) for greedy and beam search."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import _parity as P
+    cfg = getattr(P, cfg_name)
+    om, layout = P.build_oracle(cfg)
+    for p_ in om.lang_encoder.get_output_embeddings().parameters():
+        p_.data.mul_(4.0)
+    hm = P.build_hip(cfg, om, layout).eval()
+    batch = P.make_batch(cfg, layout)
+    n = int(batch["attention_mask"][0].sum())
+    ids = batch["lang_x"][:1, :n - 2].cuda()
+    vx = batch["vision_x"][:1].cuda()
+    new = torch.randint(0, 100, (1, 4), device="cuda")
+    with torch.no_grad():
+        full = hm(vx, torch.cat([ids, new], 1))["logits"].float()
+        out = hm(vx, ids, use_cache=True, clear_conditioned_layers=False)
+        hm.lang_encoder._use_cached_vision_x = True
+        try:
+            pkv = out.past_key_values
+            assert pkv.len == ids.shape[1]
+            steps = [out["logits"][:, -1].float()]
+            for j in range(4):
+                o = hm(None, new[:, j:j + 1], past_key_values=pkv, use_cache=True, clear_conditioned_layers=False)
+                steps.append(o["logits"][:, -1].float())
+        finally:
+            hm.lang_encoder._use_cached_vision_x = False
+            hm.clear_conditioned_layers()
+    L0 = ids.shape[1]
+    scale = float(full.abs().max())
+    for j, lg in enumerate(steps):
+        err = float((lg - full[:, L0 - 1 + j]).abs().max()) / scale
+        assert err < 2e-2, (j, err)
+    kw = dict(eos_token_id=layout.eos, pad_token_id=layout.eos)
+    a = hm.generate(vx, ids, max_new_tokens=6, use_cache=True, **kw)
+    b = hm.generate(vx, ids, max_new_tokens=6, use_cache=False, **kw)
+    m = min(a.shape[1], b.shape[1])
+    agree = int((a[0, :m] == b[0, :m]).long().cumprod(0).sum())
+    assert agree >= L0 + 2, (a.tolist(), b.tolist())      # a later near-tie may legitimately split in bf16
+    ka = hm.generate(vx, ids, num_beams=3, num_return_sequences=3, early_stopping=True, max_new_tokens=5, use_cache=True, **kw)
+    kb = hm.generate(vx, ids, num_beams=3, num_return_sequences=3, early_stopping=True, max_new_tokens=5, use_cache=False, **kw)
+    assert ka.shape[0] == kb.shape[0] == 3
+    assert torch.equal(ka[0, :L0 + 2], kb[0, :L0 + 2]), (ka.tolist(), kb.tolist())
+    # the HIP-graph replay of the step runs the very same kernels on the very same buffers: bit-identical tokens
+    kc = hm.generate(vx, ids, num_beams=3, num_return_sequences=3, early_stopping=True, max_new_tokens=5, use_graph=False, **kw)
+    assert torch.equal(ka, kc), (ka.tolist(), kc.tolist())
+    g0 = hm.generate(vx, ids, max_new_tokens=6, use_graph=False, **kw)
+    assert torch.equal(a, g0), (a.tolist(), g0.tolist())
+
+
+def test_full_size_generate_with_cache(cfg2):
+    """eval_rec.py:100-110's call at cfg2 size: K = 10 beams, 10 returned, 12 new tokens; the cached decode must return the
+    same best hypothesis as full re-scoring and be several times faster."""
+    import time
+    model, layout = cfg2
+    bt = _batch(layout, 1)
+    n = int(bt["attention_mask"][0].sum())
+    ids, vx = bt["lang_x"][:1, :n - 2], bt["vision_x"][:1]
+    kw = dict(num_beams=10, num_return_sequences=10, early_stopping=True, max_new_tokens=12, eos_token_id=layout.eos,
+              pad_token_id=layout.eos)
+    res = {}
+    for uc in (True, False):
+        model.generate(vx, ids, use_cache=uc, **{**kw, "max_new_tokens": 2})       # warm the GEMM shape caches
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        res[uc] = model.generate(vx, ids, use_cache=uc, **kw)
+        torch.cuda.synchronize(); res[uc, "t"] = time.perf_counter() - t0
+    print(f"generate K=10 x12 tokens on a {ids.shape[1]}-token prompt: cached {res[True, 't']:.3f}s, re-scoring {res[False, 't']:.3f}s")
+    assert res[True].shape[0] == 10 and torch.equal(res[True][:, :ids.shape[1]], ids.expand(10, -1))
+    assert res[True, "t"] < res[False, "t"]

@@ -141,6 +141,40 @@ def test_gemm_epilogue_gate_res_dact_accum(ops, M):
     close(acc, 0.5 * z + 3.0, rel=1e-5, name="accumulate f32")
 
 
+@pytest.mark.parametrize("M", [1, 10, 16, 17, 40, 64])
+@pytest.mark.parametrize("N,K", [(256, 64), (1005, 192), (2560, 2560), (24, 1344)])
+def test_gemm_skinny_decode_rows(ops, M, N, K):
+    """the weight-streaming kernel used for decode rows (M <= 64): against fp32, against the 128x128 kernel, every
+    epilogue flavour the decode GEMMs use (bias, act, gate, residual), ragged N with a padded ldc."""
+    a, b = rnd(M, K, seed=21), rnd(N, K, seed=22, scale=0.2)
+    bias, res = rnd(N, seed=23), rnd(M, N, seed=24)
+    gate = torch.tensor([0.4]).to(bf16)
+    z = a.float() @ b.float().t()
+    ad, bd = a.cuda(), b.cuda()
+    ldc = (N + 7) // 8 * 8
+    got = ops.gemm(ad, bd, ldc=ldc)                                  # routed to the skinny kernel by shape
+    close(got, z, name="skinny plain")
+    ref = ops.gemm(ad, bd, ldc=ldc, variant="v1")
+    close(got, ref.float(), rel=1e-2, name="skinny vs v1")
+    got = ops.gemm(ad, bd, variant="skinny", bias=bias.cuda(), act="gelu")
+    close(got, torch.nn.functional.gelu(z + bias.float()), name="skinny bias+gelu")
+    got = ops.gemm(ad, bd, variant="skinny", bias=bias.cuda(), res=res.cuda())
+    close(got, z + bias.float() + res.float(), name="skinny bias+res")
+    got = ops.gemm(ad, bd, variant="skinny", gate=gate.cuda(), res=res.cuda())
+    close(got, z * math.tanh(float(gate.float())) + res.float(), name="skinny gate+res")
+    got = ops.gemm(ad, bd, variant="skinny", out_f32=True)
+    close(got, z, rel=1e-5, name="skinny f32")
+
+
+def test_gemm_skinny_rejects_unsupported(ops):
+    a, b = rnd(8, 72, seed=1).cuda(), rnd(16, 72, seed=2).cuda()
+    with pytest.raises(Exception):
+        ops.gemm(a, b, variant="skinny")          # K % 64 != 0
+    a, b = rnd(128, 64, seed=1).cuda(), rnd(16, 64, seed=2).cuda()
+    with pytest.raises(Exception):
+        ops.gemm(a, b, variant="skinny")          # M > 64
+
+
 @pytest.mark.parametrize("M", [96, 1024])
 def test_gemm_padded_vocab_like(ops, M):
     """lm-head shape class: N odd (74053-like), padded ldc; dX/dW read the padded dlogits."""

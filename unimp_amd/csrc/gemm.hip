@@ -229,6 +229,92 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
 #undef EPI_TILE
 }
 
+// ---- skinny GEMM for decoding (M <= 64 rows: K beams x one new token).  Weight-bandwidth bound: every element of W is
+// used once, so W streams global -> registers directly in MFMA operand layout (no LDS); the few X rows come out of L2.
+// One block = 16 rows of W; its 4 waves take interleaved 64-k chunks (4 adjacent 128-B lines per W row and iteration) and
+// meet in LDS.  Inside a chunk lane (r, g) owns k = 16g .. 16g+15 of row r -- 32 contiguous bytes -- and feeds them to two
+// MFMAs; X uses the same k assignment, and a contraction does not care in which order k is visited.
+#define SK_U 4                      // chunks in flight per wave (8 x 16 B of W per lane)
+template <int MB>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmParams p) {
+  __shared__ f32x4 red[4][MB][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int g = lane >> 4, r = lane & 15;
+  const int n0 = blockIdx.x * 16;
+  const bf16* wp = p.B + (long)min(n0 + r, p.N - 1) * p.ldb + g * 16;
+  const bf16* xp[MB];
+#pragma unroll
+  for (int i = 0; i < MB; ++i) xp[i] = p.A + (long)min(i * 16 + r, p.M - 1) * p.lda + g * 16;
+  f32x4 acc[MB];
+#pragma unroll
+  for (int i = 0; i < MB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nchunk = p.K >> 6;
+  int c = w;
+  for (; c + 4 * (SK_U - 1) < nchunk; c += 4 * SK_U) {
+    u32x4 wv[SK_U][2];
+#pragma unroll
+    for (int u = 0; u < SK_U; ++u) {
+      const bf16* q = wp + (long)(c + 4 * u) * 64;
+      wv[u][0] = __builtin_nontemporal_load((const u32x4*)q);
+      wv[u][1] = __builtin_nontemporal_load((const u32x4*)(q + 8));
+    }
+#pragma unroll
+    for (int u = 0; u < SK_U; ++u) {
+#pragma unroll
+      for (int i = 0; i < MB; ++i) {
+        const bf16* q = xp[i] + (long)(c + 4 * u) * 64;
+        u32x4 x0 = *(const u32x4*)q, x1 = *(const u32x4*)(q + 8);
+        acc[i] = MFMA16(wv[u][0], x0, acc[i]);
+        acc[i] = MFMA16(wv[u][1], x1, acc[i]);
+      }
+    }
+  }
+  for (; c < nchunk; c += 4) {
+    const bf16* q = wp + (long)c * 64;
+    u32x4 w0 = *(const u32x4*)q, w1 = *(const u32x4*)(q + 8);
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+      const bf16* qx = xp[i] + (long)c * 64;
+      acc[i] = MFMA16(w0, *(const u32x4*)qx, acc[i]);
+      acc[i] = MFMA16(w1, *(const u32x4*)(qx + 8), acc[i]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MB; ++i) red[w][i][lane] = acc[i];
+  __syncthreads();
+  float gate = 1.f;
+  if (p.gate) gate = tanhf(bf2f(*p.gate));
+  bool fast = ((p.N & 3) == 0) && (((p.ldc | p.ldres | p.ldaux | p.ldpre) & 3) == 0);
+  for (int i = w; i < MB; i += 4) {
+    f32x4 a = red[0][i][lane] + red[1][i][lane] + red[2][i][lane] + red[3][i][lane];
+    if (fast) epi_tile<true>(p, a, i * 16 + r, n0 + g * 4, gate);
+    else epi_tile<false>(p, a, i * 16 + r, n0 + g * 4, gate);
+  }
+}
+
+static bool skinny_ok(const unimp_gemm_desc* d) {
+  return d->M <= 64 && !d->a_kstrided && !d->b_kstrided && (d->K & 63) == 0;
+}
+
+static void launch_skinny(const unimp_gemm_desc* d, void* stream) {
+  GemmParams p;
+  p.A = (const bf16*)d->A; p.B = (const bf16*)d->B; p.C = d->C;
+  p.M = d->M; p.N = d->N; p.K = d->K; p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;
+  p.bias = (const bf16*)d->bias; p.res = (const bf16*)d->res; p.ldres = d->ldres;
+  p.aux = (const bf16*)d->aux; p.ldaux = d->ldaux; p.pre = (bf16*)d->pre; p.ldpre = d->ldpre;
+  p.gate = (const bf16*)d->gate; p.alpha = d->alpha; p.act = d->act; p.dact = d->dact;
+  p.out_f32 = d->out_f32; p.accumulate = d->accumulate; p.pre_deriv = d->pre_deriv;
+  p.nbm = 1; p.nbn = (d->N + 15) / 16; p.ksplit = 0;
+  dim3 grid(p.nbn), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  switch ((d->M + 15) / 16) {
+    case 1: hipLaunchKernelGGL((gemm_skinny_kernel<1>), grid, block, 0, s, p); break;
+    case 2: hipLaunchKernelGGL((gemm_skinny_kernel<2>), grid, block, 0, s, p); break;
+    case 3: hipLaunchKernelGGL((gemm_skinny_kernel<3>), grid, block, 0, s, p); break;
+    default: hipLaunchKernelGGL((gemm_skinny_kernel<4>), grid, block, 0, s, p); break;
+  }
+}
+
 extern "C" int unimp_gemm2_launch(const unimp_gemm_desc* d, int bn, void* stream);   // gemm2.hip: 256-row tiles, LDS-DMA, 2-stage
 extern "C" int unimp_gemm3_launch(const unimp_gemm_desc* d, int bn, void* stream);   // gemm3.hip: 256-row tiles, LDS-DMA, ping-pong
 
@@ -277,6 +363,7 @@ static void launch_v1(const unimp_gemm_desc* d, void* stream, int splits = 1, fl
 // default choice when the caller does not autotune: the ping-pong kernel once there are enough rows for 256-row tiles,
 // tile width by round quantisation over the 256 CUs; the 128x128 kernel otherwise.
 static int auto_variant(const unimp_gemm_desc* d) {
+  if (skinny_ok(d)) return UNIMP_GEMM_SKINNY;
   if (d->M < 1024 || d->N < 128 || d->K < 128) return UNIMP_GEMM_V1;
   long nbm = (d->M + 255) / 256;
   long t256 = nbm * ((d->N + 255) / 256), t128 = nbm * ((d->N + 127) / 128);
@@ -295,6 +382,9 @@ extern "C" int unimp_gemm_bf16_variant(const unimp_gemm_desc* d, int variant, vo
     case UNIMP_GEMM_DMA128: unimp_gemm2_launch(d, 128, stream); break;
     case UNIMP_GEMM_PP256: unimp_gemm3_launch(d, 256, stream); break;
     case UNIMP_GEMM_PP128: unimp_gemm3_launch(d, 128, stream); break;
+    case UNIMP_GEMM_SKINNY:
+      if (!skinny_ok(d)) return unimp_set_error(UNIMP_ERR_UNSUPPORTED, "gemm: the skinny kernel needs M <= 64, k-contiguous operands, K %% 64 == 0");
+      launch_skinny(d, stream); break;
     default: return unimp_set_error(UNIMP_ERR_ARG, "gemm: unknown variant");
   }
   return unimp_check_launch("gemm");

@@ -88,7 +88,7 @@ class GatedCrossAttentionBlock(nn.Module):
         self.ff = FeedForward(dim, ff_mult)
         self.ff_gate = nn.Parameter(torch.tensor([0.0]))
 
-    def forward(self, x, media, media_locations=None, use_cached_media=False, media_time=None):
+    def forward(self, x, media, media_locations=None, use_cached_media=False, media_time=None, cache=None):
         """x [B, L, D]; media [B, T, n, Dv]; media_time int32 [B, L] = cumsum(media_locations) (text_time)."""
         B, T, n = media.shape[:3]
         if media_time is None:
@@ -97,8 +97,12 @@ class GatedCrossAttentionBlock(nn.Module):
             media_time = (media_locations.sum(-1, keepdim=True).expand(-1, x.shape[1]) if use_cached_media
                           else media_locations.cumsum(-1)).to(torch.int32).contiguous()
         a = self.attn
-        x = F_.gated_xattn(x, media.reshape(B, T * n, -1), media_time, a.norm.weight, a.norm.bias, a.to_q.weight, a.to_kv.weight,
-                           a.to_out.weight, self.attn_gate, a.heads, n, a.norm.eps)
+        if cache is not None:
+            x = F_.gated_xattn_cached(x, media.reshape(B, T * n, -1), media_time, a.norm.weight, a.norm.bias, a.to_q.weight,
+                                      a.to_kv.weight, a.to_out.weight, self.attn_gate, a.heads, n, cache, a.norm.eps)
+        else:
+            x = F_.gated_xattn(x, media.reshape(B, T * n, -1), media_time, a.norm.weight, a.norm.bias, a.to_q.weight,
+                               a.to_kv.weight, a.to_out.weight, self.attn_gate, a.heads, n, a.norm.eps)
         return _ff_block(self.ff, x, gate=self.ff_gate)
 
 
@@ -125,7 +129,8 @@ class FlamingoLayer(nn.Module):
             if self.media_locations is None:
                 raise ValueError("media_locations must be conditioned before forward pass")
             lang_x = self.gated_cross_attn_layer(lang_x, self.vis_x, media_locations=self.media_locations,
-                                                 use_cached_media=self.use_cached_media, media_time=self.media_time)
+                                                 use_cached_media=self.use_cached_media, media_time=self.media_time,
+                                                 cache=decoder_layer_kwargs.get("cache"))
         return self.decoder_layer(lang_x, attention_mask=attention_mask, **decoder_layer_kwargs)
 
 
@@ -179,14 +184,17 @@ class Flamingo(nn.Module):
         assert self.lang_encoder.initialized_flamingo, "Flamingo layers are not initialized. Please call `init_flamingo` first."
         assert self.lang_encoder._use_cached_vision_x or vision_x is not None, \
             "Must provide either vision_x or have precached media using cache_media()."
-        if past_key_values is not None or use_cache:
-            raise NotImplementedError("KV-cache decode (generate) is SURVEY.md §8(f) F1, not built yet")
         if self.lang_encoder._use_cached_vision_x:
             assert vision_x is None and self.lang_encoder.is_conditioned()
         else:
             self._encode_vision_x(vision_x=vision_x)
             self._condition_media_locations(input_ids=lang_x)
-        output = self.lang_encoder(input_ids=lang_x, attention_mask=attention_mask, labels=labels)
+        if past_key_values is not None:
+            self._condition_cached_media(past_key_values, lang_x.shape[1])
+        output = self.lang_encoder(input_ids=lang_x, attention_mask=attention_mask, labels=labels,
+                                   past_key_values=past_key_values, use_cache=use_cache)
+        if output.past_key_values is not None and output.past_key_values.media_count is None:
+            output.past_key_values.media_count = (lang_x == self.media_token_id).sum(1, keepdim=True).to(torch.int32)
         if clear_conditioned_layers:
             self.clear_conditioned_layers()
         return output
@@ -214,6 +222,15 @@ class Flamingo(nn.Module):
             layer.condition_media_time(media_time)
             layer.condition_use_cached_media(False)
 
+    def _condition_cached_media(self, cache, n_new):
+        """decode steps (FlamingoLMMixin.forward with ``use_cached_media_locations``, MaskedCrossAttention with
+        ``use_cached_media``): every new token attends with text_time = #<image> in the prompt."""
+        media_time = cache.media_count.expand(-1, n_new).contiguous()
+        for layer in self._layers():
+            layer.condition_media_locations(media_time > 0)
+            layer.condition_media_time(media_time)
+            layer.condition_use_cached_media(True)
+
     def clear_conditioned_layers(self):
         for layer in self._layers():
             layer.condition_vis_x(None)
@@ -224,9 +241,12 @@ class Flamingo(nn.Module):
     @torch.no_grad()
     def generate(self, vision_x, lang_x, attention_mask=None, **kwargs):
         """open_flamingo ``Flamingo.generate`` (eval_rec.py:100-110): vision encoded once (repeated per beam),
-        then greedy / beam search over the LM (generate.py: transformers' BeamSearchScorer semantics).  The decode loop has
-        no KV cache yet: every step re-scores the full sequences with the media kept conditioned."""
+        then greedy / beam search over the LM (generate.py: transformers' BeamSearchScorer semantics).  ``use_cache=True``
+        (transformers' default) decodes with the KV cache: one prefill over the prompt, then one token per row and step,
+        the cache rows following their beams, the step replayed as a HIP graph (decode.py; ``use_graph=False`` launches it
+        kernel by kernel); ``use_cache=False`` re-scores the full sequences every step."""
         from .generate import beam_search, greedy_search
+        from .decode import DecodeSession
         if attention_mask is not None and not bool(attention_mask.all()):
             raise NotImplementedError("generate() with padded prompts (UniMP evaluates one user at a time, eval_rec.py:32-110)")
         num_beams = kwargs.pop("num_beams", 1)
@@ -239,6 +259,8 @@ class Flamingo(nn.Module):
         early = kwargs.pop("early_stopping", False)
         ngram = kwargs.pop("no_repeat_ngram_size", 0)
         lp = kwargs.pop("length_penalty", 1.0)
+        use_cache = kwargs.pop("use_cache", True)
+        use_graph = kwargs.pop("use_graph", True)      # replay the decode step as one HIP graph (decode.py)
         if kwargs.pop("do_sample", False) or kwargs:
             raise NotImplementedError(f"unsupported generate() arguments: do_sample / {sorted(kwargs)}")
         was_training = self.training
@@ -246,11 +268,19 @@ class Flamingo(nn.Module):
         self.lang_encoder._use_cached_vision_x = True
         self._encode_vision_x(vision_x=vision_x)
         try:
-            def logits_fn(seqs):
-                self._condition_media_locations(input_ids=seqs)
-                return self.lang_encoder(input_ids=seqs, attention_mask=None, logits_last_only=True)["logits"][:, -1]
+            session = [None]
+
+            def logits_fn(seqs, src=None):
+                if not use_cache:
+                    self._condition_media_locations(input_ids=seqs)
+                    return self.lang_encoder(input_ids=seqs, attention_mask=None, logits_last_only=True)["logits"][:, -1]
+                if session[0] is None:
+                    session[0] = DecodeSession(self, max_new_tokens, reorder=num_beams > 1, graph=use_graph)
+                    return session[0].prefill(seqs)
+                return session[0].step(seqs[:, -1], src)
             if num_beams > 1:
-                out = beam_search(logits_fn, lang_x, num_beams, max_new_tokens, eos_token_id, pad_token_id, nret, early, lp, ngram)
+                out = beam_search(logits_fn, lang_x, num_beams, max_new_tokens, eos_token_id, pad_token_id, nret, early, lp,
+                                  ngram, stateful=True)
             else:
                 out = greedy_search(logits_fn, lang_x, max_new_tokens, eos_token_id, pad_token_id)
         finally:

@@ -270,6 +270,134 @@ def self_attn_block(x, ln_w, ln_b, wqkv, bqkv, wd, bd, nh, *, rope=None, kv_len=
                                  q_scale if q_scale is not None else hd ** -0.5)
 
 
+# ----------------------------------------------------------------------------------------------- KV-cache decode (F1)
+class LayerKV:
+    """decode state of one decoder layer: views ``k``, ``v`` [rows, capacity, nh, hd] into the cache's single K/V tensor
+    (keys after RoPE) and the gated cross-attention's projected media ``xkv`` [rows, T*n, 2*inner] (constant over a decode)."""
+    __slots__ = ("owner", "k", "v", "xkv")
+
+    def __init__(self, owner):
+        self.owner = owner
+        self.k = self.v = self.xkv = None
+
+
+class StepState:
+    """device-resident position of a static decode step: ``pos_idx`` int64 [1] = slot the new token's K/V go to,
+    ``kv_len`` int32 [rows] = keys visible to it (pos + 1).  Nothing on the host depends on the position, so one step can
+    be captured in a HIP graph and replayed (decode.py)."""
+
+    def __init__(self, rows, pos, device):
+        self.pos_idx = torch.full((1,), pos, dtype=torch.long, device=device)
+        self.kv_len = torch.full((rows,), pos + 1, dtype=torch.int32, device=device)
+
+    def advance(self):
+        self.pos_idx.add_(1)
+        self.kv_len.add_(1)
+
+
+class DecodeCache:
+    """``past_key_values`` of the towers (inference only).  One tensor ``kv`` [layers, 2, rows, capacity, nh, hd] holds
+    every layer's keys and values, ``len`` tokens are cached per row; ``media_count`` [rows, 1] int32 is the number of
+    <image> tokens in the prompt = the text_time every generated token attends with (open_flamingo ``use_cached_media``,
+    SURVEY.md A.3).  ``shared_prefix``: the first tokens are identical in all rows that can exchange hypotheses (the
+    beams of one prompt), so a beam reorder only has to move the generated tail."""
+
+    def __init__(self, n_layers, capacity=0):
+        self.layers = [LayerKV(self) for _ in range(n_layers)]
+        self.len = 0
+        self.capacity = capacity
+        self.kv = None
+        self.media_count = None
+        self.shared_prefix = 0
+        self.step = None                   # StepState while decoding with device-side positions
+
+    def _reserve(self, like, need):
+        R, _, nh, hd = like.shape
+        if self.kv is not None and self.kv.shape[3] >= need:
+            return
+        cap = max(self.capacity, need + 64) if self.kv is None else max(need + 64, 2 * self.kv.shape[3])
+        # zeros, not empty: the kernels load whole 64-key tiles and weight the slots beyond kv_len with p = 0, which
+        # only cancels finite values (0 * NaN from recycled memory would poison the row)
+        new = torch.zeros((len(self.layers), 2, R, cap, nh, hd), dtype=like.dtype, device=like.device)
+        if self.kv is not None:
+            new[:, :, :, :self.kv.shape[3]].copy_(self.kv)      # a layer may grow it mid-forward: keep every slot
+        self.kv = new
+        for i, l in enumerate(self.layers):
+            l.k, l.v = new[i, 0], new[i, 1]
+
+    def reorder(self, idx):
+        """beam search: row r continues the hypothesis that lived in row idx[r].  The projected media are not moved:
+        beams of one batch item share their images, and a beam never migrates to another item."""
+        if self.kv is not None and self.len > self.shared_prefix:
+            tail = self.kv[:, :, :, self.shared_prefix:self.len]
+            tail.copy_(tail.index_select(2, idx))
+        if self.media_count is not None:
+            self.media_count = self.media_count.index_select(0, idx)
+
+
+def _kv_append(lc, k, v, pos0):
+    need = pos0 + k.shape[1]
+    lc.owner._reserve(k, need)
+    lc.k[:, pos0:need].copy_(k)
+    lc.v[:, pos0:need].copy_(v)
+    return lc.k[:, :need], lc.v[:, :need]
+
+
+@torch.no_grad()
+def self_attn_block_cached(x, ln_w, ln_b, wqkv, bqkv, wd, bd, nh, lc, pos0, *, rope=None, interleaved=True, eps=1e-5,
+                           rms=False, res=None, q_scale=None):
+    """SelfAttnBlockFn.forward for decoding: the new rows' keys/values are appended to ``lc``; a prefill (pos0 == 0) runs
+    the causal kernel on the prompt, a decode step (one new token per row) attends to every cached key.  With
+    ``lc.owner.step`` set the position lives on the device (StepState): ``rope`` then holds the one table row of the
+    current position, K/V go to slot ``pos_idx`` and the kernel reads the visible length from ``kv_len``."""
+    R, Ln, H = x.shape
+    hd = H // nh
+    step = lc.owner.step
+    x2 = x.reshape(R * Ln, H)
+    r2 = x2 if res is None else res.reshape(R * Ln, H)
+    h, _, _ = ops.layernorm_fwd(x2, ln_w, ln_b, eps, rms=rms)
+    qkv = ops.gemm(h, wqkv, bias=bqkv)
+    q, k, v, hs, offs = _split_qkv(qkv, R, Ln, nh, hd, interleaved)
+    scale = q_scale if q_scale is not None else hd ** -0.5
+    if step is not None:
+        if Ln != 1:
+            raise NotImplementedError("a static decode step feeds one new token per row")
+        if rope is not None:
+            ops.rope_(qkv, 1, nh, hs, rope[2], offs, rope[0], rope[1])
+        lc.k.index_copy_(1, step.pos_idx, k)
+        lc.v.index_copy_(1, step.pos_idx, v)
+        o, _ = ops.attn_fwd(q, lc.k, lc.v, scale, ops.MASK_NONE, step.kv_len)
+        return ops.gemm(o.view(R, H), wd, bias=bd, res=r2).view(R, 1, H)
+    if rope is not None:
+        cos, sin, rot = rope
+        ops.rope_(qkv, Ln, nh, hs, rot, offs, cos[pos0:], sin[pos0:])
+    kc, vc = _kv_append(lc, k, v, pos0)
+    if pos0 == 0:
+        o, _ = ops.attn_fwd(q, k, v, scale, ops.MASK_CAUSAL, None)
+    else:
+        if Ln != 1:
+            raise NotImplementedError("cached decode feeds one new token per row (chunked prefill is not built)")
+        o, _ = ops.attn_fwd(q, kc, vc, scale, ops.MASK_NONE, None)
+    return ops.gemm(o.view(R * Ln, H), wd, bias=bd, res=r2).view(R, Ln, H)
+
+
+@torch.no_grad()
+def gated_xattn_cached(x, media, seg, ln_w, ln_b, wq, wkv, wo, gate, heads, n_lat, lc, eps=1e-5):
+    """GatedXAttnFn.forward for decoding: to_kv(media) is projected once per decode and kept in ``lc.xkv``."""
+    R, Ln, D = x.shape
+    Sk = media.shape[1]
+    inner = wq.shape[0]
+    dh = inner // heads
+    x2 = x.reshape(R * Ln, D)
+    h, _, _ = ops.layernorm_fwd(x2, ln_w, ln_b, eps)
+    q = ops.gemm(h, wq)
+    if lc.xkv is None:
+        lc.xkv = ops.gemm(media.reshape(R * Sk, -1), wkv)
+    kv5 = lc.xkv.view(R, Sk, 2, heads, dh)
+    o, _ = ops.attn_fwd(q.view(R, Ln, heads, dh), kv5[:, :, 0], kv5[:, :, 1], dh ** -0.5, ops.MASK_SEGMENT, None, seg, n_lat)
+    return ops.gemm(o.view(R * Ln, inner), wo, gate=gate, res=x2).view(R, Ln, D)
+
+
 # ----------------------------------------------------------------------------------------------- gated cross-attention
 class GatedXAttnFn(Function):
     """out = x + tanh(gate) * to_out(softmax_seg(to_q(LN(x)) to_kv(media)^T) V)   (open_flamingo MaskedCrossAttention)."""

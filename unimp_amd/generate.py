@@ -64,7 +64,7 @@ class _Hyps:
 
 @torch.no_grad()
 def beam_search(logits_fn, input_ids, num_beams, max_new_tokens, eos_token_id, pad_token_id=None, num_return_sequences=1,
-                early_stopping=True, length_penalty=1.0, no_repeat_ngram_size=0):
+                early_stopping=True, length_penalty=1.0, no_repeat_ngram_size=0, stateful=False):
     """input_ids [B, L0] -> [B * num_return_sequences, <= L0 + max_new_tokens] (right-padded with pad_token_id)."""
     dev = input_ids.device
     B, L0 = input_ids.shape
@@ -75,9 +75,10 @@ def beam_search(logits_fn, input_ids, num_beams, max_new_tokens, eos_token_id, p
     beam_scores[:, 1:] = -1e9
     hyps = [_Hyps(K, length_penalty, early_stopping) for _ in range(B)]
     done = [False] * B
+    src = None
     for step in range(max_new_tokens):
         cur_len = seqs.shape[1]
-        logp = torch.log_softmax(logits_fn(seqs).float(), -1)
+        logp = torch.log_softmax((logits_fn(seqs, src) if stateful else logits_fn(seqs)).float(), -1)
         _ban_repeated_ngrams(seqs, logp, no_repeat_ngram_size)
         V = logp.shape[-1]
         scores = (logp + beam_scores.view(-1, 1)).view(B, K * V)
@@ -104,7 +105,8 @@ def beam_search(logits_fn, input_ids, num_beams, max_new_tokens, eos_token_id, p
                 if n == K:
                     break
             done[b] = done[b] or hyps[b].is_done(max(top_s_h[b]), cur_len + 1 - L0)
-        seqs = torch.cat([seqs[new_src.view(-1).to(dev)], new_tok.view(-1, 1).to(dev)], 1)
+        src = new_src.view(-1).to(dev)
+        seqs = torch.cat([seqs[src], new_tok.view(-1, 1).to(dev)], 1)
         beam_scores = new_scores.to(dev)
         if all(done):
             break

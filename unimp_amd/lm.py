@@ -20,8 +20,8 @@ bf16 = torch.bfloat16
 class LMOutput:
     """``out[0]`` = loss when labels were passed (else logits); ``out["logits"]`` (UniMP/mmrec.py:182,190)."""
 
-    def __init__(self, loss, logits, stats=None):
-        self.loss, self.logits, self.stats = loss, logits, stats
+    def __init__(self, loss, logits, stats=None, past_key_values=None):
+        self.loss, self.logits, self.stats, self.past_key_values = loss, logits, stats, past_key_values
 
     def __getitem__(self, k):
         if isinstance(k, str):
@@ -106,6 +106,24 @@ class _TowerBase(nn.Module):
             return None
         return attention_mask.sum(1).to(torch.int32)          # right padding (collate_rec.py:38-74)
 
+    def _decode_state(self, past_key_values, use_cache, labels, attention_mask):
+        """(cache, pos0) for a forward with ``use_cache`` / ``past_key_values`` (inference, unpadded rows), else (None, 0)."""
+        if past_key_values is None and not use_cache:
+            return None, 0
+        if labels is not None or torch.is_grad_enabled():
+            raise NotImplementedError("the KV cache is a decoding path: call under torch.no_grad() and without labels")
+        if attention_mask is not None and not bool(attention_mask.all()):
+            raise NotImplementedError("KV-cache decode with padded rows (UniMP evaluates one user at a time, eval_rec.py:32-110)")
+        cache = past_key_values if past_key_values is not None else F_.DecodeCache(len(self._get_decoder_layers()))
+        return cache, cache.len
+
+    @staticmethod
+    def _step_rope(cache, rope):
+        """static decode step: the table row of the device-side position, gathered once per forward for all layers."""
+        if cache is None or cache.step is None:
+            return rope
+        return rope[0].index_select(0, cache.step.pos_idx), rope[1].index_select(0, cache.step.pos_idx), rope[2]
+
     def _head(self, h, labels, last_only=False):
         w = self.get_output_embeddings().weight
         V = w.shape[0]
@@ -143,12 +161,17 @@ class GPTNeoXLayer(nn.Module):
         self.attention = _NeoXAttnParams(c)
         self.mlp = _NeoXMLPParams(c)
 
-    def forward(self, x, attention_mask=None, rope=None, **kw):
+    def forward(self, x, attention_mask=None, rope=None, cache=None, pos0=0, **kw):
         c, a, m = self.c, self.attention, self.mlp
         l1, l2 = self.input_layernorm, self.post_attention_layernorm
-        att = F_.self_attn_block(x, l1.weight, l1.bias, a.query_key_value.weight, a.query_key_value.bias, a.dense.weight,
-                                 a.dense.bias, c.num_attention_heads, rope=rope, kv_len=attention_mask, interleaved=True,
-                                 causal=True, eps=l1.eps)
+        if cache is not None:
+            att = F_.self_attn_block_cached(x, l1.weight, l1.bias, a.query_key_value.weight, a.query_key_value.bias,
+                                            a.dense.weight, a.dense.bias, c.num_attention_heads, cache, pos0, rope=rope,
+                                            interleaved=True, eps=l1.eps)
+        else:
+            att = F_.self_attn_block(x, l1.weight, l1.bias, a.query_key_value.weight, a.query_key_value.bias, a.dense.weight,
+                                     a.dense.bias, c.num_attention_heads, rope=rope, kv_len=attention_mask, interleaved=True,
+                                     causal=True, eps=l1.eps)
         if c.use_parallel_residual:      # x + attn(ln1(x)) + mlp(ln2(x))
             return F_.mlp_block(x, l2.weight, l2.bias, m.dense_h_to_4h.weight, m.dense_h_to_4h.bias, m.dense_4h_to_h.weight,
                                 m.dense_4h_to_h.bias, "gelu", res=att, eps=l2.eps)
@@ -189,16 +212,22 @@ class GPTNeoXForCausalLM(_TowerBase):
             self._rope = (fr.cos().contiguous().to(device), fr.sin().contiguous().to(device), rot)
         return self._rope
 
-    def forward(self, input_ids, attention_mask=None, labels=None, **kw):
+    def forward(self, input_ids, attention_mask=None, labels=None, past_key_values=None, use_cache=False, **kw):
         B, L = input_ids.shape
+        cache, pos0 = self._decode_state(past_key_values, use_cache, labels, attention_mask)
         x = F_.embedding(input_ids, self.gpt_neox.embed_in.weight)
         kv_len = self._kv_len(attention_mask)
-        rope = self._rope_tables(L, x.device)
-        for layer in self.gpt_neox.layers:
-            x = layer(x, attention_mask=kv_len, rope=rope)
+        rope = self._step_rope(cache, self._rope_tables(max(pos0 + L, cache.kv.shape[3] if cache and cache.kv is not None else 0), x.device))
+        for i, layer in enumerate(self.gpt_neox.layers):
+            x = layer(x, attention_mask=kv_len, rope=rope, cache=cache.layers[i] if cache else None, pos0=pos0)
         f = self.gpt_neox.final_layer_norm
         h = F_.layer_norm(x, f.weight, f.bias, f.eps)
-        return self._head(h, labels, kw.get("logits_last_only", False))
+        out = self._head(h, labels, kw.get("logits_last_only", False))
+        if cache is not None:
+            if cache.step is None:
+                cache.len = pos0 + L
+            out.past_key_values = cache
+        return out
 
 
 # --------------------------------------------------------------------------- OPT
@@ -230,11 +259,15 @@ class OPTDecoderLayer(nn.Module):
         self.fc2 = nn.Linear(c.ffn_dim, c.hidden_size)
         self.final_layer_norm = nn.LayerNorm(c.hidden_size)
 
-    def forward(self, x, attention_mask=None, **kw):
+    def forward(self, x, attention_mask=None, cache=None, pos0=0, **kw):
         a, l1, l2 = self.self_attn, self.self_attn_layer_norm, self.final_layer_norm
         wqkv, bqkv = a.fused_qkv()
-        x = F_.self_attn_block(x, l1.weight, l1.bias, wqkv, bqkv, a.out_proj.weight, a.out_proj.bias,
-                               self.c.num_attention_heads, kv_len=attention_mask, interleaved=False, causal=True, eps=l1.eps)
+        if cache is not None:
+            x = F_.self_attn_block_cached(x, l1.weight, l1.bias, wqkv, bqkv, a.out_proj.weight, a.out_proj.bias,
+                                          self.c.num_attention_heads, cache, pos0, interleaved=False, eps=l1.eps)
+        else:
+            x = F_.self_attn_block(x, l1.weight, l1.bias, wqkv, bqkv, a.out_proj.weight, a.out_proj.bias,
+                                   self.c.num_attention_heads, kv_len=attention_mask, interleaved=False, causal=True, eps=l1.eps)
         return F_.mlp_block(x, l2.weight, l2.bias, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, "relu", eps=l2.eps)
 
 
@@ -269,18 +302,25 @@ class OPTForCausalLM(_TowerBase):
     def get_output_embeddings(self): return self.lm_head
     def set_output_embeddings(self, m): self.lm_head = m
 
-    def forward(self, input_ids, attention_mask=None, labels=None, **kw):
+    def forward(self, input_ids, attention_mask=None, labels=None, past_key_values=None, use_cache=False, **kw):
         d = self.model.decoder
         B, L = input_ids.shape
+        cache, pos0 = self._decode_state(past_key_values, use_cache, labels, attention_mask)
         am = attention_mask if attention_mask is not None else torch.ones_like(input_ids)
         pos = (torch.cumsum(am, 1) * am).long() + 1                      # OPTLearnedPositionalEmbedding (offset 2)
+        pos = pos + (cache.step.pos_idx if cache is not None and cache.step is not None else pos0)
         x = F_.embedding(input_ids, d.embed_tokens.weight, pos, d.embed_positions.weight)
         kv_len = self._kv_len(attention_mask)
-        for layer in d.layers:
-            x = layer(x, attention_mask=kv_len)
+        for i, layer in enumerate(d.layers):
+            x = layer(x, attention_mask=kv_len, cache=cache.layers[i] if cache else None, pos0=pos0)
         f = d.final_layer_norm
         h = F_.layer_norm(x, f.weight, f.bias, f.eps)
-        return self._head(h, labels, kw.get("logits_last_only", False))
+        out = self._head(h, labels, kw.get("logits_last_only", False))
+        if cache is not None:
+            if cache.step is None:
+                cache.len = pos0 + L
+            out.past_key_values = cache
+        return out
 
 
 # --------------------------------------------------------------------------- Llama (in-tree UniMP/xformers_model/llama.py)
@@ -343,8 +383,14 @@ class LlamaDecoderLayer(nn.Module):
         wqkv = self._fqkv.get([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], "Llama q/k/v")
         wgu = self._fgu.get([m.gate_proj.weight, m.up_proj.weight], "Llama gate/up")
         # training path of the in-tree model: LowerTriangularMask only, padding masks are ignored (llama.py:287-293)
-        x = F_.self_attn_block(x, self.input_layernorm.weight, None, wqkv, None, a.o_proj.weight, None, c.num_attention_heads,
-                               rope=rope, kv_len=None, interleaved=False, causal=True, eps=c.rms_norm_eps, rms=True)
+        if kw.get("cache") is not None:
+            x = F_.self_attn_block_cached(x, self.input_layernorm.weight, None, wqkv, None, a.o_proj.weight, None,
+                                          c.num_attention_heads, kw["cache"], kw.get("pos0", 0), rope=rope, interleaved=False,
+                                          eps=c.rms_norm_eps, rms=True)
+        else:
+            x = F_.self_attn_block(x, self.input_layernorm.weight, None, wqkv, None, a.o_proj.weight, None,
+                                   c.num_attention_heads, rope=rope, kv_len=None, interleaved=False, causal=True,
+                                   eps=c.rms_norm_eps, rms=True)
         return F_.swiglu_block(x, self.post_attention_layernorm.weight, wgu, m.down_proj.weight, c.rms_norm_eps)
 
 
@@ -381,15 +427,21 @@ class LlamaForCausalLM(_TowerBase):
             self._rope = (fr.cos().contiguous().to(device), fr.sin().contiguous().to(device), hd)
         return self._rope
 
-    def forward(self, input_ids, attention_mask=None, labels=None, **kw):
+    def forward(self, input_ids, attention_mask=None, labels=None, past_key_values=None, use_cache=False, **kw):
         B, L = input_ids.shape
+        cache, pos0 = self._decode_state(past_key_values, use_cache, labels, None)
         x = F_.embedding(input_ids, self.model.embed_tokens.weight)
-        rope = self._rope_tables(L, x.device)
-        for layer in self.model.layers:
-            x = layer(x, attention_mask=None, rope=rope)
+        rope = self._step_rope(cache, self._rope_tables(max(pos0 + L, cache.kv.shape[3] if cache and cache.kv is not None else 0), x.device))
+        for i, layer in enumerate(self.model.layers):
+            x = layer(x, attention_mask=None, rope=rope, cache=cache.layers[i] if cache else None, pos0=pos0)
         n = self.model.norm
         h = F_.layer_norm(x, n.weight, None, n.variance_epsilon, rms=True)
-        return self._head(h, labels, kw.get("logits_last_only", False))
+        out = self._head(h, labels, kw.get("logits_last_only", False))
+        if cache is not None:
+            if cache.step is None:
+                cache.len = pos0 + L
+            out.past_key_values = cache
+        return out
 
 
 def build_lm(name_or_config):

@@ -17,7 +17,7 @@ bf16 = torch.bfloat16
 
 GEMM_PROFILE = None      # bench.py sets this to a list: (start_event, end_event, flops) per GEMM launch
 GEMM_AUTOTUNE = True     # time the kernel variants once per (M, N, K, layout) on scratch operands and keep the fastest
-GEMM_VARIANTS = {"auto": 0, "v1": 1, "dma256": 2, "dma128": 3, "pp256": 4, "pp128": 5}
+GEMM_VARIANTS = {"auto": 0, "v1": 1, "dma256": 2, "dma128": 3, "pp256": 4, "pp128": 5, "skinny": 6}
 _GEMM_CHOICE = {}
 _TUNE_FILE = os.environ.get("UNIMP_GEMM_TUNE_FILE")       # optional JSON cache of the autotune table (profiling runs reuse it)
 if _TUNE_FILE and os.path.exists(_TUNE_FILE):
@@ -129,6 +129,8 @@ def gemm(a, b, *, a_ks=False, b_ks=False, bias=None, act=None, res=None, aux=Non
     d.pre_deriv = int(pre_deriv)
     plain = bias is None and res is None and aux is None and pre is None and act is None and dact is None and not accumulate
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    if variant is None and M <= 64 and not a_ks and not b_ks and K % 64 == 0:
+        variant = 6                      # decode rows: the weight-streaming kernel, any epilogue
     if variant is None and plain and tiles <= 96 and K >= 2048 and N % 4 == 0 and out.stride(0) % 4 == 0:
         # weight gradient of a narrow projection: far fewer tiles than CUs, very deep K -> split-K over the chip
         splits = max(2, min(32, 320 // tiles, K // 512))
