@@ -111,8 +111,8 @@ def cpu_baseline(T, L, layout, fps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("UNIMP_BENCH_BATCH", 48)), help="samples per GPU per step")
     ap.add_argument("--images", type=int, default=8)
     ap.add_argument("--seq", type=int, default=512)

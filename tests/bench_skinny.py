@@ -1,0 +1,25 @@
+"""Decode-row GEMM microbench: achieved weight bandwidth of the skinny kernel per cfg2 decode shape.  Not a pytest file."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from unimp_amd import ops
+
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+shapes = [(7680, 2560), (2560, 2560), (10240, 2560), (2560, 10240), (512, 2560), (2560, 512), (74053, 2560)]
+tot_b, tot_t = 0, 0
+for N, K in shapes:
+    a = torch.randn(M, K, device="cuda").bfloat16()
+    ws = [torch.randn(N, K, device="cuda").bfloat16() for _ in range(max(2, int(1.2e9 / (N * K * 2))))]   # rotate: defeat the 256 MB MALL
+    ldc = (N + 7) // 8 * 8
+    for variant in ("skinny", "v1"):
+        for w in ws[:2]:
+            ops.gemm(a, w, ldc=ldc, variant=variant)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        n = 0
+        for _ in range(3):
+            for w in ws:
+                ops.gemm(a, w, ldc=ldc, variant=variant); n += 1
+        e1.record(); e1.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / n
+        print(f"M={M} N={N:6d} K={K:6d} {variant:7s} {us:8.1f} us  {N * K * 2 / us / 1e6:7.2f} TB/s")
