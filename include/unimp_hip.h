@@ -182,6 +182,29 @@ int unimp_adamw_flat(float* master, float* m, float* v, void* param_bf16, void* 
                      float lr, float beta1, float beta2, float eps, float wd, int step, const float* sumsq,
                      float gscale, float max_norm, int zero_grad, void* stream);
 
+/* ---- image preprocessing ----------------------------------------------------------------
+ * replaces `patch_resize_transform` (UniMP/pipeline/mm_utils/rec_dataset.py:91-107): RandomResize([(S, S)]) =
+ * transforms.py:102-136 `F.resize(image, (S, S), interpolation=Image.BICUBIC)` on a PIL image (= Pillow Image.resize,
+ * 8-bit two-pass fixed-point resampler), ToTensor (uint8 / 255 in fp32), Normalize(FLAMINGO_MEAN, FLAMINGO_STD)
+ * (rec_dataset.py:30-31), then the cast of mmrec.py:135-141.  JPEG decoding stays on the host.
+ * src: all decoded RGB images of the batch packed as [H][W][3] uint8 (device); descs: one per image (device);
+ * tables: int32 tap tables (device), one row of (2 + ks) ints per output coordinate: first source index, tap count,
+ * taps in 22-bit fixed point exactly as Pillow computes them (the host side builds them: unimp_amd/data.py);
+ * tmp: scratch for the horizontal pass ([H][out_w][3] per image at tmp_off); mean / std: HOST arrays of 3 floats.
+ * out: [n][3][out_h][out_w] bf16 (or f32 when out_f32); out_u8 (optional, may be NULL): the resized bytes
+ * [n][out_h][out_w][3] -- bit-exact with Pillow.  max_h: largest H in the batch (grid sizing only).
+ */
+typedef struct unimp_image_desc {
+  int64_t src_off;          /* byte offset of the image in src */
+  int64_t H, W;
+  int64_t kx_off, ky_off;   /* int32 element offsets of the per-axis tap tables in `tables` */
+  int64_t ksx, ksy;         /* taps per row of the table; 0 = this axis already has the output size (no resampling) */
+  int64_t tmp_off;          /* byte offset of this image's horizontal-pass result in tmp */
+} unimp_image_desc;
+int unimp_image_resize_normalize(const uint8_t* src, const unimp_image_desc* descs, int n_images, int max_h,
+                                 const int32_t* tables, uint8_t* tmp, int out_h, int out_w, const float* mean,
+                                 const float* std, void* out, int out_f32, uint8_t* out_u8, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,54 @@
+"""The HIP image preprocessing (csrc/preprocess.hip through the C-ABI): resized bytes bit-exact with Pillow (committed
+golden + the oracle restatement on ragged batches), normalised output bit-exact in fp32 and the bf16 rounding of it."""
+import os
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def pre():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from unimp_amd.data import ImagePreprocessor
+    return ImagePreprocessor
+
+
+def test_resize_bit_exact_with_pillow_golden(pre):
+    from oracle.make_golden_preprocess import synth_image
+    from oracle import preprocess as OP
+    g = np.load(os.path.join(GOLD, "preprocess_pillow.npz"))
+    imgs = [synth_image(int(s), int(h), int(w)) for s, (h, w) in zip(g["seeds"], g["shapes"])]
+    out, u8 = pre(dtype=torch.float32)(imgs, return_u8=True)            # one ragged batch: every size class at once
+    assert np.array_equal(u8.cpu().numpy(), g["resized"])
+    want = np.stack([OP.to_tensor_normalize(r) for r in g["resized"]])
+    assert np.array_equal(out.cpu().numpy(), want)                       # fp32: /255, -mean, /std are IEEE ops
+    out16 = pre()(imgs)
+    assert out16.dtype == torch.bfloat16 and torch.equal(out16.cpu(), torch.from_numpy(want).to(torch.bfloat16))
+
+
+def test_ragged_batch_against_oracle(pre):
+    from oracle import preprocess as OP
+    rng = np.random.default_rng(9)
+    shapes = [(1, 1), (2, 700), (700, 2), (224, 224), (224, 97), (97, 224), (333, 512), (1024, 768), (50, 50), (225, 225)]
+    imgs = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in shapes]
+    out, u8 = pre(dtype=torch.float32)(imgs, return_u8=True)
+    for i, im in enumerate(imgs):
+        want = OP.resize_bicubic_u8(im, 224, 224)
+        assert np.array_equal(u8[i].cpu().numpy(), want), shapes[i]
+        assert np.array_equal(out[i].cpu().numpy(), OP.to_tensor_normalize(want)), shapes[i]
+    assert pre()([]).shape == (0, 3, 224, 224)
+    with pytest.raises(ValueError):
+        pre()([np.zeros((4, 4), dtype=np.uint8)])
+
+
+def test_feeds_the_model_contract(pre):
+    """a (b, T) list of decoded images becomes vision_x (b, T, 1, 3, 224, 224) bf16 on the device (mmrec.py:135-141)."""
+    rng = np.random.default_rng(1)
+    imgs = [rng.integers(0, 256, (300 + 7 * i, 280, 3), dtype=np.uint8) for i in range(6)]
+    x = pre()(imgs).view(2, 3, 1, 3, 224, 224)
+    assert x.is_cuda and x.dtype == torch.bfloat16 and torch.isfinite(x.float()).all()
+    assert float(x.float().abs().max()) < 3.0

@@ -58,6 +58,7 @@ _SIGS = {
     "unimp_focal_ce_bwd": [c_p, c_l, c_p, c_p, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "unimp_sumsq_bf16": [c_p, c_l, c_p, c_p],
     "unimp_adamw_flat": [c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_f, c_f, c_f, c_f, c_f, c_i, c_p, c_f, c_f, c_i, c_p],
+    "unimp_image_resize_normalize": [c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_p],
 }
 
 _lib = None

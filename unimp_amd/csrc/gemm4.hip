@@ -82,8 +82,8 @@ __global__ __launch_bounds__(256, 1) void gemm4_bf16_kernel(Gemm2Params p) {
     _Pragma("unroll") for (int j = 0; j < 8; ++j) mfma_agpr(acc[I][j], fb_[j], fa_);                                \
     /* after the row's MFMAs: hipcc's own waitcnt for this half-stage's fragments (it cannot see the asm wait) */    \
     /* then sits in front of the very first MFMA, where nothing is outstanding                                  */    \
-    if ((I) < 4) { LOADA(SN, (H) + 1, 2 * (I)); LOADA(SN, (H) + 1, 2 * (I) + 1);                                    \
-                   LOADB(SN, (H) + 1, 2 * (I)); LOADB(SN, (H) + 1, 2 * (I) + 1); }                                  \
+    if ((I) < 4) { LOADA(SN, (H) + 1, (2 * (I)) & 7); LOADA(SN, (H) + 1, (2 * (I) + 1) & 7);                        \
+                   LOADB(SN, (H) + 1, (2 * (I)) & 7); LOADB(SN, (H) + 1, (2 * (I) + 1) & 7); }                      \
     if (fast_) {                                                                                                    \
       if ((I) < 4) dma_one<AKS, G4_BM, 4>(p.A, p.lda, (H) + PD, smem + (((H) + PD) % G4_NST) * SUB, wave, aoff, (I) & 3);          \
       else dma_one<BKS, G4_BN, 4>(p.B, p.ldb, (H) + PD, smem + (((H) + PD) % G4_NST) * SUB + A_SUB, wave, boff, (I) & 3); } } while (0)

@@ -1,0 +1,172 @@
+"""Input pipeline either side of the training step.
+
+* ``ImagePreprocessor``: the reference's ``patch_resize_transform`` (UniMP/pipeline/mm_utils/rec_dataset.py:91-107:
+  bicubic resize to 224 x 224 via Pillow, ToTensor, Normalize with the CLIP statistics of rec_dataset.py:30-31) on the GPU:
+  the host hands over DECODED uint8 RGB images of any size (JPEG decoding stays on the host), the resize / scale /
+  normalise / cast run as HIP kernels (csrc/preprocess.hip), bit-exact with Pillow's 8-bit resampler.  Instead of
+  4.8 MB of fp32 pixels per sample the PCIe link carries the raw bytes.
+* ``collate_fn`` / ``collate_tokens``: UniMP/pipeline/mm_utils/collate_rec.py:38-115 (right padding with pad_idx, attention
+  masks padded with 0, per-sample loss weights, stacked images).
+* ``rec_prompt``: the text side of ``process_train_rec_pair`` (rec_dataset.py:372-437).
+"""
+import ctypes as C
+import numpy as np
+import torch
+
+from . import _lib
+from . import ops
+
+FLAMINGO_MEAN = (0.48145466, 0.4578275, 0.40821073)      # rec_dataset.py:30
+FLAMINGO_STD = (0.26862954, 0.26130258, 0.27577711)      # rec_dataset.py:31
+_PBITS = 22                                               # Pillow: PRECISION_BITS = 32 - 8 - 2
+
+
+def bicubic_taps(in_size, out_size):
+    """Pillow's tap table for one axis (libImaging/Resample.c precompute_coeffs + normalize_coeffs_8bpc, bicubic a = -0.5),
+    vectorised over the output coordinate with the SAME double-precision operation order, so the 22-bit integers are
+    Pillow's.  -> int32 [out_size, 2 + ksize]: (first source index, tap count, taps...)."""
+    scale = in_size / out_size
+    fs = max(scale, 1.0)
+    support = 2.0 * fs
+    ksize = int(np.ceil(support)) * 2 + 1
+    ss = 1.0 / fs
+    center = (np.arange(out_size, dtype=np.float64) + 0.5) * scale
+    xmin = np.trunc(center - support + 0.5).astype(np.int64)
+    xmin = np.maximum(xmin, 0)
+    xmax = np.trunc(center + support + 0.5).astype(np.int64)
+    xmax = np.minimum(xmax, in_size) - xmin
+    k = np.zeros((out_size, ksize), dtype=np.float64)
+    ww = np.zeros(out_size, dtype=np.float64)
+    a = -0.5
+    for x in range(ksize):
+        t = np.abs((x + xmin - center + 0.5) * ss)
+        w = np.where(t < 1.0, ((a + 2.0) * t - (a + 3.0)) * t * t + 1, np.where(t < 2.0, (((t - 5) * t + 8) * t - 4) * a, 0.0))
+        w = np.where(x < xmax, w, 0.0)
+        k[:, x] = w
+        ww = ww + w                                   # same left-to-right accumulation as the C loop
+    nz = ww != 0.0
+    k[nz] = k[nz] / ww[nz, None]
+    fixed = np.trunc(k * float(1 << _PBITS) + np.where(k < 0, -0.5, 0.5)).astype(np.int32)
+    fixed[np.arange(ksize)[None, :] >= xmax[:, None]] = 0
+    out = np.empty((out_size, 2 + ksize), dtype=np.int32)
+    out[:, 0], out[:, 1], out[:, 2:] = xmin, xmax, fixed
+    return out
+
+
+class _ImageDesc(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("src_off", "H", "W", "kx_off", "ky_off", "ksx", "ksy", "tmp_off")]
+
+
+class ImagePreprocessor:
+    """callable: list of decoded RGB images (uint8 [H, W, 3] numpy arrays / torch tensors / PIL images, any sizes) ->
+    [n, 3, size, size] tensor on `device` (bf16 by default, like ``images.to(device, dtype=cast_dtype)`` at mmrec.py:135)."""
+
+    def __init__(self, size=224, mean=FLAMINGO_MEAN, std=FLAMINGO_STD, device="cuda", dtype=torch.bfloat16):
+        if dtype not in (torch.bfloat16, torch.float32):
+            raise ValueError("ImagePreprocessor: dtype must be bfloat16 or float32")
+        self.size, self.device, self.dtype = size, torch.device(device), dtype
+        self._mean = (C.c_float * 3)(*mean)
+        self._std = (C.c_float * 3)(*std)
+        self._taps = {}                      # in_size -> int32 table (host), shared by both axes
+
+    def _table(self, n):
+        t = self._taps.get(n)
+        if t is None:
+            t = self._taps[n] = bicubic_taps(n, self.size)
+        return t
+
+    @staticmethod
+    def _as_u8(img):
+        if isinstance(img, torch.Tensor):
+            img = img.cpu().numpy()
+        a = np.asarray(img if isinstance(img, np.ndarray) else img.convert("RGB"))
+        if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3:
+            raise ValueError(f"ImagePreprocessor: expected a decoded RGB uint8 [H, W, 3] image, got {a.dtype} {a.shape}")
+        return np.ascontiguousarray(a)
+
+    def __call__(self, images, return_u8=False):
+        S = self.size
+        imgs = [self._as_u8(i) for i in images]
+        n = len(imgs)
+        out = torch.empty((n, 3, S, S), dtype=self.dtype, device=self.device)
+        u8 = torch.empty((n, S, S, 3), dtype=torch.uint8, device=self.device) if return_u8 else None
+        if n == 0:
+            return (out, u8) if return_u8 else out
+        descs = (_ImageDesc * n)()
+        tabs, tab_off, src_off, tmp_off, tpos = [], {}, 0, 0, 0
+        for i, a in enumerate(imgs):
+            H, W = a.shape[:2]
+            d = descs[i]
+            d.src_off, d.H, d.W, d.tmp_off = src_off, H, W, tmp_off
+            for axis, nn in (("x", W), ("y", H)):
+                if nn == S:
+                    ks, off = 0, 0
+                else:
+                    if nn not in tab_off:
+                        t = self._table(nn)
+                        tab_off[nn] = (tpos, t.shape[1] - 2)
+                        tabs.append(t.reshape(-1))
+                        tpos += t.size
+                    off, ks = tab_off[nn]
+                if axis == "x":
+                    d.kx_off, d.ksx = off, ks
+                else:
+                    d.ky_off, d.ksy = off, ks
+            src_off += H * W * 3
+            tmp_off += H * S * 3
+        src = torch.from_numpy(np.concatenate([a.reshape(-1) for a in imgs])).to(self.device, non_blocking=True)
+        tables = torch.from_numpy(np.concatenate(tabs) if tabs else np.zeros(1, np.int32)).to(self.device, non_blocking=True)
+        dd = torch.from_numpy(np.frombuffer(descs, dtype=np.int64).copy()).to(self.device, non_blocking=True)
+        tmp = torch.empty(max(tmp_off, 1), dtype=torch.uint8, device=self.device)
+        _lib.check(_lib.lib().unimp_image_resize_normalize(
+            src.data_ptr(), dd.data_ptr(), n, max(a.shape[0] for a in imgs), tables.data_ptr(), tmp.data_ptr(), S, S,
+            C.cast(self._mean, C.c_void_p), C.cast(self._std, C.c_void_p), out.data_ptr(), int(self.dtype == torch.float32),
+            u8.data_ptr() if u8 is not None else None, ops._stream()), "image_resize_normalize")
+        return (out, u8) if return_u8 else out
+
+
+# ------------------------------------------------------------------------------------------------ collate (host logic)
+def collate_tokens(values, pad_idx, eos_idx=None, left_pad=False, move_eos_to_beginning=False, pad_to_length=None,
+                   pad_to_multiple=1, pad_to_bsz=None):
+    """list of 1-D (or 2-D) tensors -> one padded tensor (collate_rec.py:77-115)."""
+    size = max(v.size(0) for v in values)
+    size = size if pad_to_length is None else max(size, pad_to_length)
+    if pad_to_multiple != 1 and size % pad_to_multiple != 0:
+        size = int(((size - 0.1) // pad_to_multiple + 1) * pad_to_multiple)
+    if values[0].dim() == 1:
+        res = values[0].new_full((len(values), size), pad_idx)
+    elif values[0].dim() == 2:
+        if move_eos_to_beginning:
+            raise AssertionError("move_eos_to_beginning needs 1-D inputs")
+        res = values[0].new_full((len(values), size, values[0].size(1)), pad_idx)
+    else:
+        raise NotImplementedError
+    for i, v in enumerate(values):
+        dst = res[i][size - len(v):] if left_pad else res[i][:len(v)]
+        if move_eos_to_beginning:
+            dst[0] = v[-1] if eos_idx is None else eos_idx
+            dst[1:] = v[:-1]
+        else:
+            dst.copy_(v)
+    return res
+
+
+def collate_fn(samples, pad_idx, eos_idx):
+    """collate_rec.py:38-74: samples are ``{"net_input": {"input_ids", "attention_masks", "patch_images", "weights"}}``."""
+    if len(samples) == 0:
+        return {}
+    ni = [s["net_input"] for s in samples]
+    longest = max(x["input_ids"].size(0) for x in ni)
+    batch = {"net_input": {
+        "input_ids": collate_tokens([x["input_ids"] for x in ni], pad_idx, eos_idx=eos_idx, pad_to_length=longest),
+        "attention_masks": collate_tokens([x["attention_masks"] for x in ni], 0, eos_idx=eos_idx, pad_to_length=longest),
+        "weights": torch.tensor([x["weights"] for x in ni]),
+    }}
+    batch["net_input"]["patch_images"] = torch.stack([x["patch_images"] for x in ni], dim=0)
+    return batch
+
+
+def rec_prompt(history, target, question="What is the next item recommended to the user?"):
+    """text of ``process_train_rec_pair`` (rec_dataset.py:395-424, naive item ids): history = [(item_id, meta_text), ...]."""
+    s = "".join(f"<image> {meta} <answer> item_{item} <|endofchunk|> " for item, meta in history)
+    return s + f"{question} <answer> item_{target}"

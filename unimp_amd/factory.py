@@ -14,8 +14,8 @@ from .flamingo import Flamingo, freeze_like_factory
 from .lm import build_lm
 from .vit import VisionTransformer, CLIPStub, VISION_CONFIGS
 
-FLAMINGO_MEAN = [0.481, 0.458, 0.408]      # rec_dataset.py:30-31
-FLAMINGO_STD = [0.269, 0.261, 0.276]
+FLAMINGO_MEAN = [0.48145466, 0.4578275, 0.40821073]      # rec_dataset.py:30-31 (unify_dataset.py:34 rounds them to 3 digits;
+FLAMINGO_STD = [0.26862954, 0.26130258, 0.27577711]       #  the recommendation pipeline this build targets uses the full ones)
 
 
 class SyntheticTokenizer:
@@ -100,6 +100,15 @@ class ImageProcessor:
         img = img.convert("RGB").resize((self.size, self.size), Image.BICUBIC)
         x = torch.from_numpy(np.asarray(img, dtype=np.float32) / 255.0).permute(2, 0, 1)
         return (x - self.mean) / self.std
+
+    def batch(self, images, device="cuda", dtype=torch.bfloat16):
+        """the same transform for a list of decoded images on the GPU (unimp_amd.data.ImagePreprocessor: HIP kernels,
+        bit-exact with Pillow's resize) -> [n, 3, S, S] on `device`."""
+        from .data import ImagePreprocessor
+        key = (str(device), dtype)
+        if getattr(self, "_dev", None) is None or self._dev[0] != key:
+            self._dev = (key, ImagePreprocessor(self.size, device=device, dtype=dtype))
+        return self._dev[1](images)
 
 
 def _load_tokenizer(tokenizer_path, use_local_files):
