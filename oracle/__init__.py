@@ -23,7 +23,15 @@ reference executes for one optimizer step:
 * ``oracle.train_step`` -- label mask, weighted focal CE, AdamW grouping, clip, schedule
                             (UniMP/mmrec.py:143-168,190-213,247-256,609-631,676-697)
 
+* ``oracle.preprocess`` -- image half of the input pipeline: Pillow's 8-bit bicubic resampler (numpy restatement),
+                            ToTensor, Normalize (UniMP/pipeline/mm_utils/rec_dataset.py:30-31,91-107;
+                             transforms.py:102-136)
+
 Parity pinning status (see DESIGN.md "Oracle"):
+  - preprocess:   PINNED against Pillow itself (the third-party library the reference's transform calls,
+                  requirements.txt:17; 12.2.0 here): tests/golden/preprocess_pillow.npz + live comparison,
+                  generator oracle/make_golden_preprocess.py.  collate_fn is checked against the reference's own
+                  collate_rec.py output (tests/golden/collate_rec.npz, same generator).
   - train_step:   PINNED against the reference itself (UniMP/mmrec.py:train_one_epoch run
                   in the build container with stubbed third-party imports; fixtures in
                   tests/golden/train_step_*.npz, generator oracle/make_golden.py).
