@@ -18,6 +18,7 @@
 // Block ids are remapped XCD-contiguously and then swept in GROUP_M-row groups for L2 reuse.
 #include <stdlib.h>
 #include "common.h"
+#include <cstdlib>
 #include "unimp_hip.h"
 
 struct GemmParams {
@@ -234,10 +235,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
 // One block = 16 rows of W; its 4 waves take interleaved 64-k chunks (4 adjacent 128-B lines per W row and iteration) and
 // meet in LDS.  Inside a chunk lane (r, g) owns k = 16g .. 16g+15 of row r -- 32 contiguous bytes -- and feeds them to two
 // MFMAs; X uses the same k assignment, and a contraction does not care in which order k is visited.
+#ifndef SK_U
 #define SK_U 4                      // chunks in flight per wave (8 x 16 B of W per lane)
-template <int MB>
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmParams p) {
-  __shared__ f32x4 red[4][MB][64];
+#endif
+template <int MB, int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(GemmParams p) {
+  __shared__ f32x4 red[NW][MB][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int g = lane >> 4, r = lane & 15;
   const int n0 = blockIdx.x * 16;
@@ -250,11 +253,11 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmParams p) {
   for (int i = 0; i < MB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int nchunk = p.K >> 6;
   int c = w;
-  for (; c + 4 * (SK_U - 1) < nchunk; c += 4 * SK_U) {
+  for (; c + NW * (SK_U - 1) < nchunk; c += NW * SK_U) {
     u32x4 wv[SK_U][2];
 #pragma unroll
     for (int u = 0; u < SK_U; ++u) {
-      const bf16* q = wp + (long)(c + 4 * u) * 64;
+      const bf16* q = wp + (long)(c + NW * u) * 64;
       wv[u][0] = __builtin_nontemporal_load((const u32x4*)q);
       wv[u][1] = __builtin_nontemporal_load((const u32x4*)(q + 8));
     }
@@ -262,14 +265,14 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmParams p) {
     for (int u = 0; u < SK_U; ++u) {
 #pragma unroll
       for (int i = 0; i < MB; ++i) {
-        const bf16* q = xp[i] + (long)(c + 4 * u) * 64;
+        const bf16* q = xp[i] + (long)(c + NW * u) * 64;
         u32x4 x0 = *(const u32x4*)q, x1 = *(const u32x4*)(q + 8);
         acc[i] = MFMA16(wv[u][0], x0, acc[i]);
         acc[i] = MFMA16(wv[u][1], x1, acc[i]);
       }
     }
   }
-  for (; c < nchunk; c += 4) {
+  for (; c < nchunk; c += NW) {
     const bf16* q = wp + (long)c * 64;
     u32x4 w0 = *(const u32x4*)q, w1 = *(const u32x4*)(q + 8);
 #pragma unroll
@@ -285,8 +288,10 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmParams p) {
   float gate = 1.f;
   if (p.gate) gate = tanhf(bf2f(*p.gate));
   bool fast = ((p.N & 3) == 0) && (((p.ldc | p.ldres | p.ldaux | p.ldpre) & 3) == 0);
-  for (int i = w; i < MB; i += 4) {
-    f32x4 a = red[0][i][lane] + red[1][i][lane] + red[2][i][lane] + red[3][i][lane];
+  for (int i = w; i < MB; i += NW) {
+    f32x4 a = red[0][i][lane];
+#pragma unroll
+    for (int ww = 1; ww < NW; ++ww) a += red[ww][i][lane];
     if (fast) epi_tile<true>(p, a, i * 16 + r, n0 + g * 4, gate);
     else epi_tile<false>(p, a, i * 16 + r, n0 + g * 4, gate);
   }
@@ -305,14 +310,21 @@ static void launch_skinny(const unimp_gemm_desc* d, void* stream) {
   p.gate = (const bf16*)d->gate; p.alpha = d->alpha; p.act = d->act; p.dact = d->dact;
   p.out_f32 = d->out_f32; p.accumulate = d->accumulate; p.pre_deriv = d->pre_deriv;
   p.nbm = 1; p.nbn = (d->N + 15) / 16; p.ksplit = 0;
-  dim3 grid(p.nbn), block(256);
+  dim3 grid(p.nbn);
   hipStream_t s = (hipStream_t)stream;
+  // few row groups (N small) or a long K: 8 waves per block split K eight ways so enough loads are in flight chip-wide
+  static int force_nw = -1;
+  if (force_nw < 0) { const char* e = getenv("UNIMP_SKINNY_NW"); force_nw = e ? atoi(e) : 0; }
+  bool wide = force_nw ? force_nw == 8 : (p.nbn < 512 && d->K >= 1024);
+#define SK_LAUNCH(MB_) do { if (wide) hipLaunchKernelGGL((gemm_skinny_kernel<MB_, 8>), grid, dim3(512), 0, s, p);   \
+                            else hipLaunchKernelGGL((gemm_skinny_kernel<MB_, 4>), grid, dim3(256), 0, s, p); } while (0)
   switch ((d->M + 15) / 16) {
-    case 1: hipLaunchKernelGGL((gemm_skinny_kernel<1>), grid, block, 0, s, p); break;
-    case 2: hipLaunchKernelGGL((gemm_skinny_kernel<2>), grid, block, 0, s, p); break;
-    case 3: hipLaunchKernelGGL((gemm_skinny_kernel<3>), grid, block, 0, s, p); break;
-    default: hipLaunchKernelGGL((gemm_skinny_kernel<4>), grid, block, 0, s, p); break;
+    case 1: SK_LAUNCH(1); break;
+    case 2: SK_LAUNCH(2); break;
+    case 3: SK_LAUNCH(3); break;
+    default: SK_LAUNCH(4); break;
   }
+#undef SK_LAUNCH
 }
 
 extern "C" int unimp_gemm2_launch(const unimp_gemm_desc* d, int bn, void* stream);   // gemm2.hip: 256-row tiles, LDS-DMA, 2-stage
