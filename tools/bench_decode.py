@@ -1,5 +1,5 @@
 """Decode-loop timing at cfg2 size (eval_rec.py:100-110: K = 10 beams, 50 new tokens).  Not a pytest file.
-usage: python tests/bench_decode.py [new_tokens] [beams]"""
+usage: python tools/bench_decode.py [new_tokens] [beams]"""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,5 +1,5 @@
 """GEMM micro-benchmark on the step's real shapes (random data): TFLOP/s per operand form, v1 (128^2) vs v2 (256-row).
-usage: python tests/bench_gemm.py [tokens]      env UNIMP_GEMM_V1=1 forces the 128x128 kernel"""
+usage: python tools/bench_gemm.py [tokens]      env UNIMP_GEMM_V1=1 forces the 128x128 kernel"""
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from unimp_amd import ops
