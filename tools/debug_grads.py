@@ -1,5 +1,5 @@
 import sys, torch
-sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+sys.path.insert(0, "tests"); sys.path.insert(0, ".")      # run from the repo root
 import _parity as P
 from unimp_amd.train import Trainer
 for name in sys.argv[1:] or ["TINY_OPT"]:
