@@ -62,7 +62,7 @@ def test_gemm_layouts(ops, M, N, K, a_ks, b_ks):
     bd = (b.t().contiguous() if b_ks else b).cuda()
     got = ops.gemm(ad, bd, a_ks=a_ks, b_ks=b_ks)                  # autotuned choice
     close(got, want, name=f"gemm {M}x{N}x{K} {a_ks}{b_ks}")
-    for variant in (["v1"] if M < 256 else ["v1", "dma256", "dma128", "pp256", "pp128", "w4"]):   # every kernel, explicitly
+    for variant in (["v1"] if M < 256 else ["v1", "dma256", "dma128", "pp256", "pp128", "w4", "w8"]):   # every kernel, explicitly
         got = ops.gemm(ad, bd, a_ks=a_ks, b_ks=b_ks, variant=variant)
         close(got, want, name=f"gemm[{variant}] {M}x{N}x{K} {a_ks}{b_ks}")
     got32 = ops.gemm(ad, bd, a_ks=a_ks, b_ks=b_ks, out_f32=True, variant="pp256" if M >= 256 else "v1")

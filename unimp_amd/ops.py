@@ -17,7 +17,7 @@ bf16 = torch.bfloat16
 
 GEMM_PROFILE = None      # bench.py sets this to a list: (start_event, end_event, flops) per GEMM launch
 GEMM_AUTOTUNE = True     # time the kernel variants once per (M, N, K, layout) on scratch operands and keep the fastest
-GEMM_VARIANTS = {"auto": 0, "v1": 1, "dma256": 2, "dma128": 3, "pp256": 4, "pp128": 5, "skinny": 6, "w4": 7}
+GEMM_VARIANTS = {"auto": 0, "v1": 1, "dma256": 2, "dma128": 3, "pp256": 4, "pp128": 5, "skinny": 6, "w4": 7, "w8": 8}
 _GEMM_CHOICE = {}
 _TUNE_FILE = os.environ.get("UNIMP_GEMM_TUNE_FILE")       # optional JSON cache of the autotune table (profiling runs reuse it)
 if _TUNE_FILE and os.path.exists(_TUNE_FILE):
@@ -38,7 +38,7 @@ def _tune_gemm(M, N, K, a_ks, b_ks, device):
         return v
     if not GEMM_AUTOTUNE or torch.cuda.is_current_stream_capturing():
         return 0
-    cands = [1] if (M < 512 or N < 128 or K < 128) else [1, 4, 5, 2, 3]
+    cands = [1] if (M < 512 or N < 128 or K < 128) else [1, 4, 5, 2, 3, 8]
     if len(cands) == 1:
         _GEMM_CHOICE[key] = cands[0]
         return cands[0]
