@@ -31,7 +31,8 @@ Parity pinning status (see DESIGN.md "Oracle"):
   - preprocess:   PINNED against Pillow itself (the third-party library the reference's transform calls,
                   requirements.txt:17; 12.2.0 here): tests/golden/preprocess_pillow.npz + live comparison,
                   generator oracle/make_golden_preprocess.py.  collate_fn is checked against the reference's own
-                  collate_rec.py output (tests/golden/collate_rec.npz, same generator).
+                  collate_rec.py output (tests/golden/collate_rec.npz, same generator); the rec-task dataset reader
+                  against the reference's own RecDataset class (tests/golden/rec_dataset.npz).
   - train_step:   PINNED against the reference itself (UniMP/mmrec.py:train_one_epoch run
                   in the build container with stubbed third-party imports; fixtures in
                   tests/golden/train_step_*.npz, generator oracle/make_golden.py).

@@ -66,3 +66,62 @@ def test_rec_prompt_template():
     s = D.rec_prompt([(11, "Name a Color b"), (12, "Name c")], 13)
     assert s == ("<image> Name a Color b <answer> item_11 <|endofchunk|> <image> Name c <answer> item_12 <|endofchunk|> "
                  "What is the next item recommended to the user? <answer> item_13")
+
+
+def _materialise_rec_dataset(tmp_path):
+    g = np.load(os.path.join(GOLD, "rec_dataset.npz"))
+    for i, name in enumerate(g["file_names"]):
+        p = tmp_path / str(name)
+        p.parent.mkdir(parents=True, exist_ok=True)
+        p.write_bytes(g[f"file_{i}"].tobytes())
+    return g
+
+
+def _tokenizer():
+    from unimp_amd.factory import SyntheticTokenizer
+    tok = SyntheticTokenizer()
+    tok.add_special_tokens({"additional_special_tokens": ["<|endofchunk|>", "<image>", "<answer>"]})
+    tok.add_special_tokens({"pad_token": "<PAD>"})
+    return tok
+
+
+def test_rec_dataset_matches_reference_golden(tmp_path):
+    """unimp_amd.data.RecDataset against samples produced by the reference's own RecDataset class on the same files, the
+    same tokenizer and the same numpy seed (oracle/make_golden_preprocess.py --rec-dataset)."""
+    pytest.importorskip("PIL.Image")
+    from unimp_amd.factory import ImageProcessor
+    g = _materialise_rec_dataset(tmp_path)
+    for split in ("train", "test"):
+        ds = D.RecDataset(str(tmp_path), "all", _tokenizer(), split=split, image_transform=ImageProcessor(224))
+        assert len(ds) == 4
+        np.random.seed(11)
+        for idx in range(3):
+            s = ds[idx]
+            ni = s["net_input"]
+            assert np.array_equal(ni["input_ids"].numpy(), g[f"{split}{idx}_ids"]), (split, idx)
+            assert np.array_equal(ni["attention_masks"].numpy(), g[f"{split}{idx}_mask"])
+            assert np.array_equal(ni["patch_images"][:, :, ::16, ::16].numpy(), g[f"{split}{idx}_img_sub"])
+            sums = np.array([float(ni["patch_images"].double().sum()), float(ni["patch_images"].double().abs().sum())])
+            assert np.array_equal(sums, g[f"{split}{idx}_img_sum"])
+            if split == "train":
+                assert float(ni["weights"]) == float(g[f"{split}{idx}_w"]) == 2.0
+            else:
+                assert s["net_output"]["output_ids"] == str(g[f"{split}{idx}_target"])
+                assert ni["input_len"] == int(g[f"{split}{idx}_input_len"])
+
+
+def test_rec_dataset_deferred_images_and_collate(tmp_path):
+    pytest.importorskip("PIL.Image")
+    _materialise_rec_dataset(tmp_path)
+    tok = _tokenizer()
+    ds = D.RecDataset(str(tmp_path), "all", tok, split="train", defer_images=True)
+    np.random.seed(11)
+    samples = [ds[i] for i in range(3)]
+    assert all(len(s["net_input"]["patch_images"]) == 5 and s["net_input"]["patch_images"][0].dtype == np.uint8 for s in samples)
+    b = ds.collate(samples)["net_input"]
+    L = max(s["net_input"]["input_ids"].numel() for s in samples)
+    assert b["input_ids"].shape == (3, L) and b["attention_masks"].shape == (3, L) and b["weights"].tolist() == [2.0] * 3
+    assert (b["input_ids"][b["attention_masks"] == 0] == tok.pad_token_id).all()
+    assert len(b["patch_images_raw"]) == 3 and "patch_images" not in b
+    with pytest.raises(ValueError):
+        D.RecDataset(str(tmp_path), "all", tok)

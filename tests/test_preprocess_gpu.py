@@ -52,3 +52,21 @@ def test_feeds_the_model_contract(pre):
     x = pre()(imgs).view(2, 3, 1, 3, 224, 224)
     assert x.is_cuda and x.dtype == torch.bfloat16 and torch.isfinite(x.float()).all()
     assert float(x.float().abs().max()) < 3.0
+
+
+def test_dataset_to_device_pipeline_matches_reference_images(pre, tmp_path):
+    """RecDataset(defer_images=True) -> collate -> ImagePreprocessor on the GPU gives the reference dataset's own
+    patch_images (tests/golden/rec_dataset.npz: produced by UniMP's RecDataset class with the host transform)."""
+    pytest.importorskip("PIL.Image")
+    from test_preprocess_cpu import _materialise_rec_dataset, _tokenizer
+    from unimp_amd.data import RecDataset
+    g = _materialise_rec_dataset(tmp_path)
+    ds = RecDataset(str(tmp_path), "all", _tokenizer(), split="train", defer_images=True)
+    np.random.seed(11)
+    batch = ds.collate([ds[i] for i in range(3)])["net_input"]
+    flat = [im for sample in batch["patch_images_raw"] for im in sample]
+    x = pre(dtype=torch.float32)(flat).view(3, 5, 3, 224, 224)
+    for i in range(3):
+        assert np.array_equal(x[i][:, :, ::16, ::16].cpu().numpy(), g[f"train{i}_img_sub"]), i
+        sums = np.array([float(x[i].double().sum()), float(x[i].double().abs().sum())])
+        assert np.allclose(sums, g[f"train{i}_img_sum"], rtol=1e-9)

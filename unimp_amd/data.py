@@ -170,3 +170,110 @@ def rec_prompt(history, target, question="What is the next item recommended to t
     """text of ``process_train_rec_pair`` (rec_dataset.py:395-424, naive item ids): history = [(item_id, meta_text), ...]."""
     s = "".join(f"<image> {meta} <answer> item_{item} <|endofchunk|> " for item, meta in history)
     return s + f"{question} <answer> item_{target}"
+
+
+# ------------------------------------------------------------------------------------------------ dataset (host logic)
+class RecDataset:
+    """The sequential-recommendation task of UniMP's ``RecDataset`` (UniMP/pipeline/mm_utils/rec_dataset.py:57-297 for the
+    on-disk layout, 300-370 for the item descriptions, 372-456 / 458-533 for the train / eval samples, 1260-1278 collate).
+
+    Layout under ``folder``: ``{split}_users.json`` (``test_users.json`` for every non-train split) = {user: [[item, ...],
+    ...]}; ``meta_{subset}.json``; ``{subset}/{item}.jpg``; ``id2semantic.json`` when ``use_semantic``.
+    The numpy global RNG is consumed exactly like the reference does (one ``np.random.choice`` per training sample for the
+    history window, one unused ``np.random.random()`` inside every item description), so a seeded run yields the same
+    samples.  ``image_transform``: per-image host callable (the factory's ``image_processor``); with ``defer_images=True``
+    the decoded uint8 arrays are kept instead and ``collate`` returns them under ``patch_images_raw`` for
+    ``ImagePreprocessor`` to resize / normalise on the GPU."""
+
+    HISTORY = {"all": 5, "netflix": 3, "hm": 8}
+    QUESTION = "What is the next item recommended to the user?"
+
+    def __init__(self, folder, subset, tokenizer, split="train", use_semantic=False, image_transform=None, defer_images=False):
+        import json
+        import os
+        if subset not in self.HISTORY:
+            raise ValueError(f"RecDataset: unknown subset {subset!r}")
+        if image_transform is None and not defer_images:
+            raise ValueError("RecDataset: pass image_transform or defer_images=True")
+        self.folder, self.subset, self.split, self.tokenizer = folder, subset, split, tokenizer
+        self.use_semantic, self.transform, self.defer = use_semantic, image_transform, defer_images
+        self.img_folder = os.path.join(folder, subset)
+        self.history_len = self.HISTORY[subset]
+        with open(os.path.join(folder, f"meta_{subset}.json")) as f:
+            self.meta_data = json.load(f)
+        with open(os.path.join(folder, f"{split}_users.json" if split == "train" else "test_users.json")) as f:
+            self.data = json.load(f)
+        self.seqs, self.keys = list(self.data.values()), list(self.data.keys())
+        if use_semantic:
+            self.len_semanticid = 3
+            with open(os.path.join(folder, "id2semantic.json")) as f:
+                self.id2semantic = json.load(f)
+        self.bos_item = torch.LongTensor([tokenizer.bos_token_id])
+        self.eos_item = torch.LongTensor([tokenizer.eos_token_id])
+
+    def __len__(self):
+        return len(self.seqs)
+
+    # rec_dataset.py:300-370
+    def describe(self, item):
+        cut = lambda s: " ".join(s.split()[:20])
+        s = self.meta_data[str(item)]
+        np.random.random()                                     # the reference draws (and ignores) p here
+        if self.subset == "all":
+            g = lambda k: "Unknown" if s[k] == "" else s[k]
+            return f"Category {cut(g('category'))} Price {g('price')} Brand {cut(g('brand'))} Title {cut(g('title'))}"
+        if self.subset == "netflix":
+            return f"Title {cut(s[1])} Release Date {s[0]}"
+        return f"Name {cut(s[0])} Appearance {cut(s[1])} Color {cut(s[2])} Section {cut(s[3])}"
+
+    def _item_token(self, item):
+        if not self.use_semantic:
+            return f"item_{item}"
+        ids = self.id2semantic[str(item)].split(",")
+        return "".join(f"item_{v}" if i < self.len_semanticid else f"item_last_{v}" for i, v in enumerate(ids))
+
+    def _image(self, item):
+        import os
+        from PIL import Image
+        img = Image.open(os.path.join(self.img_folder, f"{item}.jpg")).convert("RGB")
+        return np.asarray(img).copy() if self.defer else self.transform(img)
+
+    def _tokenize(self, text):
+        t = self.tokenizer(text, return_tensors="pt", add_special_tokens=False, truncation=True)
+        return t["input_ids"].squeeze(0), t["attention_mask"].squeeze(0)
+
+    def __getitem__(self, index):
+        seq = [it[0] for it in self.seqs[index]]
+        imgs, text = [], ""
+        if self.split == "train":                              # rec_dataset.py:372-456
+            start = np.random.choice(list(range(0, len(seq) - self.history_len)), 1)[0]
+            end = start + self.history_len
+            for item in seq[start:end]:
+                imgs.append(self._image(item))
+                text += f"<image> {self.describe(item)} <answer> {self._item_token(item)} <|endofchunk|> "
+            text += f"{self.QUESTION} <answer> {self._item_token(seq[end])}"
+            ids, mask = self._tokenize(text)
+            one = torch.LongTensor([1])
+            net = {"input_ids": torch.cat([self.bos_item, ids, self.eos_item]), "attention_masks": torch.cat([one, mask, one]),
+                   "patch_images": imgs if self.defer else torch.stack(imgs, dim=0), "weights": torch.tensor(2.0)}
+            return {"net_input": net}
+        test_len = 20 if self.subset == "hm" else 5            # rec_dataset.py:458-533
+        for item in seq[-test_len:-1]:
+            desc = self.describe(item)
+            imgs.append(self._image(item))
+            text += f"<image> {desc} {self._item_token(item)} <|endofchunk|> "
+        text += f"{self.QUESTION} <answer>"
+        ids, mask = self._tokenize(text)
+        net = {"input_ids": ids, "attention_masks": mask, "patch_images": imgs if self.defer else torch.stack(imgs, dim=0),
+               "input_len": len(text.split(" "))}
+        return {"net_input": net, "net_output": {"output_ids": self._item_token(seq[-1])}}
+
+    def collate(self, samples):
+        if not self.defer:
+            return collate_fn(samples, pad_idx=self.tokenizer.pad_token_id, eos_idx=self.tokenizer.eos_token_id)
+        raw = [s["net_input"]["patch_images"] for s in samples]
+        stub = [{"net_input": {**s["net_input"], "patch_images": torch.zeros(len(r), 0)}} for s, r in zip(samples, raw)]
+        batch = collate_fn(stub, pad_idx=self.tokenizer.pad_token_id, eos_idx=self.tokenizer.eos_token_id)
+        del batch["net_input"]["patch_images"]
+        batch["net_input"]["patch_images_raw"] = raw           # [b][T] uint8 arrays -> ImagePreprocessor on the device
+        return batch
