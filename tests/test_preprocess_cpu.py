@@ -125,3 +125,16 @@ def test_rec_dataset_deferred_images_and_collate(tmp_path):
     assert len(b["patch_images_raw"]) == 3 and "patch_images" not in b
     with pytest.raises(ValueError):
         D.RecDataset(str(tmp_path), "all", tok)
+
+
+def test_rec_metrics_match_reference_golden():
+    from unimp_amd import eval as E
+    g = np.load(os.path.join(GOLD, "rec_metrics.npz"))
+    for r, want in zip(g["r"], g["metrics"]):
+        got = [E.hit_at_k(r, k) for k in (3, 5, 10)] + [E.ndcg_at_k(r, k, 1) for k in (3, 5, 10)] + [E.mrr_at_k(r, k) for k in (3, 5, 10)]
+        assert np.array_equal(np.array(got), want), r
+    assert E.ndcg_at_k([0, 0, 1, 0, 0, 0, 0, 0, 0, 0], 10, 1) == 0.5          # hit at rank 3
+    r = E.relevance(["a b? item_7", "q? item_9</s> junk", "item_7"], "item_7")
+    assert r.tolist() == [1, 0, 1, 0, 0, 0, 0, 0, 0, 0]
+    m = E.user_metrics(r)
+    assert m["hr@3"] == 1.0 and m["mrr@10"] == 1.0

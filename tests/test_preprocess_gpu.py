@@ -70,3 +70,30 @@ def test_dataset_to_device_pipeline_matches_reference_images(pre, tmp_path):
         assert np.array_equal(x[i][:, :, ::16, ::16].cpu().numpy(), g[f"train{i}_img_sub"]), i
         sums = np.array([float(x[i].double().sum()), float(x[i].double().abs().sum())])
         assert np.allclose(sums, g[f"train{i}_img_sum"], rtol=1e-9)
+
+
+def test_eval_loop_generate_to_metrics(tmp_path):
+    """eval_rec.py's loop end to end on a tiny random model: RecDataset (eval split, raw images) -> GPU preprocessing ->
+    Flamingo.generate (beams, KV cache, HIP-graph step) -> decoded texts -> HR / NDCG / MRR."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    pytest.importorskip("PIL.Image")
+    from test_preprocess_cpu import _materialise_rec_dataset
+    from unimp_amd import create_model_and_transforms
+    from unimp_amd.data import ImagePreprocessor, RecDataset
+    from unimp_amd.eval import eval_model_rec
+    from unimp_amd.factory import SyntheticTokenizer
+    from unimp_amd.lm import NeoXConfig
+    _materialise_rec_dataset(tmp_path)
+    tok = SyntheticTokenizer(base_vocab=400)
+    tok.add_special_tokens({"additional_special_tokens": ["<answer>"]})
+    torch.manual_seed(0)
+    model, image_processor, tok = create_model_and_transforms(
+        dict(image_size=32, patch_size=8, width=128, layers=1, heads=2, mlp_dim=256, output_dim=64), None,
+        NeoXConfig(vocab_size=512, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256),
+        None, cross_attn_every_n_layers=1, tokenizer=tok, device="cuda")
+    ds = RecDataset(str(tmp_path), "all", tok, split="test", defer_images=True)
+    samples = [ds[i] for i in range(2)]
+    m = eval_model_rec(model, samples, tok, K=4, max_new_tokens=4, image_preprocessor=ImagePreprocessor(32))
+    assert set(m) == {f"{n}@{k}" for n in ("hr", "ndcg", "mrr") for k in (3, 5, 4)}
+    assert all(0.0 <= v <= 1.0 for v in m.values())

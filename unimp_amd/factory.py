@@ -81,6 +81,9 @@ class SyntheticTokenizer:
             return {"input_ids": ids, "attention_mask": mask}
         return {"input_ids": seqs[0] if single else seqs, "attention_mask": [1] * len(seqs[0]) if single else [[1] * len(s) for s in seqs]}
 
+    def batch_decode(self, seqs, skip_special_tokens=False):
+        return [self.decode(s, skip_special_tokens) for s in seqs]
+
     def decode(self, ids, skip_special_tokens=False):
         inv = {v: k for k, v in self.added.items()}
         return " ".join(inv.get(int(i), f"tok{int(i)}") for i in ids if not (skip_special_tokens and int(i) in inv))
