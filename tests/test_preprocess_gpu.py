@@ -97,3 +97,36 @@ def test_eval_loop_generate_to_metrics(tmp_path):
     m = eval_model_rec(model, samples, tok, K=4, max_new_tokens=4, image_preprocessor=ImagePreprocessor(32))
     assert set(m) == {f"{n}@{k}" for n in ("hr", "ndcg", "mrr") for k in (3, 5, 4)}
     assert all(0.0 <= v <= 1.0 for v in m.values())
+
+
+def test_train_loop_from_dataset(tmp_path):
+    """INTEGRATION.md's end-to-end flow on the tiny dataset: RecDataset -> collate -> GPU preprocessing -> Trainer.step."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    pytest.importorskip("PIL.Image")
+    from test_preprocess_cpu import _materialise_rec_dataset
+    from unimp_amd import create_model_and_transforms
+    from unimp_amd.data import ImagePreprocessor, RecDataset
+    from unimp_amd.factory import SyntheticTokenizer
+    from unimp_amd.lm import NeoXConfig
+    from unimp_amd.train import Trainer
+    _materialise_rec_dataset(tmp_path)
+    tok = SyntheticTokenizer(base_vocab=400)
+    tok.add_special_tokens({"additional_special_tokens": ["<answer>"]})
+    torch.manual_seed(0)
+    model, _, tok = create_model_and_transforms(
+        dict(image_size=32, patch_size=8, width=128, layers=1, heads=2, mlp_dim=256, output_dim=64), None,
+        NeoXConfig(vocab_size=512, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256),
+        None, cross_attn_every_n_layers=1, tokenizer=tok, device="cuda")
+    ids = dict(answer_id=tok.encode("<answer>")[-1], eoc_id=model.eoc_token_id, pad_id=tok.pad_token_id, media_id=model.media_token_id)
+    ds = RecDataset(str(tmp_path), "all", tok, split="train", defer_images=True)
+    pre_, trainer = ImagePreprocessor(32), Trainer(model, ids, lr=5e-3, lr_scheduler="constant", total_steps=10)
+    losses = []
+    for _ in range(8):
+        np.random.seed(0)                                   # the same history windows every step: the loss must go down
+        b = ds.collate([ds[i] for i in range(4)])["net_input"]
+        vx = pre_([im for s in b["patch_images_raw"] for im in s]).view(4, 5, 1, 3, 32, 32)
+        loss, stats = trainer.step(dict(vision_x=vx, lang_x=b["input_ids"].cuda(), attention_mask=b["attention_masks"].cuda(),
+                                        weights=b["weights"].cuda()))
+        losses.append(float(loss))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
