@@ -250,3 +250,34 @@ def test_full_size_generate_with_cache(cfg2):
     print(f"generate K=10 x12 tokens on a {ids.shape[1]}-token prompt: cached {res[True, 't']:.3f}s, re-scoring {res[False, 't']:.3f}s")
     assert res[True].shape[0] == 10 and torch.equal(res[True][:, :ids.shape[1]], ids.expand(10, -1))
     assert res[True, "t"] < res[False, "t"]
+
+
+def test_full_size_cached_decode_logits(cfg2):
+    """cfg2 dims (hd = 80, 32 heads, V = 74 053): logits of prefill + cached one-token steps -- eager, then replayed through
+    the HIP graph -- against a full forward over the grown sequence."""
+    from unimp_amd.decode import DecodeSession
+    model, layout = cfg2
+    model.eval()
+    bt = _batch(layout, 1)
+    n = int(bt["attention_mask"][0].sum())
+    ids, vx = bt["lang_x"][:1, :n - 2], bt["vision_x"][:1]
+    new = torch.randint(0, 50000, (1, 4), device="cuda")
+    with torch.no_grad():
+        full = model(vx, torch.cat([ids, new], 1))["logits"].float()
+        model.lang_encoder._use_cached_vision_x = True
+        model._encode_vision_x(vision_x=vx)
+        try:
+            sess = DecodeSession(model, max_new_tokens=8, reorder=False, graph=True)
+            steps = [sess.prefill(ids).float().clone()]
+            for j in range(4):                                   # step 0 eager, steps 1.. replayed from the graph
+                steps.append(sess.step(new[:, j]).float().clone())
+        finally:
+            model.clear_conditioned_layers()
+            model.lang_encoder._use_cached_vision_x = False
+    L0 = ids.shape[1]
+    scale = float(full.abs().max())
+    for j, lg in enumerate(steps):
+        want = full[:, L0 - 1 + j]
+        err = float((lg - want).abs().max()) / scale
+        assert err < 2e-2, (j, err)
+        assert int(lg.argmax()) == int(want.argmax()) or float(want.topk(2).values.diff().abs()) < 2e-2 * scale
