@@ -91,10 +91,12 @@ def test_rec_dataset_matches_reference_golden(tmp_path):
     pytest.importorskip("PIL.Image")
     from unimp_amd.factory import ImageProcessor
     g = _materialise_rec_dataset(tmp_path)
-    for split in ("train", "test"):
-        ds = D.RecDataset(str(tmp_path), "all", _tokenizer(), split=split, image_transform=ImageProcessor(224))
+    for split, task in (("train", "rec"), ("test", "rec"), ("train", "search"), ("test", "search")):
+        ds = D.RecDataset(str(tmp_path), "all", _tokenizer(), split=split, image_transform=ImageProcessor(224), task=task)
         assert len(ds) == 4
         np.random.seed(11)
+        if task == "search":
+            split = "search_" + split
         for idx in range(3):
             s = ds[idx]
             ni = s["net_input"]
@@ -103,8 +105,8 @@ def test_rec_dataset_matches_reference_golden(tmp_path):
             assert np.array_equal(ni["patch_images"][:, :, ::16, ::16].numpy(), g[f"{split}{idx}_img_sub"])
             sums = np.array([float(ni["patch_images"].double().sum()), float(ni["patch_images"].double().abs().sum())])
             assert np.array_equal(sums, g[f"{split}{idx}_img_sum"])
-            if split == "train":
-                assert float(ni["weights"]) == float(g[f"{split}{idx}_w"]) == 2.0
+            if split.endswith("train"):
+                assert float(ni["weights"]) == float(g[f"{split}{idx}_w"]) == (2.0 if task == "rec" else 1.0)
             else:
                 assert s["net_output"]["output_ids"] == str(g[f"{split}{idx}_target"])
                 assert ni["input_len"] == int(g[f"{split}{idx}_input_len"])

@@ -188,11 +188,15 @@ class RecDataset:
     HISTORY = {"all": 5, "netflix": 3, "hm": 8}
     QUESTION = "What is the next item recommended to the user?"
 
-    def __init__(self, folder, subset, tokenizer, split="train", use_semantic=False, image_transform=None, defer_images=False):
+    def __init__(self, folder, subset, tokenizer, split="train", use_semantic=False, image_transform=None, defer_images=False,
+                 task="rec"):
         import json
         import os
         if subset not in self.HISTORY:
             raise ValueError(f"RecDataset: unknown subset {subset!r}")
+        if task not in ("rec", "search"):
+            raise NotImplementedError(f"RecDataset: task {task!r} (rec and search are built; exp / img_sel / img_gen are not)")
+        self.task = task
         if image_transform is None and not defer_images:
             raise ValueError("RecDataset: pass image_transform or defer_images=True")
         self.folder, self.subset, self.split, self.tokenizer = folder, subset, split, tokenizer
@@ -230,7 +234,8 @@ class RecDataset:
         if not self.use_semantic:
             return f"item_{item}"
         ids = self.id2semantic[str(item)].split(",")
-        return "".join(f"item_{v}" if i < self.len_semanticid else f"item_last_{v}" for i, v in enumerate(ids))
+        sep = " " if self.task == "search" else ""             # rec_dataset.py:866 vs :411
+        return sep.join(f"item_{v}" if i < self.len_semanticid else f"item_last_{v}" for i, v in enumerate(ids))
 
     def _image(self, item):
         import os
@@ -239,10 +244,38 @@ class RecDataset:
         return np.asarray(img).copy() if self.defer else self.transform(img)
 
     def _tokenize(self, text):
-        t = self.tokenizer(text, return_tensors="pt", add_special_tokens=False, truncation=True)
+        kw = {"truncation": True} if self.task == "rec" else {}          # the search task tokenises without truncation
+        t = self.tokenizer(text, return_tensors="pt", add_special_tokens=False, **kw)
         return t["input_ids"].squeeze(0), t["attention_mask"].squeeze(0)
 
+    def _search_item(self, index):
+        """rec_dataset.py:842-913 (train) / 915-979 (eval): history as in rec, then "Query: <category of the target>"."""
+        seq = [it[0] for it in self.seqs[index]]
+        imgs, text = [], ""
+        ask = "What is the related item ID to the query based on the history?"
+        query = lambda item: self.meta_data[str(item)]["keywords" if self.subset == "cloth" else "category"]
+        if self.split == "train":
+            start = np.random.choice(list(range(0, len(seq) - self.history_len)), 1)[0]
+            end = start + self.history_len
+            for item in seq[start:end]:
+                imgs.append(self._image(item))
+                text += f"<image> {self.describe(item)} <answer> {self._item_token(item)} <|endofchunk|> "
+            text += f"Query: {query(seq[end])} {ask} <answer> {self._item_token(seq[end])}"
+            ids, mask = self._tokenize(text)
+            one = torch.LongTensor([1])
+            return {"net_input": {"input_ids": torch.cat([self.bos_item, ids, self.eos_item]), "attention_masks": torch.cat([one, mask, one]),
+                                  "patch_images": imgs if self.defer else torch.stack(imgs, dim=0), "weights": torch.tensor(1.0)}}
+        for item in seq[-5:-1]:
+            imgs.append(self._image(item))
+            text += f"<image> {self.describe(item)} {self._item_token(item)} <|endofchunk|> "
+        text += f"Query: {query(seq[-1])} {ask} <answer>"
+        ids, mask = self._tokenize(text)
+        return {"net_input": {"input_ids": ids, "attention_masks": mask, "patch_images": imgs if self.defer else torch.stack(imgs, dim=0),
+                              "input_len": len(text.split(" "))}, "net_output": {"output_ids": self._item_token(seq[-1])}}
+
     def __getitem__(self, index):
+        if self.task == "search":
+            return self._search_item(index)
         seq = [it[0] for it in self.seqs[index]]
         imgs, text = [], ""
         if self.split == "train":                              # rec_dataset.py:372-456
