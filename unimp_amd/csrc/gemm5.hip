@@ -61,24 +61,27 @@ __global__ __launch_bounds__(512, 2) void gemm5_bf16_kernel(Gemm2Params p) {
 #define FB(S, J) (BKS ? join_halves(lb##S[J], hb##S[J]) : rb##S[J])
 // row I of the wave tile: 4 MFMAs sharing one A fragment.  Riding along: rows 0-3 fetch the next half-stage's fragments
 // (2 of A + 1 of B each; unconditionally -- past the end of K they read a ring slot nobody uses into registers nobody
-// reads); rows 0, 2, 4, 6 issue the wave's 4 DMA instructions of half-stage H+PD.
+// reads).  ds_read issue between MFMAs is nearly free (tools/micro/mfma_mix.hip: +4 %); an LDS-DMA instruction is not --
+// it holds its wave ~75 cycles while the CU's 64 B/clk load path takes the 1 KB -- so the 4 DMA instructions of
+// half-stage H+PD are issued as one block OUTSIDE the MFMA stream: by group A (waves 0-3) before its MFMAs, by group B
+// after, so that one group's DMA block runs under the other group's MFMAs.
 #define ROW(SC, SN, H, I) do {                                                                                      \
     bf16x8 fa_ = FA(SC, I);                                                                                         \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[I][j] = MFMA16(fb_[j], fa_, acc[I][j]);                       \
     if ((I) < 4) { LOADA(SN, (H) + 1, (2 * (I)) & 7); LOADA(SN, (H) + 1, (2 * (I) + 1) & 7); LOADB(SN, (H) + 1, (I) & 3); }  \
-    if (fast_ && !((I) & 1)) {                                                                                      \
-      if ((I) < 4) dma_one<AKS, G5_BM, 8>(p.A, p.lda, (H) + PD, smem + (((H) + PD) % G5_NST) * SUB, wave, aoff, ((I) >> 1) & 1);   \
-      else dma_one<BKS, G5_BN, 8>(p.B, p.ldb, (H) + PD, smem + (((H) + PD) % G5_NST) * SUB + A_SUB, wave, boff, ((I) >> 1) & 1); } } while (0)
+  } while (0)
 #define STEP(H, SC, SN) do {                                                                                        \
     if ((H) + PD <= nh) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((PD - 2) * NEW) : "memory");                      \
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                           \
     G5_FENCE(); __builtin_amdgcn_s_barrier(); G5_FENCE();                                                           \
-    bool fast_ = ((H) + PD) * 32 + 32 <= p.K;                 /* full half-stage: DMA spread over the rows */       \
-    if (!fast_ && (H) + PD < nh) DMA((H) + PD);               /* ragged / zero half-stage: predicated path */       \
+    if (wm == 0 && (H) + PD < nh) DMA((H) + PD);                                                                    \
+    G5_FENCE();                                                                                                     \
     bf16x8 fb_[4];                                                                                                  \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) fb_[j] = FB(SC, j);                                               \
     ROW(SC, SN, H, 0); ROW(SC, SN, H, 1); ROW(SC, SN, H, 2); ROW(SC, SN, H, 3);                                     \
     ROW(SC, SN, H, 4); ROW(SC, SN, H, 5); ROW(SC, SN, H, 6); ROW(SC, SN, H, 7);                                     \
+    G5_FENCE();                                                                                                     \
+    if (wm == 1 && (H) + PD < nh) DMA((H) + PD);                                                                    \
     G5_FENCE(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); G5_FENCE(); } while (0)
 
   // K is eaten in PAIRS of half-stages by one straight-line loop body; an odd count is padded with a half-stage of
