@@ -194,3 +194,30 @@ def test_vit_vs_intree_clip_reference(P, golden_dir):
     assert e <= 1e-2, f"tokens rel L2 {e}"
     e = P.rel_l2(pooled, torch.from_numpy(z["pooler_output"])[:, :8])
     assert e <= 1e-2, f"pooled rel L2 {e}"
+
+
+def test_sparse_head_step_equals_dense_step():
+    """Trainer(sparse_head=True) -- head + focal loss on the labeled rows only -- gives the dense step's loss and update
+    (unlabeled rows contribute nothing to either; the GEMMs just see fewer rows, so agreement is at bf16 rounding level)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import _parity as P
+    from unimp_amd.train import Trainer
+    cfg = P.TINY
+    om, layout = P.build_oracle(cfg)
+    batch = {k: v.cuda() for k, v in P.make_batch(cfg, layout).items()}
+    batch["vision_x"] = batch["vision_x"].to(torch.bfloat16)
+    res = {}
+    for sparse in (False, True):
+        hm = P.build_hip(cfg, om, layout)
+        tr = Trainer(hm, layout.special(), lr=1e-2, lr_scheduler="constant", sparse_head=sparse)
+        before = tr.opt.master.clone()
+        loss, stats = tr.step(batch)
+        res[sparse] = (float(loss), stats.float().cpu(), (tr.opt.master - before).cpu())
+    (l0, s0, d0), (l1, s1, d1) = res[False], res[True]
+    assert abs(l0 - l1) <= 2e-3 * abs(l0), (l0, l1)
+    assert float(s0[1]) == float(s1[1]) > 0                               # same number of labeled tokens
+    rel = float((d0 - d1).norm() / d0.norm())
+    assert rel < 0.1, rel                                                 # Adam's sign-like first step amplifies rounding: compare directions
+    cos = float((d0 * d1).sum() / (d0.norm() * d1.norm()))
+    assert cos > 0.99, cos

@@ -180,7 +180,7 @@ class Flamingo(nn.Module):
         return _getattr_path(self.lang_encoder, self.lang_encoder.decoder_layers_attr)
 
     def forward(self, vision_x, lang_x, attention_mask=None, labels=None, clear_conditioned_layers=True,
-                past_key_values=None, use_cache=False):
+                past_key_values=None, use_cache=False, head_rows=None):
         assert self.lang_encoder.initialized_flamingo, "Flamingo layers are not initialized. Please call `init_flamingo` first."
         assert self.lang_encoder._use_cached_vision_x or vision_x is not None, \
             "Must provide either vision_x or have precached media using cache_media()."
@@ -192,7 +192,7 @@ class Flamingo(nn.Module):
         if past_key_values is not None:
             self._condition_cached_media(past_key_values, lang_x.shape[1])
         output = self.lang_encoder(input_ids=lang_x, attention_mask=attention_mask, labels=labels,
-                                   past_key_values=past_key_values, use_cache=use_cache)
+                                   past_key_values=past_key_values, use_cache=use_cache, head_rows=head_rows)
         if output.past_key_values is not None and output.past_key_values.media_count is None:
             output.past_key_values.media_count = (lang_x == self.media_token_id).sum(1, keepdim=True).to(torch.int32)
         if clear_conditioned_layers:

@@ -575,6 +575,45 @@ class FocalCEFn(Function):
         return dl, None, None, None, None
 
 
+class SparseHeadLossFn(Function):
+    """Head + weighted focal CE on the supervised rows only: ``h_rows`` [n, H] are the hidden states of the n positions
+    whose next token carries a label, ``targets`` [n] those labels, ``row_w`` [n] the per-sample weights.  The same loss,
+    dX and dW as LinearFn + FocalCEFn over all B*L rows (rows with label -100 contribute nothing to either), without the
+    (B*L) x V logits: the rows are laid out as n two-token sequences so the unchanged focal kernels see
+    logits[:, :-1] against labels[:, 1:]."""
+
+    @staticmethod
+    def forward(ctx, h_rows, w, targets, row_w, gamma, use_reweight):
+        n, V = h_rows.shape[0], w.shape[0]
+        ldv = (V + 7) // 8 * 8
+        buf = torch.empty((n, 2, ldv), dtype=bf16, device=h_rows.device)
+        ops.gemm(h_rows, w, out=buf.view(n, 2 * ldv)[:, :V])
+        logits = buf[..., :V]
+        labels = torch.stack([torch.full_like(targets, -100), targets], 1)
+        lse, zy, out3 = ops.focal_ce_fwd(logits, V, labels, row_w, gamma, use_reweight)
+        ctx.save_for_backward(h_rows, w, logits, labels, row_w, lse, zy, out3)
+        ctx.cfg = (gamma, use_reweight)
+        ctx.mark_non_differentiable(out3)
+        return out3[0] / out3[1], out3
+
+    @staticmethod
+    def backward(ctx, dloss, _):
+        h_rows, w, logits, labels, row_w, lse, zy, out3 = ctx.saved_tensors
+        gamma, rw = ctx.cfg
+        n, _, V = logits.shape
+        ldv = logits.stride(1)
+        buf = torch.empty((n, 2, ldv), dtype=bf16, device=logits.device)
+        ops.focal_ce_bwd(logits, V, labels, row_w, gamma, rw, lse, zy, out3, dloss.float().reshape(1), buf[..., :V])
+        dl = buf.view(n, 2 * ldv)[:, :V]                          # row i of the first position, leading dimension 2*ldv
+        dh = ops.gemm(dl, w, b_ks=True) if _need(ctx, 0) else None
+        dw = ops.gemm(dl, h_rows, a_ks=True, b_ks=True) if _need(ctx, 1) else None
+        return dh, dw, None, None, None, None
+
+
+def sparse_head_loss(h_rows, w, targets, row_w, gamma, use_reweight=True):
+    return SparseHeadLossFn.apply(h_rows, w, targets, row_w, float(gamma), bool(use_reweight))
+
+
 def focal_ce(logits, labels, weights, gamma, use_reweight=True):
     """returns (loss, stats) with stats = [loss_sum, n_labeled, ce_sum] (fp32 device tensor)."""
     return FocalCEFn.apply(logits, labels, weights, float(gamma), bool(use_reweight))

@@ -20,8 +20,9 @@ bf16 = torch.bfloat16
 class LMOutput:
     """``out[0]`` = loss when labels were passed (else logits); ``out["logits"]`` (UniMP/mmrec.py:182,190)."""
 
-    def __init__(self, loss, logits, stats=None, past_key_values=None):
+    def __init__(self, loss, logits, stats=None, past_key_values=None, hidden_rows=None):
         self.loss, self.logits, self.stats, self.past_key_values = loss, logits, stats, past_key_values
+        self.hidden_rows = hidden_rows          # head_rows path: final hidden states of the requested rows, no logits
 
     def __getitem__(self, k):
         if isinstance(k, str):
@@ -124,7 +125,9 @@ class _TowerBase(nn.Module):
             return rope
         return rope[0].index_select(0, cache.step.pos_idx), rope[1].index_select(0, cache.step.pos_idx), rope[2]
 
-    def _head(self, h, labels, last_only=False):
+    def _head(self, h, labels, last_only=False, head_rows=None):
+        if head_rows is not None:          # the caller applies the head itself on these flattened (b*L + j) rows (train.py)
+            return LMOutput(None, None, hidden_rows=h.reshape(-1, h.shape[-1]).index_select(0, head_rows))
         w = self.get_output_embeddings().weight
         V = w.shape[0]
         if last_only:                      # decoding: score only the final position (generate.py)
@@ -222,7 +225,7 @@ class GPTNeoXForCausalLM(_TowerBase):
             x = layer(x, attention_mask=kv_len, rope=rope, cache=cache.layers[i] if cache else None, pos0=pos0)
         f = self.gpt_neox.final_layer_norm
         h = F_.layer_norm(x, f.weight, f.bias, f.eps)
-        out = self._head(h, labels, kw.get("logits_last_only", False))
+        out = self._head(h, labels, kw.get("logits_last_only", False), kw.get("head_rows"))
         if cache is not None:
             if cache.step is None:
                 cache.len = pos0 + L
@@ -315,7 +318,7 @@ class OPTForCausalLM(_TowerBase):
             x = layer(x, attention_mask=kv_len, cache=cache.layers[i] if cache else None, pos0=pos0)
         f = d.final_layer_norm
         h = F_.layer_norm(x, f.weight, f.bias, f.eps)
-        out = self._head(h, labels, kw.get("logits_last_only", False))
+        out = self._head(h, labels, kw.get("logits_last_only", False), kw.get("head_rows"))
         if cache is not None:
             if cache.step is None:
                 cache.len = pos0 + L
@@ -436,7 +439,7 @@ class LlamaForCausalLM(_TowerBase):
             x = layer(x, attention_mask=None, rope=rope, cache=cache.layers[i] if cache else None, pos0=pos0)
         n = self.model.norm
         h = F_.layer_norm(x, n.weight, None, n.variance_epsilon, rms=True)
-        out = self._head(h, labels, kw.get("logits_last_only", False))
+        out = self._head(h, labels, kw.get("logits_last_only", False), kw.get("head_rows"))
         if cache is not None:
             if cache.step is None:
                 cache.len = pos0 + L

@@ -81,8 +81,12 @@ def load_checkpoint(path, model, trainer=None):
 
 class Trainer:
     def __init__(self, model, special_ids, lr=2e-4, weight_decay=0.1, gamma=2.0, use_reweight=True, max_grad_norm=1.0,
-                 lr_scheduler="cosine", warmup_steps=0, total_steps=1000, bucket_bytes=256 << 20, process_group=None):
-        self.model = model
+                 lr_scheduler="cosine", warmup_steps=0, total_steps=1000, bucket_bytes=256 << 20, process_group=None,
+                 sparse_head=False):
+        """sparse_head (off by default): apply the LM head and the loss only to the positions whose next token carries a
+        label -- identical loss / gradients / update (unlabeled rows contribute nothing), ~5 % fewer FLOPs at cfg2; the
+        returned model output then has no logits.  Costs one host sync per step (the row count)."""
+        self.model, self.sparse_head = model, sparse_head
         self.ids = special_ids                   # dict(answer_id, eoc_id, pad_id, media_id)
         self.gamma, self.use_reweight = gamma, use_reweight
         self.opt = FlatAdamW(model.named_parameters(), lr=lr, weight_decay=weight_decay, max_grad_norm=max_grad_norm)
@@ -103,8 +107,17 @@ class Trainer:
         ids = batch["lang_x"]
         labels, _ = ops.label_mask(ids, self.ids["answer_id"], self.ids["eoc_id"], self.ids["pad_id"], self.ids["media_id"],
                                    want_media_time=False)
-        out = self.model(vision_x=batch["vision_x"].unsqueeze(2) if batch["vision_x"].ndim == 5 else batch["vision_x"],
-                         lang_x=ids, attention_mask=batch["attention_mask"], labels=None)
+        vx = batch["vision_x"].unsqueeze(2) if batch["vision_x"].ndim == 5 else batch["vision_x"]
+        if self.sparse_head:
+            bj = (labels[:, 1:] != -100).nonzero()                       # (b, j): position j predicts the labeled token j+1
+            if bj.shape[0] > 0:
+                rows = bj[:, 0] * ids.shape[1] + bj[:, 1]
+                out = self.model(vision_x=vx, lang_x=ids, attention_mask=batch["attention_mask"], labels=None, head_rows=rows)
+                w = self.model.lang_encoder.get_output_embeddings().weight
+                loss, stats = F_.sparse_head_loss(out.hidden_rows, w, labels[bj[:, 0], bj[:, 1] + 1].contiguous(),
+                                                  batch["weights"].float()[bj[:, 0]].contiguous(), self.gamma, self.use_reweight)
+                return loss, stats, out, labels
+        out = self.model(vision_x=vx, lang_x=ids, attention_mask=batch["attention_mask"], labels=None)
         loss, stats = F_.focal_ce(out["logits"], labels, batch["weights"], self.gamma, self.use_reweight)
         return loss, stats, out, labels
 
