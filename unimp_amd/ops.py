@@ -169,7 +169,7 @@ def layernorm_fwd(x, gamma, beta, eps, *, rms=False, out=None, grp=0, grp_stride
     return out, mean, rstd
 
 
-_PARTIAL_BLOCKS = 256
+_PARTIAL_BLOCKS = 512       # 2 blocks per CU: the wgrad variant holds 244 VGPRs (occupancy 2), 256 blocks left half the SIMDs with one wave
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, *, dres=None, dy2=None, want_wgrad=False, has_beta=True, rms=False, grp=0,
