@@ -12,6 +12,7 @@ Arithmetic restated (reference file:line):
   perceiver_attn     open_flamingo PerceiverAttention (A.2)
   focal_ce           UniMP/mmrec.py:190-213
 """
+import weakref
 import torch
 from torch.autograd import Function
 
@@ -277,7 +278,7 @@ class LayerKV:
     __slots__ = ("owner", "k", "v", "xkv")
 
     def __init__(self, owner):
-        self.owner = owner
+        self.owner = weakref.proxy(owner)      # no DecodeCache <-> LayerKV cycle: the K/V tensor must die with its last user, not at the next gc pass
         self.k = self.v = self.xkv = None
 
 
