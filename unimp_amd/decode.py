@@ -13,11 +13,13 @@ from . import functional as F_
 
 
 class DecodeSession:
-    def __init__(self, model, max_new_tokens, reorder, graph=True):
-        """model: Flamingo with the vision features already conditioned (``_encode_vision_x``).  ``reorder``: beam search
-        (rows exchange hypotheses between steps); ``graph=False`` keeps launching the step kernel by kernel."""
+    def __init__(self, model, max_new_tokens, reorder, graph=True, beams=1):
+        """model: Flamingo with the vision features of the PROMPTS already conditioned (``_encode_vision_x``, one row per
+        prompt).  ``reorder``: beam search (rows exchange hypotheses between steps); ``graph=False`` keeps launching the
+        step kernel by kernel; ``beams``: rows per prompt -- the prompt is prefilled ONCE per prompt and its K/V, projected
+        media and vision features are then repeated for the beams (the rows of a beam group are identical at that point)."""
         self.model, self.lm = model, model.lang_encoder
-        self.max_new, self.reorder, self.use_graph = max_new_tokens, reorder, graph
+        self.max_new, self.reorder, self.use_graph, self.beams = max_new_tokens, reorder, graph, beams
         self.cache = None
         self.graph = None
         self.steps = 0
@@ -26,16 +28,34 @@ class DecodeSession:
     def prefill(self, input_ids):
         m = self.model
         R, L0 = input_ids.shape
+        K = self.beams
         self.L0 = L0
-        self.cache = F_.DecodeCache(len(self.lm._get_decoder_layers()), capacity=L0 + self.max_new)
-        self.cache.shared_prefix = L0 if self.reorder else 0
-        m._condition_media_locations(input_ids=input_ids)
-        out = self.lm(input_ids=input_ids, past_key_values=self.cache, use_cache=True, logits_last_only=True)
-        self.cache.media_count = (input_ids == m.media_token_id).sum(1, keepdim=True).to(torch.int32)
+        prompts = input_ids[::K].contiguous() if K > 1 else input_ids          # one row per beam group
+        n_layers = len(self.lm._get_decoder_layers())
+        pc = F_.DecodeCache(n_layers, capacity=L0 if K > 1 else L0 + self.max_new)
+        m._condition_media_locations(input_ids=prompts)
+        out = self.lm(input_ids=prompts, past_key_values=pc, use_cache=True, logits_last_only=True)
+        logits = out["logits"][:, -1]
+        if K > 1:                               # give every beam its copy of the prompt's K/V, projected media and vision rows
+            c = F_.DecodeCache(n_layers, capacity=L0 + self.max_new)
+            c._reserve(pc.kv.new_empty((R, 0) + tuple(pc.kv.shape[4:])), L0)     # [R, 0, nh, hd] template: allocates the full tensor
+            c.kv[:, :, :, :L0].copy_(pc.kv[:, :, :, :L0].repeat_interleave(K, 2))
+            B = prompts.shape[0]
+            for lk, lp in zip(c.layers, pc.layers):          # xkv is [B * T*n, 2*inner]: repeat whole prompts, not single key rows
+                lk.xkv = (lp.xkv.view(B, lp.xkv.shape[0] // B, -1).repeat_interleave(K, 0).reshape(-1, lp.xkv.shape[1])
+                          if lp.xkv is not None else None)
+            c.len = L0
+            m._repeat_conditioned_vision(K)
+            logits = logits.repeat_interleave(K, 0)
+        else:
+            c = pc
+        self.cache = c
+        c.shared_prefix = L0 if self.reorder else 0
+        c.media_count = (input_ids == m.media_token_id).sum(1, keepdim=True).to(torch.int32)
         dev = input_ids.device
         self.tok = torch.zeros((R, 1), dtype=torch.long, device=dev)
         self.src = torch.arange(R, dtype=torch.long, device=dev)
-        return out["logits"][:, -1]
+        return logits
 
     # -- one token per row
     def _step_body(self):

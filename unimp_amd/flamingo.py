@@ -222,6 +222,13 @@ class Flamingo(nn.Module):
             layer.condition_media_time(media_time)
             layer.condition_use_cached_media(False)
 
+    def _repeat_conditioned_vision(self, k):
+        """rows of the conditioned Perceiver output repeated k times (one copy per beam)."""
+        layers = list(self._layers())
+        vis = layers[0].vis_x.repeat_interleave(k, dim=0)
+        for layer in layers:
+            layer.condition_vis_x(vis)
+
     def _condition_cached_media(self, cache, n_new):
         """decode steps (FlamingoLMMixin.forward with ``use_cached_media_locations``, MaskedCrossAttention with
         ``use_cached_media``): every new token attends with text_time = #<image> in the prompt."""
@@ -250,8 +257,8 @@ class Flamingo(nn.Module):
         if attention_mask is not None and not bool(attention_mask.all()):
             raise NotImplementedError("generate() with padded prompts (UniMP evaluates one user at a time, eval_rec.py:32-110)")
         num_beams = kwargs.pop("num_beams", 1)
-        if num_beams > 1:
-            vision_x = vision_x.repeat_interleave(num_beams, dim=0)
+        # upstream repeats vision_x per beam BEFORE encoding it; the rows are identical, so the images are encoded once per
+        # prompt here and the Perceiver output is repeated instead (same values row for row, 1/num_beams of the ViT work)
         eos_token_id = kwargs.pop("eos_token_id", self.eoc_token_id)
         pad_token_id = kwargs.pop("pad_token_id", eos_token_id)
         max_new_tokens = kwargs.pop("max_new_tokens", 20)
@@ -267,6 +274,8 @@ class Flamingo(nn.Module):
         self.eval()
         self.lang_encoder._use_cached_vision_x = True
         self._encode_vision_x(vision_x=vision_x)
+        if num_beams > 1 and not use_cache:
+            self._repeat_conditioned_vision(num_beams)
         try:
             session = [None]
 
@@ -275,7 +284,7 @@ class Flamingo(nn.Module):
                     self._condition_media_locations(input_ids=seqs)
                     return self.lang_encoder(input_ids=seqs, attention_mask=None, logits_last_only=True)["logits"][:, -1]
                 if session[0] is None:
-                    session[0] = DecodeSession(self, max_new_tokens, reorder=num_beams > 1, graph=use_graph)
+                    session[0] = DecodeSession(self, max_new_tokens, reorder=num_beams > 1, graph=use_graph, beams=num_beams)
                     return session[0].prefill(seqs)
                 return session[0].step(seqs[:, -1], src)
             if num_beams > 1:
