@@ -235,9 +235,11 @@ def test_kv_cache_decode_matches_full_rescoring(cfg_name):
                 hm._repeat_conditioned_vision(3)
             try:
                 sess = DecodeSession(hm, max_new_tokens=8, reorder=True, graph=False, beams=beams)
-                out = [sess.prefill(ids.repeat_interleave(3, 0)).float().clone()]
+                out = [sess.prefill(ids if beams == 3 else ids.repeat_interleave(3, 0)).float().clone()]
                 for j in range(3):
-                    out.append(sess.step(new[:, j].repeat(3), torch.tensor([1, 0, 2], device="cuda")).float().clone())
+                    # rows may only move inside their beam group; the three rows carry identical histories here, so the
+                    # reorder of the 3-beam session is a semantic no-op and the 3-prompt session runs without one
+                    out.append(sess.step(new[:, j].repeat(3), torch.tensor([1, 0, 2], device="cuda") if beams == 3 else None).float().clone())
                 lg[beams] = torch.stack(out)
             finally:
                 hm.clear_conditioned_layers()
@@ -300,3 +302,58 @@ def test_full_size_cached_decode_logits(cfg2):
         err = float((lg - want).abs().max()) / scale
         assert err < 2e-2, (j, err)
         assert int(lg.argmax()) == int(want.argmax()) or float(want.topk(2).values.diff().abs()) < 2e-2 * scale
+
+
+@pytest.mark.parametrize("cfg_name", ["TINY", "TINY_OPT"])
+def test_generate_batch_of_padded_prompts(cfg_name):
+    """several users per generate() call: right-padded prompts of different lengths decode at per-row positions.  Logits of
+    the batched session (prefill + forced steps, beams = 2, HIP-graph replay) against each prompt's own session, then the
+    batched generate() against the per-user calls."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import _parity as P
+    from unimp_amd.decode import DecodeSession
+    cfg = getattr(P, cfg_name)
+    om, layout = P.build_oracle(cfg)
+    for p_ in om.lang_encoder.get_output_embeddings().parameters():
+        p_.data.mul_(4.0)
+    hm = P.build_hip(cfg, om, layout).eval()
+    batch = P.make_batch(cfg, layout)
+    n0 = int(batch["attention_mask"][0].sum()) - 2
+    n1 = min(int(batch["attention_mask"][1].sum()) - 2, n0 - 5)            # a shorter second prompt
+    L = max(n0, n1)
+    ids = torch.full((2, L), layout.pad, dtype=torch.long)
+    ids[0, :n0], ids[1, :n1] = batch["lang_x"][0, :n0], batch["lang_x"][1, :n1]
+    ids, vx = ids.cuda(), batch["vision_x"][:2].cuda()
+    lengths = torch.tensor([n0, n1], device="cuda")
+    mask = (torch.arange(L, device="cuda")[None, :] < lengths[:, None]).long()
+    forced = torch.randint(0, 100, (3, 4), device="cuda")                    # [step, row] for 2 prompts x 2 beams
+    src = torch.tensor([1, 0, 2, 3], device="cuda")
+
+    def run(prompts, lens, vis, cols):
+        with torch.no_grad():
+            hm.lang_encoder._use_cached_vision_x = True
+            hm._encode_vision_x(vision_x=vis)
+            try:
+                sess = DecodeSession(hm, max_new_tokens=8, reorder=True, graph=True, beams=2)
+                out = [sess.prefill(prompts, lens).float().clone()]
+                for j in range(3):
+                    local = src[cols] - cols[0]                  # the same moves inside each beam group as in the batched run
+                    out.append(sess.step(forced[j, cols], local).float().clone())
+                return torch.stack(out)
+            finally:
+                hm.clear_conditioned_layers()
+                hm.lang_encoder._use_cached_vision_x = False
+    both = run(ids, lengths, vx, [0, 1, 2, 3])
+    one0 = run(ids[:1, :n0], None, vx[:1], [0, 1])
+    one1 = run(ids[1:, :n1], None, vx[1:], [2, 3])
+    scale = float(one0.abs().max())
+    assert float((both[:, :2] - one0).abs().max()) < 2e-2 * scale and float((both[:, 2:] - one1).abs().max()) < 2e-2 * scale
+    kw = dict(max_new_tokens=5, eos_token_id=layout.eos, pad_token_id=layout.eos)
+    gb = hm.generate(vx, ids, attention_mask=mask, **kw)
+    g0 = hm.generate(vx[:1], ids[:1, :n0], **kw)
+    g1 = hm.generate(vx[1:], ids[1:, :n1], **kw)
+    assert torch.equal(gb[0, L:L + 2], g0[0, n0:n0 + 2]) and torch.equal(gb[1, L:L + 2], g1[0, n1:n1 + 2]), (gb.tolist(), g0.tolist(), g1.tolist())
+    assert torch.equal(gb[1, L - n1:L], ids[1, :n1])                        # prompts come back left-padded, like transformers'
+    bb = hm.generate(vx, ids, attention_mask=mask, num_beams=3, num_return_sequences=2, early_stopping=True, **kw)
+    assert bb.shape[0] == 4 and torch.equal(bb[2, L - n1:L], ids[1, :n1])

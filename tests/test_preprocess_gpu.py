@@ -97,6 +97,9 @@ def test_eval_loop_generate_to_metrics(tmp_path):
     m = eval_model_rec(model, samples, tok, K=4, max_new_tokens=4, image_preprocessor=ImagePreprocessor(32))
     assert set(m) == {f"{n}@{k}" for n in ("hr", "ndcg", "mrr") for k in (3, 5, 4)}
     assert all(0.0 <= v <= 1.0 for v in m.values())
+    samples3 = [ds[i] for i in range(3)]                       # prompts of different lengths, two users per generate() call
+    m2 = eval_model_rec(model, samples3, tok, K=4, max_new_tokens=4, image_preprocessor=ImagePreprocessor(32), users_per_batch=2)
+    assert set(m2) == set(m) and all(0.0 <= v <= 1.0 for v in m2.values())
 
 
 def test_train_loop_from_dataset(tmp_path):

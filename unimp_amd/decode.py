@@ -25,56 +25,68 @@ class DecodeSession:
         self.steps = 0
 
     # -- prompt
-    def prefill(self, input_ids):
+    def prefill(self, prompts, lengths=None):
+        """prompts [B, Lmax] (right-padded when ``lengths`` [B] is given) -> logits [B * beams, V] of each prompt's last token."""
         m = self.model
-        R, L0 = input_ids.shape
+        B, Lmax = prompts.shape
         K = self.beams
-        self.L0 = L0
-        prompts = input_ids[::K].contiguous() if K > 1 else input_ids          # one row per beam group
+        R = B * K
+        dev = prompts.device
+        self.host_len = [Lmax] * B if lengths is None else [int(x) for x in lengths.tolist()]
         n_layers = len(self.lm._get_decoder_layers())
-        pc = F_.DecodeCache(n_layers, capacity=L0 if K > 1 else L0 + self.max_new)
+        pc = F_.DecodeCache(n_layers, capacity=Lmax if K > 1 else Lmax + self.max_new)
         m._condition_media_locations(input_ids=prompts)
-        out = self.lm(input_ids=prompts, past_key_values=pc, use_cache=True, logits_last_only=True)
+        if lengths is None:
+            out = self.lm(input_ids=prompts, past_key_values=pc, use_cache=True, logits_last_only=True)
+            row_len = torch.full((B,), Lmax, dtype=torch.long, device=dev)
+        else:
+            mask = (torch.arange(Lmax, device=dev)[None, :] < lengths.to(dev)[:, None]).long()
+            out = self.lm(input_ids=prompts, attention_mask=mask, past_key_values=pc, use_cache=True,
+                          last_index=lengths.to(dev).long() - 1)
+            row_len = lengths.to(dev).long()
         logits = out["logits"][:, -1]
         if K > 1:                               # give every beam its copy of the prompt's K/V, projected media and vision rows
-            c = F_.DecodeCache(n_layers, capacity=L0 + self.max_new)
-            c._reserve(pc.kv.new_empty((R, 0) + tuple(pc.kv.shape[4:])), L0)     # [R, 0, nh, hd] template: allocates the full tensor
-            c.kv[:, :, :, :L0].copy_(pc.kv[:, :, :, :L0].repeat_interleave(K, 2))
-            B = prompts.shape[0]
+            c = F_.DecodeCache(n_layers, capacity=Lmax + self.max_new)
+            c._reserve(pc.kv.new_empty((R, 0) + tuple(pc.kv.shape[4:])), Lmax)    # [R, 0, nh, hd] template: allocates the full tensor
+            c.kv[:, :, :, :Lmax].copy_(pc.kv[:, :, :, :Lmax].repeat_interleave(K, 2))
             for lk, lp in zip(c.layers, pc.layers):          # xkv is [B * T*n, 2*inner]: repeat whole prompts, not single key rows
                 lk.xkv = (lp.xkv.view(B, lp.xkv.shape[0] // B, -1).repeat_interleave(K, 0).reshape(-1, lp.xkv.shape[1])
                           if lp.xkv is not None else None)
-            c.len = L0
             m._repeat_conditioned_vision(K)
             logits = logits.repeat_interleave(K, 0)
+            row_len = row_len.repeat_interleave(K)
         else:
             c = pc
-        self.cache = c
-        c.shared_prefix = L0 if self.reorder else 0
-        c.media_count = (input_ids == m.media_token_id).sum(1, keepdim=True).to(torch.int32)
-        dev = input_ids.device
+        c.len = Lmax                             # capacity bookkeeping on the host; the rows' true lengths live in StepState
+        c.row_len = None
+        self.cache, self.Lmax = c, Lmax
+        c.media_count = ((prompts == m.media_token_id) & (torch.arange(Lmax, device=dev)[None, :] < row_len[::K, None])) \
+            .sum(1, keepdim=True).to(torch.int32).repeat_interleave(K, 0)
+        c.step = F_.StepState(R, row_len, dev)
         self.tok = torch.zeros((R, 1), dtype=torch.long, device=dev)
         self.src = torch.arange(R, dtype=torch.long, device=dev)
+        self.base = (torch.arange(R, device=dev) // K) * K               # first row of each row's beam group
         return logits
 
     # -- one token per row
     def _step_body(self):
         c = self.cache
-        if self.reorder:                       # generated tail only: the prompt part is identical in all beams of an item
-            tail = c.kv[:, :, :, self.L0:self.L0 + self.max_new]
-            tail.copy_(tail.index_select(2, self.src))
+        if self.reorder:          # generated tail only (a group's rows share their prompt), group by group: tails start at the prompt lengths
+            local = self.src - self.base
+            for b, L0 in enumerate(self.host_len):
+                tail = c.kv[:, :, b * self.beams:(b + 1) * self.beams, L0:L0 + self.max_new]
+                tail.copy_(tail.index_select(2, local[b * self.beams:(b + 1) * self.beams]))
         self.model._condition_cached_media(c, 1)
         out = self.lm(input_ids=self.tok, past_key_values=c, use_cache=True)
         c.step.advance()
         return out["logits"][:, -1]
 
     def step(self, tokens, src=None):
-        """tokens [rows] = the token each row was extended with; src [rows] = the row whose hypothesis it continues."""
+        """tokens [rows] = the token each row was extended with; src [rows] = the row whose hypothesis it continues (a row
+        of the SAME beam group: hypotheses never move between prompts; not checked -- that would need a host sync)."""
         c = self.cache
-        if c.len >= self.L0 + self.max_new:
+        if self.steps >= self.max_new:
             raise RuntimeError("DecodeSession: more steps than max_new_tokens")
-        if c.step is None:
-            c.step = F_.StepState(self.tok.shape[0], c.len, self.tok.device)
         self.tok.copy_(tokens.view(-1, 1))
         if src is not None:
             self.src.copy_(src)

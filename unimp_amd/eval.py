@@ -49,25 +49,44 @@ def user_metrics(r, K=10):
 
 
 @torch.no_grad()
-def eval_model_rec(model, samples, tokenizer, K=10, max_new_tokens=50, image_preprocessor=None, device="cuda"):
+def eval_model_rec(model, samples, tokenizer, K=10, max_new_tokens=50, image_preprocessor=None, device="cuda", users_per_batch=1):
     """samples: iterable of eval samples (``RecDataset(split != "train")[i]``, one user each, as UniMP's eval loader yields).
     ``image_preprocessor``: an ``ImagePreprocessor`` for samples that carry raw uint8 images (``defer_images=True``).
-    Returns the mean of every metric over the users."""
+    ``users_per_batch`` > 1 decodes several users per ``generate`` call (right-padded prompts, per-row positions): the
+    decode step is bound by the weight reads, which the users then share.  Returns the mean of every metric over the users."""
     model.eval()
-    rows = []
-    for s in samples:
-        ni = s["net_input"]
-        imgs = ni["patch_images"]
-        if isinstance(imgs, (list, tuple)):
-            if image_preprocessor is None:
-                raise ValueError("eval_model_rec: raw images need an image_preprocessor")
-            imgs = image_preprocessor(imgs)
-        vision_x = imgs.to(device=device, dtype=torch.bfloat16).unsqueeze(0).unsqueeze(2)          # (1, T, 1, 3, H, W)
-        ids = ni["input_ids"].to(device).unsqueeze(0)
-        mask = ni["attention_masks"].to(device).unsqueeze(0)
-        gen = model.generate(vision_x=vision_x, lang_x=ids, attention_mask=mask, num_beams=K, num_return_sequences=K,
-                             early_stopping=True, max_new_tokens=max_new_tokens, eos_token_id=tokenizer.eos_token_id,
-                             pad_token_id=tokenizer.eos_token_id)
+    rows, group = [], []
+
+    def flush():
+        if not group:
+            return
+        imgs = []
+        for s in group:
+            im = s["net_input"]["patch_images"]
+            if isinstance(im, (list, tuple)):
+                if image_preprocessor is None:
+                    raise ValueError("eval_model_rec: raw images need an image_preprocessor")
+                im = image_preprocessor(im)
+            imgs.append(im.to(device=device, dtype=torch.bfloat16))
+        vision_x = torch.stack(imgs).unsqueeze(2)                                        # (users, T, 1, 3, H, W)
+        lens = [s["net_input"]["input_ids"].numel() for s in group]
+        L = max(lens)
+        pad = tokenizer.pad_token_id if tokenizer.pad_token_id is not None else tokenizer.eos_token_id
+        ids = torch.full((len(group), L), pad, dtype=torch.long)
+        for i, s in enumerate(group):
+            ids[i, :lens[i]] = s["net_input"]["input_ids"]
+        mask = (torch.arange(L)[None, :] < torch.tensor(lens)[:, None]).long()
+        gen = model.generate(vision_x=vision_x, lang_x=ids.to(device), attention_mask=mask.to(device), num_beams=K,
+                             num_return_sequences=K, early_stopping=True, max_new_tokens=max_new_tokens,
+                             eos_token_id=tokenizer.eos_token_id, pad_token_id=tokenizer.eos_token_id)
         texts = tokenizer.batch_decode(gen, skip_special_tokens=True)
-        rows.append(user_metrics(relevance(texts, s["net_output"]["output_ids"], K), K))
+        for i, s in enumerate(group):
+            rows.append(user_metrics(relevance(texts[i * K:(i + 1) * K], s["net_output"]["output_ids"], K), K))
+        group.clear()
+
+    for s in samples:
+        group.append(s)
+        if len(group) == users_per_batch:
+            flush()
+    flush()
     return {k: float(np.mean([r[k] for r in rows])) for k in rows[0]} if rows else {}

@@ -254,8 +254,6 @@ class Flamingo(nn.Module):
         kernel by kernel); ``use_cache=False`` re-scores the full sequences every step."""
         from .generate import beam_search, greedy_search
         from .decode import DecodeSession
-        if attention_mask is not None and not bool(attention_mask.all()):
-            raise NotImplementedError("generate() with padded prompts (UniMP evaluates one user at a time, eval_rec.py:32-110)")
         num_beams = kwargs.pop("num_beams", 1)
         # upstream repeats vision_x per beam BEFORE encoding it; the rows are identical, so the images are encoded once per
         # prompt here and the Perceiver output is repeated instead (same values row for row, 1/num_beams of the ViT work)
@@ -272,6 +270,19 @@ class Flamingo(nn.Module):
             raise NotImplementedError(f"unsupported generate() arguments: do_sample / {sorted(kwargs)}")
         was_training = self.training
         self.eval()
+        lengths, seqs0 = None, lang_x
+        if attention_mask is not None and not bool(attention_mask.all()):
+            # a batch of prompts of different lengths, right-padded as collate_fn pads them (the reference evaluates one user
+            # per call; several users per call share every weight read of the decode).  The KV-cache path runs every row at its
+            # own position; the search bookkeeping sees the prompts left-padded, as transformers' generate would.
+            if not use_cache:
+                raise NotImplementedError("generate() with padded prompts needs use_cache=True")
+            lengths = attention_mask.sum(1)
+            L = lang_x.shape[1]
+            if not bool((attention_mask == (torch.arange(L, device=lang_x.device)[None, :] < lengths[:, None])).all()):
+                raise ValueError("generate(): attention_mask must be a right-padding mask")
+            shift = (torch.arange(L, device=lang_x.device)[None, :] - (L - lengths)[:, None])
+            seqs0 = torch.where(shift >= 0, lang_x.gather(1, shift.clamp(min=0)), torch.full_like(lang_x, pad_token_id))
         self.lang_encoder._use_cached_vision_x = True
         self._encode_vision_x(vision_x=vision_x)
         if num_beams > 1 and not use_cache:
@@ -285,13 +296,13 @@ class Flamingo(nn.Module):
                     return self.lang_encoder(input_ids=seqs, attention_mask=None, logits_last_only=True)["logits"][:, -1]
                 if session[0] is None:
                     session[0] = DecodeSession(self, max_new_tokens, reorder=num_beams > 1, graph=use_graph, beams=num_beams)
-                    return session[0].prefill(seqs)
+                    return session[0].prefill(lang_x, lengths)
                 return session[0].step(seqs[:, -1], src)
             if num_beams > 1:
-                out = beam_search(logits_fn, lang_x, num_beams, max_new_tokens, eos_token_id, pad_token_id, nret, early, lp,
+                out = beam_search(logits_fn, seqs0, num_beams, max_new_tokens, eos_token_id, pad_token_id, nret, early, lp,
                                   ngram, stateful=True)
             else:
-                out = greedy_search(logits_fn, lang_x, max_new_tokens, eos_token_id, pad_token_id)
+                out = greedy_search(logits_fn, seqs0, max_new_tokens, eos_token_id, pad_token_id)
         finally:
             self.clear_conditioned_layers()
             self.lang_encoder._use_cached_vision_x = False

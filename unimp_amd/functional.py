@@ -283,13 +283,19 @@ class LayerKV:
 
 
 class StepState:
-    """device-resident position of a static decode step: ``pos_idx`` int64 [1] = slot the new token's K/V go to,
-    ``kv_len`` int32 [rows] = keys visible to it (pos + 1).  Nothing on the host depends on the position, so one step can
-    be captured in a HIP graph and replayed (decode.py)."""
+    """device-resident positions of a static decode step, one per row (rows may sit at different lengths: a batch of
+    prompts): ``pos_idx`` int64 [rows] = slot the row's new K/V go to, ``kv_len`` int32 [rows] = keys visible to it
+    (pos + 1).  Nothing on the host depends on the positions, so one step can be captured in a HIP graph and replayed
+    (decode.py)."""
 
     def __init__(self, rows, pos, device):
-        self.pos_idx = torch.full((1,), pos, dtype=torch.long, device=device)
-        self.kv_len = torch.full((rows,), pos + 1, dtype=torch.int32, device=device)
+        """pos: int (all rows) or an integer tensor [rows]."""
+        if torch.is_tensor(pos):
+            self.pos_idx = pos.to(device=device, dtype=torch.long).clone()
+        else:
+            self.pos_idx = torch.full((rows,), pos, dtype=torch.long, device=device)
+        self.kv_len = (self.pos_idx + 1).to(torch.int32)
+        self.rows = torch.arange(rows, dtype=torch.long, device=device)
 
     def advance(self):
         self.pos_idx.add_(1)
@@ -309,6 +315,7 @@ class DecodeCache:
         self.capacity = capacity
         self.kv = None
         self.media_count = None
+        self.row_len = None                # prefill of right-padded prompts: valid tokens per row (device tensor)
         self.shared_prefix = 0
         self.step = None                   # StepState while decoding with device-side positions
 
@@ -363,10 +370,10 @@ def self_attn_block_cached(x, ln_w, ln_b, wqkv, bqkv, wd, bd, nh, lc, pos0, *, r
     if step is not None:
         if Ln != 1:
             raise NotImplementedError("a static decode step feeds one new token per row")
-        if rope is not None:
-            ops.rope_(qkv, 1, nh, hs, rope[2], offs, rope[0], rope[1])
-        lc.k.index_copy_(1, step.pos_idx, k)
-        lc.v.index_copy_(1, step.pos_idx, v)
+        if rope is not None:                   # rope = the table rows of the R positions: "sequence" of R rows, row r at its own position
+            ops.rope_(qkv, R, nh, hs, rope[2], offs, rope[0], rope[1])
+        lc.k.index_put_((step.rows, step.pos_idx), k[:, 0])
+        lc.v.index_put_((step.rows, step.pos_idx), v[:, 0])
         o, _ = ops.attn_fwd(q, lc.k, lc.v, scale, ops.MASK_NONE, step.kv_len)
         return ops.gemm(o.view(R, H), wd, bias=bd, res=r2).view(R, 1, H)
     if rope is not None:
@@ -374,7 +381,7 @@ def self_attn_block_cached(x, ln_w, ln_b, wqkv, bqkv, wd, bd, nh, lc, pos0, *, r
         ops.rope_(qkv, Ln, nh, hs, rot, offs, cos[pos0:], sin[pos0:])
     kc, vc = _kv_append(lc, k, v, pos0)
     if pos0 == 0:
-        o, _ = ops.attn_fwd(q, k, v, scale, ops.MASK_CAUSAL, None)
+        o, _ = ops.attn_fwd(q, k, v, scale, ops.MASK_CAUSAL, lc.owner.row_len)       # row_len: right-padded prompts
     else:
         if Ln != 1:
             raise NotImplementedError("cached decode feeds one new token per row (chunked prefill is not built)")

@@ -113,9 +113,13 @@ class _TowerBase(nn.Module):
             return None, 0
         if labels is not None or torch.is_grad_enabled():
             raise NotImplementedError("the KV cache is a decoding path: call under torch.no_grad() and without labels")
-        if attention_mask is not None and not bool(attention_mask.all()):
-            raise NotImplementedError("KV-cache decode with padded rows (UniMP evaluates one user at a time, eval_rec.py:32-110)")
         cache = past_key_values if past_key_values is not None else F_.DecodeCache(len(self._get_decoder_layers()))
+        if attention_mask is not None and not bool(attention_mask.all()):
+            # right-padded prompts are fine for the PREFILL (keys beyond a row's length are masked by kv_len and the decode
+            # steps then run with per-row positions: decode.DecodeSession); a host-position step needs equal lengths
+            if cache.len != 0:
+                raise NotImplementedError("past_key_values with padded rows: use decode.DecodeSession (per-row positions)")
+            cache.row_len = attention_mask.sum(1).to(torch.int32)
         return cache, cache.len
 
     @staticmethod
@@ -125,7 +129,10 @@ class _TowerBase(nn.Module):
             return rope
         return rope[0].index_select(0, cache.step.pos_idx), rope[1].index_select(0, cache.step.pos_idx), rope[2]
 
-    def _head(self, h, labels, last_only=False, head_rows=None):
+    def _head(self, h, labels, last_only=False, head_rows=None, last_index=None):
+        if last_index is not None:          # padded prompts: every row's own last valid position
+            h = h[torch.arange(h.shape[0], device=h.device), last_index].unsqueeze(1)
+            last_only = False
         if head_rows is not None:          # the caller applies the head itself on these flattened (b*L + j) rows (train.py)
             return LMOutput(None, None, hidden_rows=h.reshape(-1, h.shape[-1]).index_select(0, head_rows))
         w = self.get_output_embeddings().weight
@@ -225,7 +232,7 @@ class GPTNeoXForCausalLM(_TowerBase):
             x = layer(x, attention_mask=kv_len, rope=rope, cache=cache.layers[i] if cache else None, pos0=pos0)
         f = self.gpt_neox.final_layer_norm
         h = F_.layer_norm(x, f.weight, f.bias, f.eps)
-        out = self._head(h, labels, kw.get("logits_last_only", False), kw.get("head_rows"))
+        out = self._head(h, labels, kw.get("logits_last_only", False), kw.get("head_rows"), kw.get("last_index"))
         if cache is not None:
             if cache.step is None:
                 cache.len = pos0 + L
@@ -311,14 +318,14 @@ class OPTForCausalLM(_TowerBase):
         cache, pos0 = self._decode_state(past_key_values, use_cache, labels, attention_mask)
         am = attention_mask if attention_mask is not None else torch.ones_like(input_ids)
         pos = (torch.cumsum(am, 1) * am).long() + 1                      # OPTLearnedPositionalEmbedding (offset 2)
-        pos = pos + (cache.step.pos_idx if cache is not None and cache.step is not None else pos0)
+        pos = pos + (cache.step.pos_idx[:, None] if cache is not None and cache.step is not None else pos0)
         x = F_.embedding(input_ids, d.embed_tokens.weight, pos, d.embed_positions.weight)
         kv_len = self._kv_len(attention_mask)
         for i, layer in enumerate(d.layers):
             x = layer(x, attention_mask=kv_len, cache=cache.layers[i] if cache else None, pos0=pos0)
         f = d.final_layer_norm
         h = F_.layer_norm(x, f.weight, f.bias, f.eps)
-        out = self._head(h, labels, kw.get("logits_last_only", False), kw.get("head_rows"))
+        out = self._head(h, labels, kw.get("logits_last_only", False), kw.get("head_rows"), kw.get("last_index"))
         if cache is not None:
             if cache.step is None:
                 cache.len = pos0 + L
@@ -439,7 +446,7 @@ class LlamaForCausalLM(_TowerBase):
             x = layer(x, attention_mask=None, rope=rope, cache=cache.layers[i] if cache else None, pos0=pos0)
         n = self.model.norm
         h = F_.layer_norm(x, n.weight, None, n.variance_epsilon, rms=True)
-        out = self._head(h, labels, kw.get("logits_last_only", False), kw.get("head_rows"))
+        out = self._head(h, labels, kw.get("logits_last_only", False), kw.get("head_rows"), kw.get("last_index"))
         if cache is not None:
             if cache.step is None:
                 cache.len = pos0 + L
