@@ -91,12 +91,13 @@ def test_rec_dataset_matches_reference_golden(tmp_path):
     pytest.importorskip("PIL.Image")
     from unimp_amd.factory import ImageProcessor
     g = _materialise_rec_dataset(tmp_path)
-    for split, task in (("train", "rec"), ("test", "rec"), ("train", "search"), ("test", "search")):
-        ds = D.RecDataset(str(tmp_path), "all", _tokenizer(), split=split, image_transform=ImageProcessor(224), task=task)
+    for split, task in (("train", "rec"), ("test", "rec"), ("train", "search"), ("test", "search"), ("train", "exp"), ("test", "exp"),
+                        ("train", "img_sel"), ("test", "img_sel")):
+        ds = D.RecDataset(str(tmp_path), "all", _tokenizer(), split=split, image_transform=ImageProcessor(224), task=task, n_items=14)
         assert len(ds) == 4
         np.random.seed(11)
-        if task == "search":
-            split = "search_" + split
+        if task != "rec":
+            split = task + "_" + split
         for idx in range(3):
             s = ds[idx]
             ni = s["net_input"]
@@ -108,7 +109,13 @@ def test_rec_dataset_matches_reference_golden(tmp_path):
             if split.endswith("train"):
                 assert float(ni["weights"]) == float(g[f"{split}{idx}_w"]) == (2.0 if task == "rec" else 1.0)
             else:
-                assert s["net_output"]["output_ids"] == str(g[f"{split}{idx}_target"])
+                no = s["net_output"]
+                if task == "exp":
+                    assert f"{no['output_ratings']}|{no['output_exps']}" == str(g[f"{split}{idx}_target"])
+                elif task == "img_sel":
+                    assert no["output_ids"].tolist() == g[f"{split}{idx}_target"].tolist()
+                else:
+                    assert no["output_ids"] == str(g[f"{split}{idx}_target"])
                 assert ni["input_len"] == int(g[f"{split}{idx}_input_len"])
 
 

@@ -188,15 +188,18 @@ class RecDataset:
     HISTORY = {"all": 5, "netflix": 3, "hm": 8}
     QUESTION = "What is the next item recommended to the user?"
 
+    ALL_ITEMS = {"all": 22738, "netflix": 1870, "hm": 14901}           # rec_dataset.py:274-279 (negatives of the selection task)
+
     def __init__(self, folder, subset, tokenizer, split="train", use_semantic=False, image_transform=None, defer_images=False,
-                 task="rec"):
+                 task="rec", n_items=None):
         import json
         import os
         if subset not in self.HISTORY:
             raise ValueError(f"RecDataset: unknown subset {subset!r}")
-        if task not in ("rec", "search"):
-            raise NotImplementedError(f"RecDataset: task {task!r} (rec and search are built; exp / img_sel / img_gen are not)")
+        if task not in ("rec", "search", "exp", "img_sel"):
+            raise NotImplementedError(f"RecDataset: task {task!r} (rec, search, exp and img_sel are built; img_gen is not)")
         self.task = task
+        self.all_items = set(range(n_items if n_items is not None else self.ALL_ITEMS[subset]))
         if image_transform is None and not defer_images:
             raise ValueError("RecDataset: pass image_transform or defer_images=True")
         self.folder, self.subset, self.split, self.tokenizer = folder, subset, split, tokenizer
@@ -205,7 +208,8 @@ class RecDataset:
         self.history_len = self.HISTORY[subset]
         with open(os.path.join(folder, f"meta_{subset}.json")) as f:
             self.meta_data = json.load(f)
-        with open(os.path.join(folder, f"{split}_users.json" if split == "train" else "test_users.json")) as f:
+        name = {"rec": None, "search": None, "exp": f"{split}_{subset}_exp.json", "img_sel": f"{split}_{subset}_img_sel.json"}[task]
+        with open(os.path.join(folder, name or (f"{split}_users.json" if split == "train" else "test_users.json"))) as f:
             self.data = json.load(f)
         self.seqs, self.keys = list(self.data.values()), list(self.data.keys())
         if use_semantic:
@@ -273,9 +277,81 @@ class RecDataset:
         return {"net_input": {"input_ids": ids, "attention_masks": mask, "patch_images": imgs if self.defer else torch.stack(imgs, dim=0),
                               "input_len": len(text.split(" "))}, "net_output": {"output_ids": self._item_token(seq[-1])}}
 
+    def _finish(self, text, imgs, weight=None, **net_output):
+        ids, mask = self._tokenize(text)
+        patch = imgs if self.defer else torch.stack(imgs, dim=0)
+        if weight is not None:                                 # training sample: BOS + text + EOS
+            one = torch.LongTensor([1])
+            return {"net_input": {"input_ids": torch.cat([self.bos_item, ids, self.eos_item]), "attention_masks": torch.cat([one, mask, one]),
+                                  "patch_images": patch, "weights": torch.tensor(weight)}}
+        return {"net_input": {"input_ids": ids, "attention_masks": mask, "patch_images": patch, "input_len": len(text.split(" "))},
+                "net_output": net_output}
+
+    def _exp_item(self, index):
+        """rating + explanation (rec_dataset.py:1100-1156 train, 1158-1212 eval); sequences of [item, text, rating]."""
+        full, imgs, text = self.seqs[index], [], ""
+        ask = "What is the rating and explanation for the item? <answer>"
+        if self.split == "train":
+            start = np.random.choice(list(range(0, len(full) - self.history_len + 1)), 1)[0]
+            end = start + self.history_len - 1
+            cut = lambda t: " ".join(t.split()[:30])
+            for it in full[start:end]:
+                imgs.append(self._image(it[0]))
+                text += f"<image> {self.describe(it[0])} <answer> rate_{int(it[2])} {cut(it[1])} <|endofchunk|> "
+            it = full[end]
+            imgs.append(self._image(it[0]))
+            return self._finish(text + f"<image> {self.describe(it[0])} {ask} rate_{int(it[2])} {cut(it[1])}", imgs, weight=1.0)
+        for it in full[-5:-1]:
+            imgs.append(self._image(it[0]))
+            text += f"<image> {self.describe(it[0])} <answer> rate_{int(it[2])} {it[1]} <|endofchunk|> "
+        it = full[-1]
+        imgs.append(self._image(it[0]))
+        return self._finish(text + f"<image> {self.describe(it[0])} {ask}", imgs, output_ratings=[int(it[2])], output_exps=[it[1]])
+
+    def _img_sel_item(self, index):
+        """item selection (rec_dataset.py:981-1046 train, 1048-1098 eval); the last element ends with (candidate set, indices
+        of the right ones)."""
+        full, imgs, text = self.seqs[index], [], "User history: "
+        ask = "Can you select the suitable item from above for the user? <answer>"
+        if self.split == "train":
+            num_items, cur = 3, []
+            for it in full[-(self.history_len - num_items + 1):-1]:
+                cur.append(it[0])
+                imgs.append(self._image(it[0]))
+                text += f"<image> {self.describe(it[0])} <|endofchunk|> "
+            text += "Select from: "
+            cand = full[-1][-2]
+            gt = [cand[i] for i in full[-1][-1]]
+            cur += gt
+            labels = np.random.choice(list(range(num_items)), len(gt), replace=False)
+            neg_index = list(set(range(num_items)) - set(labels))
+            negs = np.random.choice(list(self.all_items - set(cur)), num_items - len(gt), replace=False)
+            chosen = [0] * num_items
+            for i, item in enumerate(gt):
+                chosen[labels[i]] = item
+            for i, item in enumerate(negs):
+                chosen[neg_index[i]] = item
+            for i, item in enumerate(chosen):
+                imgs.append(self._image(item))
+                text += f"<image> Selection s_{i} {self.describe(item)} <|endofchunk|> "
+            text += ask + " " + "".join(f"s_{l} " for l in labels)
+            return self._finish(text, imgs, weight=1.0)
+        for it in full[-5:-1]:
+            imgs.append(self._image(it[0]))
+            text += f"<image> {self.describe(it[0])} <|endofchunk|> "
+        text += "Select from: "
+        for i, item in enumerate(full[-1][-2]):
+            imgs.append(self._image(item))
+            text += f"<image> Selection s_{i} {self.describe(item)} <|endofchunk|> "
+        return self._finish(text + ask, imgs, output_ids=torch.tensor(full[-1][-1]))
+
     def __getitem__(self, index):
         if self.task == "search":
             return self._search_item(index)
+        if self.task == "exp":
+            return self._exp_item(index)
+        if self.task == "img_sel":
+            return self._img_sel_item(index)
         seq = [it[0] for it in self.seqs[index]]
         imgs, text = [], ""
         if self.split == "train":                              # rec_dataset.py:372-456
