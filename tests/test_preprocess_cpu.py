@@ -147,3 +147,22 @@ def test_rec_metrics_match_reference_golden():
     assert r.tolist() == [1, 0, 1, 0, 0, 0, 0, 0, 0, 0]
     m = E.user_metrics(r)
     assert m["hr@3"] == 1.0 and m["mrr@10"] == 1.0
+
+
+def test_mixed_task_dataset_matches_reference_mixture(tmp_path):
+    """which users of which task end up in the multi-task training set, in which order: against the reference's own
+    RecDataset(task=[...], single_task=False) on the same files and numpy seed."""
+    import json
+    g = _materialise_rec_dataset(tmp_path)
+    for name in ("train_users.json", "train_all_exp.json", "train_all_img_sel.json"):     # 12 users per task file, as the generator made them
+        d = json.loads((tmp_path / name).read_text())
+        (tmp_path / name).write_text(json.dumps({f"{k}_{c}": v for c in range(3) for k, v in d.items()}))
+    np.random.seed(5)
+    mixed = D.MixedRecDataset(str(tmp_path), "all", _tokenizer(), ["img_sel", "search", "rec", "exp"], defer_images=True, n_items=14)
+    assert mixed.tasks == g["mix_tasks"].tolist() and len(mixed) == len(g["mix_tasks"])
+    seqs = [mixed.parts[t].seqs[j] for t, j in mixed.index]
+    assert [int(sq[0][0]) for sq in seqs] == g["mix_first_items"].tolist()
+    assert [len(sq) for sq in seqs] == g["mix_seq_lens"].tolist()
+    np.random.seed(1)
+    s = mixed[0]
+    assert float(s["net_input"]["weights"]) == 1.0 and float(mixed[7]["net_input"]["weights"]) == 2.0       # img_sel vs rec

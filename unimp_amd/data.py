@@ -386,3 +386,30 @@ class RecDataset:
         del batch["net_input"]["patch_images"]
         batch["net_input"]["patch_images_raw"] = raw           # [b][T] uint8 arrays -> ImagePreprocessor on the device
         return batch
+
+
+class MixedRecDataset:
+    """The task mixture of UniMP's multi-task training (rec_dataset.py:176-206, ``single_task`` off and ``task`` a list):
+    every task but the LAST of the list contributes a random quarter of its users (``np.random.shuffle`` of the user keys at
+    construction -- seed numpy before building it to reproduce a mixture), the last one all of them; samples carry their
+    task's loss weight (2.0 rec, 1.0 others: cfg3's ``weights``)."""
+
+    def __init__(self, folder, subset, tokenizer, tasks, **kw):
+        self.parts, self.index = {}, []
+        for i, t in enumerate(tasks):
+            ds = self.parts[t] = RecDataset(folder, subset, tokenizer, split="train", task=t, **kw)
+            keys = list(ds.data.keys())
+            if i < len(tasks) - 1:
+                np.random.shuffle(keys)
+                keys = keys[:int(0.25 * len(keys))]
+            ds.seqs = [ds.data[k] for k in keys]
+            self.index += [(t, j) for j in range(len(ds.seqs))]
+        self.tasks = [t for t, _ in self.index]
+        self.collate = next(iter(self.parts.values())).collate
+
+    def __len__(self):
+        return len(self.index)
+
+    def __getitem__(self, i):
+        t, j = self.index[i]
+        return self.parts[t][j]
