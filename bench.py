@@ -42,11 +42,11 @@ def flops_per_sample(T, L, V, n_patch=256, P=14, Dv=1024, vit_layers=24, vit_mlp
     return dict(vit=vit, perceiver=perc, xattn=xattn, lm=lm, total=vit + perc + xattn + lm)
 
 
-def build_cfg2(device, gate=0.5, seed=0):
+def build_cfg2(device, gate=0.5, seed=0, n_items=22738):
     from unimp_amd.factory import create_model_and_transforms, SyntheticTokenizer
     from unimp_amd.synthetic import TokenLayout
     torch.manual_seed(seed)
-    layout = TokenLayout()                       # V = 74 053 (mmrec.py:538-581, subset "all")
+    layout = TokenLayout(n_items=n_items)        # V = 74 053 (mmrec.py:538-581, subset "all"); 14 901 items (H&M) -> V = 66 216
     model, _, tok = create_model_and_transforms("ViT-L-14", "openai", "togethercomputer/RedPajama-INCITE-Instruct-3B-v1",
                                                 "togethercomputer/RedPajama-INCITE-Instruct-3B-v1", cross_attn_every_n_layers=2,
                                                 device=device, tokenizer=SyntheticTokenizer())

@@ -357,3 +357,67 @@ def test_generate_batch_of_padded_prompts(cfg_name):
     assert torch.equal(gb[1, L - n1:L], ids[1, :n1])                        # prompts come back left-padded, like transformers'
     bb = hm.generate(vx, ids, attention_mask=mask, num_beams=3, num_return_sequences=2, early_stopping=True, **kw)
     assert bb.shape[0] == 4 and torch.equal(bb[2, L - n1:L], ids[1, :n1])
+
+
+def test_cfg4_hm_shapes_train_step():
+    """BASELINE config 4 (H&M: 16 history images per user, V = 66 216, gamma-focal loss) at full width: one optimizer step,
+    image locality through the 1024-key segment-masked cross-attention, finite loss and gradient norm."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import bench
+    from unimp_amd.synthetic import make_batch
+    from unimp_amd.train import Trainer
+    model, layout = bench.build_cfg2(torch.device("cuda"), gate=0.5, n_items=14901)
+    assert layout.vocab == 66216
+    bt = make_batch(layout, 2, 16, 512, seed=3, device="cuda", vision_dtype=bf16)
+    model.eval()
+    with torch.no_grad():
+        a = model(bt["vision_x"], bt["lang_x"], bt["attention_mask"])["logits"]
+        vx = bt["vision_x"].clone()
+        vx[:, 11] += 1.0                                             # perturb history image #12 only
+        b = model(vx, bt["lang_x"], bt["attention_mask"])["logits"]
+    assert a.shape == (2, 512, 66216) and torch.isfinite(a.float()).all()
+    for r in range(2):
+        pos = (bt["lang_x"][r] == layout.media).nonzero().flatten()
+        assert pos.numel() == 16
+        assert torch.equal(a[r, :pos[11]], b[r, :pos[11]])           # everything before the 12th <image> is untouched
+        assert not torch.equal(a[r, pos[11]:pos[12]], b[r, pos[11]:pos[12]])
+    tr = Trainer(model, layout.special(), lr=2e-4, gamma=2.0, use_reweight=True, total_steps=10)
+    loss, stats = tr.step(bt)
+    assert torch.isfinite(loss) and float(stats[1]) > 0 and torch.isfinite(tr.opt.grad_norm())
+
+
+def test_cfg1_opt125m_vitb32_vs_oracle():
+    """BASELINE config 1 at its real size (OPT-125m tower + ViT-B/32, every layer cross-attended, b = 2, T = 5, L = 128,
+    full 74k vocabulary): the only published configuration the fp32 CPU oracle can run whole -- logits, loss and argmax
+    against it, then one weighted-focal training step against the oracle's loss."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import _parity as P
+    from unimp_amd.train import Trainer
+    cfg = dict(vit=dict(image_size=224, patch_size=32, width=768, layers=12, heads=12, mlp_dim=3072, output_dim=512),
+               lm=dict(kind="opt", vocab_size=50272, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, ffn_dim=3072),
+               every=1, T=5, L=128, B=2, n_items=22738, base_vocab=50272)
+    om, layout = P.build_oracle(cfg)
+    hm = P.build_hip(cfg, om, layout).eval()
+    batch = P.make_batch(cfg, layout)
+    om.eval()
+    with torch.no_grad():
+        want = om(batch["vision_x"], batch["lang_x"], batch["attention_mask"])["logits"]
+        got = hm(batch["vision_x"].cuda(), batch["lang_x"].cuda(), batch["attention_mask"].cuda())["logits"]
+    assert got.shape == want.shape == (2, 128, layout.vocab)
+    # 36 blocks deep: bf16 rounding accumulates beyond the 1e-2 of the 2-layer fixtures; the yardstick is the oracle's own
+    # arithmetic under bf16 autocast on the same weights and batch
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+        floor = P.rel_l2(om(batch["vision_x"], batch["lang_x"], batch["attention_mask"])["logits"].float(), want)
+    rel = P.rel_l2(got, want)
+    assert rel <= max(1e-2, 2.0 * floor), (rel, floor)
+    m = batch["attention_mask"].bool()
+    top2 = want.topk(2, -1).values
+    clear = m & ((top2[..., 0] - top2[..., 1]) > 0.02 * want.abs().max())
+    assert clear.sum() > 0 and torch.equal(got.cpu().argmax(-1)[clear], want.argmax(-1)[clear])
+    _, wloss, _, _ = P.oracle_step(om, layout, batch)
+    hm.train()
+    tr = Trainer(hm, layout.special(), lr=1e-4, gamma=2.0, use_reweight=True)
+    loss, _ = tr.step({k: v.cuda() for k, v in batch.items()})
+    assert abs(float(loss) - float(wloss)) <= 2e-3 * abs(float(wloss)), (float(loss), float(wloss))
