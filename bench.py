@@ -42,13 +42,13 @@ def flops_per_sample(T, L, V, n_patch=256, P=14, Dv=1024, vit_layers=24, vit_mlp
     return dict(vit=vit, perceiver=perc, xattn=xattn, lm=lm, total=vit + perc + xattn + lm)
 
 
-def build_cfg2(device, gate=0.5, seed=0, n_items=22738):
+def build_cfg2(device, gate=0.5, seed=0, n_items=22738, lang="togethercomputer/RedPajama-INCITE-Instruct-3B-v1", every=2):
+    """lang / every: the "4b-instruct" pair by default; ("anas-awadalla/mpt-7b", 4) is the reference's "9b" (mmrec.py:515-524)."""
     from unimp_amd.factory import create_model_and_transforms, SyntheticTokenizer
     from unimp_amd.synthetic import TokenLayout
     torch.manual_seed(seed)
     layout = TokenLayout(n_items=n_items)        # V = 74 053 (mmrec.py:538-581, subset "all"); 14 901 items (H&M) -> V = 66 216
-    model, _, tok = create_model_and_transforms("ViT-L-14", "openai", "togethercomputer/RedPajama-INCITE-Instruct-3B-v1",
-                                                "togethercomputer/RedPajama-INCITE-Instruct-3B-v1", cross_attn_every_n_layers=2,
+    model, _, tok = create_model_and_transforms("ViT-L-14", "openai", lang, lang, cross_attn_every_n_layers=every,
                                                 device=device, tokenizer=SyntheticTokenizer())
     model.lang_encoder.resize_token_embeddings(layout.vocab)            # mmrec.py:595 (new embeddings + head: trainable)
     model.media_token_id, model.eoc_token_id = layout.media, layout.eoc
@@ -118,6 +118,8 @@ def main():
     ap.add_argument("--seq", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--model", choices=["4b-instruct", "9b"], default="4b-instruct",
+                    help="9b = ViT-L/14 + MPT-7B, cross-attention every 4th block (mmrec.py:515-524), bf16 -- NOT the headline configuration")
     ap.add_argument("--sparse-head", action="store_true", help="Trainer(sparse_head=True): head + loss on the labeled rows only "
                     "(same loss / gradients; NOT the default and not the headline configuration)")
     args = ap.parse_args()
@@ -137,13 +139,14 @@ def main():
     from unimp_amd.synthetic import make_batch
     from unimp_amd.train import Trainer
 
-    model, layout = build_cfg2(dev)
+    nine = args.model == "9b"
+    model, layout = build_cfg2(dev, lang="anas-awadalla/mpt-7b", every=4) if nine else build_cfg2(dev)
     trainer = Trainer(model, layout.special(), lr=2e-4, weight_decay=0.1, gamma=2.0, use_reweight=True,
                       lr_scheduler="cosine", warmup_steps=10, total_steps=10000, sparse_head=args.sparse_head)
     n_train = sum(p.numel() for p in model.parameters() if p.requires_grad)
     T, L, B = args.images, args.seq, args.batch
     pool = [make_batch(layout, B, T, L, seed=1234 + rank + 1000 * i, device=dev, vision_dtype=torch.bfloat16) for i in range(2)]
-    fps = flops_per_sample(T, L, layout.vocab)
+    fps = flops_per_sample(T, L, layout.vocab, H=4096, F=16384, lm_layers=32, n_xattn=8) if nine else flops_per_sample(T, L, layout.vocab)
 
     for i in range(args.warmup):
         trainer.step(pool[i % 2])
@@ -210,7 +213,8 @@ def main():
         line = {"metric": "train samples/sec (user sequences) at 4B-instruct", "value": round(value, 3), "unit": "samples/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-                "config": {"workload": "cfg2: 4b-instruct Flamingo (ViT-L/14 + GPT-NeoX-3B RedPajama dims, xattn every 2), "
+                "config": {"workload": ("cfg5 model in bf16: 9b Flamingo (ViT-L/14 + MPT-7B dims, xattn every 4), " if nine else
+                                        "cfg2: 4b-instruct Flamingo (ViT-L/14 + GPT-NeoX-3B RedPajama dims, xattn every 2), ") +
                                        "single-task rec, full optimizer step" + (", LM head on labeled rows only" if args.sparse_head else ""), "per_gpu_batch": B, "global_batch": B * world,
                            "history_images": T, "seq_len": L, "vocab": layout.vocab, "trainable_params": n_train,
                            "parallelism": f"dp{world}", "weights": "random-init", "loss": float(loss),

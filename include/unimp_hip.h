@@ -120,6 +120,8 @@ typedef struct {
   /* backward only */
   const void* d_o; void* dq; void* dk; void* dv; float* delta;   /* delta: fp32 [B][H][Sq] workspace */
   int64_t do_bs, do_ss, do_hs, dq_bs, dq_ss, dq_hs, dk_bs, dk_ss, dk_hs, dv_bs, dv_ss, dv_hs;
+  const float* alibi_slopes;   /* NULL, or fp32 [H]: score(i, j) += slope[h] * j (MPT's key-position ALiBi: softmax is shift-invariant
+                                  per row, so this equals slope * (j - i) and transformers' slope * (j - (Sk - 1))) */
 } unimp_attn_desc;
 int unimp_attn_fwd(const unimp_attn_desc* d, void* stream);
 int unimp_attn_bwd(const unimp_attn_desc* d, void* stream);

@@ -421,3 +421,28 @@ def test_cfg1_opt125m_vitb32_vs_oracle():
     tr = Trainer(hm, layout.special(), lr=1e-4, gamma=2.0, use_reweight=True)
     loss, _ = tr.step({k: v.cuda() for k, v in batch.items()})
     assert abs(float(loss) - float(wloss)) <= 2e-3 * abs(float(wloss)), (float(loss), float(wloss))
+
+
+def test_cfg5_9b_mpt_tower_train_step():
+    """BASELINE config 5's model in bf16 (ViT-L/14 + MPT-7B, gated cross-attention every 4th block; the fp8 weights and the
+    VQGAN task of that config are not built): forward properties and one optimizer step at full width."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import bench
+    from unimp_amd.synthetic import make_batch
+    from unimp_amd.train import Trainer
+    model, layout = bench.build_cfg2(torch.device("cuda"), gate=0.5, lang="anas-awadalla/mpt-7b", every=4)
+    le = model.lang_encoder
+    assert sum(g is not None for g in le.gated_cross_attn_layers) == 8 and le.config.d_model == 4096
+    assert le.lm_head.weight is le.transformer.wte.weight                    # tied head survives resize_token_embeddings
+    n_params = sum(p.numel() for p in model.parameters())
+    assert 7.5e9 < n_params < 9.5e9, n_params
+    bt = make_batch(layout, 2, 8, 512, seed=5, device="cuda", vision_dtype=bf16)
+    model.eval()
+    with torch.no_grad():
+        a = model(bt["vision_x"], bt["lang_x"], bt["attention_mask"])["logits"]
+        c = model(bt["vision_x"][1:], bt["lang_x"][1:], bt["attention_mask"][1:])["logits"]
+    assert a.shape == (2, 512, layout.vocab) and torch.isfinite(a.float()).all() and torch.equal(a[1:], c)
+    tr = Trainer(model, layout.special(), lr=1e-4, gamma=2.0, total_steps=10)
+    loss, stats = tr.step(bt)
+    assert torch.isfinite(loss) and float(stats[1]) > 0 and torch.isfinite(tr.opt.grad_norm())

@@ -487,3 +487,52 @@ def test_sumsq_adamw(ops):
     assert torch.allclose(master.cpu(), pr, rtol=1e-4, atol=1e-6)
     assert torch.allclose(m.cpu(), mr, rtol=1e-4, atol=1e-7) and torch.allclose(v.cpu(), vr, rtol=1e-4, atol=1e-9)
     assert torch.equal(p16.cpu(), master.cpu().to(bf16))
+
+
+def mpt_alibi_slopes(n_heads, alibi_bias_max=8):
+    """transformers' build_mpt_alibi_tensor slopes (models/mpt/modeling_mpt.py)."""
+    import math
+    n2 = 2 ** math.ceil(math.log2(n_heads))
+    base = torch.arange(1, n2 + 1, dtype=torch.float32) * (alibi_bias_max / n2)
+    slopes = 1.0 / torch.pow(2, base)
+    if n2 != n_heads:
+        slopes = torch.cat([slopes[1::2], slopes[::2]])[:n_heads]
+    return slopes.contiguous()
+
+
+@pytest.mark.parametrize("B,H,S,D,kvpad", [(2, 4, 200, 64, True), (1, 6, 512, 128, False), (2, 3, 96, 80, True)])
+def test_attention_alibi_causal(ops, B, H, S, D, kvpad):
+    """ALiBi as MPT applies it (bias = slope_h * (j - (S - 1)), causal): forward and all three gradients, plus a single
+    query row against a longer key cache (the decode shape)."""
+    g = torch.Generator().manual_seed(S + D)
+    qkv = torch.randn(B, S, H, 3 * D, generator=g).to(bf16)
+    q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+    slopes = mpt_alibi_slopes(H)
+    kv_len = torch.tensor([S, S - 29][:B], dtype=torch.int32) if kvpad else None
+    scale = D ** -0.5
+    qr, kr, vr = (t.float().requires_grad_(True) for t in (q, k, v))
+    s = torch.einsum("bqhd,bkhd->bhqk", qr, kr) * scale
+    s = s + slopes[None, :, None, None] * (torch.arange(S)[None, None, None, :] - (S - 1))
+    ok = torch.arange(S)[None, None, None, :] <= torch.arange(S)[None, None, :, None]
+    if kv_len is not None:
+        ok = ok & (torch.arange(S)[None, None, None, :] < kv_len.long()[:, None, None, None])
+    want = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(s.masked_fill(~ok, float("-inf")), -1), vr)
+    do = torch.randn(B, S, H, D, generator=g).to(bf16)
+    want.backward(do.float())
+    qkv_d = qkv.cuda()
+    qd, kd, vd = qkv_d[..., :D], qkv_d[..., D:2 * D], qkv_d[..., 2 * D:]
+    kvl = None if kv_len is None else kv_len.cuda()
+    out, lse = ops.attn_fwd(qd, kd, vd, scale, ops.MASK_CAUSAL, kvl, alibi=slopes.cuda())
+    close(out, want.detach(), rel=2 ** -6, name="alibi fwd")
+    dqkv = torch.full_like(qkv_d, float("nan"))
+    dq, dk, dv = dqkv[..., :D], dqkv[..., D:2 * D], dqkv[..., 2 * D:]
+    ops.attn_bwd(qd, kd, vd, out, lse, do.cuda(), dq, dk, dv, scale, ops.MASK_CAUSAL, kvl, alibi=slopes.cuda())
+    close(dq, qr.grad, rel=2 ** -5, name="alibi dq")
+    close(dk, kr.grad, rel=2 ** -5, name="alibi dk")
+    close(dv, vr.grad, rel=2 ** -5, name="alibi dv")
+    # decode: the last query row alone against the whole key range (MASK_NONE + kv_len)
+    n = S if kv_len is None else int(kv_len.min())
+    o1, _ = ops.attn_fwd(qd[:, n - 1:n], kd, vd, scale, ops.MASK_NONE, torch.full((B,), n, dtype=torch.int32, device="cuda"), alibi=slopes.cuda())
+    rows = torch.softmax((torch.einsum("bhd,bkhd->bhk", q[:, n - 1].float(), k[:, :n].float()) * scale
+                          + slopes[None, :, None] * torch.arange(n)[None, None, :]), -1)
+    close(o1[:, 0], torch.einsum("bhk,bkhd->bhd", rows, v[:, :n].float()), rel=2 ** -6, name="alibi decode row")

@@ -221,3 +221,48 @@ def test_sparse_head_step_equals_dense_step():
     assert rel < 0.1, rel                                                 # Adam's sign-like first step amplifies rounding: compare directions
     cos = float((d0 * d1).sum() / (d0.norm() * d1.norm()))
     assert cos > 0.99, cos
+
+
+@pytest.mark.parametrize("n_heads,d_model", [(2, 128), (6, 384)])
+def test_mpt_tower_vs_transformers(n_heads, d_model):
+    """The MPT tower (OpenFlamingo-9B's language model: ALiBi, no biases, tied head) against the installed transformers'
+    MptForCausalLM on identical bf16-representable weights: logits, the tied-embedding gradient of a CE loss, and the KV-cached
+    decode.  6 heads exercise the interleaved slopes of a non-power-of-two head count."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    transformers = pytest.importorskip("transformers")
+    from transformers import MptConfig, MptForCausalLM as HFMpt
+    from unimp_amd.lm import MPTConfig, build_lm
+    torch.manual_seed(0)
+    V, L, B = 320, 96, 2
+    hf = HFMpt(MptConfig(d_model=d_model, n_heads=n_heads, n_layers=2, expansion_ratio=4, max_seq_len=256, vocab_size=V,
+                         no_bias=True, layer_norm_epsilon=1e-5)).eval()
+    with torch.no_grad():
+        for p_ in hf.parameters():
+            p_.copy_((p_ * (3.0 if p_.dim() >= 2 else 1.0)).to(torch.bfloat16).float())
+    mine = build_lm(MPTConfig(vocab_size=V, d_model=d_model, n_layers=2, n_heads=n_heads)).to(device="cuda", dtype=torch.bfloat16)
+    missing, unexpected = mine.load_state_dict(hf.state_dict(), strict=False)
+    assert not [k for k in missing if "lm_head" not in k] and not [k for k in unexpected if "lm_head" not in k], (missing, unexpected)
+    ids = torch.randint(0, V, (B, L))
+    mask = torch.ones(B, L, dtype=torch.long); mask[1, 70:] = 0
+    labels = ids.clone(); labels[mask == 0] = -100
+    out = hf(input_ids=ids, attention_mask=mask, labels=labels)
+    out.loss.backward()
+    got = mine(ids.cuda(), mask.cuda(), labels=labels.cuda())
+    valid = mask.bool()
+    rel = float((got["logits"].float().cpu()[valid] - out.logits[valid]).norm() / out.logits[valid].norm())
+    assert rel <= 1e-2, rel
+    assert abs(float(got[0]) - float(out.loss)) <= 2e-3 * float(out.loss)
+    got[0].backward()
+    gw, ww = mine.transformer.wte.weight.grad.float().cpu(), hf.transformer.wte.weight.grad
+    assert float((gw - ww).norm() / ww.norm()) <= 3e-2
+    # cached decode: prefill on the first 60 tokens, then 3 single-token steps == full forward
+    with torch.no_grad():
+        full = mine(ids[:1, :63].cuda())["logits"].float()
+        o = mine(ids[:1, :60].cuda(), use_cache=True)
+        steps = [o["logits"][:, -1].float()]
+        for j in range(60, 63):
+            o = mine(ids[:1, j:j + 1].cuda(), past_key_values=o.past_key_values, use_cache=True)
+            steps.append(o["logits"][:, -1].float())
+    for j, lg in enumerate(steps):
+        assert float((lg - full[:, 59 + j]).abs().max()) <= 2e-2 * float(full.abs().max()), j

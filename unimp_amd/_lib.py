@@ -28,7 +28,7 @@ class AttnDesc(C.Structure):
                 ("kv_len", c_p), ("seg", c_p), ("seg_len", c_i),
                 ("d_o", c_p), ("dq", c_p), ("dk", c_p), ("dv", c_p), ("delta", c_p)] + \
                [(n, c_l) for n in ("do_bs", "do_ss", "do_hs", "dq_bs", "dq_ss", "dq_hs", "dk_bs", "dk_ss", "dk_hs",
-                                   "dv_bs", "dv_ss", "dv_hs")]
+                                   "dv_bs", "dv_ss", "dv_hs")] + [("alibi_slopes", c_p)]
 
 
 # name -> argtypes (every entry point returns int status)

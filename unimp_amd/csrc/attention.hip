@@ -30,6 +30,7 @@ struct AttnP {
   const int* kv_len; const int* seg; int seg_len;
   const bf16* d_o; bf16* dq; bf16* dk; bf16* dv; float* delta;
   long do_bs, do_ss, do_hs, dq_bs, dq_ss, dq_hs, dk_bs, dk_ss, dk_hs, dv_bs, dv_ss, dv_hs;
+  const float* alibi;        // per-head slopes or null: raw score += slope / scale * key  (so that score * scale gains slope * key)
 };
 
 // key range [lo, hi) attended by query row `qr` of batch b
@@ -173,6 +174,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
   int kt_lo, kt_hi;
   block_key_tiles(p, b, blockIdx.x * 128, blockIdx.x * 128 + 127, kt_lo, kt_hi);
   float sc2 = p.scale * LOG2E;
+  const float ab = p.alibi ? p.alibi[h] / p.scale : 0.f;
   float m[2] = {-INFINITY, -INFINITY}, lsum[2] = {0.f, 0.f};
   f32x4 o[2][ND];
 #pragma unroll
@@ -210,6 +212,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
         s[0][nt] = MFMA16(kf, qf[0][ks], s[0][nt]);
         s[1][nt] = MFMA16(kf, qf[1][ks], s[1][nt]);
       }
+    }
+    if (ab != 0.f) {                    // ALiBi (wave-uniform): bias every score by its key position
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float kb = ab * (float)(kt * 64 + nt * 16 + g * 4 + r);
+          s[0][nt][r] += kb; s[1][nt][r] += kb;
+        }
     }
     bf16x8 pf[2][2];
 #pragma unroll
@@ -336,6 +347,7 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(AttnP p) {
   int kt_lo, kt_hi;
   block_key_tiles(p, b, blockIdx.x * 128, blockIdx.x * 128 + 127, kt_lo, kt_hi);
   float sc2 = p.scale * LOG2E;
+  const float ab = p.alibi ? p.alibi[h] / p.scale : 0.f;
   f32x4 dq[2][ND];
 #pragma unroll
   for (int u = 0; u < 2; ++u)
@@ -373,6 +385,15 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(AttnP p) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) { s[u][nt] = MFMA16(kf, qf[u][ks], s[u][nt]); dp[u][nt] = MFMA16(vf, dof[u][ks], dp[u][nt]); }
       }
+    }
+    if (ab != 0.f) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float kb = ab * (float)(kt * 64 + nt * 16 + g * 4 + r);
+          s[0][nt][r] += kb; s[1][nt][r] += kb;
+        }
     }
     bf16x8 dsf[2][2];
 #pragma unroll
@@ -453,6 +474,7 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p) {
     for (int nd = 0; nd < ND; ++nd) { dk[u][nd] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[u][nd] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   }
   float sc2 = p.scale * LOG2E;
+  const float ab = p.alibi ? p.alibi[h] / p.scale : 0.f;
   int nqt = (p.Sq + 31) >> 5;
   int kfirst = kblk * 128, klast = kblk * 128 + 127;
   // block-uniform list of query tiles that can see this key block: [qt_a, qt_b)
@@ -526,6 +548,13 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       int key = key0 + u * 16 + (l & 15);
+      if (ab != 0.f) {
+        float kb = ab * (float)key;
+#pragma unroll
+        for (int qb2 = 0; qb2 < 2; ++qb2)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[u][qb2][r] += kb;
+      }
       if (all_visible && key < p.Sk) {
 #pragma unroll
         for (int qb2 = 0; qb2 < 2; ++qb2)
@@ -593,7 +622,7 @@ static int fill(AttnP& p, const unimp_attn_desc* d, bool bwd) {
   p.q_bs = d->q_bs; p.q_ss = d->q_ss; p.q_hs = d->q_hs; p.k_bs = d->k_bs; p.k_ss = d->k_ss; p.k_hs = d->k_hs;
   p.v_bs = d->v_bs; p.v_ss = d->v_ss; p.v_hs = d->v_hs; p.o_bs = d->o_bs; p.o_ss = d->o_ss; p.o_hs = d->o_hs;
   p.B = d->B; p.H = d->H; p.Sq = d->Sq; p.Sk = d->Sk; p.D = d->D; p.scale = d->scale; p.mask_mode = d->mask_mode;
-  p.kv_len = d->kv_len; p.seg = d->seg; p.seg_len = d->seg_len;
+  p.kv_len = d->kv_len; p.seg = d->seg; p.seg_len = d->seg_len; p.alibi = d->alibi_slopes;
   p.d_o = nullptr; p.dq = p.dk = p.dv = nullptr; p.delta = nullptr;
   if (bwd) {
     if (!d->d_o || !d->dq || !d->dk || !d->dv || !d->delta || !d->lse) return unimp_set_error(UNIMP_ERR_ARG, "attn_bwd: null pointer");

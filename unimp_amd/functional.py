@@ -207,7 +207,7 @@ class SelfAttnBlockFn(Function):
     or [B, L, 3, nh, hd] (blocked q|k|v: OPT / Llama / ViT)."""
 
     @staticmethod
-    def forward(ctx, x, res, ln_w, ln_b, wqkv, bqkv, wd, bd, rope, kv_len, nh, interleaved, causal, eps, rms, q_scale):
+    def forward(ctx, x, res, ln_w, ln_b, wqkv, bqkv, wd, bd, rope, kv_len, nh, interleaved, causal, eps, rms, q_scale, alibi=None):
         B, L, H = x.shape
         hd = H // nh
         x2 = x.reshape(B * L, H)
@@ -218,18 +218,18 @@ class SelfAttnBlockFn(Function):
         if rope is not None:
             cos, sin, rot = rope
             ops.rope_(qkv, L, nh, hs, rot, offs, cos, sin)
-        o, lse = ops.attn_fwd(q, k, v, q_scale, ops.MASK_CAUSAL if causal else ops.MASK_NONE, kv_len)
+        o, lse = ops.attn_fwd(q, k, v, q_scale, ops.MASK_CAUSAL if causal else ops.MASK_NONE, kv_len, alibi=alibi)
         o2 = o.view(B * L, H)
         out = ops.gemm(o2, wd, bias=bd, res=r2)
         ctx.save_for_backward(x2, ln_w, mean, rstd, wqkv, wd, qkv, o, lse, kv_len, h if wqkv.requires_grad else None,
-                              rope[0] if rope is not None else None, rope[1] if rope is not None else None)
+                              rope[0] if rope is not None else None, rope[1] if rope is not None else None, alibi)
         ctx.cfg = (B, L, H, nh, hd, interleaved, causal, rms, q_scale, rope[2] if rope is not None else 0, res is None,
                    ln_b is not None)
         return out.view(B, L, H)
 
     @staticmethod
     def backward(ctx, dy):
-        x2, ln_w, mean, rstd, wqkv, wd, qkv, o, lse, kv_len, h, cos, sin = ctx.saved_tensors
+        x2, ln_w, mean, rstd, wqkv, wd, qkv, o, lse, kv_len, h, cos, sin, alibi = ctx.saved_tensors
         B, L, H, nh, hd, interleaved, causal, rms, q_scale, rot, res_is_x, has_lnb = ctx.cfg
         _no_bias_grad(ctx, 5, "qkv bias")
         _no_bias_grad(ctx, 7, "dense bias")
@@ -242,7 +242,7 @@ class SelfAttnBlockFn(Function):
         q, k, v, hs, offs = _split_qkv(qkv, B, L, nh, hd, interleaved)
         dqkv = torch.empty_like(qkv)
         dq, dk, dv, _, _ = _split_qkv(dqkv, B, L, nh, hd, interleaved)
-        ops.attn_bwd(q, k, v, o, lse, do, dq, dk, dv, q_scale, ops.MASK_CAUSAL if causal else ops.MASK_NONE, kv_len)
+        ops.attn_bwd(q, k, v, o, lse, do, dq, dk, dv, q_scale, ops.MASK_CAUSAL if causal else ops.MASK_NONE, kv_len, alibi=alibi)
         if cos is not None:
             ops.rope_(dqkv, L, nh, hs, rot, offs, cos, sin, inverse=True)
         dwqkv = ops.gemm(dqkv, h, a_ks=True, b_ks=True) if _need(ctx, 4) else None
@@ -251,7 +251,7 @@ class SelfAttnBlockFn(Function):
         dx, dg, db = ops.layernorm_bwd(dh, x2, ln_w, mean, rstd, dres=dy2 if res_is_x else None, want_wgrad=wg,
                                        has_beta=has_lnb, rms=rms)
         dres = None if res_is_x else dy
-        return (dx.view(B, L, H), dres, dg, db, dwqkv, None, dwd, None) + (None,) * 8
+        return (dx.view(B, L, H), dres, dg, db, dwqkv, None, dwd, None) + (None,) * 9
 
 
 def _split_qkv(qkv, B, L, nh, hd, interleaved):
@@ -265,10 +265,10 @@ def _split_qkv(qkv, B, L, nh, hd, interleaved):
 
 
 def self_attn_block(x, ln_w, ln_b, wqkv, bqkv, wd, bd, nh, *, rope=None, kv_len=None, interleaved=True, causal=True,
-                    eps=1e-5, rms=False, res=None, q_scale=None):
+                    eps=1e-5, rms=False, res=None, q_scale=None, alibi=None):
     hd = x.shape[-1] // nh
     return SelfAttnBlockFn.apply(x, res, ln_w, ln_b, wqkv, bqkv, wd, bd, rope, kv_len, nh, interleaved, causal, eps, rms,
-                                 q_scale if q_scale is not None else hd ** -0.5)
+                                 q_scale if q_scale is not None else hd ** -0.5, alibi)
 
 
 # ----------------------------------------------------------------------------------------------- KV-cache decode (F1)
@@ -353,7 +353,7 @@ def _kv_append(lc, k, v, pos0):
 
 @torch.no_grad()
 def self_attn_block_cached(x, ln_w, ln_b, wqkv, bqkv, wd, bd, nh, lc, pos0, *, rope=None, interleaved=True, eps=1e-5,
-                           rms=False, res=None, q_scale=None):
+                           rms=False, res=None, q_scale=None, alibi=None):
     """SelfAttnBlockFn.forward for decoding: the new rows' keys/values are appended to ``lc``; a prefill (pos0 == 0) runs
     the causal kernel on the prompt, a decode step (one new token per row) attends to every cached key.  With
     ``lc.owner.step`` set the position lives on the device (StepState): ``rope`` then holds the one table row of the
@@ -374,18 +374,18 @@ def self_attn_block_cached(x, ln_w, ln_b, wqkv, bqkv, wd, bd, nh, lc, pos0, *, r
             ops.rope_(qkv, R, nh, hs, rope[2], offs, rope[0], rope[1])
         lc.k.index_put_((step.rows, step.pos_idx), k[:, 0])
         lc.v.index_put_((step.rows, step.pos_idx), v[:, 0])
-        o, _ = ops.attn_fwd(q, lc.k, lc.v, scale, ops.MASK_NONE, step.kv_len)
+        o, _ = ops.attn_fwd(q, lc.k, lc.v, scale, ops.MASK_NONE, step.kv_len, alibi=alibi)
         return ops.gemm(o.view(R, H), wd, bias=bd, res=r2).view(R, 1, H)
     if rope is not None:
         cos, sin, rot = rope
         ops.rope_(qkv, Ln, nh, hs, rot, offs, cos[pos0:], sin[pos0:])
     kc, vc = _kv_append(lc, k, v, pos0)
     if pos0 == 0:
-        o, _ = ops.attn_fwd(q, k, v, scale, ops.MASK_CAUSAL, lc.owner.row_len)       # row_len: right-padded prompts
+        o, _ = ops.attn_fwd(q, k, v, scale, ops.MASK_CAUSAL, lc.owner.row_len, alibi=alibi)       # row_len: right-padded prompts
     else:
         if Ln != 1:
             raise NotImplementedError("cached decode feeds one new token per row (chunked prefill is not built)")
-        o, _ = ops.attn_fwd(q, kc, vc, scale, ops.MASK_NONE, None)
+        o, _ = ops.attn_fwd(q, kc, vc, scale, ops.MASK_NONE, None, alibi=alibi)
     return ops.gemm(o.view(R * Ln, H), wd, bias=bd, res=r2).view(R, Ln, H)
 
 

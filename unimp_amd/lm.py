@@ -54,6 +54,8 @@ LM_CONFIGS = {
                                       intermediate_size=3072, rotary_pct=0.25, use_parallel_residual=True),
     "opt-125m": lambda: OPTConfig(),
     "opt-1.3b": lambda: OPTConfig(hidden_size=2048, num_hidden_layers=24, num_attention_heads=32, ffn_dim=8192),
+    "mpt-7b": lambda: MPTConfig(),                                                      # OpenFlamingo-9B (mmrec.py:515-524)
+    "mpt-1b-redpajama-200b": lambda: MPTConfig(vocab_size=50432, d_model=2048, n_layers=24, n_heads=16),
 }
 
 
@@ -454,6 +456,112 @@ class LlamaForCausalLM(_TowerBase):
         return out
 
 
+# --------------------------------------------------------------------------- MPT (OpenFlamingo-9B / -3B towers, mmrec.py:515-524)
+def MPTConfig(vocab_size=50432, d_model=4096, n_layers=32, n_heads=32, expansion_ratio=4, max_seq_len=2048,
+              layer_norm_epsilon=1e-5, alibi_bias_max=8):
+    c = _Cfg(model_type="mpt", **{k: v for k, v in locals().items()})
+    c.hidden_size = d_model
+    return c
+
+
+def mpt_alibi_slopes(n_heads, alibi_bias_max=8):
+    """transformers' build_mpt_alibi_tensor: 2^-(i * bias_max / n2), interleaved when n_heads is not a power of two."""
+    n2 = 2 ** math.ceil(math.log2(n_heads))
+    base = torch.arange(1, n2 + 1, dtype=torch.float32) * (alibi_bias_max / n2)
+    slopes = 1.0 / torch.pow(2, base)
+    if n2 != n_heads:
+        slopes = torch.cat([slopes[1::2], slopes[::2]])[:n_heads]
+    return slopes.contiguous()
+
+
+class _MPTAttnParams(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.Wqkv = nn.Linear(d, 3 * d, bias=False)
+        self.out_proj = nn.Linear(d, d, bias=False)
+
+
+class _MPTFFNParams(nn.Module):
+    def __init__(self, d, r):
+        super().__init__()
+        self.up_proj = nn.Linear(d, r * d, bias=False)
+        self.down_proj = nn.Linear(r * d, d, bias=False)
+
+
+class _LNNoBias(nn.Module):
+    def __init__(self, d, eps):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(d))
+        self.eps = eps
+
+
+class MptBlock(nn.Module):
+    """x += out_proj(causal_attn_alibi(Wqkv(norm_1(x))));  x += down_proj(gelu(up_proj(norm_2(x))))  -- no biases anywhere
+    (transformers models/mpt/modeling_mpt.py MptBlock / MptAttention / MptMLP)."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.c = c
+        self.norm_1 = _LNNoBias(c.d_model, c.layer_norm_epsilon)
+        self.attn = _MPTAttnParams(c.d_model)
+        self.norm_2 = _LNNoBias(c.d_model, c.layer_norm_epsilon)
+        self.ffn = _MPTFFNParams(c.d_model, c.expansion_ratio)
+
+    def forward(self, x, attention_mask=None, alibi=None, cache=None, pos0=0, **kw):
+        c, a, f = self.c, self.attn, self.ffn
+        if cache is not None:
+            x = F_.self_attn_block_cached(x, self.norm_1.weight, None, a.Wqkv.weight, None, a.out_proj.weight, None, c.n_heads,
+                                          cache, pos0, interleaved=False, eps=self.norm_1.eps, alibi=alibi)
+        else:
+            x = F_.self_attn_block(x, self.norm_1.weight, None, a.Wqkv.weight, None, a.out_proj.weight, None, c.n_heads,
+                                   kv_len=attention_mask, interleaved=False, causal=True, eps=self.norm_1.eps, alibi=alibi)
+        return F_.mlp_block(x, self.norm_2.weight, None, f.up_proj.weight, None, f.down_proj.weight, None, "gelu", eps=self.norm_2.eps)
+
+
+class _MPTBody(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.wte = nn.Embedding(c.vocab_size, c.d_model)
+        self.blocks = nn.ModuleList([MptBlock(c) for _ in range(c.n_layers)])
+        self.norm_f = _LNNoBias(c.d_model, c.layer_norm_epsilon)
+
+
+class MptForCausalLM(_TowerBase):
+    decoder_layers_attr = "transformer.blocks"
+    tied = True
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.transformer = _MPTBody(config)
+        self.lm_head = nn.Linear(config.d_model, config.vocab_size, bias=False)
+        self.lm_head.weight = self.transformer.wte.weight
+        self._slopes = None
+
+    def get_input_embeddings(self): return self.transformer.wte
+    def set_input_embeddings(self, m): self.transformer.wte = m
+    def get_output_embeddings(self): return self.lm_head
+    def set_output_embeddings(self, m): self.lm_head = m
+
+    def forward(self, input_ids, attention_mask=None, labels=None, past_key_values=None, use_cache=False, **kw):
+        B, L = input_ids.shape
+        cache, pos0 = self._decode_state(past_key_values, use_cache, labels, attention_mask)
+        x = F_.embedding(input_ids, self.transformer.wte.weight)
+        if self._slopes is None or self._slopes.device != x.device:
+            self._slopes = mpt_alibi_slopes(self.config.n_heads, self.config.alibi_bias_max).to(x.device)
+        kv_len = self._kv_len(attention_mask)
+        for i, blk in enumerate(self.transformer.blocks):
+            x = blk(x, attention_mask=kv_len, alibi=self._slopes, cache=cache.layers[i] if cache else None, pos0=pos0)
+        f = self.transformer.norm_f
+        h = F_.layer_norm(x, f.weight, None, f.eps)
+        out = self._head(h, labels, kw.get("logits_last_only", False), kw.get("head_rows"), kw.get("last_index"))
+        if cache is not None:
+            if cache.step is None:
+                cache.len = pos0 + L
+            out.past_key_values = cache
+        return out
+
+
 def build_lm(name_or_config):
     if isinstance(name_or_config, _Cfg):
         c = name_or_config
@@ -462,4 +570,4 @@ def build_lm(name_or_config):
         if not key:
             raise ValueError(f"unknown lang_encoder_path {name_or_config!r}; known: {sorted(LM_CONFIGS)} (or pass a config object)")
         c = LM_CONFIGS[key[0]]()
-    return {"gpt_neox": GPTNeoXForCausalLM, "opt": OPTForCausalLM, "llama": LlamaForCausalLM}[c.model_type](c)
+    return {"gpt_neox": GPTNeoXForCausalLM, "opt": OPTForCausalLM, "llama": LlamaForCausalLM, "mpt": MptForCausalLM}[c.model_type](c)

@@ -202,7 +202,7 @@ def rope_(x2d, L, heads, head_stride, rot, offs, cos, sin, inverse=False):
     return x2d
 
 
-def _fill_attn(d, q, k, v, o, lse, B, H, Sq, Sk, D, scale, mask_mode, kv_len, seg, seg_len, qs, ks, vs, os_):
+def _fill_attn(d, q, k, v, o, lse, B, H, Sq, Sk, D, scale, mask_mode, kv_len, seg, seg_len, qs, ks, vs, os_, alibi=None):
     d.q, d.k, d.v, d.o, d.lse = q, k, v, o, lse
     d.q_bs, d.q_ss, d.q_hs = qs
     d.k_bs, d.k_ss, d.k_hs = ks
@@ -211,6 +211,9 @@ def _fill_attn(d, q, k, v, o, lse, B, H, Sq, Sk, D, scale, mask_mode, kv_len, se
     d.B, d.H, d.Sq, d.Sk, d.D = B, H, Sq, Sk, D
     d.scale, d.mask_mode = scale, mask_mode
     d.kv_len, d.seg, d.seg_len = _p(kv_len), _p(seg), seg_len
+    if alibi is not None:
+        assert alibi.dtype == torch.float32 and alibi.numel() == H and alibi.is_contiguous()
+    d.alibi_slopes = _p(alibi)
 
 
 def _view4(t):
@@ -219,7 +222,7 @@ def _view4(t):
     return _dev(t).data_ptr(), (t.stride(0), t.stride(1), t.stride(2))
 
 
-def attn_fwd(q, k, v, scale, mask_mode=MASK_NONE, kv_len=None, seg=None, seg_len=0, out=None):
+def attn_fwd(q, k, v, scale, mask_mode=MASK_NONE, kv_len=None, seg=None, seg_len=0, out=None, alibi=None):
     """q [B,Sq,H,D], k/v [B,Sk,H,D] strided views; returns o [B,Sq,H,D] (contiguous unless `out`), lse [B,H,Sq]."""
     B, Sq, H, D = q.shape
     Sk = k.shape[1]
@@ -228,19 +231,19 @@ def attn_fwd(q, k, v, scale, mask_mode=MASK_NONE, kv_len=None, seg=None, seg_len
     lse = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device)
     d = AttnDesc()
     (qp, qs), (kp, ks), (vp, vs), (op, os_) = _view4(q), _view4(k), _view4(v), _view4(out)
-    _fill_attn(d, qp, kp, vp, op, lse.data_ptr(), B, H, Sq, Sk, D, scale, mask_mode, kv_len, seg, seg_len, qs, ks, vs, os_)
+    _fill_attn(d, qp, kp, vp, op, lse.data_ptr(), B, H, Sq, Sk, D, scale, mask_mode, kv_len, seg, seg_len, qs, ks, vs, os_, alibi)
     check(_lib.lib().unimp_attn_fwd(C.byref(d), _stream()), "attn_fwd")
     return out, lse
 
 
-def attn_bwd(q, k, v, o, lse, do, dq, dk, dv, scale, mask_mode=MASK_NONE, kv_len=None, seg=None, seg_len=0):
+def attn_bwd(q, k, v, o, lse, do, dq, dk, dv, scale, mask_mode=MASK_NONE, kv_len=None, seg=None, seg_len=0, alibi=None):
     """writes dq/dk/dv (strided [B,S,H,D] views, every element of the views is overwritten)."""
     B, Sq, H, D = q.shape
     Sk = k.shape[1]
     delta = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device)
     d = AttnDesc()
     (qp, qs), (kp, ks), (vp, vs), (op, os_) = _view4(q), _view4(k), _view4(v), _view4(o)
-    _fill_attn(d, qp, kp, vp, op, lse.data_ptr(), B, H, Sq, Sk, D, scale, mask_mode, kv_len, seg, seg_len, qs, ks, vs, os_)
+    _fill_attn(d, qp, kp, vp, op, lse.data_ptr(), B, H, Sq, Sk, D, scale, mask_mode, kv_len, seg, seg_len, qs, ks, vs, os_, alibi)
     d.d_o, (d.do_bs, d.do_ss, d.do_hs) = _view4(do)
     d.dq, (d.dq_bs, d.dq_ss, d.dq_hs) = _view4(dq)
     d.dk, (d.dk_bs, d.dk_ss, d.dk_hs) = _view4(dk)
