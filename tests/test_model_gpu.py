@@ -266,3 +266,41 @@ def test_mpt_tower_vs_transformers(n_heads, d_model):
             steps.append(o["logits"][:, -1].float())
     for j, lg in enumerate(steps):
         assert float((lg - full[:, 59 + j]).abs().max()) <= 2e-2 * float(full.abs().max()), j
+
+
+def test_flamingo_over_mpt_generate_cached_equals_rescoring():
+    """Flamingo over an MPT tower end to end: the KV-cached / HIP-graph decode (ALiBi through the decode step, tied head)
+    returns the tokens of full re-scoring."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from unimp_amd import create_model_and_transforms
+    from unimp_amd.factory import SyntheticTokenizer
+    from unimp_amd.lm import MPTConfig
+    from unimp_amd.synthetic import TokenLayout, make_batch
+    torch.manual_seed(1)
+    tok = SyntheticTokenizer(base_vocab=300)
+    model, _, tok = create_model_and_transforms(
+        dict(image_size=32, patch_size=8, width=128, layers=1, heads=2, mlp_dim=256, output_dim=64), None,
+        MPTConfig(vocab_size=400, d_model=256, n_layers=2, n_heads=4), None, cross_attn_every_n_layers=1, tokenizer=tok, device="cuda")
+    layout = TokenLayout(300, 40, 16)
+    model.lang_encoder.resize_token_embeddings(layout.vocab)
+    model.media_token_id = model.lang_encoder.media_token_id = layout.media
+    model.eoc_token_id = layout.eoc
+    with torch.no_grad():
+        for n, p_ in model.named_parameters():
+            if p_.dim() >= 2 and "latents" not in n:
+                p_.normal_(0, 0.08)
+        for g_ in model.lang_encoder.gated_cross_attn_layers:
+            g_.attn_gate.fill_(0.5); g_.ff_gate.fill_(0.5)
+    bt = make_batch(layout, 1, 2, 40, image_size=32, seed=3, device="cuda", vision_dtype=torch.bfloat16)
+    n = int(bt["attention_mask"][0].sum()) - 2
+    ids, vx = bt["lang_x"][:, :n], bt["vision_x"]
+    kw = dict(max_new_tokens=6, eos_token_id=layout.eos, pad_token_id=layout.eos)
+    a = model.generate(vx, ids, use_cache=True, **kw)
+    b = model.generate(vx, ids, use_cache=False, **kw)
+    m = min(a.shape[1], b.shape[1])
+    assert int((a[0, :m] == b[0, :m]).long().cumprod(0).sum()) >= n + 2, (a.tolist(), b.tolist())
+    c = model.generate(vx, ids, use_cache=True, use_graph=False, **kw)
+    assert torch.equal(a, c)
+    k = model.generate(vx, ids, num_beams=3, num_return_sequences=3, early_stopping=True, **kw)
+    assert k.shape[0] == 3 and torch.equal(k[:, :n], ids.expand(3, -1))
