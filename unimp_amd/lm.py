@@ -55,7 +55,7 @@ LM_CONFIGS = {
     "opt-125m": lambda: OPTConfig(),
     "opt-1.3b": lambda: OPTConfig(hidden_size=2048, num_hidden_layers=24, num_attention_heads=32, ffn_dim=8192),
     "mpt-7b": lambda: MPTConfig(),                                                      # OpenFlamingo-9B (mmrec.py:515-524)
-    "mpt-1b-redpajama-200b": lambda: MPTConfig(vocab_size=50432, d_model=2048, n_layers=24, n_heads=16),
+    # the "3b" options of mmrec.py:475-494 (mpt-1b-redpajama-200b[-dolly]) use the QK-LayerNorm MPT variant: not built
 }
 
 
