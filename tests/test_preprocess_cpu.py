@@ -92,7 +92,7 @@ def test_rec_dataset_matches_reference_golden(tmp_path):
     from unimp_amd.factory import ImageProcessor
     g = _materialise_rec_dataset(tmp_path)
     for split, task in (("train", "rec"), ("test", "rec"), ("train", "search"), ("test", "search"), ("train", "exp"), ("test", "exp"),
-                        ("train", "img_sel"), ("test", "img_sel")):
+                        ("train", "img_sel"), ("test", "img_sel"), ("train", "img_gen"), ("test", "img_gen")):
         ds = D.RecDataset(str(tmp_path), "all", _tokenizer(), split=split, image_transform=ImageProcessor(224), task=task, n_items=14)
         assert len(ds) == 4
         np.random.seed(11)
@@ -114,6 +114,8 @@ def test_rec_dataset_matches_reference_golden(tmp_path):
                     assert f"{no['output_ratings']}|{no['output_exps']}" == str(g[f"{split}{idx}_target"])
                 elif task == "img_sel":
                     assert no["output_ids"].tolist() == g[f"{split}{idx}_target"].tolist()
+                elif task == "img_gen":
+                    assert f"{no['output_ids']}|{no['items']}" == str(g[f"{split}{idx}_target"])
                 else:
                     assert no["output_ids"] == str(g[f"{split}{idx}_target"])
                 assert ni["input_len"] == int(g[f"{split}{idx}_input_len"])

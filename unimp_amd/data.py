@@ -196,8 +196,8 @@ class RecDataset:
         import os
         if subset not in self.HISTORY:
             raise ValueError(f"RecDataset: unknown subset {subset!r}")
-        if task not in ("rec", "search", "exp", "img_sel"):
-            raise NotImplementedError(f"RecDataset: task {task!r} (rec, search, exp and img_sel are built; img_gen is not)")
+        if task not in ("rec", "search", "exp", "img_sel", "img_gen"):
+            raise NotImplementedError(f"RecDataset: unknown task {task!r}")
         self.task = task
         self.all_items = set(range(n_items if n_items is not None else self.ALL_ITEMS[subset]))
         if image_transform is None and not defer_images:
@@ -205,13 +205,19 @@ class RecDataset:
         self.folder, self.subset, self.split, self.tokenizer = folder, subset, split, tokenizer
         self.use_semantic, self.transform, self.defer = use_semantic, image_transform, defer_images
         self.img_folder = os.path.join(folder, subset)
-        self.history_len = self.HISTORY[subset]
+        self.history_len = 2 if (task == "img_gen" and subset == "all") else self.HISTORY[subset]          # rec_dataset.py:143-152
         with open(os.path.join(folder, f"meta_{subset}.json")) as f:
             self.meta_data = json.load(f)
-        name = {"rec": None, "search": None, "exp": f"{split}_{subset}_exp.json", "img_sel": f"{split}_{subset}_img_sel.json"}[task]
+        name = {"rec": None, "search": None, "exp": f"{split}_{subset}_exp.json", "img_sel": f"{split}_{subset}_img_sel.json",
+                "img_gen": f"{split}_{subset}.json" if split == "train" else None}[task]
         with open(os.path.join(folder, name or (f"{split}_users.json" if split == "train" else "test_users.json"))) as f:
             self.data = json.load(f)
         self.seqs, self.keys = list(self.data.values()), list(self.data.keys())
+        if task == "img_gen":        # image-token generation: item sequences from the retrieval file, targets = VQGAN code ids
+            with open(os.path.join(folder, f"search_merge_{split}.txt")) as f:
+                self.seqs = list(json.load(f))
+            with open(os.path.join(folder, "img_id2semantic.json")) as f:
+                self.img_id2semantic = json.load(f)
         if use_semantic:
             self.len_semanticid = 3
             with open(os.path.join(folder, "id2semantic.json")) as f:
@@ -345,7 +351,28 @@ class RecDataset:
             text += f"<image> Selection s_{i} {self.describe(item)} <|endofchunk|> "
         return self._finish(text + ask, imgs, output_ids=torch.tensor(full[-1][-1]))
 
+    def _img_gen_item(self, index):
+        """rec_dataset.py:613-664 (train) / 666-717 (eval): history of (title, image code ids), query keywords, target = the
+        next item's VQGAN code ids as ``img_k,`` tokens."""
+        seq, imgs, text = self.seqs[index], [], ""
+        codes = lambda item: "".join(f"img_{c}," for c in self.img_id2semantic[str(item)])
+        for item in seq[-1 - self.history_len:-1]:
+            imgs.append(self._image(item))
+            np.random.random()                                 # extract_meta_gen draws (and ignores) p
+            title = self.meta_data[str(item)]["title"]
+            title = " ".join(("Unknown" if title == "" else title).split()[:20])
+            text += f"<image> Title {title} ID {codes(item)} <|endofchunk|> "
+        item = seq[-1]
+        query = " ".join(self.meta_data[str(item)]["keywords"].split()[:30])
+        if self.split == "train":
+            return self._finish(text + f"Query: {query} What is the generated image ID to the query based on the history? <answer> {codes(item)}",
+                                imgs, weight=1.0)
+        return self._finish(text + f"Query: {query} What is the generated Image ID to the query based on the history? <answer>",
+                            imgs, output_ids=codes(item), items=item)
+
     def __getitem__(self, index):
+        if self.task == "img_gen":
+            return self._img_gen_item(index)
         if self.task == "search":
             return self._search_item(index)
         if self.task == "exp":
