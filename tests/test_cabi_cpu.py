@@ -38,3 +38,16 @@ def test_product_does_not_import_oracle():
     bad = subprocess.run(["grep", "-rlE", r"^\s*(from|import)\s+oracle", os.path.join(ROOT, "unimp_amd")],
                          capture_output=True, text=True).stdout.split()
     assert bad == [], bad
+
+
+def test_ctypes_mirrors_have_the_c_struct_sizes():
+    """the ctypes Structures of the binding (and of INTEGRATION.md's stub) against sizeof() inside the library."""
+    import ctypes as C
+    from unimp_amd import _lib
+    from unimp_amd.data import _ImageDesc
+    lib = C.CDLL(_lib._LIB_PATH) if hasattr(_lib, "_LIB_PATH") else _lib.lib()
+    lib.unimp_struct_size.restype = C.c_int
+    assert lib.unimp_struct_size(0) == C.sizeof(_lib.GemmDesc)
+    assert lib.unimp_struct_size(1) == C.sizeof(_lib.AttnDesc)
+    assert lib.unimp_struct_size(2) == C.sizeof(_ImageDesc)
+    assert lib.unimp_struct_size(9) == -1

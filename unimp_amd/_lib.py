@@ -96,4 +96,4 @@ def check(rc, what):
 
 
 def declared_symbols():
-    return ["unimp_abi_version", "unimp_last_error", "unimp_set_error", "unimp_check_launch"] + list(_SIGS)
+    return ["unimp_abi_version", "unimp_struct_size", "unimp_last_error", "unimp_set_error", "unimp_check_launch"] + list(_SIGS)

@@ -20,3 +20,13 @@ extern "C" int unimp_check_launch(const char* what) {
   }
   return UNIMP_OK;
 }
+
+// sizeof of the descriptor structs, so a binding can verify its mirror of them (0: gemm, 1: attention, 2: image)
+extern "C" int unimp_struct_size(int which) {
+  switch (which) {
+    case 0: return (int)sizeof(unimp_gemm_desc);
+    case 1: return (int)sizeof(unimp_attn_desc);
+    case 2: return (int)sizeof(unimp_image_desc);
+    default: return -1;
+  }
+}
