@@ -123,29 +123,20 @@ __global__ __launch_bounds__(512, 2) void gemm3_bf16_kernel(Gemm2Params p) {
   if (p.gate) gate = tanhf(bf2f(*p.gate));
   bool fast = ((p.N & 7) == 0) && (((p.ldc | p.ldres | p.ldaux | p.ldpre) & 7) == 0);
   constexpr int LPR = WN / 8, RPI = 64 / LPR;
-#pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-    for (int i2 = 0; i2 < 4; ++i2)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        int row = i2 * 16 + (lane & 15), u = j * 4 + (lane >> 4);
-        *(f32x4*)(er + row * ESTR + ((u ^ (row & (UNITS - 1))) << 4)) = acc[pass * 4 + i2][j];
-      }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    for (int it = 0; it < 64 / RPI; ++it) {
-      int row = it * RPI + lane / LPR, cg = lane % LPR;
-      int m = m0 + wm * 128 + pass * 64 + row, n = n0 + wn * WN + cg * 8;
-      int sw = row & (UNITS - 1);
-      f32x4 x0 = *(const f32x4*)(er + row * ESTR + (((2 * cg) ^ sw) << 4));
-      f32x4 x1 = *(const f32x4*)(er + row * ESTR + (((2 * cg + 1) ^ sw) << 4));
-      if (m < p.M && n < p.N) {
-        float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-        if (fast) epi8<true>(p, v, m, n, gate); else epi8<false>(p, v, m, n, gate);
-      }
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-  }
+  // the two 64-row passes are written out (a loop the compiler declines to unroll would index acc at run time and
+  // demote the whole accumulator array to scratch)
+#define EPI_PASS(PASS) do {                                                                                       \
+    _Pragma("unroll") for (int i2 = 0; i2 < 4; ++i2)                                                               \
+      _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                           \
+        int row = i2 * 16 + (lane & 15), u = j * 4 + (lane >> 4);                                                  \
+        *(f32x4*)(er + row * ESTR + ((u ^ (row & (UNITS - 1))) << 4)) = acc[(PASS) * 4 + i2][j];                   \
+      }                                                                                                            \
+    __builtin_amdgcn_s_waitcnt(0xc07f);                                                                            \
+    epi_pass<WN>(p, er, lane, m0 + wm * 128 + (PASS) * 64, n0 + wn * WN, gate, fast);                              \
+    __builtin_amdgcn_s_waitcnt(0xc07f); } while (0)
+  EPI_PASS(0);
+  EPI_PASS(1);
+#undef EPI_PASS
 }
 
 template <bool AKS, bool BKS, int BN>

@@ -24,9 +24,10 @@ __device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-// 8 consecutive columns of one output row
-template <bool FAST>
-__device__ __forceinline__ void epi8(const Gemm2Params& p, float (&v)[8], int m, int n, float gate) {
+// 8 consecutive columns of one output row.  PRE: the caller already fetched this row group's aux / res chunks (FAST only).
+template <bool FAST, bool PRE = false>
+__device__ __forceinline__ void epi8(const Gemm2Params& p, float (&v)[8], int m, int n, float gate,
+                                     bf16x8 auxv = bf16x8{}, bf16x8 resv = bf16x8{}) {
   int nv = FAST ? 8 : min(8, p.N - n);
 #pragma unroll
   for (int r = 0; r < 8; ++r) v[r] *= p.alpha;
@@ -62,7 +63,7 @@ __device__ __forceinline__ void epi8(const Gemm2Params& p, float (&v)[8], int m,
   }
   if (p.aux) {
     const bf16* s = p.aux + (long)m * p.ldaux + n;
-    if (FAST) { bf16x8 x = *(const bf16x8*)s;
+    if (FAST) { bf16x8 x = PRE ? auxv : *(const bf16x8*)s;
 #pragma unroll
       for (int r = 0; r < 8; ++r) v[r] *= act_bwd(p.dact, bf2f(x[r])); }
     else { for (int r = 0; r < nv; ++r) v[r] *= act_bwd(p.dact, bf2f(s[r])); }
@@ -71,7 +72,7 @@ __device__ __forceinline__ void epi8(const Gemm2Params& p, float (&v)[8], int m,
   for (int r = 0; r < 8; ++r) v[r] *= gate;
   if (p.res) {
     const bf16* s = p.res + (long)m * p.ldres + n;
-    if (FAST) { bf16x8 x = *(const bf16x8*)s;
+    if (FAST) { bf16x8 x = PRE ? resv : *(const bf16x8*)s;
 #pragma unroll
       for (int r = 0; r < 8; ++r) v[r] += bf2f(x[r]); }
     else { for (int r = 0; r < nv; ++r) v[r] += bf2f(s[r]); }
@@ -97,3 +98,46 @@ __device__ __forceinline__ void epi8(const Gemm2Params& p, float (&v)[8], int m,
   }
 }
 
+
+// One pass of the LDS-staged epilogue: the wave's [64][WN] f32 region (16-B units XOR-swizzled by row) -> global memory.
+// Row groups are processed U at a time with their aux / res chunks fetched up front: one global-load latency per U groups
+// instead of one per group (the dX GEMM that multiplies by the stored act'(z), and every GEMM with a residual, spent
+// 10-25 % of their time there).
+template <int WN, int U = 4>
+__device__ __forceinline__ void epi_pass(const Gemm2Params& p, const char* er, int lane, int mbase, int nbase, float gate, bool fast) {
+  constexpr int ESTR = WN * 4, UNITS = WN / 4, LPR = WN / 8, RPI = 64 / LPR, NIT = 64 / RPI;
+  static_assert(NIT % U == 0, "row groups per pass must be a multiple of U");
+  const int cg = lane % LPR, n = nbase + cg * 8;
+  if (!fast || n >= p.N) {                       // ragged N / odd leading dimensions: element-wise path, one group at a time
+    for (int it = 0; it < NIT; ++it) {
+      int row = it * RPI + lane / LPR, m = mbase + row, sw = row & (UNITS - 1);
+      f32x4 x0 = *(const f32x4*)(er + row * ESTR + (((2 * cg) ^ sw) << 4));
+      f32x4 x1 = *(const f32x4*)(er + row * ESTR + (((2 * cg + 1) ^ sw) << 4));
+      if (m < p.M && n < p.N) {
+        float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+        if (fast) epi8<true>(p, v, m, n, gate); else epi8<false>(p, v, m, n, gate);
+      }
+    }
+    return;
+  }
+  for (int it0 = 0; it0 < NIT; it0 += U) {
+    bf16x8 av[U], rv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int m = min(mbase + (it0 + u) * RPI + lane / LPR, p.M - 1);          // clamped: rows beyond M are loaded, never stored
+      av[u] = bf16x8{}; rv[u] = bf16x8{};
+      if (p.aux) av[u] = *(const bf16x8*)(p.aux + (long)m * p.ldaux + n);
+      if (p.res) rv[u] = *(const bf16x8*)(p.res + (long)m * p.ldres + n);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int row = (it0 + u) * RPI + lane / LPR, m = mbase + row, sw = row & (UNITS - 1);
+      f32x4 x0 = *(const f32x4*)(er + row * ESTR + (((2 * cg) ^ sw) << 4));
+      f32x4 x1 = *(const f32x4*)(er + row * ESTR + (((2 * cg + 1) ^ sw) << 4));
+      if (m < p.M) {
+        float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+        epi8<true, true>(p, v, m, n, gate, av[u], rv[u]);
+      }
+    }
+  }
+}
