@@ -304,3 +304,27 @@ def test_flamingo_over_mpt_generate_cached_equals_rescoring():
     assert torch.equal(a, c)
     k = model.generate(vx, ids, num_beams=3, num_return_sequences=3, early_stopping=True, **kw)
     assert k.shape[0] == 3 and torch.equal(k[:, :n], ids.expand(3, -1))
+
+
+def test_gradient_accumulation_equals_one_step_on_the_same_batch():
+    """grad_accum = 2 over two identical micro-batches is one optimizer step with that batch's gradient ((g + g) / 2)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import _parity as P
+    from unimp_amd.train import Trainer
+    cfg = P.TINY
+    om, layout = P.build_oracle(cfg)
+    batch = {k: v.cuda() for k, v in P.make_batch(cfg, layout).items()}
+    res = {}
+    for ga in (1, 2):
+        hm = P.build_hip(cfg, om, layout)
+        tr = Trainer(hm, layout.special(), lr=1e-2, lr_scheduler="constant", grad_accum=ga)
+        before = tr.opt.master.clone()
+        for _ in range(ga):
+            tr.step(batch)
+            if ga == 2 and _ == 0:
+                assert torch.equal(tr.opt.master, before) and tr.sched_step == 0        # no update after the first micro-batch
+        res[ga] = (tr.opt.master - before).cpu()
+        assert tr.sched_step == 1 and tr.opt.step_count == 1
+    cos = float((res[1] * res[2]).sum() / (res[1].norm() * res[2].norm()))
+    assert cos > 0.995 and float((res[1] - res[2]).norm() / res[1].norm()) < 0.1, cos

@@ -36,12 +36,13 @@ class GradBucketer:
         self._pending = [b[2] for b in self.buckets]
         self._handles = []
         self._hooks = []
+        self.sync = True          # False: gradient-accumulation micro-step, gradients only add up locally (accelerate's no_sync)
         if self.world > 1:
             for n, p, o, k in optimizer.layout:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
     def _on_grad(self, p):
-        if id(p) in self._late:
+        if id(p) in self._late or not self.sync:
             return
         bi = self.param_bucket[id(p)]
         self._pending[bi] -= 1
@@ -57,7 +58,7 @@ class GradBucketer:
         if self.world > 1:
             self.opt._reattach()
             for bi, left in enumerate(self._pending):
-                if left > 0:
+                if left > 0 or not self.sync:      # accumulated micro-steps ran without exchange: reduce everything now
                     self._launch(bi)
             for h in self._handles:
                 h.wait()

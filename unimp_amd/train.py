@@ -82,11 +82,12 @@ def load_checkpoint(path, model, trainer=None):
 class Trainer:
     def __init__(self, model, special_ids, lr=2e-4, weight_decay=0.1, gamma=2.0, use_reweight=True, max_grad_norm=1.0,
                  lr_scheduler="cosine", warmup_steps=0, total_steps=1000, bucket_bytes=256 << 20, process_group=None,
-                 sparse_head=False):
+                 sparse_head=False, grad_accum=1):
         """sparse_head (off by default): apply the LM head and the loss only to the positions whose next token carries a
         label -- identical loss / gradients / update (unlabeled rows contribute nothing), ~5 % fewer FLOPs at cfg2; the
         returned model output then has no logits.  Costs one host sync per step (the row count)."""
         self.model, self.sparse_head = model, sparse_head
+        self.grad_accum, self._micro = grad_accum, 0       # mmrec.py's --gradient_accumulation_steps (accelerator.accumulate)
         self.ids = special_ids                   # dict(answer_id, eoc_id, pad_id, media_id)
         self.gamma, self.use_reweight = gamma, use_reweight
         self.opt = FlatAdamW(model.named_parameters(), lr=lr, weight_decay=weight_decay, max_grad_norm=max_grad_norm)
@@ -125,6 +126,19 @@ class Trainer:
         """returns (loss, stats) device tensors; no host synchronisation."""
         self.model.train()
         loss, stats, out, _ = self.forward_loss(batch)
+        if self.grad_accum > 1:
+            # micro-batches add their gradients into the flat buffer (zeroed by the optimizer kernel only); ranks exchange
+            # once, after the last one; 1/GA is folded into the optimizer's gradient scale like 1/W.  The LR schedule
+            # advances once per optimizer step (mmrec.py:691-692 sizes its schedule in optimizer steps).
+            self._micro += 1
+            self.dp.sync = False
+            loss.backward()
+            if self._micro % self.grad_accum == 0:
+                gscale = self.dp.finish() / self.grad_accum
+                self.dp.sync = True
+                self.opt.step(lr=self.current_lr(), grad_scale=gscale)
+                self.sched_step += 1
+            return loss.detach(), stats
         loss.backward()
         gscale = self.dp.finish()
         self.opt.step(lr=self.current_lr(), grad_scale=gscale)
