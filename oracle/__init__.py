@@ -13,6 +13,9 @@ reference executes for one optimizer step:
 * ``oracle.lm``         -- GPT-NeoX / OPT causal-LM towers
                             (transformers gpt_neox / opt modelling files; call sites
                              UniMP/mmrec.py:475-524)
+* ``oracle.mpt``        -- MPT tower of OpenFlamingo-9B (ALiBi, bias-free, tied head; transformers' mpt modelling
+                            file; call site UniMP/mmrec.py:515-524); cross-checked like ``oracle.lm``
+                            (tests/golden/mpt_tiny_h{4,6}.npz)
 * ``oracle.llama``      -- RMSNorm / RoPE / SwiGLU / causal attention of the in-tree
                             UniMP/xformers_model/llama.py:101-308
 * ``oracle.flamingo``   -- Flamingo, PerceiverResampler, MaskedCrossAttention,

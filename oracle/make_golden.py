@@ -244,6 +244,18 @@ def gen_hf_towers():
     np.savez_compressed(os.path.join(OUT, "opt_tiny.npz"), ids=ids.numpy(), mask=mask.numpy(), logits=lg.numpy(),
                         **{"sd." + k: v for k, v in _np(m.state_dict()).items()})
     print("opt_tiny", tuple(lg.shape))
+    from transformers import MptConfig, MptForCausalLM
+    for heads in (4, 6):                               # 6: the interleaved slopes of a non-power-of-two head count
+        m = MptForCausalLM(MptConfig(d_model=16 * heads, n_heads=heads, n_layers=2, expansion_ratio=4, max_seq_len=64, vocab_size=128,
+                                     no_bias=True, layer_norm_epsilon=1e-5)).eval()
+        for p in m.parameters():
+            p.data.normal_(0, 0.2)
+        with torch.no_grad():
+            lg = m(input_ids=ids, attention_mask=mask).logits
+        sd = {k: v for k, v in m.state_dict().items() if not k.startswith("lm_head")}
+        np.savez_compressed(os.path.join(OUT, f"mpt_tiny_h{heads}.npz"), ids=ids.numpy(), mask=mask.numpy(), logits=lg.numpy(),
+                            **{"sd." + k: v for k, v in _np(sd).items()})
+        print("mpt_tiny", heads, tuple(lg.shape))
 
 
 if __name__ == "__main__":

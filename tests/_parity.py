@@ -2,7 +2,7 @@
 same (bf16-representable) weights and the same synthetic batch.  TEST INFRASTRUCTURE (imports oracle/)."""
 import torch
 
-from oracle import flamingo as ofl, lm as olm, vit as ovit, train_step as ots
+from oracle import flamingo as ofl, lm as olm, mpt as ompt, vit as ovit, train_step as ots
 
 bf16 = torch.bfloat16
 
@@ -16,6 +16,9 @@ TINY_PAR = dict(vit=dict(image_size=32, patch_size=8, width=128, layers=1, heads
                 lm=dict(kind="neox", vocab_size=512, hidden_size=256, num_hidden_layers=2, num_attention_heads=2,
                         intermediate_size=512, rotary_pct=0.25, use_parallel_residual=True), every=1, T=2, L=40, B=2,
                 n_items=40, base_vocab=300)
+TINY_MPT = dict(vit=dict(image_size=32, patch_size=8, width=128, layers=1, heads=2, mlp_dim=256, output_dim=64),
+                lm=dict(kind="mpt", vocab_size=512, d_model=192, n_layers=2, n_heads=3), every=1, T=2, L=40, B=2,
+                n_items=40, base_vocab=300)          # 3 heads of 64: non-power-of-two ALiBi slopes, tied head
 
 
 def build_oracle(cfg, gate=0.5, seed=0):
@@ -28,6 +31,8 @@ def build_oracle(cfg, gate=0.5, seed=0):
     v = ovit.VisionTransformer(**cfg["vit"])
     if kind == "neox":
         lm = olm.GPTNeoXForCausalLM(olm.NeoXConfig(**lmc))
+    elif kind == "mpt":
+        lm = ompt.MptForCausalLM(ompt.MPTConfig(**lmc))
     else:
         lm = olm.OPTForCausalLM(olm.OPTConfig(**lmc))
     m = ofl.Flamingo(v, lm, layout.eoc, layout.media, vis_dim=cfg["vit"]["width"], cross_attn_every_n_layers=cfg["every"])
@@ -49,14 +54,14 @@ def build_oracle(cfg, gate=0.5, seed=0):
 
 def build_hip(cfg, oracle_model, layout, device="cuda"):
     from unimp_amd.flamingo import Flamingo, freeze_like_factory
-    from unimp_amd.lm import build_lm, NeoXConfig, OPTConfig
+    from unimp_amd.lm import build_lm, NeoXConfig, OPTConfig, MPTConfig
     from unimp_amd.vit import VisionTransformer, CLIPStub
     lmc = dict(cfg["lm"])
     kind = lmc.pop("kind")
     lmc["vocab_size"] = layout.vocab
     with torch.device(device):
         v = VisionTransformer(**cfg["vit"])
-        lm = build_lm(NeoXConfig(**lmc) if kind == "neox" else OPTConfig(**lmc))
+        lm = build_lm({"neox": NeoXConfig, "opt": OPTConfig, "mpt": MPTConfig}[kind](**lmc))
         m = Flamingo(CLIPStub(v), lm, layout.eoc, layout.media, vis_dim=cfg["vit"]["width"], cross_attn_every_n_layers=cfg["every"])
     m.to(dtype=bf16)
     missing, unexpected = m.load_state_dict(oracle_model.state_dict(), strict=False)

@@ -106,3 +106,16 @@ def test_opt_vs_transformers():
     with torch.no_grad():
         out = m(torch.from_numpy(z["ids"]), torch.from_numpy(z["mask"]))
     assert np.allclose(out["logits"].numpy(), z["logits"], rtol=1e-4, atol=1e-4)
+
+
+def test_mpt_vs_transformers():
+    from oracle import mpt as ompt
+    for heads in (4, 6):
+        z = np.load(os.path.join(G, f"mpt_tiny_h{heads}.npz"))
+        m = ompt.MptForCausalLM(ompt.MPTConfig(vocab_size=128, d_model=16 * heads, n_layers=2, n_heads=heads, max_seq_len=64))
+        missing, unexpected = m.load_state_dict(_sd(z), strict=False)
+        assert not unexpected and all("lm_head" in k for k in missing)
+        with torch.no_grad():
+            out = m(torch.from_numpy(z["ids"]), torch.from_numpy(z["mask"]))
+        valid = torch.from_numpy(z["mask"]).bool()
+        assert np.allclose(out["logits"][valid].numpy(), z["logits"][valid.numpy()], rtol=1e-4, atol=1e-4)
