@@ -113,7 +113,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("UNIMP_BENCH_BATCH", 48)), help="samples per GPU per step")
+    ap.add_argument("--batch", type=int, default=None, help="samples per GPU per step (default 48; 24 for --model 9b; env UNIMP_BENCH_BATCH)")
     ap.add_argument("--images", type=int, default=8)
     ap.add_argument("--seq", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -146,6 +146,8 @@ def main():
     from unimp_amd.train import Trainer
 
     nine = args.model == "9b"
+    if args.batch is None:
+        args.batch = int(os.environ.get("UNIMP_BENCH_BATCH", 24 if nine else 48))
     model, layout = build_cfg2(dev, lang="anas-awadalla/mpt-7b", every=4) if nine else build_cfg2(dev)
     trainer = Trainer(model, layout.special(), lr=2e-4, weight_decay=0.1, gamma=2.0, use_reweight=True,
                       lr_scheduler="cosine", warmup_steps=10, total_steps=10000, sparse_head=args.sparse_head)
