@@ -151,7 +151,7 @@ __device__ __forceinline__ void lds_zero(char* smem, int bytes) {
 // ------------------------------------------------------------------------------------------- forward
 // block = 4 waves x 32 query rows (two 16-row MFMA blocks per wave share every K / V fragment read); 64-key tiles,
 // two LDS stages, one barrier per tile.
-template <int DQK, int DV>
+template <int DQK, int DV, bool ALIBI>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
   constexpr int KSTR = DQK * 2 + 16, VSTR = DV * 2 + 16, NKS = DQK / 32, ND = DV / 16;
   constexpr int STAGE = 64 * KSTR + 64 * VSTR;
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
   int kt_lo, kt_hi;
   block_key_tiles(p, b, blockIdx.x * 128, blockIdx.x * 128 + 127, kt_lo, kt_hi);
   float sc2 = p.scale * LOG2E;
-  const float ab = p.alibi ? p.alibi[h] / p.scale : 0.f;
+  const float ab = ALIBI ? p.alibi[h] / p.scale : 0.f;
   float m[2] = {-INFINITY, -INFINITY}, lsum[2] = {0.f, 0.f};
   f32x4 o[2][ND];
 #pragma unroll
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
         s[1][nt] = MFMA16(kf, qf[1][ks], s[1][nt]);
       }
     }
-    if (ab != 0.f) {                    // ALiBi (wave-uniform): bias every score by its key position
+    if (ALIBI) {                        // ALiBi (its own kernel instantiation: the plain kernels keep their registers)
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -320,7 +320,7 @@ __global__ void attn_delta_kernel(AttnP p) {
 // ------------------------------------------------------------------------------------------- dQ
 // same geometry as the forward: 4 waves x 32 query rows, 64-key tiles double-buffered; K and V tiles share one image
 // layout (row reads for S and dP, transposed K reads for dQ).
-template <int DQK, int DV>
+template <int DQK, int DV, bool ALIBI>
 __global__ __launch_bounds__(256) void attn_dq_kernel(AttnP p) {
   constexpr int STR = DQK * 2 + 16, NKS = DQK / 32, ND = DV / 16;
   constexpr int STAGE = 2 * 64 * STR;
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(AttnP p) {
   int kt_lo, kt_hi;
   block_key_tiles(p, b, blockIdx.x * 128, blockIdx.x * 128 + 127, kt_lo, kt_hi);
   float sc2 = p.scale * LOG2E;
-  const float ab = p.alibi ? p.alibi[h] / p.scale : 0.f;
+  const float ab = ALIBI ? p.alibi[h] / p.scale : 0.f;
   f32x4 dq[2][ND];
 #pragma unroll
   for (int u = 0; u < 2; ++u)
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(AttnP p) {
         for (int u = 0; u < 2; ++u) { s[u][nt] = MFMA16(kf, qf[u][ks], s[u][nt]); dp[u][nt] = MFMA16(vf, dof[u][ks], dp[u][nt]); }
       }
     }
-    if (ab != 0.f) {
+    if (ALIBI) {
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(AttnP p) {
 // ------------------------------------------------------------------------------------------- dK, dV
 // block = 128 keys: each wave owns 32 keys (two 16-key blocks whose K / V fragments live in registers) and sweeps the
 // query tiles (32 rows, double-buffered Q / dO images + per-row lse / delta / key range); P and dS stay in registers.
-template <int DQK, int DV>
+template <int DQK, int DV, bool ALIBI>
 __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p) {
   constexpr int STR = DQK * 2 + 16, NKS = DQK / 32, ND = DV / 16;
   constexpr int STAGE = 2 * 32 * STR + 32 * 16 + 16;
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p) {
     for (int nd = 0; nd < ND; ++nd) { dk[u][nd] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[u][nd] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   }
   float sc2 = p.scale * LOG2E;
-  const float ab = p.alibi ? p.alibi[h] / p.scale : 0.f;
+  const float ab = ALIBI ? p.alibi[h] / p.scale : 0.f;
   int nqt = (p.Sq + 31) >> 5;
   int kfirst = kblk * 128, klast = kblk * 128 + 127;
   // block-uniform list of query tiles that can see this key block: [qt_a, qt_b)
@@ -548,7 +548,7 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       int key = key0 + u * 16 + (l & 15);
-      if (ab != 0.f) {
+      if (ALIBI) {
         float kb = ab * (float)key;
 #pragma unroll
         for (int qb2 = 0; qb2 < 2; ++qb2)
@@ -643,9 +643,11 @@ extern "C" int unimp_attn_fwd(const unimp_attn_desc* d, void* stream) {
   if (p.B <= 0 || p.H <= 0 || p.Sq <= 0) return UNIMP_OK;
   dim3 grid((p.Sq + 127) / 128, p.H, p.B), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (p.D == 64) hipLaunchKernelGGL((attn_fwd_kernel<64, 64>), grid, block, 0, s, p);
-  else if (p.D == 80) hipLaunchKernelGGL((attn_fwd_kernel<96, 80>), grid, block, 0, s, p);
-  else hipLaunchKernelGGL((attn_fwd_kernel<128, 128>), grid, block, 0, s, p);
+#define FWD(A_) do { if (p.D == 64) hipLaunchKernelGGL((attn_fwd_kernel<64, 64, A_>), grid, block, 0, s, p);       \
+    else if (p.D == 80) hipLaunchKernelGGL((attn_fwd_kernel<96, 80, A_>), grid, block, 0, s, p);                     \
+    else hipLaunchKernelGGL((attn_fwd_kernel<128, 128, A_>), grid, block, 0, s, p); } while (0)
+  if (p.alibi) FWD(true); else FWD(false);
+#undef FWD
   return unimp_check_launch("attn_fwd");
 }
 
@@ -658,8 +660,11 @@ extern "C" int unimp_attn_bwd(const unimp_attn_desc* d, void* stream) {
   long n = (long)p.B * p.H * p.Sq;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((n * 16 + 255) / 256)), dim3(256), 0, s, p);
   dim3 gq((p.Sq + 127) / 128, p.H, p.B), gk((p.Sk + 127) / 128, p.H, p.B), block(256);
-  if (p.D == 64) { hipLaunchKernelGGL((attn_dq_kernel<64, 64>), gq, block, 0, s, p); hipLaunchKernelGGL((attn_dkv_kernel<64, 64>), gk, block, 0, s, p); }
-  else if (p.D == 80) { hipLaunchKernelGGL((attn_dq_kernel<96, 80>), gq, block, 0, s, p); hipLaunchKernelGGL((attn_dkv_kernel<96, 80>), gk, block, 0, s, p); }
-  else { hipLaunchKernelGGL((attn_dq_kernel<128, 128>), gq, block, 0, s, p); hipLaunchKernelGGL((attn_dkv_kernel<128, 128>), gk, block, 0, s, p); }
+#define BWD(A_) do {                                                                                                   \
+    if (p.D == 64) { hipLaunchKernelGGL((attn_dq_kernel<64, 64, A_>), gq, block, 0, s, p); hipLaunchKernelGGL((attn_dkv_kernel<64, 64, A_>), gk, block, 0, s, p); }            \
+    else if (p.D == 80) { hipLaunchKernelGGL((attn_dq_kernel<96, 80, A_>), gq, block, 0, s, p); hipLaunchKernelGGL((attn_dkv_kernel<96, 80, A_>), gk, block, 0, s, p); }       \
+    else { hipLaunchKernelGGL((attn_dq_kernel<128, 128, A_>), gq, block, 0, s, p); hipLaunchKernelGGL((attn_dkv_kernel<128, 128, A_>), gk, block, 0, s, p); } } while (0)
+  if (p.alibi) BWD(true); else BWD(false);
+#undef BWD
   return unimp_check_launch("attn_bwd");
 }
