@@ -51,3 +51,45 @@ def test_ctypes_mirrors_have_the_c_struct_sizes():
     assert lib.unimp_struct_size(1) == C.sizeof(_lib.AttnDesc)
     assert lib.unimp_struct_size(2) == C.sizeof(_ImageDesc)
     assert lib.unimp_struct_size(9) == -1
+
+
+def test_kernel_register_budgets():
+    """Compile-time guard for the regressions that cost real time before: an accumulator array demoted to scratch
+    (GEMM 632 -> 162 TFLOP/s), a kernel losing its second wave per SIMD to a few extra registers (dK/dV 19 -> 32 ms/step).
+    hipcc's resource remarks for the hot kernels must stay inside their budgets."""
+    import os
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        import pytest
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "unimp_amd", "csrc")
+
+    def remarks(name, extra=()):
+        out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", *extra, f"-I{root}/include", f"-I{src}", "-c",
+                              "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-o", os.devnull, os.path.join(src, name)],
+                             capture_output=True, text=True, timeout=600).stderr
+        res, cur = {}, None
+        for line in out.splitlines():
+            m = re.search(r"Function Name: (\S+)", line)
+            if m:
+                cur = res.setdefault(m.group(1), {})
+            m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)", line)
+            if m and cur is not None:
+                cur[m.group(1).strip()] = int(m.group(2))
+        return res
+    vg = ("-mllvm", "-amdgpu-mfma-vgpr-form")
+    g3 = remarks("gemm3.hip", vg)
+    assert len(g3) == 8
+    for k, r in g3.items():
+        assert r["ScratchSize"] == 0 and r["VGPRs"] + r.get("AGPRs", 0) <= 256 and r["Occupancy"] >= 2, (k, r)
+    at = remarks("attention.hip", vg)
+    plain = {k: r for k, r in at.items() if "Li96ELi80ELb0" in k}
+    assert len(plain) == 3
+    for k, r in plain.items():
+        assert r["ScratchSize"] == 0, (k, r)
+        if "attn_dq" not in k:                                  # dQ holds two 32-row blocks of q, dO, dq: one wave per SIMD by design
+            assert r["Occupancy"] >= 2, (k, r)
