@@ -10,7 +10,7 @@ def run(name, m, n, k, aks, bks, lda=None, ldb=None):
     b = torch.randn(sb, device="cuda").to(torch.bfloat16)[:, :(n if bks else k)]
     out = torch.empty((m, n), dtype=torch.bfloat16, device="cuda")
     res = []
-    for variant in ("pp256", "w8"):
+    for variant in ("pp256", "w8", "w4"):
         for _ in range(2): ops.gemm(a, b, a_ks=bool(aks), b_ks=bool(bks), out=out, variant=variant)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -21,6 +21,7 @@
 #define G4_NST 4
 #endif
 
+
 // The 64 accumulator tiles must live in AGPRs (256 of them; the VGPR half holds fragments and addresses).  Left to the
 // builtin, hipcc keeps ~40 tiles in VGPRs across the loop back-edge and shuttles them with v_accvgpr_write + s_nop before
 // every use; an "a"-constrained asm operand pins the class.  No MFMA hazard needs software help inside the loop (a tile
@@ -29,6 +30,15 @@ __device__ __forceinline__ void mfma_agpr(f32x4& c, bf16x8 a, bf16x8 b) {
   asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
 
+#ifdef G4_STAMP      // debug build: cycle stamps of one block's waves (tools/stamp_gemm4.py); LDS bytes [128 KiB, +8 KiB) hold them
+__device__ unsigned long long g4_stamps[4 * 64 * 4];
+extern "C" int unimp_debug_g4_stamps(void* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g4_stamps), sizeof(g4_stamps)); }
+#define STAMP(H, K_) do { if (blockIdx.x == 300 && (H) < 64) { unsigned long long t_;                               \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");                                     \
+    if (lane == 0) ((unsigned long long*)(smem + 131072))[(wave * 64 + (H)) * 4 + (K_)] = t_; } } while (0)
+#else
+#define STAMP(H, K_) do {} while (0)
+#endif
 #define G4_FENCE() do { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); } while (0)
 
 template <bool AKS, bool BKS>
@@ -74,29 +84,36 @@ __global__ __launch_bounds__(256, 1) void gemm4_bf16_kernel(Gemm2Params p) {
     else rb##S[J] = frag_kc32(smem + ((H) % G4_NST) * SUB + A_SUB, wn * 128 + (J) * 16); } while (0)
 #define FA(S, I) (AKS ? join_halves(la##S[I], ha##S[I]) : ra##S[I])
 #define FB(S, J) (BKS ? join_halves(lb##S[J], hb##S[J]) : rb##S[J])
-// row I of the wave tile: 8 MFMAs sharing one A fragment.  Riding along: rows 0-3 fetch the next half-stage's fragments
-// (2 of A + 2 of B each, so they have 4 rows of MFMAs to land; unconditionally -- past the end of K they read a ring slot
-// nobody uses into registers nobody reads); every row issues one of the 8 DMA instructions of half-stage H+PD.
+// row I of the wave tile: 8 MFMAs sharing one A fragment.  An MFMA occupies the matrix pipe for 16 cycles, so ~3 cheap
+// instructions issue in its shadow for free while a CLUSTER of them idles the pipe (measured with G4_STAMP: with the 4
+// fragment reads + 1 DMA + their address math bunched at the end of a row the 64 MFMAs of a half-stage took 1 610 cycles
+// to issue instead of 1 088).  So everything that rides along is spread one piece per MFMA gap: row I fetches fragment I
+// of A and of B for the next half-stage (unconditionally -- past the end of K they read a ring slot nobody uses into
+// registers nobody reads) and issues one of the 8 DMA instructions of half-stage H+PD.
+#define MF(I, J) mfma_agpr(acc[I][J], fb_[J], fa_)
 #define ROW(SC, SN, H, I) do {                                                                                      \
     bf16x8 fa_ = FA(SC, I);                                                                                         \
-    _Pragma("unroll") for (int j = 0; j < 8; ++j) mfma_agpr(acc[I][j], fb_[j], fa_);                                \
-    /* after the row's MFMAs: hipcc's own waitcnt for this half-stage's fragments (it cannot see the asm wait) */    \
-    /* then sits in front of the very first MFMA, where nothing is outstanding                                  */    \
-    if ((I) < 4) { LOADA(SN, (H) + 1, (2 * (I)) & 7); LOADA(SN, (H) + 1, (2 * (I) + 1) & 7);                        \
-                   LOADB(SN, (H) + 1, (2 * (I)) & 7); LOADB(SN, (H) + 1, (2 * (I) + 1) & 7); }                      \
-    if (fast_) {                                                                                                    \
+    MF(I, 0); G4_FENCE(); LOADA(SN, (H) + 1, I); G4_FENCE();                                                        \
+    MF(I, 1); MF(I, 2); G4_FENCE(); LOADB(SN, (H) + 1, I); G4_FENCE();                                              \
+    MF(I, 3); MF(I, 4); G4_FENCE(); if (fast_) DMA_ROW(H, I); G4_FENCE();                                           \
+    MF(I, 5); MF(I, 6); MF(I, 7); } while (0)
+#define DMA_ROW(H, I) do {                                                                                           \
       if ((I) < 4) dma_one<AKS, G4_BM, 4>(p.A, p.lda, (H) + PD, smem + (((H) + PD) % G4_NST) * SUB, wave, aoff, (I) & 3);          \
-      else dma_one<BKS, G4_BN, 4>(p.B, p.ldb, (H) + PD, smem + (((H) + PD) % G4_NST) * SUB + A_SUB, wave, boff, (I) & 3); } } while (0)
+      else dma_one<BKS, G4_BN, 4>(p.B, p.ldb, (H) + PD, smem + (((H) + PD) % G4_NST) * SUB + A_SUB, wave, boff, (I) & 3); } while (0)
 #define STEP(H, SC, SN) do {                                                                                        \
+    STAMP(H, 0);                                                                                                    \
     if ((H) + PD <= nh) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((PD - 2) * NEW) : "memory");                      \
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                           \
+    STAMP(H, 1);                                                                                                    \
     G4_FENCE(); __builtin_amdgcn_s_barrier(); G4_FENCE();                                                           \
+    STAMP(H, 2);                                                                                                    \
     bool fast_ = ((H) + PD) * 32 + 32 <= p.K;                 /* full half-stage: DMA spread over the rows */       \
     if (!fast_ && (H) + PD < nh) DMA((H) + PD);               /* ragged / zero half-stage: predicated path */       \
     bf16x8 fb_[8];                                                                                                  \
     _Pragma("unroll") for (int j = 0; j < 8; ++j) fb_[j] = FB(SC, j);                                               \
     ROW(SC, SN, H, 0); ROW(SC, SN, H, 1); ROW(SC, SN, H, 2); ROW(SC, SN, H, 3);                                     \
     ROW(SC, SN, H, 4); ROW(SC, SN, H, 5); ROW(SC, SN, H, 6); ROW(SC, SN, H, 7);                                     \
+    STAMP(H, 3);                                                                                                    \
     G4_FENCE(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); G4_FENCE(); } while (0)
 
   // K is eaten in PAIRS of half-stages by one straight-line loop body (any control flow that forks the 64 accumulator
@@ -120,6 +137,9 @@ __global__ __launch_bounds__(256, 1) void gemm4_bf16_kernel(Gemm2Params p) {
   SETTLE(0); SETTLE(1); SETTLE(2); SETTLE(3); SETTLE(4); SETTLE(5); SETTLE(6); SETTLE(7);
 #undef SETTLE
   G4_FENCE(); __builtin_amdgcn_s_barrier(); G4_FENCE();   // every wave is done with the ring: the epilogue reuses it
+#ifdef G4_STAMP
+  if (blockIdx.x == 300) for (int i = threadIdx.x; i < 1024; i += 256) g4_stamps[i] = ((unsigned long long*)(smem + 131072))[i];
+#endif
 #undef DMA
 #undef LOADA
 #undef LOADB
@@ -127,6 +147,8 @@ __global__ __launch_bounds__(256, 1) void gemm4_bf16_kernel(Gemm2Params p) {
 #undef FA
 #undef FB
 #undef ROW
+#undef MF
+#undef DMA_ROW
 #undef STEP
 
   // ---- epilogue through LDS: wave-private [64][128] f32 region (32 KiB), 16-B units XOR-swizzled by row, two passes
@@ -155,7 +177,11 @@ __global__ __launch_bounds__(256, 1) void gemm4_bf16_kernel(Gemm2Params p) {
 template <bool AKS, bool BKS>
 static void launch4(const Gemm2Params& p, hipStream_t s) {
   static bool attr_set = false;
+#ifdef G4_STAMP
+  constexpr size_t lds = G4_NST * (G4_BM * 64 + G4_BN * 64) + 8192;
+#else
   constexpr size_t lds = G4_NST * (G4_BM * 64 + G4_BN * 64);
+#endif
   auto kern = gemm4_bf16_kernel<AKS, BKS>;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
   hipLaunchKernelGGL(kern, dim3(p.nbm * p.nbn), dim3(256), lds, s, p);
