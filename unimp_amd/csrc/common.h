@@ -81,6 +81,102 @@ __device__ __forceinline__ float act_bwd(int act, float x) {   // d act(x) / dx 
   }
 }
 
+
+// ---- the same activations over a register array, dispatched ONCE per array and in packed fp32 (v_pk_fma_f32 & co.: two
+// elements per instruction).  The GEMM epilogues run these on 8 (or 4) consecutive outputs; with the scalar forms above the
+// compiler kept the switch inside the element loop (one branch tree + register copies per element) and used IEEE division
+// sequences for the sigmoids -- the GELU epilogue cost the up-projection GEMM 15 % of its time.
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ f32x2 rcp2(f32x2 x) { return f32x2{__builtin_amdgcn_rcpf(x[0]), __builtin_amdgcn_rcpf(x[1])}; }
+__device__ __forceinline__ f32x2 exp2_2(f32x2 x) { return f32x2{__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])}; }
+__device__ __forceinline__ void gelu_parts2(f32x2 x, f32x2& cdf, f32x2& e) {            // gelu_parts on two elements
+  f32x2 z = f32x2{fabsf(x[0]), fabsf(x[1])} * 0.70710678118654752f;
+  f32x2 t = rcp2(z * 0.3275911f + 1.0f);
+  e = exp2_2(z * z * -1.4426950408889634f);
+  f32x2 poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  f32x2 ea = 1.0f - poly * e;
+  cdf = f32x2{copysignf(ea[0], x[0]), copysignf(ea[1], x[1])} * 0.5f + 0.5f;
+}
+__device__ __forceinline__ f32x2 sigmoid2(f32x2 x, float k) {                            // 1 / (1 + exp(-k x))
+  return rcp2(exp2_2(x * (-k * 1.4426950408889634f)) + 1.0f);
+}
+template <int N>
+__device__ __forceinline__ void act_fwd_n(int act, float (&v)[N]) {                      // v = act(v)
+  static_assert(N % 2 == 0, "pairs");
+  switch (act) {
+    case ACT_GELU:
+#pragma unroll
+      for (int r = 0; r < N; r += 2) { f32x2 x = {v[r], v[r + 1]}, c, e; gelu_parts2(x, c, e); x *= c; v[r] = x[0]; v[r + 1] = x[1]; }
+      break;
+    case ACT_QUICKGELU: case ACT_SILU: {
+      float k = act == ACT_SILU ? 1.0f : 1.702f;
+#pragma unroll
+      for (int r = 0; r < N; r += 2) { f32x2 x = {v[r], v[r + 1]}; x *= sigmoid2(x, k); v[r] = x[0]; v[r + 1] = x[1]; }
+      break; }
+    case ACT_RELU:
+#pragma unroll
+      for (int r = 0; r < N; ++r) v[r] = fmaxf(v[r], 0.f);
+      break;
+    default: break;
+  }
+}
+template <int N>
+__device__ __forceinline__ void act_fwd_deriv_n(int act, float (&v)[N], float (&d)[N]) {  // d = act'(v), then v = act(v)
+  static_assert(N % 2 == 0, "pairs");
+  switch (act) {
+    case ACT_GELU:
+#pragma unroll
+      for (int r = 0; r < N; r += 2) {
+        f32x2 x = {v[r], v[r + 1]}, c, e; gelu_parts2(x, c, e);
+        f32x2 dd = c + x * 0.3989422804014327f * e; x *= c;
+        v[r] = x[0]; v[r + 1] = x[1]; d[r] = dd[0]; d[r + 1] = dd[1]; }
+      break;
+    case ACT_QUICKGELU: case ACT_SILU: {
+      float k = act == ACT_SILU ? 1.0f : 1.702f;
+#pragma unroll
+      for (int r = 0; r < N; r += 2) {
+        f32x2 x = {v[r], v[r + 1]}, sg = sigmoid2(x, k);
+        f32x2 dd = sg * (1.0f + k * x * (1.0f - sg)); x *= sg;
+        v[r] = x[0]; v[r + 1] = x[1]; d[r] = dd[0]; d[r + 1] = dd[1]; }
+      break; }
+    case ACT_RELU:
+#pragma unroll
+      for (int r = 0; r < N; ++r) { d[r] = v[r] > 0.f ? 1.f : 0.f; v[r] = fmaxf(v[r], 0.f); }
+      break;
+    default:
+#pragma unroll
+      for (int r = 0; r < N; ++r) d[r] = 1.f;
+  }
+}
+template <int N>
+__device__ __forceinline__ void act_bwd_mul_n(int dact, float (&v)[N], const float (&x)[N]) {   // v *= act'(x)
+  static_assert(N % 2 == 0, "pairs");
+  switch (dact) {
+    case ACT_DERIV:
+#pragma unroll
+      for (int r = 0; r < N; ++r) v[r] *= x[r];
+      break;
+    case ACT_GELU:
+#pragma unroll
+      for (int r = 0; r < N; r += 2) {
+        f32x2 xx = {x[r], x[r + 1]}, c, e; gelu_parts2(xx, c, e);
+        f32x2 dd = c + xx * 0.3989422804014327f * e; v[r] *= dd[0]; v[r + 1] *= dd[1]; }
+      break;
+    case ACT_QUICKGELU: case ACT_SILU: {
+      float k = dact == ACT_SILU ? 1.0f : 1.702f;
+#pragma unroll
+      for (int r = 0; r < N; r += 2) {
+        f32x2 xx = {x[r], x[r + 1]}, sg = sigmoid2(xx, k);
+        f32x2 dd = sg * (1.0f + k * xx * (1.0f - sg)); v[r] *= dd[0]; v[r + 1] *= dd[1]; }
+      break; }
+    case ACT_RELU:
+#pragma unroll
+      for (int r = 0; r < N; ++r) v[r] = x[r] > 0.f ? v[r] : 0.f;
+      break;
+    default: break;
+  }
+}
+
 // ---- LDS tile images for 16x16x32 bf16 MFMA operands --------------------------------------
 // KC image: [rows][64 k] bf16, 128 B per row, eight 16-B chunks per row, chunk index XOR-swizzled
 //           so that the ds_read_b128 of 16 consecutive rows at one k-chunk is conflict-free.

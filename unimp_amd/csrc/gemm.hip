@@ -93,8 +93,7 @@ __device__ __forceinline__ void epi_tile(const GemmParams& p, f32x4 a, int m, in
   }
   if (p.pre && p.pre_deriv) {
     float dv[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) act_fwd_deriv(p.act, v[r], v[r], dv[r]);
+    act_fwd_deriv_n<4>(p.act, v, dv);
     bf16* d = p.pre + (long)m * p.ldpre + n;
     if (FAST) { bf16x4 o = {f2bf(dv[0]), f2bf(dv[1]), f2bf(dv[2]), f2bf(dv[3])}; *(bf16x4*)d = o; }
     else { for (int r = 0; r < nv; ++r) d[r] = f2bf(dv[r]); }
@@ -104,16 +103,13 @@ __device__ __forceinline__ void epi_tile(const GemmParams& p, f32x4 a, int m, in
       if (FAST) { bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])}; *(bf16x4*)d = o; }
       else { for (int r = 0; r < nv; ++r) d[r] = f2bf(v[r]); }
     }
-    if (p.act) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = act_fwd(p.act, v[r]);
-    }
+    if (p.act) act_fwd_n<4>(p.act, v);
   }
   if (p.aux) {
     const bf16* s = p.aux + (long)m * p.ldaux + n;
     if (FAST) { bf16x4 x = *(const bf16x4*)s;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] *= act_bwd(p.dact, bf2f(x[r])); }
+      float xf[4] = {bf2f(x[0]), bf2f(x[1]), bf2f(x[2]), bf2f(x[3])};
+      act_bwd_mul_n<4>(p.dact, v, xf); }
     else { for (int r = 0; r < nv; ++r) v[r] *= act_bwd(p.dact, bf2f(s[r])); }
   }
 #pragma unroll

@@ -39,8 +39,7 @@ __device__ __forceinline__ void epi8(const Gemm2Params& p, float (&v)[8], int m,
   }
   if (p.pre && p.pre_deriv) {                 // y = act(v) and act'(v) from one exponential; store the derivative
     float dv[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) act_fwd_deriv(p.act, v[r], v[r], dv[r]);
+    act_fwd_deriv_n<8>(p.act, v, dv);
     bf16* d = p.pre + (long)m * p.ldpre + n;
     if (FAST) { bf16x8 o;
 #pragma unroll
@@ -56,16 +55,15 @@ __device__ __forceinline__ void epi8(const Gemm2Params& p, float (&v)[8], int m,
         *(bf16x8*)d = o; }
       else { for (int r = 0; r < nv; ++r) d[r] = f2bf(v[r]); }
     }
-    if (p.act) {
-#pragma unroll
-      for (int r = 0; r < 8; ++r) v[r] = act_fwd(p.act, v[r]);
-    }
+    if (p.act) act_fwd_n<8>(p.act, v);
   }
   if (p.aux) {
     const bf16* s = p.aux + (long)m * p.ldaux + n;
     if (FAST) { bf16x8 x = PRE ? auxv : *(const bf16x8*)s;
+      float xf[8];
 #pragma unroll
-      for (int r = 0; r < 8; ++r) v[r] *= act_bwd(p.dact, bf2f(x[r])); }
+      for (int r = 0; r < 8; ++r) xf[r] = bf2f(x[r]);
+      act_bwd_mul_n<8>(p.dact, v, xf); }
     else { for (int r = 0; r < nv; ++r) v[r] *= act_bwd(p.dact, bf2f(s[r])); }
   }
 #pragma unroll
@@ -102,8 +100,9 @@ __device__ __forceinline__ void epi8(const Gemm2Params& p, float (&v)[8], int m,
 // One pass of the LDS-staged epilogue: the wave's [64][WN] f32 region (16-B units XOR-swizzled by row) -> global memory.
 // Row groups are processed U at a time with their aux / res chunks fetched up front: one global-load latency per U groups
 // instead of one per group (the dX GEMM that multiplies by the stored act'(z), and every GEMM with a residual, spent
-// 10-25 % of their time there).
-template <int WN, int U = 4>
+// 10-25 % of their time there).  U = 8 (a whole pass of a 64-column wave tile in one round trip; the fragment registers
+// are dead by now).
+template <int WN, int U = (64 / (64 / (WN / 8)) < 8 ? 64 / (64 / (WN / 8)) : 8)>
 __device__ __forceinline__ void epi_pass(const Gemm2Params& p, const char* er, int lane, int mbase, int nbase, float gate, bool fast) {
   constexpr int ESTR = WN * 4, UNITS = WN / 4, LPR = WN / 8, RPI = 64 / LPR, NIT = 64 / RPI;
   static_assert(NIT % U == 0, "row groups per pass must be a multiple of U");
