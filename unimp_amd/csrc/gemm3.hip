@@ -125,18 +125,24 @@ __global__ __launch_bounds__(512, 2) void gemm3_bf16_kernel(Gemm2Params p) {
   constexpr int LPR = WN / 8, RPI = 64 / LPR;
   // the two 64-row passes are written out (a loop the compiler declines to unroll would index acc at run time and
   // demote the whole accumulator array to scratch)
-#define EPI_PASS(PASS) do {                                                                                       \
+#define EPI_STAGE(PASS) do {                                                                                      \
     _Pragma("unroll") for (int i2 = 0; i2 < 4; ++i2)                                                               \
       _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                           \
         int row = i2 * 16 + (lane & 15), u = j * 4 + (lane >> 4);                                                  \
         *(f32x4*)(er + row * ESTR + ((u ^ (row & (UNITS - 1))) << 4)) = acc[(PASS) * 4 + i2][j];                   \
       }                                                                                                            \
-    __builtin_amdgcn_s_waitcnt(0xc07f);                                                                            \
-    epi_pass<WN>(p, er, lane, m0 + wm * 128 + (PASS) * 64, n0 + wn * WN, gate, fast);                              \
     __builtin_amdgcn_s_waitcnt(0xc07f); } while (0)
-  EPI_PASS(0);
-  EPI_PASS(1);
-#undef EPI_PASS
+  // aux / residual chunks of both passes are requested up front (pass 1's fly under pass 0's compute and stores)
+  const int em = m0 + wm * 128, en = n0 + wn * WN;
+  EpiPre<WN> pre0, pre1;
+  epi_fetch<WN>(p, lane, em, en, fast, pre0);
+  EPI_STAGE(0);
+  epi_fetch<WN>(p, lane, em + 64, en, fast, pre1);
+  epi_pass_pre<WN>(p, er, lane, em, en, gate, fast, pre0);
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  EPI_STAGE(1);
+  epi_pass_pre<WN>(p, er, lane, em + 64, en, gate, fast, pre1);
+#undef EPI_STAGE
 }
 
 template <bool AKS, bool BKS, int BN>

@@ -140,3 +140,43 @@ __device__ __forceinline__ void epi_pass(const Gemm2Params& p, const char* er, i
     }
   }
 }
+
+
+// Whole-pass variant for wave tiles of <= 64 columns (<= 8 row groups per pass): the aux / residual chunks of a pass are
+// fetched by epi_fetch() BEFORE the accumulators of that pass are staged through LDS -- and, for the second pass, before the
+// first pass is computed and stored -- so their global-load latency is not on the epilogue's critical path.
+template <int WN>
+struct EpiPre {
+  static constexpr int LPR = WN / 8, RPI = 64 / LPR, NIT = 64 / RPI;
+  bf16x8 av[NIT], rv[NIT];
+};
+template <int WN>
+__device__ __forceinline__ void epi_fetch(const Gemm2Params& p, int lane, int mbase, int nbase, bool fast, EpiPre<WN>& e) {
+  constexpr int LPR = EpiPre<WN>::LPR, RPI = EpiPre<WN>::RPI, NIT = EpiPre<WN>::NIT;
+  const int n = nbase + (lane % LPR) * 8;
+  if (!fast || n >= p.N) return;
+#pragma unroll
+  for (int u = 0; u < NIT; ++u) {
+    int m = min(mbase + u * RPI + lane / LPR, p.M - 1);                    // clamped: rows beyond M are loaded, never stored
+    e.av[u] = bf16x8{}; e.rv[u] = bf16x8{};
+    if (p.aux) e.av[u] = *(const bf16x8*)(p.aux + (long)m * p.ldaux + n);
+    if (p.res) e.rv[u] = *(const bf16x8*)(p.res + (long)m * p.ldres + n);
+  }
+}
+template <int WN>
+__device__ __forceinline__ void epi_pass_pre(const Gemm2Params& p, const char* er, int lane, int mbase, int nbase, float gate, bool fast,
+                                             const EpiPre<WN>& e) {
+  constexpr int ESTR = WN * 4, UNITS = WN / 4, LPR = EpiPre<WN>::LPR, RPI = EpiPre<WN>::RPI, NIT = EpiPre<WN>::NIT;
+  const int cg = lane % LPR, n = nbase + cg * 8;
+  if (!fast || n >= p.N) { epi_pass<WN>(p, er, lane, mbase, nbase, gate, fast); return; }
+#pragma unroll
+  for (int u = 0; u < NIT; ++u) {
+    int row = u * RPI + lane / LPR, m = mbase + row, sw = row & (UNITS - 1);
+    f32x4 x0 = *(const f32x4*)(er + row * ESTR + (((2 * cg) ^ sw) << 4));
+    f32x4 x1 = *(const f32x4*)(er + row * ESTR + (((2 * cg + 1) ^ sw) << 4));
+    if (m < p.M) {
+      float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+      epi8<true, true>(p, v, m, n, gate, e.av[u], e.rv[u]);
+    }
+  }
+}
