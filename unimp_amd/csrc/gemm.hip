@@ -217,13 +217,28 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
   if (p.gate) gate = tanhf(bf2f(*p.gate));
   bool fast = ((p.N & 3) == 0) && (((p.ldc | p.ldres | p.ldaux | p.ldpre) & 3) == 0);
   int mb = m0 + wm * 64 + (lane & 15), nb = n0 + wn * 64 + (lane >> 4) * 4;
-#define EPI_TILE(F, i, j) epi_tile<F>(p, acc[i][j], mb + (i) * 16, nb + (j) * 16, gate);
+#define EPI_TILE_true(i, j) epi_tile<true>(p, acc[i][j], mb + (i) * 16, nb + (j) * 16, gate);
+#define EPI_TILE_false(i, j) epi_tile<false>(p, acc[i][j], mb + (i) * 16, nb + (j) * 16, gate);
+#define EPI_TILE_EPI_PLAIN_(i, j) EPI_PLAIN(i, j)
+#define EPI_TILE(F, i, j) EPI_TILE_##F(i, j)
 #define EPI_ROW(F, i) EPI_TILE(F, i, 0) EPI_TILE(F, i, 1) EPI_TILE(F, i, 2) EPI_TILE(F, i, 3)
 #define EPI_ALL(F) EPI_ROW(F, 0) EPI_ROW(F, 1) EPI_ROW(F, 2) EPI_ROW(F, 3)
-  if (fast) { EPI_ALL(true) } else { EPI_ALL(false) }
+  // the plain form (alpha only: split-K slabs, weight gradients) has its own compact code: the 32 inlined copies of the fully
+  // general epi_tile are 110 KiB, and running through them costs more instruction-cache misses than the stores cost cycles
+  bool plain = fast && !p.bias && !p.act && !p.pre && !p.aux && !p.res && !p.gate && !p.accumulate;
+#define EPI_PLAIN(i, j) { int m = mb + (i) * 16, n = nb + (j) * 16;                                                   \
+    if (m < p.M && n < p.N) { f32x4 v = acc[i][j] * p.alpha;                                                          \
+      if (p.out_f32) *(f32x4*)((float*)p.C + (long)m * p.ldc + n) = v;                                                \
+      else { bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])}; *(bf16x4*)((bf16*)p.C + (long)m * p.ldc + n) = o; } } }
+  if (plain) { EPI_ALL(EPI_PLAIN_) }
+  else if (fast) { EPI_ALL(true) } else { EPI_ALL(false) }
+#undef EPI_PLAIN
 #undef EPI_ALL
 #undef EPI_ROW
 #undef EPI_TILE
+#undef EPI_TILE_true
+#undef EPI_TILE_false
+#undef EPI_TILE_EPI_PLAIN_
 }
 
 // ---- skinny GEMM for decoding (M <= 64 rows: K beams x one new token).  Weight-bandwidth bound: every element of W is

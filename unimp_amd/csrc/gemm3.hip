@@ -31,12 +31,26 @@
 #else
 #define G3_PRIO(x) __builtin_amdgcn_s_setprio(x)
 #endif
+#ifdef G3_STAMP      // debug build: per-block wall-clock stamps (100 MHz s_memrealtime) + the CU it ran on (tools/stamp_gemm3.py)
+__device__ unsigned long long g3_stamps[8192 * 12];
+extern "C" int unimp_debug_g3_stamps(void* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g3_stamps), sizeof(g3_stamps)); }
+#define G3_T(K_) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g3_stamps[blockIdx.x * 12 + (K_)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define G3_T(K_) do {} while (0)
+#endif
 #define G3_FENCE() do { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); } while (0)
 #define G3_BARRIER() do { G3_FENCE(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); G3_FENCE(); } while (0)
 
 template <bool AKS, bool BKS, int BN>
 __global__ __launch_bounds__(512, 2) void gemm3_bf16_kernel(Gemm2Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  G3_T(0);
+#ifdef G3_STAMP
+  if (threadIdx.x == 0 && blockIdx.x < 8192) {
+    g3_stamps[blockIdx.x * 12 + 10] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID
+    g3_stamps[blockIdx.x * 12 + 11] = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // XCC_ID
+  }
+#endif
   constexpr int NJ = BN / 64, WN = BN / 4;
   constexpr int A_SUB = G3_BM * 64, B_SUB = BN * 64, SUB = A_SUB + B_SUB;
   constexpr int NEW = G3_BM / 128 + BN / 128;          // LDS-DMA instructions a wave issues per half-step
@@ -105,12 +119,14 @@ __global__ __launch_bounds__(512, 2) void gemm3_bf16_kernel(Gemm2Params p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   G3_BARRIER();
   LOADF(0, 0);
+  G3_T(1);
   if (wm == 1) G3_BARRIER();                            // group B runs one phase behind group A
   for (int h = 0; h < nh; h += 2) {
     HALF_STEP(h, 0, 1);
     if (h + 1 < nh) HALF_STEP(h + 1, 1, 0);
   }
   if (wm == 0) G3_BARRIER();                            // equalise the barrier count; all LDS reads are complete
+  G3_T(2);
 #undef DMA
 #undef LOADF
 #undef MFMAS
@@ -132,17 +148,25 @@ __global__ __launch_bounds__(512, 2) void gemm3_bf16_kernel(Gemm2Params p) {
         *(f32x4*)(er + row * ESTR + ((u ^ (row & (UNITS - 1))) << 4)) = acc[(PASS) * 4 + i2][j];                   \
       }                                                                                                            \
     __builtin_amdgcn_s_waitcnt(0xc07f); } while (0)
-  // aux / residual chunks of both passes are requested up front (pass 1's fly under pass 0's compute and stores)
+  // the epilogue kind is chosen once per tile; every global load goes out before the first store (see gemm_tile.h)
   const int em = m0 + wm * 128, en = n0 + wn * WN;
+  const int kind = epi_kind(p, fast);
   EpiPre<WN> pre0, pre1;
-  epi_fetch<WN>(p, lane, em, en, fast, pre0);
+  bf16x8 biasv = epi_bias<WN>(p, lane, en, kind);
+  epi_fetch<WN>(p, lane, em, en, kind, pre0);
+  G3_T(4);
   EPI_STAGE(0);
-  epi_fetch<WN>(p, lane, em + 64, en, fast, pre1);
-  epi_pass_pre<WN>(p, er, lane, em, en, gate, fast, pre0);
+  G3_T(5);
+  epi_fetch<WN>(p, lane, em + 64, en, kind, pre1);
+  if (kind != EK_GENERIC) epi_inputs_ready();
+  epi_pass_kind<WN>(p, er, lane, em, en, gate, fast, kind, pre0, biasv);
   __builtin_amdgcn_s_waitcnt(0xc07f);
+  G3_T(6);
   EPI_STAGE(1);
-  epi_pass_pre<WN>(p, er, lane, em + 64, en, gate, fast, pre1);
+  G3_T(7);
+  epi_pass_kind<WN>(p, er, lane, em + 64, en, gate, fast, kind, pre1, biasv);
 #undef EPI_STAGE
+  G3_T(3);
 }
 
 template <bool AKS, bool BKS, int BN>

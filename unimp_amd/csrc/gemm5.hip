@@ -122,16 +122,19 @@ __global__ __launch_bounds__(512, 2) void gemm5_bf16_kernel(Gemm2Params p) {
         *(f32x4*)(er + row * ESTR + ((u ^ (row & (UNITS - 1))) << 4)) = acc[(PASS) * 4 + i2][j];                   \
       }                                                                                                            \
     __builtin_amdgcn_s_waitcnt(0xc07f); } while (0)
-  // aux / residual chunks of both passes are requested up front (pass 1's fly under pass 0's compute and stores)
+  // the epilogue kind is chosen once per tile; every global load goes out before the first store (see gemm_tile.h)
   const int em = m0 + wm * 128, en = n0 + wn * WN;
+  const int kind = epi_kind(p, fast);
   EpiPre<WN> pre0, pre1;
-  epi_fetch<WN>(p, lane, em, en, fast, pre0);
+  bf16x8 biasv = epi_bias<WN>(p, lane, en, kind);
+  epi_fetch<WN>(p, lane, em, en, kind, pre0);
   EPI_STAGE(0);
-  epi_fetch<WN>(p, lane, em + 64, en, fast, pre1);
-  epi_pass_pre<WN>(p, er, lane, em, en, gate, fast, pre0);
+  epi_fetch<WN>(p, lane, em + 64, en, kind, pre1);
+  if (kind != EK_GENERIC) epi_inputs_ready();
+  epi_pass_kind<WN>(p, er, lane, em, en, gate, fast, kind, pre0, biasv);
   __builtin_amdgcn_s_waitcnt(0xc07f);
   EPI_STAGE(1);
-  epi_pass_pre<WN>(p, er, lane, em + 64, en, gate, fast, pre1);
+  epi_pass_kind<WN>(p, er, lane, em + 64, en, gate, fast, kind, pre1, biasv);
 #undef EPI_STAGE
 }
 

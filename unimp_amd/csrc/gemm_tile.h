@@ -27,12 +27,12 @@ __device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
 // 8 consecutive columns of one output row.  PRE: the caller already fetched this row group's aux / res chunks (FAST only).
 template <bool FAST, bool PRE = false>
 __device__ __forceinline__ void epi8(const Gemm2Params& p, float (&v)[8], int m, int n, float gate,
-                                     bf16x8 auxv = bf16x8{}, bf16x8 resv = bf16x8{}) {
+                                     bf16x8 auxv = bf16x8{}, bf16x8 resv = bf16x8{}, bf16x8 biasv = bf16x8{}) {
   int nv = FAST ? 8 : min(8, p.N - n);
 #pragma unroll
   for (int r = 0; r < 8; ++r) v[r] *= p.alpha;
   if (p.bias) {
-    if (FAST) { bf16x8 b = *(const bf16x8*)(p.bias + n);
+    if (FAST) { bf16x8 b = PRE ? biasv : *(const bf16x8*)(p.bias + n);
 #pragma unroll
       for (int r = 0; r < 8; ++r) v[r] += bf2f(b[r]); }
     else { for (int r = 0; r < nv; ++r) v[r] += bf2f(p.bias[n + r]); }
@@ -75,6 +75,9 @@ __device__ __forceinline__ void epi8(const Gemm2Params& p, float (&v)[8], int m,
       for (int r = 0; r < 8; ++r) v[r] += bf2f(x[r]); }
     else { for (int r = 0; r < nv; ++r) v[r] += bf2f(s[r]); }
   }
+#ifdef G3_NOSTORE
+  if (gate != 12345.f) return;
+#endif
   if (p.out_f32) {
     float* d = (float*)p.C + (long)m * p.ldc + n;
     if (FAST) {
@@ -98,85 +101,147 @@ __device__ __forceinline__ void epi8(const Gemm2Params& p, float (&v)[8], int m,
 
 
 // One pass of the LDS-staged epilogue: the wave's [64][WN] f32 region (16-B units XOR-swizzled by row) -> global memory.
-// Row groups are processed U at a time with their aux / res chunks fetched up front: one global-load latency per U groups
-// instead of one per group (the dX GEMM that multiplies by the stored act'(z), and every GEMM with a residual, spent
-// 10-25 % of their time there).  U = 8 (a whole pass of a 64-column wave tile in one round trip; the fragment registers
-// are dead by now).
-template <int WN, int U = (64 / (64 / (WN / 8)) < 8 ? 64 / (64 / (WN / 8)) : 8)>
+// GENERIC form: every fused option behind run-time branches, one row group at a time in a ROLLED loop.  It is the fallback
+// (accumulate into C, aux AND residual, ragged N / odd leading dimensions); the hot combinations use epi_groups<KIND> below.
+// Code size matters here: with the row-group loop unrolled around the fully general epi8 the epilogue was 185 KiB of a
+// 191 KiB kernel -- three times the instruction cache two CUs share -- and a 256 x 256 tile spent 9.5 us (idle chip) to
+// 15 us (loaded) in it against 18-26 us for its whole K = 1024 main loop (s_memrealtime stamps, -DG3_STAMP).
+template <int WN>
 __device__ __forceinline__ void epi_pass(const Gemm2Params& p, const char* er, int lane, int mbase, int nbase, float gate, bool fast) {
   constexpr int ESTR = WN * 4, UNITS = WN / 4, LPR = WN / 8, RPI = 64 / LPR, NIT = 64 / RPI;
-  static_assert(NIT % U == 0, "row groups per pass must be a multiple of U");
   const int cg = lane % LPR, n = nbase + cg * 8;
-  if (!fast || n >= p.N) {                       // ragged N / odd leading dimensions: element-wise path, one group at a time
-    for (int it = 0; it < NIT; ++it) {
-      int row = it * RPI + lane / LPR, m = mbase + row, sw = row & (UNITS - 1);
-      f32x4 x0 = *(const f32x4*)(er + row * ESTR + (((2 * cg) ^ sw) << 4));
-      f32x4 x1 = *(const f32x4*)(er + row * ESTR + (((2 * cg + 1) ^ sw) << 4));
-      if (m < p.M && n < p.N) {
-        float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-        if (fast) epi8<true>(p, v, m, n, gate); else epi8<false>(p, v, m, n, gate);
-      }
-    }
-    return;
-  }
-  for (int it0 = 0; it0 < NIT; it0 += U) {
-    bf16x8 av[U], rv[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      int m = min(mbase + (it0 + u) * RPI + lane / LPR, p.M - 1);          // clamped: rows beyond M are loaded, never stored
-      av[u] = bf16x8{}; rv[u] = bf16x8{};
-      if (p.aux) av[u] = *(const bf16x8*)(p.aux + (long)m * p.ldaux + n);
-      if (p.res) rv[u] = *(const bf16x8*)(p.res + (long)m * p.ldres + n);
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      int row = (it0 + u) * RPI + lane / LPR, m = mbase + row, sw = row & (UNITS - 1);
-      f32x4 x0 = *(const f32x4*)(er + row * ESTR + (((2 * cg) ^ sw) << 4));
-      f32x4 x1 = *(const f32x4*)(er + row * ESTR + (((2 * cg + 1) ^ sw) << 4));
-      if (m < p.M) {
-        float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-        epi8<true, true>(p, v, m, n, gate, av[u], rv[u]);
-      }
+#pragma unroll 1
+  for (int it = 0; it < NIT; ++it) {
+    int row = it * RPI + lane / LPR, m = mbase + row, sw = row & (UNITS - 1);
+    f32x4 x0 = *(const f32x4*)(er + row * ESTR + (((2 * cg) ^ sw) << 4));
+    f32x4 x1 = *(const f32x4*)(er + row * ESTR + (((2 * cg + 1) ^ sw) << 4));
+    if (m < p.M && n < p.N) {
+      float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+      if (fast) epi8<true>(p, v, m, n, gate); else epi8<false>(p, v, m, n, gate);
     }
   }
 }
 
-
-// Whole-pass variant for wave tiles of <= 64 columns (<= 8 row groups per pass): the aux / residual chunks of a pass are
-// fetched by epi_fetch() BEFORE the accumulators of that pass are staged through LDS -- and, for the second pass, before the
-// first pass is computed and stored -- so their global-load latency is not on the epilogue's critical path.
+// ---- specialised epilogues ---------------------------------------------------------------------------------------------
+// The combinations the step actually uses, chosen once per tile (epi_kind) and compiled without inner option branches:
+//   EK_PLAIN  alpha (+bias)                                   -> C                 (qkv, dX of plain linears, weight gradients)
+//   EK_ACT    alpha (+bias), act, optional second output      -> C, pre            (MLP up-projection: act(z) and z or act'(z))
+//   EK_AUX    alpha (+bias), x stored act'(z)                 -> C                 (dX through the activation)
+//   EK_RES    alpha (+bias), x tanh(gate), + residual         -> C                 (attention-out / MLP down-projection, gated xattn)
+// Every global load (bias, aux / residual chunks) is issued by epi_fetch() BEFORE the accumulators are staged and waited for
+// once (epi_inputs_ready) before the first store: a load consumed inside the store loop makes hipcc emit `s_waitcnt vmcnt(0)`
+// there (it cannot count in-flight stores across branches), which also waits for the previous row group's store to be
+// acknowledged.  EK_PLAIN / EK_ACT have no per-row-group input and run as a rolled loop; EK_AUX / EK_RES unroll their <= 8
+// row groups around the prefetched registers.
+enum { EK_PLAIN = 0, EK_ACT = 1, EK_AUX = 2, EK_RES = 3, EK_GENERIC = 4 };
+__device__ __forceinline__ int epi_kind(const Gemm2Params& p, bool fast) {
+  if (!fast || p.accumulate || (p.aux && p.res)) return EK_GENERIC;
+  if (p.aux) return (p.dact == ACT_DERIV && !p.act && !p.pre && !p.gate) ? EK_AUX : EK_GENERIC;
+  if (p.res) return (!p.act && !p.pre) ? EK_RES : EK_GENERIC;
+  if (p.gate) return EK_GENERIC;
+  return (p.act || p.pre) ? EK_ACT : EK_PLAIN;
+}
 template <int WN>
 struct EpiPre {
   static constexpr int LPR = WN / 8, RPI = 64 / LPR, NIT = 64 / RPI;
-  bf16x8 av[NIT], rv[NIT];
+  bf16x8 xv[NIT];                   // the aux OR the residual chunk of each row group
 };
 template <int WN>
-__device__ __forceinline__ void epi_fetch(const Gemm2Params& p, int lane, int mbase, int nbase, bool fast, EpiPre<WN>& e) {
+__device__ __forceinline__ bf16x8 epi_bias(const Gemm2Params& p, int lane, int nbase, int kind) {
+  const int n = nbase + (lane % (WN / 8)) * 8;
+  bf16x8 b = bf16x8{};
+  if (kind != EK_GENERIC && n < p.N && p.bias) b = *(const bf16x8*)(p.bias + n);
+  return b;
+}
+template <int WN>
+__device__ __forceinline__ void epi_fetch(const Gemm2Params& p, int lane, int mbase, int nbase, int kind, EpiPre<WN>& e) {
   constexpr int LPR = EpiPre<WN>::LPR, RPI = EpiPre<WN>::RPI, NIT = EpiPre<WN>::NIT;
   const int n = nbase + (lane % LPR) * 8;
-  if (!fast || n >= p.N) return;
+  if ((kind != EK_AUX && kind != EK_RES) || n >= p.N) return;
+  const bf16* src = kind == EK_AUX ? p.aux : p.res;
+  const long ld = kind == EK_AUX ? p.ldaux : p.ldres;
 #pragma unroll
   for (int u = 0; u < NIT; ++u) {
     int m = min(mbase + u * RPI + lane / LPR, p.M - 1);                    // clamped: rows beyond M are loaded, never stored
-    e.av[u] = bf16x8{}; e.rv[u] = bf16x8{};
-    if (p.aux) e.av[u] = *(const bf16x8*)(p.aux + (long)m * p.ldaux + n);
-    if (p.res) e.rv[u] = *(const bf16x8*)(p.res + (long)m * p.ldres + n);
+    e.xv[u] = *(const bf16x8*)(src + (long)m * ld + n);
   }
 }
-template <int WN>
-__device__ __forceinline__ void epi_pass_pre(const Gemm2Params& p, const char* er, int lane, int mbase, int nbase, float gate, bool fast,
-                                             const EpiPre<WN>& e) {
+// all epilogue inputs have landed; from here on only stores are in flight (vmcnt(0); expcnt / lgkmcnt untouched)
+__device__ __forceinline__ void epi_inputs_ready() { __builtin_amdgcn_s_waitcnt(0x0f70); }
+
+template <int KIND>
+__device__ __forceinline__ void epi8k(const Gemm2Params& p, float (&v)[8], int m, int n, float gate, bf16x8 x, bf16x8 biasv) {
+#pragma unroll
+  for (int r = 0; r < 8; ++r) v[r] *= p.alpha;
+  if (p.bias) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] += bf2f(biasv[r]);
+  }
+  if (KIND == EK_ACT) {
+    if (p.pre) {
+      float dv[8];
+      if (p.pre_deriv) act_fwd_deriv_n<8>(p.act, v, dv);
+      else {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) dv[r] = v[r];
+        act_fwd_n<8>(p.act, v);
+      }
+      bf16x8 o;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) o[r] = f2bf(dv[r]);
+      *(bf16x8*)(p.pre + (long)m * p.ldpre + n) = o;
+    } else act_fwd_n<8>(p.act, v);
+  }
+  if (KIND == EK_AUX) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] *= bf2f(x[r]);
+  }
+  if (KIND == EK_RES) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = v[r] * gate + bf2f(x[r]);
+  }
+  if (p.out_f32) {
+    float* d = (float*)p.C + (long)m * p.ldc + n;
+    *(f32x4*)d = f32x4{v[0], v[1], v[2], v[3]}; *(f32x4*)(d + 4) = f32x4{v[4], v[5], v[6], v[7]};
+  } else {
+    bf16x8 o;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) o[r] = f2bf(v[r]);
+    *(bf16x8*)((bf16*)p.C + (long)m * p.ldc + n) = o;
+  }
+}
+template <int WN, int KIND>
+__device__ __forceinline__ void epi_groups(const Gemm2Params& p, const char* er, int lane, int mbase, int nbase, float gate,
+                                           const EpiPre<WN>& e, bf16x8 biasv) {
   constexpr int ESTR = WN * 4, UNITS = WN / 4, LPR = EpiPre<WN>::LPR, RPI = EpiPre<WN>::RPI, NIT = EpiPre<WN>::NIT;
   const int cg = lane % LPR, n = nbase + cg * 8;
-  if (!fast || n >= p.N) { epi_pass<WN>(p, er, lane, mbase, nbase, gate, fast); return; }
+  if (n >= p.N) return;
+#define EPI_GROUP(U_, X_) do {                                                                                     \
+    int row = (U_) * RPI + lane / LPR, m = mbase + row, sw = row & (UNITS - 1);                                    \
+    f32x4 x0 = *(const f32x4*)(er + row * ESTR + (((2 * cg) ^ sw) << 4));                                          \
+    f32x4 x1 = *(const f32x4*)(er + row * ESTR + (((2 * cg + 1) ^ sw) << 4));                                      \
+    if (m < p.M) {                                                                                                 \
+      float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};                                       \
+      epi8k<KIND>(p, v, m, n, gate, (X_), biasv);                                                                  \
+    } } while (0)
+  if (KIND == EK_AUX || KIND == EK_RES) {
 #pragma unroll
-  for (int u = 0; u < NIT; ++u) {
-    int row = u * RPI + lane / LPR, m = mbase + row, sw = row & (UNITS - 1);
-    f32x4 x0 = *(const f32x4*)(er + row * ESTR + (((2 * cg) ^ sw) << 4));
-    f32x4 x1 = *(const f32x4*)(er + row * ESTR + (((2 * cg + 1) ^ sw) << 4));
-    if (m < p.M) {
-      float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-      epi8<true, true>(p, v, m, n, gate, e.av[u], e.rv[u]);
-    }
+    for (int u = 0; u < NIT; ++u) EPI_GROUP(u, e.xv[u]);
+  } else {
+#pragma unroll 1
+    for (int u = 0; u < NIT; ++u) EPI_GROUP(u, bf16x8{});
+  }
+#undef EPI_GROUP
+}
+// one pass of the chosen kind
+template <int WN>
+__device__ __forceinline__ void epi_pass_kind(const Gemm2Params& p, const char* er, int lane, int mbase, int nbase, float gate, bool fast,
+                                              int kind, const EpiPre<WN>& e, bf16x8 biasv) {
+  switch (kind) {
+    case EK_PLAIN: epi_groups<WN, EK_PLAIN>(p, er, lane, mbase, nbase, gate, e, biasv); break;
+    case EK_ACT:   epi_groups<WN, EK_ACT>(p, er, lane, mbase, nbase, gate, e, biasv); break;
+    case EK_AUX:   epi_groups<WN, EK_AUX>(p, er, lane, mbase, nbase, gate, e, biasv); break;
+    case EK_RES:   epi_groups<WN, EK_RES>(p, er, lane, mbase, nbase, gate, e, biasv); break;
+    default:       epi_pass<WN>(p, er, lane, mbase, nbase, gate, fast);
   }
 }
