@@ -62,7 +62,7 @@ def test_gemm_layouts(ops, M, N, K, a_ks, b_ks):
     bd = (b.t().contiguous() if b_ks else b).cuda()
     got = ops.gemm(ad, bd, a_ks=a_ks, b_ks=b_ks)                  # autotuned choice
     close(got, want, name=f"gemm {M}x{N}x{K} {a_ks}{b_ks}")
-    for variant in (["v1"] if M < 256 else ["v1", "dma256", "dma128", "pp256", "pp128", "w4", "w8"]):   # every kernel, explicitly
+    for variant in (["v1"] if M < 256 else ["v1", "dma256", "dma128", "pp256", "pp128", "w4", "w8", "pp256p"]):   # every kernel, explicitly
         got = ops.gemm(ad, bd, a_ks=a_ks, b_ks=b_ks, variant=variant)
         close(got, want, name=f"gemm[{variant}] {M}x{N}x{K} {a_ks}{b_ks}")
     got32 = ops.gemm(ad, bd, a_ks=a_ks, b_ks=b_ks, out_f32=True, variant="pp256" if M >= 256 else "v1")
@@ -78,11 +78,37 @@ def test_gemm_pingpong_long_k_race_screen(ops):
         ad, bd = a.cuda(), b.cuda()
         ref = ops.gemm(ad, bd, variant="v1")
         close(ref, want, name="v1 long k")
-        for variant in ("pp256", "pp128", "dma256"):
+        for variant in ("pp256", "pp128", "dma256", "pp256p"):
             outs = [ops.gemm(ad, bd, variant=variant) for _ in range(6)]
             for o in outs:
                 assert torch.equal(o, outs[0]), f"{variant}: run-to-run mismatch at K={K}"
             close(outs[0], want, name=f"{variant} long k")
+
+
+def test_gemm_persistent_many_tiles_per_workgroup(ops):
+    """pp256p walks several tiles per workgroup (more tiles than CUs), ragged M / N edges, each epilogue kind; results must
+    equal the one-tile-per-workgroup ping-pong kernel bit for bit (same accumulation order)."""
+    M, N, K = 256 * 37 + 40, 256 * 9 + 136, 32 * 21
+    a, b = rnd(M, K, seed=11), rnd(N, K, seed=12, scale=0.2)
+    bias, res = rnd(N, seed=13), rnd(M, N, seed=14)
+    ad, bd, biasd, resd = a.cuda(), b.cuda(), bias.cuda(), res.cuda()
+    gate = torch.tensor([0.3], dtype=bf16, device="cuda")
+    for kw in (dict(), dict(bias=biasd), dict(bias=biasd, act="gelu"), dict(res=resd), dict(bias=biasd, res=resd, gate=gate),
+               dict(aux=resd, dact="deriv"), dict(out_f32=True)):
+        want = ops.gemm(ad, bd, variant="pp256", **kw)
+        for _ in range(3):
+            got = ops.gemm(ad, bd, variant="pp256p", **kw)
+            assert torch.equal(got, want), f"pp256p != pp256 for {sorted(kw)}"
+    pre_w = torch.empty(M, N, dtype=bf16, device="cuda"); pre_g = torch.empty_like(pre_w)
+    want = ops.gemm(ad, bd, variant="pp256", bias=biasd, act="gelu", pre=pre_w, pre_deriv=True)
+    got = ops.gemm(ad, bd, variant="pp256p", bias=biasd, act="gelu", pre=pre_g, pre_deriv=True)
+    assert torch.equal(got, want) and torch.equal(pre_g, pre_w)
+    for a_ks, b_ks in ((False, True), (True, True), (True, False)):
+        a2 = (a[:M - 40].t().contiguous() if a_ks else a[:M - 40]).cuda()
+        b2 = (b.t().contiguous() if b_ks else b).cuda()
+        want = ops.gemm(a2, b2, a_ks=a_ks, b_ks=b_ks, variant="pp256")
+        got = ops.gemm(a2, b2, a_ks=a_ks, b_ks=b_ks, variant="pp256p")
+        assert torch.equal(got, want), f"pp256p != pp256 for layout {a_ks}{b_ks}"
 
 
 def test_gemm_asymmetric_identity(ops):
@@ -100,7 +126,7 @@ def test_gemm_epilogue_bias_act_pre(ops, act, M):
     N, K = 264, 136
     a, b, bias = rnd(M, K, seed=3), rnd(N, K, seed=4, scale=0.2), rnd(N, seed=5)
     z = a.float() @ b.float().t() + bias.float()
-    for variant in (["v1"] if M < 256 else ["v1", "dma128", "pp256", "pp128"]):
+    for variant in (["v1"] if M < 256 else ["v1", "dma128", "pp256", "pp128", "pp256p"]):
         pre = torch.empty(M, N, dtype=bf16, device="cuda")
         got = ops.gemm(a.cuda(), b.cuda(), bias=bias.cuda(), act=act, pre=pre, variant=variant)
         close(pre, z, name="pre")

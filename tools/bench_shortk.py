@@ -12,7 +12,7 @@ def t(fn):
     for _ in range(6): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / 6 * 1e3
-for N in (1024, 4096):
+for N in (int(a) for a in (sys.argv[1:] or ("1024", "4096"))):
     res = torch.randn(M, N, device="cuda").to(torch.bfloat16); bias = torch.randn(N, device="cuda").to(torch.bfloat16)
     out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
     for K in (512, 1024, 2048, 4096):

@@ -342,6 +342,7 @@ extern "C" int unimp_gemm2_launch(const unimp_gemm_desc* d, int bn, void* stream
 extern "C" int unimp_gemm3_launch(const unimp_gemm_desc* d, int bn, void* stream);   // gemm3.hip: 256-row tiles, LDS-DMA, ping-pong
 extern "C" int unimp_gemm4_launch(const unimp_gemm_desc* d, void* stream);           // gemm4.hip: 256 x 256 tiles, one wave per SIMD
 extern "C" int unimp_gemm5_launch(const unimp_gemm_desc* d, void* stream);           // gemm5.hip: 8 self-interleaving waves, one barrier per half-stage
+extern "C" int unimp_gemm6_launch(const unimp_gemm_desc* d, void* stream);           // gemm6.hip: persistent ping-pong, next tile's prologue under the epilogue
 
 static int check_operand(const void* p, long ld, int ks, int rows) {
   if (((uintptr_t)p & 15) != 0) return UNIMP_ERR_ALIGN;
@@ -409,6 +410,7 @@ extern "C" int unimp_gemm_bf16_variant(const unimp_gemm_desc* d, int variant, vo
     case UNIMP_GEMM_PP128: unimp_gemm3_launch(d, 128, stream); break;
     case UNIMP_GEMM_W4: unimp_gemm4_launch(d, stream); break;
     case UNIMP_GEMM_W8: unimp_gemm5_launch(d, stream); break;
+    case UNIMP_GEMM_PP256P: unimp_gemm6_launch(d, stream); break;
     case UNIMP_GEMM_SKINNY:
       if (!skinny_ok(d)) return unimp_set_error(UNIMP_ERR_UNSUPPORTED, "gemm: the skinny kernel needs M <= 64, k-contiguous operands, K %% 64 == 0");
       launch_skinny(d, stream); break;

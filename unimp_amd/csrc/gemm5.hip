@@ -112,7 +112,6 @@ __global__ __launch_bounds__(512, 2) void gemm5_bf16_kernel(Gemm2Params p) {
   float gate = 1.f;
   if (p.gate) gate = tanhf(bf2f(*p.gate));
   bool fast = ((p.N & 7) == 0) && (((p.ldc | p.ldres | p.ldaux | p.ldpre) & 7) == 0);
-  constexpr int LPR = WN / 8, RPI = 64 / LPR;
   // the two 64-row passes are written out (a loop the compiler declines to unroll would index acc at run time and
   // demote the whole accumulator array to scratch)
 #define EPI_STAGE(PASS) do {                                                                                      \

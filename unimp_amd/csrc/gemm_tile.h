@@ -106,9 +106,9 @@ __device__ __forceinline__ void epi8(const Gemm2Params& p, float (&v)[8], int m,
 // Code size matters here: with the row-group loop unrolled around the fully general epi8 the epilogue was 185 KiB of a
 // 191 KiB kernel -- three times the instruction cache two CUs share -- and a 256 x 256 tile spent 9.5 us (idle chip) to
 // 15 us (loaded) in it against 18-26 us for its whole K = 1024 main loop (s_memrealtime stamps, -DG3_STAMP).
-template <int WN>
+template <int WN, int ROWS = 64>
 __device__ __forceinline__ void epi_pass(const Gemm2Params& p, const char* er, int lane, int mbase, int nbase, float gate, bool fast) {
-  constexpr int ESTR = WN * 4, UNITS = WN / 4, LPR = WN / 8, RPI = 64 / LPR, NIT = 64 / RPI;
+  constexpr int ESTR = WN * 4, UNITS = WN / 4, LPR = WN / 8, RPI = 64 / LPR, NIT = ROWS / RPI;
   const int cg = lane % LPR, n = nbase + cg * 8;
 #pragma unroll 1
   for (int it = 0; it < NIT; ++it) {
@@ -141,9 +141,9 @@ __device__ __forceinline__ int epi_kind(const Gemm2Params& p, bool fast) {
   if (p.gate) return EK_GENERIC;
   return (p.act || p.pre) ? EK_ACT : EK_PLAIN;
 }
-template <int WN>
+template <int WN, int ROWS = 64>
 struct EpiPre {
-  static constexpr int LPR = WN / 8, RPI = 64 / LPR, NIT = 64 / RPI;
+  static constexpr int LPR = WN / 8, RPI = 64 / LPR, NIT = ROWS / RPI;
   bf16x8 xv[NIT];                   // the aux OR the residual chunk of each row group
 };
 template <int WN>
@@ -153,9 +153,9 @@ __device__ __forceinline__ bf16x8 epi_bias(const Gemm2Params& p, int lane, int n
   if (kind != EK_GENERIC && n < p.N && p.bias) b = *(const bf16x8*)(p.bias + n);
   return b;
 }
-template <int WN>
-__device__ __forceinline__ void epi_fetch(const Gemm2Params& p, int lane, int mbase, int nbase, int kind, EpiPre<WN>& e) {
-  constexpr int LPR = EpiPre<WN>::LPR, RPI = EpiPre<WN>::RPI, NIT = EpiPre<WN>::NIT;
+template <int WN, int ROWS = 64>
+__device__ __forceinline__ void epi_fetch(const Gemm2Params& p, int lane, int mbase, int nbase, int kind, EpiPre<WN, ROWS>& e) {
+  constexpr int LPR = EpiPre<WN, ROWS>::LPR, RPI = EpiPre<WN, ROWS>::RPI, NIT = EpiPre<WN, ROWS>::NIT;
   const int n = nbase + (lane % LPR) * 8;
   if ((kind != EK_AUX && kind != EK_RES) || n >= p.N) return;
   const bf16* src = kind == EK_AUX ? p.aux : p.res;
@@ -210,10 +210,10 @@ __device__ __forceinline__ void epi8k(const Gemm2Params& p, float (&v)[8], int m
     *(bf16x8*)((bf16*)p.C + (long)m * p.ldc + n) = o;
   }
 }
-template <int WN, int KIND>
+template <int WN, int KIND, int ROWS = 64>
 __device__ __forceinline__ void epi_groups(const Gemm2Params& p, const char* er, int lane, int mbase, int nbase, float gate,
-                                           const EpiPre<WN>& e, bf16x8 biasv) {
-  constexpr int ESTR = WN * 4, UNITS = WN / 4, LPR = EpiPre<WN>::LPR, RPI = EpiPre<WN>::RPI, NIT = EpiPre<WN>::NIT;
+                                           const EpiPre<WN, ROWS>& e, bf16x8 biasv) {
+  constexpr int ESTR = WN * 4, UNITS = WN / 4, LPR = EpiPre<WN, ROWS>::LPR, RPI = EpiPre<WN, ROWS>::RPI, NIT = EpiPre<WN, ROWS>::NIT;
   const int cg = lane % LPR, n = nbase + cg * 8;
   if (n >= p.N) return;
 #define EPI_GROUP(U_, X_) do {                                                                                     \
@@ -227,21 +227,24 @@ __device__ __forceinline__ void epi_groups(const Gemm2Params& p, const char* er,
   if (KIND == EK_AUX || KIND == EK_RES) {
 #pragma unroll
     for (int u = 0; u < NIT; ++u) EPI_GROUP(u, e.xv[u]);
+  } else if (KIND == EK_PLAIN) {          // small body: 4 row groups per trip so their LDS reads overlap
+#pragma unroll 4
+    for (int u = 0; u < NIT; ++u) EPI_GROUP(u, bf16x8{});
   } else {
-#pragma unroll 1
+#pragma unroll 2
     for (int u = 0; u < NIT; ++u) EPI_GROUP(u, bf16x8{});
   }
 #undef EPI_GROUP
 }
 // one pass of the chosen kind
-template <int WN>
+template <int WN, int ROWS = 64>
 __device__ __forceinline__ void epi_pass_kind(const Gemm2Params& p, const char* er, int lane, int mbase, int nbase, float gate, bool fast,
-                                              int kind, const EpiPre<WN>& e, bf16x8 biasv) {
+                                              int kind, const EpiPre<WN, ROWS>& e, bf16x8 biasv) {
   switch (kind) {
-    case EK_PLAIN: epi_groups<WN, EK_PLAIN>(p, er, lane, mbase, nbase, gate, e, biasv); break;
-    case EK_ACT:   epi_groups<WN, EK_ACT>(p, er, lane, mbase, nbase, gate, e, biasv); break;
-    case EK_AUX:   epi_groups<WN, EK_AUX>(p, er, lane, mbase, nbase, gate, e, biasv); break;
-    case EK_RES:   epi_groups<WN, EK_RES>(p, er, lane, mbase, nbase, gate, e, biasv); break;
-    default:       epi_pass<WN>(p, er, lane, mbase, nbase, gate, fast);
+    case EK_PLAIN: epi_groups<WN, EK_PLAIN, ROWS>(p, er, lane, mbase, nbase, gate, e, biasv); break;
+    case EK_ACT:   epi_groups<WN, EK_ACT, ROWS>(p, er, lane, mbase, nbase, gate, e, biasv); break;
+    case EK_AUX:   epi_groups<WN, EK_AUX, ROWS>(p, er, lane, mbase, nbase, gate, e, biasv); break;
+    case EK_RES:   epi_groups<WN, EK_RES, ROWS>(p, er, lane, mbase, nbase, gate, e, biasv); break;
+    default:       epi_pass<WN, ROWS>(p, er, lane, mbase, nbase, gate, fast);
   }
 }
