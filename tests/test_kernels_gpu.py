@@ -219,7 +219,9 @@ def test_gemm_padded_vocab_like(ops, M):
     close(dw, dl[:, :V].float().t() @ h.float(), name="head dW")
 
 
-@pytest.mark.parametrize("M,N,K,gate", [(512, 1024, 4096, False), (256, 264, 8192 + 72, True), (1024, 512, 2048, False)])
+@pytest.mark.parametrize("M,N,K,gate", [(512, 1024, 4096, False), (256, 264, 8192 + 72, True), (1024, 512, 2048, False),
+                                        # 256 x 256 ping-pong tiles under split-K: ragged M / N / K, kc and ks operand forms
+                                        (1024, 4096, 6144, False), (776, 1032, 4096 + 40, True), (128, 2560, 4096, False)])
 def test_gemm_splitk_weight_grad(ops, M, N, K, gate):
     """dW-shaped problem (both operands k-strided, tiny output, deep K): the split-K path is picked automatically."""
     dy, x = rnd(K, M, seed=1, scale=0.1), rnd(K, N, seed=2)
@@ -230,6 +232,9 @@ def test_gemm_splitk_weight_grad(ops, M, N, K, gate):
     ref = ops.gemm(dy.cuda(), x.cuda(), a_ks=True, b_ks=True, gate=g.cuda() if gate else None, variant="v1")
     close(ref, want, name="v1 dW")
     assert torch.equal(got, ops.gemm(dy.cuda(), x.cuda(), a_ks=True, b_ks=True, gate=g.cuda() if gate else None))   # reproducible
+    if K % 8 == 0:                                   # the same product from k-contiguous operands (kc x kc split-K)
+        got_kc = ops.gemm(dy.t().contiguous().cuda(), x.t().contiguous().cuda(), gate=g.cuda() if gate else None)
+        close(got_kc, want, name="splitk kc")
 
 
 def test_gemm_rejects_bad_args(ops):

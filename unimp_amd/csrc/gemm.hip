@@ -340,6 +340,7 @@ static void launch_skinny(const unimp_gemm_desc* d, void* stream) {
 
 extern "C" int unimp_gemm2_launch(const unimp_gemm_desc* d, int bn, void* stream);   // gemm2.hip: 256-row tiles, LDS-DMA, 2-stage
 extern "C" int unimp_gemm3_launch(const unimp_gemm_desc* d, int bn, void* stream);   // gemm3.hip: 256-row tiles, LDS-DMA, ping-pong
+extern "C" int unimp_gemm3_launch_splitk(const unimp_gemm_desc* d, int bn, int splits, float* slabs, void* stream);
 extern "C" int unimp_gemm4_launch(const unimp_gemm_desc* d, void* stream);           // gemm4.hip: 256 x 256 tiles, one wave per SIMD
 extern "C" int unimp_gemm5_launch(const unimp_gemm_desc* d, void* stream);           // gemm5.hip: 8 self-interleaving waves, one barrier per half-stage
 extern "C" int unimp_gemm6_launch(const unimp_gemm_desc* d, void* stream);           // gemm6.hip: persistent ping-pong, next tile's prologue under the epilogue
@@ -441,7 +442,9 @@ extern "C" int unimp_gemm_bf16_splitk(const unimp_gemm_desc* d, int splits, floa
   if (d->bias || d->res || d->aux || d->pre || d->act || d->dact || d->accumulate)
     return unimp_set_error(UNIMP_ERR_UNSUPPORTED, "gemm_splitk: only alpha / gate epilogues");
   if ((d->N & 3) || (d->ldc & 3)) return unimp_set_error(UNIMP_ERR_SHAPE, "gemm_splitk: N and ldc must be multiples of 4");
-  launch_v1(d, stream, splits, slabs);
+  // 256 x 256 ping-pong tiles once the output holds a few of them (twice the 128 x 128 kernel's rate); 128 x 128 tiles otherwise
+  if (d->M >= 256 && d->N >= 256) unimp_gemm3_launch_splitk(d, 256, splits, slabs, stream);
+  else launch_v1(d, stream, splits, slabs);
   int ks = ((d->K + splits - 1) / splits + 63) & ~63;
   int S = (d->K + ks - 1) / ks;
   long MN = (long)d->M * d->N;

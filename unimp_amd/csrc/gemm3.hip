@@ -55,6 +55,13 @@ __global__ __launch_bounds__(512, 2) void gemm3_bf16_kernel(Gemm2Params p) {
   constexpr int A_SUB = G3_BM * 64, B_SUB = BN * 64, SUB = A_SUB + B_SUB;
   constexpr int NEW = G3_BM / 128 + BN / 128;          // LDS-DMA instructions a wave issues per half-step
 
+  if (p.ksplit > 0) {               // split-K: this block reduces one K slice into its own f32 slab (summed by splitk_reduce)
+    int k_off = blockIdx.y * p.ksplit;
+    p.A += AKS ? (long)k_off * p.lda : (long)k_off;
+    p.B += BKS ? (long)k_off * p.ldb : (long)k_off;
+    p.K = min(p.K - k_off, p.ksplit);
+    p.C = (float*)p.C + (long)blockIdx.y * p.M * p.ldc;
+  }
   int nwg = p.nbm * p.nbn;
   int id = xcd_remap(blockIdx.x, nwg);
   constexpr int GM = 4;
@@ -169,16 +176,21 @@ __global__ __launch_bounds__(512, 2) void gemm3_bf16_kernel(Gemm2Params p) {
 }
 
 template <bool AKS, bool BKS, int BN>
-static void launch3(const Gemm2Params& p, hipStream_t s) {
+static void launch3(const Gemm2Params& p, hipStream_t s, int slices = 1) {
   static bool attr_set = false;
   constexpr size_t lds = G3_NST * (G3_BM * 64 + BN * 64);
   auto kern = gemm3_bf16_kernel<AKS, BKS, BN>;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
-  hipLaunchKernelGGL(kern, dim3(p.nbm * p.nbn), dim3(512), lds, s, p);
+  hipLaunchKernelGGL(kern, dim3(p.nbm * p.nbn, slices), dim3(512), lds, s, p);
 }
 
 // variant: 256 or 128 = tile width.  Returns 1 if launched.
+// splits > 1: K slices into the f32 slabs [slices][M][N] (plain stores; gemm.hip's splitk_reduce applies alpha / gate)
+extern "C" int unimp_gemm3_launch_splitk(const unimp_gemm_desc* d, int bn, int splits, float* slabs, void* stream);
 extern "C" int unimp_gemm3_launch(const unimp_gemm_desc* d, int bn, void* stream) {
+  return unimp_gemm3_launch_splitk(d, bn, 1, nullptr, stream);
+}
+extern "C" int unimp_gemm3_launch_splitk(const unimp_gemm_desc* d, int bn, int splits, float* slabs, void* stream) {
   Gemm2Params p;
   p.A = (const bf16*)d->A; p.B = (const bf16*)d->B; p.C = d->C;
   p.M = d->M; p.N = d->N; p.K = d->K; p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;
@@ -188,9 +200,17 @@ extern "C" int unimp_gemm3_launch(const unimp_gemm_desc* d, int bn, void* stream
   p.out_f32 = d->out_f32; p.accumulate = d->accumulate; p.pre_deriv = d->pre_deriv;
   p.nbm = (d->M + G3_BM - 1) / G3_BM;
   p.nbn = (d->N + bn - 1) / bn;
+  p.ksplit = 0;
+  int slices = 1;
+  if (splits > 1) {
+    p.ksplit = ((d->K + splits - 1) / splits + 63) & ~63;
+    slices = (d->K + p.ksplit - 1) / p.ksplit;
+    p.C = slabs; p.ldc = d->N; p.out_f32 = 1; p.accumulate = 0; p.alpha = 1.f;
+    p.bias = nullptr; p.res = nullptr; p.aux = nullptr; p.pre = nullptr; p.gate = nullptr; p.act = 0; p.dact = 0; p.pre_deriv = 0;
+  }
   hipStream_t s = (hipStream_t)stream;
   int a = d->a_kstrided, b = d->b_kstrided;
-#define L3(AK, BK_) do { if (bn == 256) launch3<AK, BK_, 256>(p, s); else launch3<AK, BK_, 128>(p, s); } while (0)
+#define L3(AK, BK_) do { if (bn == 256) launch3<AK, BK_, 256>(p, s, slices); else launch3<AK, BK_, 128>(p, s, slices); } while (0)
   if (!a && !b) L3(false, false); else if (!a && b) L3(false, true); else if (a && b) L3(true, true); else L3(true, false);
 #undef L3
   return 1;

@@ -15,6 +15,7 @@ struct Gemm2Params {
   float alpha;
   int act, dact, out_f32, accumulate, pre_deriv;
   int nbm, nbn;
+  int ksplit;                       // > 0 (gemm3 only): blockIdx.y reduces k in [y*ksplit, (y+1)*ksplit) into f32 slab y of C
 };
 
 static __device__ uint4 g_zero16[4];      // zero-initialised: source of every out-of-range LDS-DMA chunk

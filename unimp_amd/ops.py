@@ -134,11 +134,13 @@ def gemm(a, b, *, a_ks=False, b_ks=False, bias=None, act=None, res=None, aux=Non
     d.pre_deriv = int(pre_deriv)
     plain = bias is None and res is None and aux is None and pre is None and act is None and dact is None and not accumulate
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    tiles256 = ((M + 255) // 256) * ((N + 255) // 256)
     if variant is None and M <= 64 and not a_ks and not b_ks and K % 64 == 0:
         variant = 6                      # decode rows: the weight-streaming kernel, any epilogue
-    if variant is None and plain and tiles <= 96 and K >= 2048 and N % 4 == 0 and out.stride(0) % 4 == 0:
+    wide = M >= 256 and N >= 256                 # the split-K entry point then uses 256 x 256 ping-pong tiles
+    if variant is None and plain and (tiles256 <= 128 if wide else tiles <= 96) and K >= 2048 and N % 4 == 0 and out.stride(0) % 4 == 0:
         # weight gradient of a narrow projection: far fewer tiles than CUs, very deep K -> split-K over the chip
-        splits = max(2, min(32, 320 // tiles, K // 512))
+        splits = max(2, min(32, 512 // tiles256, K // 1024)) if wide else max(2, min(32, 320 // tiles, K // 512))
         slabs = torch.empty((splits, M, N), dtype=torch.float32, device=a.device)
         if GEMM_PROFILE is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
