@@ -132,7 +132,10 @@ def _frozen_t(w):
     return c[1]
 
 
-FROZEN_WT = True         # use the transposed copy for frozen MLP weights (costs one extra copy of them in HBM)
+import os as _os
+_FW = int(_os.environ.get("UNIMP_FROZEN_WT", "1"))
+FROZEN_WT = _FW >= 1      # use the transposed copy for frozen MLP weights (costs one extra copy of them in HBM)
+FROZEN_WT_ATTN = _FW >= 2    # same for the frozen qkv / attention-out projections
 
 
 # ----------------------------------------------------------------------------------------------- MLP sub-block
@@ -229,14 +232,16 @@ class SelfAttnBlockFn(Function):
         x2 = x.reshape(B * L, H)
         r2 = x2 if res is None else res.reshape(B * L, H)
         h, mean, rstd = ops.layernorm_fwd(x2, ln_w, ln_b, eps, rms=rms)
-        qkv = ops.gemm(h, wqkv, bias=bqkv)
+        tq = FROZEN_WT_ATTN and not wqkv.requires_grad and B * L >= 1024
+        td = FROZEN_WT_ATTN and not wd.requires_grad and B * L >= 1024
+        qkv = ops.gemm(h, _frozen_t(wqkv) if tq else wqkv, b_ks=tq, bias=bqkv)
         q, k, v, hs, offs = _split_qkv(qkv, B, L, nh, hd, interleaved)
         if rope is not None:
             cos, sin, rot = rope
             ops.rope_(qkv, L, nh, hs, rot, offs, cos, sin)
         o, lse = ops.attn_fwd(q, k, v, q_scale, ops.MASK_CAUSAL if causal else ops.MASK_NONE, kv_len, alibi=alibi)
         o2 = o.view(B * L, H)
-        out = ops.gemm(o2, wd, bias=bd, res=r2)
+        out = ops.gemm(o2, _frozen_t(wd) if td else wd, b_ks=td, bias=bd, res=r2)
         ctx.save_for_backward(x2, ln_w, mean, rstd, wqkv, wd, qkv, o, lse, kv_len, h if wqkv.requires_grad else None,
                               rope[0] if rope is not None else None, rope[1] if rope is not None else None, alibi)
         ctx.cfg = (B, L, H, nh, hd, interleaved, causal, rms, q_scale, rope[2] if rope is not None else 0, res is None,
