@@ -111,6 +111,31 @@ def test_gemm_persistent_many_tiles_per_workgroup(ops):
         assert torch.equal(got, want), f"pp256p != pp256 for layout {a_ks}{b_ks}"
 
 
+def test_gemm_ragged_n_padded_rows(ops):
+    """N % 8 != 0 with row strides padded to a multiple of 8 (the 74 053-column LM head): full 8-column groups take the vector
+    epilogue, the last partial group is written element by element; nothing beyond column N - 1 is touched."""
+    M, N, K, ld = 1100, 1003, 200, 1008
+    a, b, bias = rnd(M, K, seed=21), rnd(N, K, seed=22, scale=0.2), rnd(N, seed=23)
+    res = rnd(M, N, seed=24)
+    z = a.float() @ b.float().t() + bias.float()
+    resp = torch.zeros(M, ld, dtype=bf16); resp[:, :N] = res
+    for variant in ("pp256", "pp128", "w8", "pp256p", "v1"):
+        for kw, want in ((dict(), z), (dict(act="gelu"), act_ref("gelu", z)), (dict(res=resp.cuda()[:, :N]), z + res.float())):
+            buf = torch.full((M, ld), 7.0, dtype=bf16, device="cuda")
+            got = ops.gemm(a.cuda(), b.cuda(), bias=bias.cuda(), out=buf[:, :N], variant=variant, **kw)
+            close(got, want, name=f"ragged N [{variant}] {sorted(kw)}")
+            assert torch.all(buf[:, N:] == 7.0), f"{variant}: wrote past column N"
+        pre = torch.full((M, ld), 7.0, dtype=bf16, device="cuda")
+        buf = torch.full((M, ld), 7.0, dtype=bf16, device="cuda")
+        ops.gemm(a.cuda(), b.cuda(), bias=bias.cuda(), act="gelu", pre=pre[:, :N], out=buf[:, :N], variant=variant)
+        close(pre[:, :N], z, name=f"ragged N pre [{variant}]")
+        assert torch.all(pre[:, N:] == 7.0) and torch.all(buf[:, N:] == 7.0)
+    f32 = torch.full((M, ld), 7.0, dtype=torch.float32, device="cuda")
+    got = ops.gemm(a.cuda(), b.cuda(), out=f32[:, :N], variant="pp256")
+    close(got, a.float() @ b.float().t(), rel=1e-5, name="ragged N f32")
+    assert torch.all(f32[:, N:] == 7.0)
+
+
 def test_gemm_asymmetric_identity(ops):
     """A = I with an asymmetric B catches a transposed C write (cdna guide §3)."""
     n = 128

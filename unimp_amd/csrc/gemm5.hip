@@ -111,7 +111,7 @@ __global__ __launch_bounds__(512, 2) void gemm5_bf16_kernel(Gemm2Params p) {
   char* er = smem + wave * (64 * ESTR);
   float gate = 1.f;
   if (p.gate) gate = tanhf(bf2f(*p.gate));
-  bool fast = ((p.N & 7) == 0) && (((p.ldc | p.ldres | p.ldaux | p.ldpre) & 7) == 0);
+  bool fast = ((p.ldc | p.ldres | p.ldaux | p.ldpre) & 7) == 0;      // N may be ragged: only its last 8-column group is element-wise
   // the two 64-row passes are written out (a loop the compiler declines to unroll would index acc at run time and
   // demote the whole accumulator array to scratch)
 #define EPI_STAGE(PASS) do {                                                                                      \

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(512, 2) void gemm6_bf16_kernel(Gemm2Params p) {
     char* er = smem + PD * SUB + wave * (32 * ESTR);        // slot 3 + the spare 32 KiB: 8 KiB per wave
     float gate = 1.f;
     if (p.gate) gate = tanhf(bf2f(*p.gate));
-    bool fast = ((p.N & 7) == 0) && (((p.ldc | p.ldres | p.ldaux | p.ldpre) & 7) == 0);
+    bool fast = ((p.ldc | p.ldres | p.ldaux | p.ldpre) & 7) == 0;      // N may be ragged: only its last 8-column group is element-wise
 #define EPI_STAGE(SP) do {                                                                                         \
     _Pragma("unroll") for (int i2 = 0; i2 < 2; ++i2)                                                               \
       _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                           \

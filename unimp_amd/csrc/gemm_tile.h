@@ -118,7 +118,7 @@ __device__ __forceinline__ void epi_pass(const Gemm2Params& p, const char* er, i
     f32x4 x1 = *(const f32x4*)(er + row * ESTR + (((2 * cg + 1) ^ sw) << 4));
     if (m < p.M && n < p.N) {
       float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-      if (fast) epi8<true>(p, v, m, n, gate); else epi8<false>(p, v, m, n, gate);
+      if (fast && n + 8 <= p.N) epi8<true>(p, v, m, n, gate); else epi8<false>(p, v, m, n, gate);
     }
   }
 }
@@ -151,7 +151,13 @@ template <int WN>
 __device__ __forceinline__ bf16x8 epi_bias(const Gemm2Params& p, int lane, int nbase, int kind) {
   const int n = nbase + (lane % (WN / 8)) * 8;
   bf16x8 b = bf16x8{};
-  if (kind != EK_GENERIC && n < p.N && p.bias) b = *(const bf16x8*)(p.bias + n);
+  if (kind != EK_GENERIC && n < p.N && p.bias) {
+    if (n + 8 <= p.N) b = *(const bf16x8*)(p.bias + n);
+    else {                                                  // last, partial 8-column group of a ragged N (the 74 053-row LM head)
+#pragma unroll
+      for (int r = 0; r < 8; ++r) if (n + r < p.N) b[r] = p.bias[n + r];
+    }
+  }
   return b;
 }
 template <int WN, int ROWS = 64>
@@ -170,8 +176,17 @@ __device__ __forceinline__ void epi_fetch(const Gemm2Params& p, int lane, int mb
 // all epilogue inputs have landed; from here on only stores are in flight (vmcnt(0); expcnt / lgkmcnt untouched)
 __device__ __forceinline__ void epi_inputs_ready() { __builtin_amdgcn_s_waitcnt(0x0f70); }
 
+// 8 consecutive outputs of one row; nv < 8 only in the last column group of a ragged N (leading dimensions are multiples of 8, so
+// every full group is 16-byte aligned and the partial one is written element by element)
+__device__ __forceinline__ void store8(bf16* d, bf16x8 o, int nv) {
+  if (nv == 8) *(bf16x8*)d = o;
+  else {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) if (r < nv) d[r] = o[r];
+  }
+}
 template <int KIND>
-__device__ __forceinline__ void epi8k(const Gemm2Params& p, float (&v)[8], int m, int n, float gate, bf16x8 x, bf16x8 biasv) {
+__device__ __forceinline__ void epi8k(const Gemm2Params& p, float (&v)[8], int m, int n, float gate, bf16x8 x, bf16x8 biasv, int nv) {
 #pragma unroll
   for (int r = 0; r < 8; ++r) v[r] *= p.alpha;
   if (p.bias) {
@@ -190,7 +205,7 @@ __device__ __forceinline__ void epi8k(const Gemm2Params& p, float (&v)[8], int m
       bf16x8 o;
 #pragma unroll
       for (int r = 0; r < 8; ++r) o[r] = f2bf(dv[r]);
-      *(bf16x8*)(p.pre + (long)m * p.ldpre + n) = o;
+      store8(p.pre + (long)m * p.ldpre + n, o, nv);
     } else act_fwd_n<8>(p.act, v);
   }
   if (KIND == EK_AUX) {
@@ -203,12 +218,16 @@ __device__ __forceinline__ void epi8k(const Gemm2Params& p, float (&v)[8], int m
   }
   if (p.out_f32) {
     float* d = (float*)p.C + (long)m * p.ldc + n;
-    *(f32x4*)d = f32x4{v[0], v[1], v[2], v[3]}; *(f32x4*)(d + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    if (nv == 8) { *(f32x4*)d = f32x4{v[0], v[1], v[2], v[3]}; *(f32x4*)(d + 4) = f32x4{v[4], v[5], v[6], v[7]}; }
+    else {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) if (r < nv) d[r] = v[r];
+    }
   } else {
     bf16x8 o;
 #pragma unroll
     for (int r = 0; r < 8; ++r) o[r] = f2bf(v[r]);
-    *(bf16x8*)((bf16*)p.C + (long)m * p.ldc + n) = o;
+    store8((bf16*)p.C + (long)m * p.ldc + n, o, nv);
   }
 }
 template <int WN, int KIND, int ROWS = 64>
@@ -217,13 +236,14 @@ __device__ __forceinline__ void epi_groups(const Gemm2Params& p, const char* er,
   constexpr int ESTR = WN * 4, UNITS = WN / 4, LPR = EpiPre<WN, ROWS>::LPR, RPI = EpiPre<WN, ROWS>::RPI, NIT = EpiPre<WN, ROWS>::NIT;
   const int cg = lane % LPR, n = nbase + cg * 8;
   if (n >= p.N) return;
+  const int nv = min(8, p.N - n);
 #define EPI_GROUP(U_, X_) do {                                                                                     \
     int row = (U_) * RPI + lane / LPR, m = mbase + row, sw = row & (UNITS - 1);                                    \
     f32x4 x0 = *(const f32x4*)(er + row * ESTR + (((2 * cg) ^ sw) << 4));                                          \
     f32x4 x1 = *(const f32x4*)(er + row * ESTR + (((2 * cg + 1) ^ sw) << 4));                                      \
     if (m < p.M) {                                                                                                 \
       float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};                                       \
-      epi8k<KIND>(p, v, m, n, gate, (X_), biasv);                                                                  \
+      epi8k<KIND>(p, v, m, n, gate, (X_), biasv, nv);                                                              \
     } } while (0)
   if (KIND == EK_AUX || KIND == EK_RES) {
 #pragma unroll
