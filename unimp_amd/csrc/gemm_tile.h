@@ -26,17 +26,19 @@ __device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
 }
 
 // 8 consecutive columns of one output row.  PRE: the caller already fetched this row group's aux / res chunks (FAST only).
+// alpha / bias / gate / residual use explicitly rounded multiplies and adds (no fma contraction): every kernel variant and
+// every epilogue form must produce the same bits, or the result of a sample would depend on which variant its batch size tuned to.
 template <bool FAST, bool PRE = false>
 __device__ __forceinline__ void epi8(const Gemm2Params& p, float (&v)[8], int m, int n, float gate,
                                      bf16x8 auxv = bf16x8{}, bf16x8 resv = bf16x8{}, bf16x8 biasv = bf16x8{}) {
   int nv = FAST ? 8 : min(8, p.N - n);
 #pragma unroll
-  for (int r = 0; r < 8; ++r) v[r] *= p.alpha;
+  for (int r = 0; r < 8; ++r) v[r] = __fmul_rn(v[r], p.alpha);
   if (p.bias) {
     if (FAST) { bf16x8 b = PRE ? biasv : *(const bf16x8*)(p.bias + n);
 #pragma unroll
-      for (int r = 0; r < 8; ++r) v[r] += bf2f(b[r]); }
-    else { for (int r = 0; r < nv; ++r) v[r] += bf2f(p.bias[n + r]); }
+      for (int r = 0; r < 8; ++r) v[r] = __fadd_rn(v[r], bf2f(b[r])); }
+    else { for (int r = 0; r < nv; ++r) v[r] = __fadd_rn(v[r], bf2f(p.bias[n + r])); }
   }
   if (p.pre && p.pre_deriv) {                 // y = act(v) and act'(v) from one exponential; store the derivative
     float dv[8];
@@ -68,13 +70,13 @@ __device__ __forceinline__ void epi8(const Gemm2Params& p, float (&v)[8], int m,
     else { for (int r = 0; r < nv; ++r) v[r] *= act_bwd(p.dact, bf2f(s[r])); }
   }
 #pragma unroll
-  for (int r = 0; r < 8; ++r) v[r] *= gate;
+  for (int r = 0; r < 8; ++r) v[r] = __fmul_rn(v[r], gate);
   if (p.res) {
     const bf16* s = p.res + (long)m * p.ldres + n;
     if (FAST) { bf16x8 x = PRE ? resv : *(const bf16x8*)s;
 #pragma unroll
-      for (int r = 0; r < 8; ++r) v[r] += bf2f(x[r]); }
-    else { for (int r = 0; r < nv; ++r) v[r] += bf2f(s[r]); }
+      for (int r = 0; r < 8; ++r) v[r] = __fadd_rn(v[r], bf2f(x[r])); }
+    else { for (int r = 0; r < nv; ++r) v[r] = __fadd_rn(v[r], bf2f(s[r])); }
   }
 #ifdef G3_NOSTORE
   if (gate != 12345.f) return;
@@ -188,10 +190,10 @@ __device__ __forceinline__ void store8(bf16* d, bf16x8 o, int nv) {
 template <int KIND>
 __device__ __forceinline__ void epi8k(const Gemm2Params& p, float (&v)[8], int m, int n, float gate, bf16x8 x, bf16x8 biasv, int nv) {
 #pragma unroll
-  for (int r = 0; r < 8; ++r) v[r] *= p.alpha;
+  for (int r = 0; r < 8; ++r) v[r] = __fmul_rn(v[r], p.alpha);
   if (p.bias) {
 #pragma unroll
-    for (int r = 0; r < 8; ++r) v[r] += bf2f(biasv[r]);
+    for (int r = 0; r < 8; ++r) v[r] = __fadd_rn(v[r], bf2f(biasv[r]));
   }
   if (KIND == EK_ACT) {
     if (p.pre) {
@@ -214,7 +216,7 @@ __device__ __forceinline__ void epi8k(const Gemm2Params& p, float (&v)[8], int m
   }
   if (KIND == EK_RES) {
 #pragma unroll
-    for (int r = 0; r < 8; ++r) v[r] = v[r] * gate + bf2f(x[r]);
+    for (int r = 0; r < 8; ++r) v[r] = __fadd_rn(__fmul_rn(v[r], gate), bf2f(x[r]));
   }
   if (p.out_f32) {
     float* d = (float*)p.C + (long)m * p.ldc + n;

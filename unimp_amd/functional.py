@@ -133,7 +133,8 @@ def _frozen_t(w):
 
 
 import os as _os
-_FW = int(_os.environ.get("UNIMP_FROZEN_WT", "1"))
+_FW = int(_os.environ.get("UNIMP_FROZEN_WT", "0"))   # opt-in: +0.8 % on the step, but a k-strided weight operand is summed in a different
+# order inside the MFMA by the 128x128 and the 256-row kernels, so a sample's bits would depend on which variant its batch size tuned to
 FROZEN_WT = _FW >= 1      # use the transposed copy for frozen MLP weights (costs one extra copy of them in HBM)
 FROZEN_WT_ATTN = _FW >= 2    # same for the frozen qkv / attention-out projections
 
@@ -149,13 +150,15 @@ class MLPBlockFn(Function):
         r2 = x2 if res is None else res.reshape(-1, shp[-1])
         h, mean, rstd = ops.layernorm_fwd(x2, ln_w, ln_b, eps)
         M, F = x2.shape[0], w1.shape[0]
-        pre = torch.empty((M, F), dtype=bf16, device=x.device)
         w1g, w2g = w1.requires_grad, w2.requires_grad
-        t1, t2 = FROZEN_WT and not w1g and M >= 1024, FROZEN_WT and not w2g and M >= 1024
-        a = ops.gemm(h, _frozen_t(w1) if t1 else w1, b_ks=t1, bias=b1, act=act, pre=pre, pre_deriv=True)   # pre <- act'(z): backward needs no transcendental
-        raw = torch.empty_like(x2) if gate is not None else None
+        bwd = any(ctx.needs_input_grad)            # frozen tower on constant inputs (the ViT): no act'(z) output, nothing saved
+        pre = torch.empty((M, F), dtype=bf16, device=x.device) if bwd else None
+        t1, t2 = FROZEN_WT and not w1g and M > 64, FROZEN_WT and not w2g and M > 64      # M <= 64: the weight-streaming decode kernel
+        a = ops.gemm(h, _frozen_t(w1) if t1 else w1, b_ks=t1, bias=b1, act=act, pre=pre, pre_deriv=bwd)   # pre <- act'(z): backward needs no transcendental
+        raw = torch.empty_like(x2) if gate is not None and bwd else None
         out = ops.gemm(a, _frozen_t(w2) if t2 else w2, b_ks=t2, bias=b2, gate=gate, res=r2, pre=raw)
-        ctx.save_for_backward(x2, ln_w, mean, rstd, w1, w2, gate, pre, h if w1g else None, a if w2g else None, raw)
+        if bwd:
+            ctx.save_for_backward(x2, ln_w, mean, rstd, w1, w2, gate, pre, h if w1g else None, a if w2g else None, raw)
         ctx.act, ctx.shp, ctx.res_is_x, ctx.has_lnb = act, shp, res is None, ln_b is not None
         return out.view(shp)
 

@@ -137,7 +137,8 @@ def gemm(a, b, *, a_ks=False, b_ks=False, bias=None, act=None, res=None, aux=Non
     tiles256 = ((M + 255) // 256) * ((N + 255) // 256)
     if variant is None and M <= 64 and not a_ks and not b_ks and K % 64 == 0:
         variant = 6                      # decode rows: the weight-streaming kernel, any epilogue
-    wide = M >= 256 and N >= 256                 # the split-K entry point then uses 256 x 256 ping-pong tiles
+    wide = M >= 256 and N >= 256 and a_ks and b_ks   # weight-gradient form only (a forward GEMM of a small batch must not change
+    #                                                  its summation order with the batch size); 256 x 256 ping-pong tiles under split-K
     if variant is None and plain and (tiles256 <= 128 if wide else tiles <= 96) and K >= 2048 and N % 4 == 0 and out.stride(0) % 4 == 0:
         # weight gradient of a narrow projection: far fewer tiles than CUs, very deep K -> split-K over the chip
         splits = max(2, min(32, 512 // tiles256, K // 1024)) if wide else max(2, min(32, 320 // tiles, K // 512))
