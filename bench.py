@@ -208,7 +208,7 @@ def main():
                 note = (f"rocprofv3 --pmc FETCH_SIZE(x2, gfx950 correction)+WRITE_SIZE per launch of {j['kernel']} at M,N,K={j['shape']} "
                         f"(algorithmic {(j['shape'][0] * j['shape'][2] + j['shape'][1] * j['shape'][2] + j['shape'][0] * j['shape'][1]) * 2} B; "
                         f"L2-to-fabric requests incl. Infinity-Cache hits); MFMA pipe busy {j['mfma_util']:.3f} of SIMD cycles; {j['source']}")
-            roofline = {"bound": "mfma", "kernel": "gemm3_bf16_kernel (256-row ping-pong) + variants, all GEMM launches of the step",
+            roofline = {"bound": "mfma", "kernel": "256x256-tile bf16 MFMA GEMMs (gemm3 ping-pong, gemm6 persistent ping-pong, gemm5 8-wave; autotuned per shape), all GEMM launches of the step",
                         "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_note": note,
                         "lm_xattn_gemms": {"achieved": round(lm_ach, 2), "frac": round(lm_ach / PEAK_BF16_TFLOPS, 4),
