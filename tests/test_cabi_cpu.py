@@ -93,3 +93,42 @@ def test_kernel_register_budgets():
         assert r["ScratchSize"] == 0, (k, r)
         if "attn_dq" not in k:                                  # dQ holds two 32-row blocks of q, dO, dq: one wave per SIMD by design
             assert r["Occupancy"] >= 2, (k, r)
+
+
+def test_gemm_kernel_code_fits_the_instruction_cache():
+    """The large-tile GEMM kernels must stay inside the 64 KiB instruction cache two CUs share: with the row-group loop of
+    the epilogue unrolled around the fully general per-element code they were 191 KiB, and a 256 x 256 tile spent 15 us in its
+    epilogue.  Also: the persistent kernel keeps two waves per SIMD and only its epilogue may touch scratch."""
+    import os
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    bundler, readelf = "/opt/rocm/lib/llvm/bin/clang-offload-bundler", "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not (os.path.exists(hipcc) and os.path.exists(bundler) and os.path.exists(readelf)):
+        import pytest
+        pytest.skip("no hipcc / llvm tools")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "unimp_amd", "csrc")
+    with tempfile.TemporaryDirectory() as tmp:
+        for name in ("gemm3", "gemm5", "gemm6"):
+            obj, hsaco = os.path.join(tmp, name + ".o"), os.path.join(tmp, name + ".hsaco")
+            r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form", f"-I{root}/include",
+                                f"-I{src}", "-c", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-o", obj,
+                                os.path.join(src, name + ".hip")], capture_output=True, text=True, timeout=900)
+            assert r.returncode == 0, r.stderr[-2000:]
+            subprocess.run([bundler, "--unbundle", "--type=o", f"--input={obj}", "--targets=hip-amdgcn-amd-amdhsa--gfx950",
+                            f"--output={hsaco}"], check=True, capture_output=True)
+            syms = subprocess.run([readelf, "-s", hsaco], capture_output=True, text=True, check=True).stdout
+            sizes = {m.group(2): int(m.group(1)) for m in re.finditer(r"^\s*\d+:\s+[0-9a-f]+\s+(\d+)\s+FUNC\s+\S+\s+\S+\s+\S+\s+(\S+)", syms, re.M)}
+            kern = {k: v for k, v in sizes.items() if "bf16_kernel" in k}
+            assert kern, syms[:500]
+            # gemm6 instantiates every epilogue kind for each of its four 32-row sub-passes; a tile executes one kind only
+            limit = (112 if name == "gemm6" else 64) * 1024
+            for k, v in kern.items():
+                assert v <= limit, (k, v)
+            if name == "gemm6":
+                occ = [int(x) for x in re.findall(r"Occupancy \[waves/SIMD\]: (\d+)", r.stderr)]
+                scr = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stderr)]
+                assert occ and min(occ) >= 2 and max(scr) <= 512, (occ, scr)

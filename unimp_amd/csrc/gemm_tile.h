@@ -153,13 +153,7 @@ template <int WN>
 __device__ __forceinline__ bf16x8 epi_bias(const Gemm2Params& p, int lane, int nbase, int kind) {
   const int n = nbase + (lane % (WN / 8)) * 8;
   bf16x8 b = bf16x8{};
-  if (kind != EK_GENERIC && n < p.N && p.bias) {
-    if (n + 8 <= p.N) b = *(const bf16x8*)(p.bias + n);
-    else {                                                  // last, partial 8-column group of a ragged N (the 74 053-row LM head)
-#pragma unroll
-      for (int r = 0; r < 8; ++r) if (n + r < p.N) b[r] = p.bias[n + r];
-    }
-  }
+  if (kind != EK_GENERIC && n + 8 <= p.N && p.bias) b = *(const bf16x8*)(p.bias + n);      // a partial last group goes through epi8<false>
   return b;
 }
 template <int WN, int ROWS = 64>
@@ -178,17 +172,8 @@ __device__ __forceinline__ void epi_fetch(const Gemm2Params& p, int lane, int mb
 // all epilogue inputs have landed; from here on only stores are in flight (vmcnt(0); expcnt / lgkmcnt untouched)
 __device__ __forceinline__ void epi_inputs_ready() { __builtin_amdgcn_s_waitcnt(0x0f70); }
 
-// 8 consecutive outputs of one row; nv < 8 only in the last column group of a ragged N (leading dimensions are multiples of 8, so
-// every full group is 16-byte aligned and the partial one is written element by element)
-__device__ __forceinline__ void store8(bf16* d, bf16x8 o, int nv) {
-  if (nv == 8) *(bf16x8*)d = o;
-  else {
-#pragma unroll
-    for (int r = 0; r < 8; ++r) if (r < nv) d[r] = o[r];
-  }
-}
 template <int KIND>
-__device__ __forceinline__ void epi8k(const Gemm2Params& p, float (&v)[8], int m, int n, float gate, bf16x8 x, bf16x8 biasv, int nv) {
+__device__ __forceinline__ void epi8k(const Gemm2Params& p, float (&v)[8], int m, int n, float gate, bf16x8 x, bf16x8 biasv) {
 #pragma unroll
   for (int r = 0; r < 8; ++r) v[r] = __fmul_rn(v[r], p.alpha);
   if (p.bias) {
@@ -207,7 +192,7 @@ __device__ __forceinline__ void epi8k(const Gemm2Params& p, float (&v)[8], int m
       bf16x8 o;
 #pragma unroll
       for (int r = 0; r < 8; ++r) o[r] = f2bf(dv[r]);
-      store8(p.pre + (long)m * p.ldpre + n, o, nv);
+      *(bf16x8*)(p.pre + (long)m * p.ldpre + n) = o;
     } else act_fwd_n<8>(p.act, v);
   }
   if (KIND == EK_AUX) {
@@ -220,16 +205,12 @@ __device__ __forceinline__ void epi8k(const Gemm2Params& p, float (&v)[8], int m
   }
   if (p.out_f32) {
     float* d = (float*)p.C + (long)m * p.ldc + n;
-    if (nv == 8) { *(f32x4*)d = f32x4{v[0], v[1], v[2], v[3]}; *(f32x4*)(d + 4) = f32x4{v[4], v[5], v[6], v[7]}; }
-    else {
-#pragma unroll
-      for (int r = 0; r < 8; ++r) if (r < nv) d[r] = v[r];
-    }
+    *(f32x4*)d = f32x4{v[0], v[1], v[2], v[3]}; *(f32x4*)(d + 4) = f32x4{v[4], v[5], v[6], v[7]};
   } else {
     bf16x8 o;
 #pragma unroll
     for (int r = 0; r < 8; ++r) o[r] = f2bf(v[r]);
-    store8((bf16*)p.C + (long)m * p.ldc + n, o, nv);
+    *(bf16x8*)((bf16*)p.C + (long)m * p.ldc + n) = o;
   }
 }
 template <int WN, int KIND, int ROWS = 64>
@@ -238,14 +219,14 @@ __device__ __forceinline__ void epi_groups(const Gemm2Params& p, const char* er,
   constexpr int ESTR = WN * 4, UNITS = WN / 4, LPR = EpiPre<WN, ROWS>::LPR, RPI = EpiPre<WN, ROWS>::RPI, NIT = EpiPre<WN, ROWS>::NIT;
   const int cg = lane % LPR, n = nbase + cg * 8;
   if (n >= p.N) return;
-  const int nv = min(8, p.N - n);
+  if (n + 8 > p.N) return;                // the partial last group of a ragged N is written by the generic path (epi_pass_kind)
 #define EPI_GROUP(U_, X_) do {                                                                                     \
     int row = (U_) * RPI + lane / LPR, m = mbase + row, sw = row & (UNITS - 1);                                    \
     f32x4 x0 = *(const f32x4*)(er + row * ESTR + (((2 * cg) ^ sw) << 4));                                          \
     f32x4 x1 = *(const f32x4*)(er + row * ESTR + (((2 * cg + 1) ^ sw) << 4));                                      \
     if (m < p.M) {                                                                                                 \
       float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};                                       \
-      epi8k<KIND>(p, v, m, n, gate, (X_), biasv, nv);                                                              \
+      epi8k<KIND>(p, v, m, n, gate, (X_), biasv);                                                                  \
     } } while (0)
   if (KIND == EK_AUX || KIND == EK_RES) {
 #pragma unroll
@@ -263,11 +244,15 @@ __device__ __forceinline__ void epi_groups(const Gemm2Params& p, const char* er,
 template <int WN, int ROWS = 64>
 __device__ __forceinline__ void epi_pass_kind(const Gemm2Params& p, const char* er, int lane, int mbase, int nbase, float gate, bool fast,
                                               int kind, const EpiPre<WN, ROWS>& e, bf16x8 biasv) {
+  // generic form: the whole wave for EK_GENERIC; otherwise only the lanes that own the partial last 8-column group of a ragged N
+  // (the 74 053-column LM head) -- one copy of the general code serves both
+  const int n_ = nbase + (lane % (WN / 8)) * 8;
+  if (kind == EK_GENERIC || (n_ < p.N && n_ + 8 > p.N)) epi_pass<WN, ROWS>(p, er, lane, mbase, nbase, gate, fast);
   switch (kind) {
     case EK_PLAIN: epi_groups<WN, EK_PLAIN, ROWS>(p, er, lane, mbase, nbase, gate, e, biasv); break;
     case EK_ACT:   epi_groups<WN, EK_ACT, ROWS>(p, er, lane, mbase, nbase, gate, e, biasv); break;
     case EK_AUX:   epi_groups<WN, EK_AUX, ROWS>(p, er, lane, mbase, nbase, gate, e, biasv); break;
     case EK_RES:   epi_groups<WN, EK_RES, ROWS>(p, er, lane, mbase, nbase, gate, e, biasv); break;
-    default:       epi_pass<WN, ROWS>(p, er, lane, mbase, nbase, gate, fast);
+    default: break;
   }
 }
