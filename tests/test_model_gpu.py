@@ -69,6 +69,41 @@ def test_forward_backward_parity(P, cfgname):
             assert n not in want_grads
 
 
+def test_frozen_weight_transposed_copy_matches_default(P, monkeypatch):
+    """opt-in UNIMP_FROZEN_WT: the forward MLP GEMMs of frozen towers read a cached W^T.  Same logits / loss / gradients as the
+    default layout up to the summation order inside the MFMA, and the copy follows an in-place weight update."""
+    from unimp_amd import functional as F_
+    from unimp_amd.train import Trainer
+    cfg = P.TINY
+    om, layout = P.build_oracle(cfg)
+    batch = {k: v.cuda() for k, v in P.make_batch(cfg, layout).items()}
+    res = {}
+    for flag in (False, True):
+        monkeypatch.setattr(F_, "FROZEN_WT", flag)
+        hm = P.build_hip(cfg, om, layout)
+        tr = Trainer(hm, layout.special(), lr=1e-3, gamma=2.0, use_reweight=True)
+        hm.train()
+        loss, stats, out, labels = tr.forward_loss(batch)
+        loss.backward()
+        res[flag] = (out["logits"].float(), loss.item(), {n: p.grad.float().clone() for n, p in hm.named_parameters() if p.grad is not None})
+        if flag:                                     # a frozen weight rewritten in place: the cached copy must be rebuilt
+            frozen = [p for n, p in hm.named_parameters() if not p.requires_grad and hasattr(p, "_unimp_wt")]
+            assert frozen, "no frozen MLP weight took the transposed path"
+            with torch.no_grad():
+                for p_ in frozen:
+                    p_.mul_(0.5)
+                again = hm(batch["vision_x"], batch["lang_x"], batch["attention_mask"])["logits"].float()
+            monkeypatch.setattr(F_, "FROZEN_WT", False)
+            with torch.no_grad():
+                ref = hm(batch["vision_x"], batch["lang_x"], batch["attention_mask"])["logits"].float()
+            assert P.rel_l2(again, ref) <= 5e-3 and P.rel_l2(again, res[True][0]) > 1e-2
+    assert P.rel_l2(res[True][0], res[False][0]) <= 5e-3
+    assert abs(res[True][1] - res[False][1]) <= 2e-3 * abs(res[False][1])
+    for n, g in res[False][2].items():
+        if g.abs().max() > 0:
+            assert P.rel_l2(res[True][2][n], g) <= 3e-2, n
+
+
 def test_train_steps_match_oracle_adamw(P):
     """3 optimizer steps (clip 1.0 + AdamW with the reference's decay grouping) vs the oracle's update rule."""
     from unimp_amd.train import Trainer
