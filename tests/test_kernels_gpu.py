@@ -179,6 +179,12 @@ def test_gemm_epilogue_gate_res_dact_accum(ops, M):
     want = z * math.tanh(float(gate.float())) + res.float()
     got = ops.gemm(a.cuda(), b.cuda(), gate=gate.cuda(), res=res.cuda())
     close(got, want, name="gate+res")
+    bias = rnd(N, seed=10)
+    for variant in (["v1"] if M < 256 else ["v1", "pp256", "pp128", "w8", "pp256p", "dma128"]):   # gated block: raw (pre-gate) second output
+        raw = torch.empty(M, N, dtype=bf16, device="cuda")
+        got = ops.gemm(a.cuda(), b.cuda(), bias=bias.cuda(), gate=gate.cuda(), res=res.cuda(), pre=raw, variant=variant)
+        close(raw, z + bias.float(), name=f"raw [{variant}]")
+        close(got, (z + bias.float()) * math.tanh(float(gate.float())) + res.float(), name=f"gate+res+raw [{variant}]")
     x = aux.float().requires_grad_(True)
     torch.nn.functional.gelu(x).sum().backward()
     got = ops.gemm(a.cuda(), b.cuda(), aux=aux.cuda(), dact="gelu")

@@ -130,7 +130,7 @@ __device__ __forceinline__ void epi_pass(const Gemm2Params& p, const char* er, i
 //   EK_PLAIN  alpha (+bias)                                   -> C                 (qkv, dX of plain linears, weight gradients)
 //   EK_ACT    alpha (+bias), act, optional second output      -> C, pre            (MLP up-projection: act(z) and z or act'(z))
 //   EK_AUX    alpha (+bias), x stored act'(z)                 -> C                 (dX through the activation)
-//   EK_RES    alpha (+bias), x tanh(gate), + residual         -> C                 (attention-out / MLP down-projection, gated xattn)
+//   EK_RES    alpha (+bias), x tanh(gate), + residual         -> C (, raw pre)     (attention-out / MLP down-projection, gated xattn)
 // Every global load (bias, aux / residual chunks) is issued by epi_fetch() BEFORE the accumulators are staged and waited for
 // once (epi_inputs_ready) before the first store: a load consumed inside the store loop makes hipcc emit `s_waitcnt vmcnt(0)`
 // there (it cannot count in-flight stores across branches), which also waits for the previous row group's store to be
@@ -140,7 +140,7 @@ enum { EK_PLAIN = 0, EK_ACT = 1, EK_AUX = 2, EK_RES = 3, EK_GENERIC = 4 };
 __device__ __forceinline__ int epi_kind(const Gemm2Params& p, bool fast) {
   if (!fast || p.accumulate || (p.aux && p.res)) return EK_GENERIC;
   if (p.aux) return (p.dact == ACT_DERIV && !p.act && !p.pre && !p.gate) ? EK_AUX : EK_GENERIC;
-  if (p.res) return (!p.act && !p.pre) ? EK_RES : EK_GENERIC;
+  if (p.res) return (!p.act && !(p.pre && p.pre_deriv)) ? EK_RES : EK_GENERIC;     // a raw (pre-gate) second output is part of EK_RES
   if (p.gate) return EK_GENERIC;
   return (p.act || p.pre) ? EK_ACT : EK_PLAIN;
 }
@@ -200,6 +200,12 @@ __device__ __forceinline__ void epi8k(const Gemm2Params& p, float (&v)[8], int m
     for (int r = 0; r < 8; ++r) v[r] *= bf2f(x[r]);
   }
   if (KIND == EK_RES) {
+    if (p.pre) {                            // gated blocks keep the un-gated value for the gate's gradient
+      bf16x8 o;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) o[r] = f2bf(v[r]);
+      *(bf16x8*)(p.pre + (long)m * p.ldpre + n) = o;
+    }
 #pragma unroll
     for (int r = 0; r < 8; ++r) v[r] = __fadd_rn(__fmul_rn(v[r], gate), bf2f(x[r]));
   }
