@@ -185,6 +185,14 @@ def test_gemm_epilogue_gate_res_dact_accum(ops, M):
         got = ops.gemm(a.cuda(), b.cuda(), bias=bias.cuda(), gate=gate.cuda(), res=res.cuda(), pre=raw, variant=variant)
         close(raw, z + bias.float(), name=f"raw [{variant}]")
         close(got, (z + bias.float()) * math.tanh(float(gate.float())) + res.float(), name=f"gate+res+raw [{variant}]")
+    tg = math.tanh(float(gate.float()))
+    for variant in (["v1"] if M < 256 else ["v1", "pp256", "pp128", "w8", "pp256p", "dma128"]):   # tanh(gate) without a residual: the
+        got = ops.gemm(a.cuda(), b.cuda(), gate=gate.cuda(), variant=variant)                      # gated block's dX / dW GEMMs
+        close(got, z * tg, name=f"gate only [{variant}]")
+        got = ops.gemm(a.cuda(), b.cuda(), gate=gate.cuda(), aux=aux.cuda(), dact="deriv", variant=variant)
+        close(got, z * aux.float() * tg, name=f"aux deriv + gate [{variant}]")
+        got = ops.gemm(a.cuda(), b.cuda(), bias=bias.cuda(), act="gelu", gate=gate.cuda(), variant=variant)
+        close(got, act_ref("gelu", z + bias.float()) * tg, name=f"act + gate [{variant}]")
     x = aux.float().requires_grad_(True)
     torch.nn.functional.gelu(x).sum().backward()
     got = ops.gemm(a.cuda(), b.cuda(), aux=aux.cuda(), dact="gelu")

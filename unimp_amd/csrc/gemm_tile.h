@@ -139,10 +139,9 @@ __device__ __forceinline__ void epi_pass(const Gemm2Params& p, const char* er, i
 enum { EK_PLAIN = 0, EK_ACT = 1, EK_AUX = 2, EK_RES = 3, EK_GENERIC = 4 };
 __device__ __forceinline__ int epi_kind(const Gemm2Params& p, bool fast) {
   if (!fast || p.accumulate || (p.aux && p.res)) return EK_GENERIC;
-  if (p.aux) return (p.dact == ACT_DERIV && !p.act && !p.pre && !p.gate) ? EK_AUX : EK_GENERIC;
+  if (p.aux) return (p.dact == ACT_DERIV && !p.act && !p.pre) ? EK_AUX : EK_GENERIC;
   if (p.res) return (!p.act && !(p.pre && p.pre_deriv)) ? EK_RES : EK_GENERIC;     // a raw (pre-gate) second output is part of EK_RES
-  if (p.gate) return EK_GENERIC;
-  return (p.act || p.pre) ? EK_ACT : EK_PLAIN;
+  return (p.act || p.pre) ? EK_ACT : EK_PLAIN;                                        // every kind applies tanh(gate) (1 when absent)
 }
 template <int WN, int ROWS = 64>
 struct EpiPre {
@@ -198,6 +197,10 @@ __device__ __forceinline__ void epi8k(const Gemm2Params& p, float (&v)[8], int m
   if (KIND == EK_AUX) {
 #pragma unroll
     for (int r = 0; r < 8; ++r) v[r] *= bf2f(x[r]);
+  }
+  if (KIND != EK_RES) {                       // the gated cross-attention's dX / dW GEMMs: x tanh(gate), after act / aux like the general form
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = __fmul_rn(v[r], gate);
   }
   if (KIND == EK_RES) {
     if (p.pre) {                            // gated blocks keep the un-gated value for the gate's gradient
