@@ -78,9 +78,6 @@ __device__ __forceinline__ void epi8(const Gemm2Params& p, float (&v)[8], int m,
       for (int r = 0; r < 8; ++r) v[r] = __fadd_rn(v[r], bf2f(x[r])); }
     else { for (int r = 0; r < nv; ++r) v[r] = __fadd_rn(v[r], bf2f(s[r])); }
   }
-#ifdef G3_NOSTORE
-  if (gate != 12345.f) return;
-#endif
   if (p.out_f32) {
     float* d = (float*)p.C + (long)m * p.ldc + n;
     if (FAST) {
