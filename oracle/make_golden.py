@@ -258,9 +258,34 @@ def gen_hf_towers():
         print("mpt_tiny", heads, tuple(lg.shape))
 
 
+# ------------------------------------------------------------------ 5. checkpoint format (F3)
+def gen_checkpoint():
+    """the reference's OWN ``get_checkpoint`` (UniMP/pipeline/train/train_utils.py:258-265, what mmrec.py:873-892 saves) applied
+    to the oracle Flamingo (module tree / parameter names of open_flamingo) after the factory's freezing:
+    the key list, every tensor's shape and two small tensors -> checkpoint_keys.npz.  Note what the fixture pins: the
+    function deletes the frozen names ``named_parameters()`` yields -- the FIRST path of a shared module -- so the duplicate
+    paths (``old_decoder_blocks.*`` of the frozen LM blocks, ``gated_cross_attn_layers.*``) stay in the file."""
+    sys.path.insert(0, REF)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from pipeline.train.train_utils import get_checkpoint            # the reference's function, unmodified
+    import _parity as P
+    m, layout = P.build_oracle(P.TINY)
+    sd = get_checkpoint(m)
+    keys = sorted(sd)
+    pick = ["perceiver.latents", "lang_encoder.gated_cross_attn_layers.1.attn_gate"]
+    np.savez_compressed(os.path.join(OUT, "checkpoint_keys.npz"), keys=np.array(keys),
+                        shapes=np.array([",".join(map(str, sd[k].shape)) for k in keys]),
+                        n_named_trainable=np.array(sum(1 for _, p in m.named_parameters() if p.requires_grad)),
+                        **{"t." + k: sd[k].detach().numpy() for k in pick})
+    print("checkpoint_keys", len(keys), "keys;", sum("old_decoder_blocks" in k for k in keys), "under old_decoder_blocks")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["hf", "intree", "train"]
+    which = sys.argv[1:] or ["hf", "intree", "ckpt", "train"]
+    if "ckpt" in which:
+        gen_checkpoint()
     if "hf" in which:
         gen_hf_towers()
     if "intree" in which:

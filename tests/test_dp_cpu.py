@@ -30,7 +30,13 @@ class _FakeOpt:
             p.grad = self.flat_g[o:o + k].view(p.shape)
 
     def _reattach(self):
-        pass
+        for n, p, o, k in self.layout:
+            g, view = p.grad, self.flat_g[o:o + k]
+            if g is None:
+                p.grad = view.view(p.shape)
+            elif g.data_ptr() != view.data_ptr():
+                view.add_(g.reshape(-1).to(view.dtype))
+                p.grad = view.view(p.shape)
 
 
 def _worker(rank, world, port, q):
@@ -66,8 +72,66 @@ def _worker(rank, world, port, q):
     g = [torch.empty_like(opt.flat_g) for _ in range(world)]
     dist.all_gather(g, opt.flat_g)
     assert all(torch.equal(g[0], t) for t in g)
+    # --- collective ORDER: rank 1 leaves p0 (bucket 0) without a gradient and computes the others in the
+    # opposite order; both ranks must still issue the same bucket sequence (gloo, like RCCL, pairs collectives by order)
+    opt.flat_g.zero_()
+    names = [n for n, _ in ps]
+    use = names if rank == 0 else names[:0:-1]                  # rank 1: p4, p3, p2, p1 -- never p0
+    loss = sum((dict(ps)[n].float() * x).sum() for n in use)
+    loss.backward()
+    dp.finish()
+    logs = [None] * world
+    dist.all_gather_object(logs, dp.last_launch_log)
+    assert logs[0] == logs[1] == sorted(logs[0]) and len(logs[0]) == len(dp.buckets), logs
+    assert torch.equal(ps[0][1].grad.float(), torch.full((300,), 1.0))           # only rank 0 contributed
+    assert torch.equal(ps[4][1].grad.float(), torch.full((2048,), 3.0))
+    # --- a stray gradient tensor (foreign code set .grad = None before backward): folded into the view inside the hook,
+    # before its bucket is reduced, so it is averaged like every other gradient
+    opt.flat_g.zero_()
+    ps[2][1].grad = None
+    loss = sum((p.float() * x).sum() for n, p in ps)
+    loss.backward()
+    dp.finish()
+    assert ps[2][1].grad.data_ptr() == opt.flat_g[opt.layout[2][2]:].data_ptr()
+    assert torch.equal(ps[2][1].grad.float(), torch.full((1000,), 3.0))
     q.put((rank, "ok"))
     dist.destroy_process_group()
+
+
+def _worker_late(rank, world, port, q):
+    """a tied (late) parameter in the FIRST bucket must not hold the others back, and goes out last on every rank."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from unimp_amd.dp import GradBucketer
+    torch.manual_seed(0)
+    ps = [(f"p{i}", torch.nn.Parameter(torch.randn(2048).to(torch.bfloat16))) for i in range(4)]
+    opt = _FakeOpt(ps)
+    dp = GradBucketer(opt, bucket_bytes=4096, late_params=[ps[0][1]])
+    assert len(dp.buckets) == 4
+    x = torch.full((), float(rank + 1))
+    seen = []
+    hook = ps[1][1].register_post_accumulate_grad_hook(lambda p: seen.append(list(dp.launch_log)))
+    loss = sum((p.float() * x).sum() for n, p in ps) + (ps[0][1].float() * x).sum()        # p0 used twice
+    loss.backward()
+    dp.finish()
+    hook.remove()
+    assert dp.last_launch_log[-1] == 0 and sorted(dp.last_launch_log[:-1]) == dp.last_launch_log[:-1] == [1, 2, 3]
+    assert torch.equal(ps[0][1].grad.float(), torch.full((2048,), 6.0))
+    q.put((rank, "ok"))
+    dist.destroy_process_group()
+
+
+def test_late_bucket_goes_last_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_late, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert sorted(q.get(timeout=5) for _ in range(world)) == [(0, "ok"), (1, "ok")]
 
 
 def test_bucketed_allreduce_world2():

@@ -82,3 +82,65 @@ def test_two_rank_step_on_one_gpu():
     for p in procs:
         p.join(60)
     assert all(r[1] == "ok" for r in res), res
+
+
+def _worker_rccl(q, port):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    try:
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))      # backend "nccl" IS RCCL on ROCm
+        assert dist.get_backend() == "nccl"
+        import _parity as P
+        from unimp_amd.train import Trainer
+        cfg = P.TINY
+        om, layout = P.build_oracle(cfg)
+        batches = [{k: v.cuda() for k, v in P.make_batch(cfg, layout, seed=300 + i).items()} for i in range(3)]
+        # production Trainer with the hooks forced on: every bucket of the flat bf16 gradient buffer goes through an async
+        # RCCL all_reduce issued from the autograd hooks, the compute stream waits for the communication stream in finish()
+        hm = P.build_hip(cfg, om, layout)
+        tr = Trainer(hm, layout.special(), lr=1e-3, lr_scheduler="constant", bucket_bytes=1 << 16, force_dp_hooks=True)
+        assert tr.dp.active and tr.dp.world == 1 and len(tr.dp.buckets) > 3
+        tr.dp.record_exposed = True
+        losses = [tr.step(b)[0].item() for b in batches]
+        assert tr.dp.last_launch_log == sorted(tr.dp.last_launch_log) and len(tr.dp.last_launch_log) == len(tr.dp.buckets)
+        exposed = tr.dp.exposed_ms()
+        assert len(exposed) == 3 and all(e >= 0 for e in exposed)
+        # a sum over one rank is the identity: the same steps without any collective give the same bits
+        hm2 = P.build_hip(cfg, om, layout)
+        tr2 = Trainer(hm2, layout.special(), lr=1e-3, lr_scheduler="constant", bucket_bytes=1 << 16)
+        assert not tr2.dp.active
+        losses2 = [tr2.step(b)[0].item() for b in batches]
+        assert losses == losses2, (losses, losses2)
+        assert torch.equal(tr.opt.master, tr2.opt.master)
+        # a plain RCCL collective on a slice of the flat buffer, in place, as GradBucketer issues them
+        s, e, _ = tr.dp.buckets[1]
+        tr.opt.flat_g[s:e].fill_(1.5)
+        dist.all_reduce(tr.opt.flat_g[s:e], op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+        assert bool((tr.opt.flat_g[s:e] == 1.5).all())
+        q.put(("ok", exposed))
+    except Exception:                                                      # noqa: BLE001 -- report to the parent
+        import traceback
+        q.put(("fail", traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_one_rank_rccl_process_group():
+    """RCCL itself on the one GPU a test box has: a 1-rank ``nccl`` process group under the production Trainer /
+    GradBucketer with the hooks forced on -- RCCL init, async all_reduce of bf16 slices of the flat gradient buffer issued
+    from autograd hooks in bucket order, hand-off between RCCL's stream and the compute stream, finish()."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_rccl, args=(q, _free_port()))
+    p.start()
+    res = q.get(timeout=300)
+    p.join(60)
+    assert res[0] == "ok", res[1]

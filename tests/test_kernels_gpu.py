@@ -350,6 +350,8 @@ ATTN_CASES = [
     # B, H, Sq, Sk, D, mode
     (2, 3, 64, 64, 64, 0), (2, 2, 257, 257, 64, 0), (1, 2, 64, 320, 64, 0), (2, 4, 200, 200, 80, 1),
     (1, 2, 512, 512, 80, 1), (2, 2, 130, 130, 128, 1), (2, 8, 100, 192, 64, 2), (1, 2, 96, 96, 64, 1),
+    (2, 2, 1024, 1024, 128, 1),      # cfg5's workload: MPT head dim 128 over an image-generation sequence (L = 1024)
+    (1, 4, 1000, 1000, 80, 1), (1, 2, 257, 257, 80, 0), (1, 8, 512, 1024, 64, 2),     # cfg4: 16 images x 64 latents
 ]
 
 
@@ -570,7 +572,8 @@ def mpt_alibi_slopes(n_heads, alibi_bias_max=8):
     return slopes.contiguous()
 
 
-@pytest.mark.parametrize("B,H,S,D,kvpad", [(2, 4, 200, 64, True), (1, 6, 512, 128, False), (2, 3, 96, 80, True)])
+@pytest.mark.parametrize("B,H,S,D,kvpad", [(2, 4, 200, 64, True), (1, 6, 512, 128, False), (2, 3, 96, 80, True),
+                                           (2, 4, 1024, 128, True)])      # the last: cfg5's img-gen sequence length
 def test_attention_alibi_causal(ops, B, H, S, D, kvpad):
     """ALiBi as MPT applies it (bias = slope_h * (j - (S - 1)), causal): forward and all three gradients, plus a single
     query row against a longer key cache (the decode shape)."""

@@ -119,3 +119,19 @@ def test_mpt_vs_transformers():
             out = m(torch.from_numpy(z["ids"]), torch.from_numpy(z["mask"]))
         valid = torch.from_numpy(z["mask"]).bool()
         assert np.allclose(out["logits"][valid].numpy(), z["logits"][valid.numpy()], rtol=1e-4, atol=1e-4)
+
+
+def test_checkpoint_key_set_matches_reference_get_checkpoint(golden_dir):
+    """tests/golden/checkpoint_keys.npz = the reference's own get_checkpoint (train_utils.py:258-265) on the oracle Flamingo
+    (oracle/make_golden.py ckpt).  The product's get_checkpoint is pure host logic: same keys on the same module tree."""
+    import os
+    import numpy as np
+    import _parity as P
+    from unimp_amd.train import get_checkpoint
+    z = np.load(os.path.join(golden_dir, "checkpoint_keys.npz"))
+    om, layout = P.build_oracle(P.TINY)
+    sd = get_checkpoint(om)
+    assert sorted(sd) == [str(k) for k in z["keys"]]
+    assert any(k.startswith("lang_encoder.old_decoder_blocks.") for k in sd)        # the duplicate-path quirk
+    assert not any(k.startswith("vision_encoder.") for k in sd)
+    assert torch.equal(sd["perceiver.latents"], torch.from_numpy(z["t.perceiver.latents"]))

@@ -79,3 +79,45 @@ def test_param_names_and_freeze():
     assert "lang_encoder.gpt_neox.layers.1.gated_cross_attn_layer.ff.1.weight" in sd
     assert "lang_encoder.old_decoder_blocks.0.attention.dense.weight" in sd
     assert m.lang_encoder.gated_cross_attn_layers[0] is None
+
+
+def test_perceiver_matches_independent_idefics_implementation():
+    """An independent implementation of the same (lucidrains-derived) Perceiver resampler ships with the installed
+    transformers: ``models.idefics.perceiver`` (separate k/v projections instead of a fused ``to_kv``, optional qk-LayerNorm
+    switched off here, ReLU MLP swapped for GELU).  It does not lift the "parity unpinned" label of oracle/flamingo.py --
+    open-flamingo 2.0.1 itself is absent -- but two restatements of the published algorithm agreeing to 1e-5 narrows the risk
+    of a misreading (concat order [media; latents], pre-scaled queries, max-subtracted softmax, residuals, final LayerNorm)."""
+    import torch.nn as nn
+    from transformers.models.idefics import perceiver as ip
+    from transformers.models.idefics.configuration_idefics import IdeficsConfig
+    from oracle import flamingo as ofl
+    torch.manual_seed(3)
+    D, heads, hd, depth, n_lat = 48, 3, 16, 2, 5
+    mine = ofl.PerceiverResampler(dim=D, depth=depth, dim_head=hd, heads=heads, num_latents=n_lat)
+    cfg = IdeficsConfig()
+    cfg.perceiver_config.qk_layer_norms_perceiver = False
+    cfg.vision_config.embed_dim = D
+    ref = ip.IdeficsPerceiverResampler(cfg, D, depth, heads, hd, n_lat)
+    with torch.no_grad():
+        for p in mine.parameters():
+            p.normal_(0, 0.3)
+        ref.latents.copy_(mine.latents)
+        for (a, f), (ra, rf) in zip(mine.layers, ref.blocks):
+            ra.context_layer_norm.load_state_dict(a.norm_media.state_dict())
+            ra.latents_layer_norm.load_state_dict(a.norm_latents.state_dict())
+            ra.q_proj.weight.copy_(a.to_q.weight)
+            k, v = a.to_kv.weight.chunk(2, 0)
+            ra.k_proj.weight.copy_(k); ra.v_proj.weight.copy_(v)
+            ra.output_proj.weight.copy_(a.to_out.weight)
+            rf.ln.load_state_dict(f[0].state_dict())
+            rf.fc.weight.copy_(f[1].weight); rf.c_proj.weight.copy_(f[3].weight)
+            rf.act = nn.GELU()
+        ref.layer_norm.load_state_dict(mine.norm.state_dict())
+    x = torch.randn(2, 3, 1, 7, D)                                  # (b, T, F, v, D)
+    with torch.no_grad():
+        got = mine(x)                                              # (b, T, n, D)
+        want = ref(x.reshape(6, 7, D)).reshape(2, 3, n_lat, D)
+        assert (got - want).abs().max() <= 1e-5 * want.abs().max(), (got - want).abs().max()
+        a0 = mine.layers[0][0](x.reshape(2, 3, 7, D), mine.latents[None, None].expand(2, 3, -1, -1))
+        r0 = ref.blocks[0][0](x.reshape(6, 7, D), mine.latents[None].expand(6, -1, -1)).reshape(2, 3, n_lat, D)
+        assert (a0 - r0).abs().max() <= 1e-5 * r0.abs().max()

@@ -2,10 +2,17 @@
 while backward is still running (replaces accelerate/DeepSpeed ZeRO-2 reduce-scatter, UniMP/mmrec.py:175,215,706-721).
 
 One process per GPU; gradients live in FlatAdamW's contiguous bf16 buffer, so a bucket is a slice of it.
-Buckets are cut in flat order (= reverse execution order, see optim.py); a bucket's all-reduce is issued
-(async, on the communication stream RCCL owns) as soon as the last of its parameters has accumulated its
-gradient.  The 1/world_size average is folded into the optimizer's ``grad_scale``; the clip norm is then
-computed locally on identical reduced gradients, so no further collective is needed.
+Buckets are cut in flat order (= reverse execution order, see optim.py); a bucket becomes READY when the last of its
+parameters has accumulated its gradient, and ready buckets are issued (async, on the communication stream RCCL owns)
+**strictly in bucket-index order**: bucket i goes out only after buckets 0..i-1 have.  Every rank therefore issues the
+same sequence of collectives whatever its autograd order or a parameter without a gradient on one rank does (RCCL, like
+NCCL, pairs collectives by issue order; a bucket that never completes on some rank simply holds the later ones back until
+finish(), on that rank only).  Buckets holding a ``late_params`` entry (a tied embedding / head: its first accumulation is
+not its last) always go out in finish(), after all the others, in index order -- a static set, the same on every rank.
+A parameter whose ``.grad`` is not the flat-buffer view any more (foreign code set it to None or replaced it) is folded
+back into the view inside its hook, i.e. BEFORE its bucket can be issued.
+The 1/world_size average is folded into the optimizer's ``grad_scale``; the clip norm is then computed locally on
+identical reduced gradients, so no further collective is needed.
 xGMI is point-to-point (7 links x ~153 GB/s): few large buckets (default 256 MiB) keep each ring step long
 enough to be link-bandwidth- rather than latency-bound.
 """
@@ -14,17 +21,22 @@ import torch.distributed as dist
 
 
 class GradBucketer:
-    def __init__(self, optimizer, bucket_bytes=256 << 20, process_group=None, late_params=()):
+    def __init__(self, optimizer, bucket_bytes=256 << 20, process_group=None, late_params=(), force_hooks=False):
         """late_params: parameters used more than once per step (tied embedding/head): their bucket is only
-        reduced in finish(), because the first of their gradient accumulations does not mean the gradient is complete."""
+        reduced in finish(), because the first of their gradient accumulations does not mean the gradient is complete.
+        force_hooks: register the hooks and run the collectives even when world_size == 1 (a 1-rank process group
+        exercises the whole RCCL path -- init, async all_reduce on slices of the flat buffer, stream hand-off -- on a
+        single GPU: tests/test_dp_gpu.py)."""
         self.opt = optimizer
         self._late = {id(p) for p in late_params}
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (force_hooks and dist.is_initialized())
         self.buckets = []        # [start, end, n_params]
         elems = max(1, bucket_bytes // optimizer.flat_g.element_size())
         cur = None
         self.param_bucket = {}
+        self._slot = {}          # id(param) -> (offset, numel) of its view in the flat gradient buffer
         for n, p, o, k in optimizer.layout:
             end = o + (k + optimizer.ALIGN - 1) // optimizer.ALIGN * optimizer.ALIGN
             if cur is None or (end - cur[0]) > elems and cur[2] > 0:
@@ -33,38 +45,80 @@ class GradBucketer:
             cur[1] = end
             cur[2] += 1
             self.param_bucket[id(p)] = len(self.buckets) - 1
-        self._pending = [b[2] for b in self.buckets]
-        self._handles = []
+            self._slot[id(p)] = (o, k)
+        self._late_buckets = sorted({self.param_bucket[i] for i in self._late if i in self.param_bucket})
+        self._order = [bi for bi in range(len(self.buckets)) if bi not in self._late_buckets]     # issue order during backward
+        self._reset()
         self._hooks = []
         self.sync = True          # False: gradient-accumulation micro-step, gradients only add up locally (accelerate's no_sync)
-        if self.world > 1:
+        self.launch_log = []      # bucket indices in issue order, last step (tests)
+        self.record_exposed = False   # bench.py: bracket the waits of finish() with HIP events on the compute stream
+        self.exposed_events = []      # (start, end) per step: the part of the exchange that backward did not hide
+        if self.active:
             for n, p, o, k in optimizer.layout:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
+    def _reset(self):
+        self._pending = [b[2] for b in self.buckets]
+        self._next = 0            # position in self._order of the next bucket to issue
+        self._issued = set()
+        self._handles = []
+
     def _on_grad(self, p):
+        o, k = self._slot[id(p)]
+        view = self.opt.flat_g[o:o + k]
+        g = p.grad
+        if g is not None and g.data_ptr() != view.data_ptr():          # a stray gradient tensor: fold it in before any launch
+            view.add_(g.reshape(-1).to(view.dtype))
+            p.grad = view.view(p.shape)
         if id(p) in self._late or not self.sync:
             return
         bi = self.param_bucket[id(p)]
         self._pending[bi] -= 1
-        if self._pending[bi] == 0:
-            self._launch(bi)
+        self._drain()
+
+    def _drain(self):
+        """issue every ready bucket at the head of the order; stop at the first one that is not complete."""
+        while self._next < len(self._order) and self._pending[self._order[self._next]] <= 0:
+            self._launch(self._order[self._next])
+            self._next += 1
 
     def _launch(self, bi):
         s, e, _ = self.buckets[bi]
+        self._issued.add(bi)
+        self.launch_log.append(bi)
         self._handles.append(dist.all_reduce(self.opt.flat_g[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
     def finish(self):
-        """call after backward: flush buckets whose params got no gradient this step, wait for all reductions."""
-        if self.world > 1:
-            self.opt._reattach()
-            for bi, left in enumerate(self._pending):
-                if left > 0 or not self.sync:      # accumulated micro-steps ran without exchange: reduce everything now
-                    self._launch(bi)
+        """call after backward: issue, in index order, the buckets that did not go out during backward (parameters
+        without a gradient this step, late parameters, accumulation micro-steps), then wait for all reductions."""
+        if self.active:
+            self.opt._reattach()                     # only touches gradients of buckets that have NOT been issued (see _on_grad)
+            for bi in self._order[self._next:]:
+                self._launch(bi)
+            for bi in self._late_buckets:
+                self._launch(bi)
+            # Work.wait() on a device tensor makes the compute stream wait for the communication stream (no host block):
+            # the gap the compute stream spends there is the exposed part of the exchange
+            ev = None
+            if self.record_exposed and self.opt.flat_g.is_cuda:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             for h in self._handles:
                 h.wait()
-        self._handles = []
-        self._pending = [b[2] for b in self.buckets]
+            if ev is not None:
+                ev[1].record()
+                self.exposed_events.append(ev)
+        log = self.launch_log
+        self._reset()
+        self.launch_log = []
+        self.last_launch_log = log
         return 1.0 / self.world          # grad_scale for FlatAdamW.step
+
+    def exposed_ms(self):
+        """per-step exposed exchange time (ms) of the steps recorded so far; synchronises on the last event."""
+        out = [a.elapsed_time(b) for a, b in self.exposed_events if (b.synchronize() or True)]
+        return out
 
     def remove(self):
         for h in self._hooks:

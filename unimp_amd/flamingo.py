@@ -266,6 +266,7 @@ class Flamingo(nn.Module):
         lp = kwargs.pop("length_penalty", 1.0)
         use_cache = kwargs.pop("use_cache", True)
         use_graph = kwargs.pop("use_graph", True)      # replay the decode step as one HIP graph (decode.py)
+        trace = kwargs.pop("trace", None)              # tests: per-step candidate scores of the beam search
         if kwargs.pop("do_sample", False) or kwargs:
             raise NotImplementedError(f"unsupported generate() arguments: do_sample / {sorted(kwargs)}")
         was_training = self.training
@@ -300,7 +301,7 @@ class Flamingo(nn.Module):
                 return session[0].step(seqs[:, -1], src)
             if num_beams > 1:
                 out = beam_search(logits_fn, seqs0, num_beams, max_new_tokens, eos_token_id, pad_token_id, nret, early, lp,
-                                  ngram, stateful=True)
+                                  ngram, stateful=True, trace=trace)
             else:
                 out = greedy_search(logits_fn, seqs0, max_new_tokens, eos_token_id, pad_token_id)
         finally:

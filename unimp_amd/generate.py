@@ -64,8 +64,10 @@ class _Hyps:
 
 @torch.no_grad()
 def beam_search(logits_fn, input_ids, num_beams, max_new_tokens, eos_token_id, pad_token_id=None, num_return_sequences=1,
-                early_stopping=True, length_penalty=1.0, no_repeat_ngram_size=0, stateful=False):
-    """input_ids [B, L0] -> [B * num_return_sequences, <= L0 + max_new_tokens] (right-padded with pad_token_id)."""
+                early_stopping=True, length_penalty=1.0, no_repeat_ngram_size=0, stateful=False, trace=None):
+    """input_ids [B, L0] -> [B * num_return_sequences, <= L0 + max_new_tokens] (right-padded with pad_token_id).
+    trace: optional list; every step appends (scores, flat indices beam * V + token) of the sorted top-2K candidates per
+    batch item (tests measure the margins that decide which beams survive)."""
     dev = input_ids.device
     B, L0 = input_ids.shape
     K = num_beams
@@ -84,6 +86,8 @@ def beam_search(logits_fn, input_ids, num_beams, max_new_tokens, eos_token_id, p
         scores = (logp + beam_scores.view(-1, 1)).view(B, K * V)
         top_s, top_i = torch.topk(scores, 2 * K, dim=1, largest=True, sorted=True)
         top_s_h, top_i_h = top_s.tolist(), top_i.tolist()
+        if trace is not None:
+            trace.append((top_s_h, top_i_h))
         new_scores = torch.zeros(B, K, dtype=torch.float32)
         new_tok = torch.full((B, K), pad, dtype=torch.long)
         new_src = torch.zeros(B, K, dtype=torch.long)

@@ -67,7 +67,13 @@ class _TowerBase(nn.Module):
     """shared: resize_token_embeddings (HF semantics), kv_len from the attention mask, head + loss."""
     tied = False
 
-    def resize_token_embeddings(self, n):
+    def resize_token_embeddings(self, n, preserve_requires_grad=False):
+        """HF ``resize_token_embeddings`` (mmrec.py:595).  With the reference's pinned transformers (4.29,
+        requirements.txt:26) the new nn.Embedding -- and, for an untied tower, the new nn.Linear head -- are fresh modules
+        whose weights have ``requires_grad=True``, whatever the factory froze before: after mmrec.py:595 the 190 M-parameter
+        output head of the 4b-instruct tower is therefore TRAINABLE (the 1.34 B trainable parameters of
+        bench.py's cfg2 include it) and ``freeze_lm_embeddings=True`` is undone.  That is the default here too.
+        ``preserve_requires_grad=True`` keeps the old modules' flags instead (what newer transformers releases do)."""
         old = self.get_input_embeddings()
         if n == old.weight.shape[0]:
             return old
@@ -75,6 +81,8 @@ class _TowerBase(nn.Module):
         new.weight.data.normal_(0, 0.02)
         k = min(n, old.weight.shape[0])
         new.weight.data[:k] = old.weight.data[:k]
+        if preserve_requires_grad:
+            new.weight.requires_grad_(old.weight.requires_grad)
         self.set_input_embeddings(new)
         head = self.get_output_embeddings()
         if self.tied:
@@ -83,6 +91,8 @@ class _TowerBase(nn.Module):
             nh = nn.Linear(head.weight.shape[1], n, bias=False, device=head.weight.device, dtype=head.weight.dtype)
             nh.weight.data.normal_(0, 0.02)
             nh.weight.data[:k] = head.weight.data[:k]
+            if preserve_requires_grad:
+                nh.weight.requires_grad_(head.weight.requires_grad)
             self.set_output_embeddings(nh)
         self.config.vocab_size = n
         return new

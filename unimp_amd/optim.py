@@ -92,6 +92,7 @@ class FlatAdamW:
         """clip (global L2 norm of grad*grad_scale to max_grad_norm) + AdamW; zeroes the gradient buffer."""
         self._reattach()
         self.step_count += 1
+        self._gscale = float(grad_scale)
         self.norm_buf[0:1].zero_()
         ops.sumsq(self.flat_g, self.norm_buf)
         b1, b2 = self.betas
@@ -99,8 +100,15 @@ class FlatAdamW:
                        self.eps, self.weight_decay, self.step_count, self.norm_buf, grad_scale, self.max_grad_norm or 0.0, True)
 
     def grad_norm(self):
-        """device scalar: sqrt(sum g^2) from the last step() (before grad_scale)."""
-        return self.norm_buf[0].sqrt()
+        """device scalar: global L2 norm of the gradient the last step() clipped -- the averaged one, i.e. the summed
+        buffer times grad_scale (1 / world / grad_accum) -- the value ``clip_grad_norm_`` returns in the reference
+        (mmrec.py:247-248)."""
+        return self.norm_buf[0].sqrt() * getattr(self, "_gscale", 1.0)
+
+    def reset_state(self):
+        """forget the moments and the step count (weights loaded without their optimizer state)."""
+        self.m.zero_(); self.v.zero_()
+        self.step_count = 0
 
     def state_dict(self):
         return {"step": self.step_count, "master": self.master, "m": self.m, "v": self.v,

@@ -76,13 +76,16 @@ def load_checkpoint(path, model, trainer=None):
             r = torch.load(path + ".resume", map_location="cpu")
             trainer.opt.load_state_dict(r["optimizer"])
             trainer.sched_step, epoch = r["sched_step"], r["epoch"] + 1
+        else:
+            # weights only (the reference's own files): stale moments of the live trainer would belong to other weights
+            trainer.opt.reset_state()
     return epoch
 
 
 class Trainer:
     def __init__(self, model, special_ids, lr=2e-4, weight_decay=0.1, gamma=2.0, use_reweight=True, max_grad_norm=1.0,
                  lr_scheduler="cosine", warmup_steps=0, total_steps=1000, bucket_bytes=256 << 20, process_group=None,
-                 sparse_head=False, grad_accum=1):
+                 sparse_head=False, grad_accum=1, mask_lm_head=False, force_dp_hooks=False):
         """sparse_head (off by default): apply the LM head and the loss only to the positions whose next token carries a
         label -- identical loss / gradients / update (unlabeled rows contribute nothing), ~5 % fewer FLOPs at cfg2; the
         returned model output then has no logits.  Costs one host sync per step (the row count)."""
@@ -93,7 +96,15 @@ class Trainer:
         self.opt = FlatAdamW(model.named_parameters(), lr=lr, weight_decay=weight_decay, max_grad_norm=max_grad_norm)
         le = model.lang_encoder
         late = [le.get_input_embeddings().weight] if getattr(le, "tied", False) else []
-        self.dp = GradBucketer(self.opt, bucket_bytes=bucket_bytes, process_group=process_group, late_params=late)
+        # --mask_lm_head (mmrec.py:218-229): only the <answer> row of the embedding / head gradients survives.  The rows are
+        # cleared after backward, so these parameters' buckets must not be exchanged from the hooks: they go out in finish()
+        self._masked = []
+        if mask_lm_head:
+            self._masked = [w for w in {id(m.weight): m.weight for m in (le.get_input_embeddings(), le.get_output_embeddings())}.values()
+                            if w.requires_grad]
+            late = list({id(w): w for w in late + self._masked}.values())
+        self.dp = GradBucketer(self.opt, bucket_bytes=bucket_bytes, process_group=process_group, late_params=late,
+                               force_hooks=force_dp_hooks)
         self.sched, self.base_lr, self.warmup, self.total = lr_scheduler, lr, warmup_steps, total_steps
         self.sched_step = 0
 
@@ -122,6 +133,14 @@ class Trainer:
         loss, stats = F_.focal_ce(out["logits"], labels, batch["weights"], self.gamma, self.use_reweight)
         return loss, stats, out, labels
 
+    def _mask_lm_head_grads(self):
+        a = self.ids["answer_id"]
+        for w in self._masked:
+            g = w.grad
+            keep = g[a].clone()
+            g.zero_()
+            g[a].copy_(keep)
+
     def step(self, batch):
         """returns (loss, stats) device tensors; no host synchronisation."""
         self.model.train()
@@ -134,12 +153,14 @@ class Trainer:
             self.dp.sync = False
             loss.backward()
             if self._micro % self.grad_accum == 0:
+                self._mask_lm_head_grads()
                 gscale = self.dp.finish() / self.grad_accum
                 self.dp.sync = True
                 self.opt.step(lr=self.current_lr(), grad_scale=gscale)
                 self.sched_step += 1
             return loss.detach(), stats
         loss.backward()
+        self._mask_lm_head_grads()
         gscale = self.dp.finish()
         self.opt.step(lr=self.current_lr(), grad_scale=gscale)
         self.sched_step += 1
