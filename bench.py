@@ -27,8 +27,11 @@ PROF_STEPS = 4            # timed steps whose GEMM launches are bracketed by HIP
 
 
 def flops_per_sample(T, L, V, n_patch=256, P=14, Dv=1024, vit_layers=24, vit_mlp=4096, H=2560, F=10240, lm_layers=32,
-                     n_xattn=16, n_lat=64, perc_layers=6, inner=512, head_trainable=True):
-    """SURVEY.md §8d formulae (2MNK per GEMM, attention counted full; frozen: fwd + dX; trainable: fwd + dX + dW)."""
+                     n_xattn=16, n_lat=64, perc_layers=6, inner=512, head_trainable=True, head_bwd_rows=None):
+    """SURVEY.md §8d formulae (2MNK per GEMM, attention counted full; frozen: fwd + dX; trainable: fwd + dX + dW).
+    head_bwd_rows: positions per sample whose logit gradient is non-zero (the labeled ones: 10 in the synthetic rec template);
+    the head's dX / dW products are EXECUTED on those rows only (functional.DenseHeadLossFn), so only they are counted -- None
+    counts the reference's dense L-row products (SURVEY's 10.35 TFLOP/sample figure)."""
     t = n_patch + 1
     vit = T * (2 * n_patch * 3 * P * P * Dv + vit_layers * (2 * t * Dv * 3 * Dv + 4 * t * t * Dv + 2 * t * Dv * Dv + 4 * t * Dv * vit_mlp))
     perc_l = 2 * n_lat * Dv * inner + 2 * (n_patch + n_lat) * Dv * 2 * inner + 4 * n_lat * (n_patch + n_lat) * inner + \
@@ -39,7 +42,8 @@ def flops_per_sample(T, L, V, n_patch=256, P=14, Dv=1024, vit_layers=24, vit_mlp
     lm_gemm = lm_layers * (2 * L * H * 3 * H + 2 * L * H * H + 4 * L * H * F)
     lm_attn = lm_layers * 4 * L * L * H
     head = 2 * L * H * V
-    lm = 2 * (lm_gemm + lm_attn) + (3 if head_trainable else 2) * head
+    bwd_frac = 1.0 if head_bwd_rows is None else head_bwd_rows / L
+    lm = 2 * (lm_gemm + lm_attn) + (1 + (2 if head_trainable else 1) * bwd_frac) * head
     return dict(vit=vit, perceiver=perc, xattn=xattn, lm=lm, total=vit + perc + xattn + lm)
 
 
@@ -151,6 +155,8 @@ def main():
                     "the reference's shipped shape is --batch 3 --grad-accum 2, unimp_task.sh:2-30); a bench step = one optimizer step")
     ap.add_argument("--pool", type=int, default=32, help="pre-staged synthetic batches (every step takes a fresh one while steps + warmup <= pool)")
     ap.add_argument("--cpu-full-steps", type=int, default=2, help="timed full-depth oracle steps of the cpu_baseline leg (0: 1/8-depth sample only)")
+    ap.add_argument("--dense-head-backward", action="store_true", help="form the dense [B*L, V] logit gradient and run the head's dX / dW "
+                    "GEMMs over all rows (the reference's arithmetic incl. its ~98 %% zero rows); default: labeled rows only, same gradients")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--model", choices=["4b-instruct", "9b"], default="4b-instruct",
@@ -186,7 +192,7 @@ def main():
     model, layout = build_cfg2(dev, lang="anas-awadalla/mpt-7b", every=4) if nine else build_cfg2(dev)
     trainer = Trainer(model, layout.special(), lr=2e-4, weight_decay=0.1, gamma=2.0, use_reweight=True,
                       lr_scheduler="cosine", warmup_steps=10, total_steps=10000, sparse_head=args.sparse_head,
-                      grad_accum=args.grad_accum)
+                      grad_accum=args.grad_accum, dense_head_backward=args.dense_head_backward)
     trainer.dp.record_exposed = world > 1
     n_train = sum(p.numel() for p in model.parameters() if p.requires_grad)
     T, L, B, GA = args.images, args.seq, args.batch, args.grad_accum
@@ -201,7 +207,9 @@ def main():
             out = trainer.step(pool[it[0] % n_pool])
             it[0] += 1
         return out
-    fps = flops_per_sample(T, L, layout.vocab, H=4096, F=16384, lm_layers=32, n_xattn=8) if nine else flops_per_sample(T, L, layout.vocab)
+    hb = None if args.dense_head_backward else 10          # synthetic template: 9 item answers + EOS carry a label per sample
+    fps = flops_per_sample(T, L, layout.vocab, H=4096, F=16384, lm_layers=32, n_xattn=8, head_bwd_rows=hb) if nine else \
+        flops_per_sample(T, L, layout.vocab, head_bwd_rows=hb)
 
     for i in range(args.warmup):
         one_step()
@@ -293,6 +301,9 @@ def main():
                            "gemm_autotune": {"table": os.path.relpath(ops._TUNE_FILE, ROOT) if ops._TUNE_FILE else None,
                                              "entries": len(ops._GEMM_CHOICE), "tuned_live_this_run": len(ops.TUNE_MISSES)},
                            "tflop_per_sample": round(fps["total"] / 1e12, 3),
+                           "tflop_per_sample_note": "executed FLOPs (SURVEY 8d formulae); the LM head's backward runs on the labeled positions only"
+                                                    if hb else "SURVEY 8d formulae, dense head backward",
+                           "head_backward": "dense" if args.dense_head_backward else "labeled rows only (zero rows of dlogits skipped; same gradients)",
                            "model_tflops_per_gpu": round(value / world * fps["total"] / 1e12, 1),
                            "mfma_frac_whole_step": round(value / world * fps["total"] / 1e12 / PEAK_BF16_TFLOPS, 4),
                            **({"note": "--sparse-head: the utilisation fields above still count the dense head's FLOPs"}

@@ -128,6 +128,10 @@ typedef struct {
 } unimp_attn_desc;
 int unimp_attn_fwd(const unimp_attn_desc* d, void* stream);
 int unimp_attn_bwd(const unimp_attn_desc* d, void* stream);
+/* tuning / test knob: which generation of attention kernels serves the calls above.  2 (default; env UNIMP_ATTN_GEN):
+ * the 32x32x16-MFMA / LDS-DMA kernels of attention2.hip; 1: the first-generation kernels (kept for A/B measurements and
+ * run by the tests as a second implementation of the same contract).  Returns the previous value. */
+int unimp_attn_set_generation(int generation);
 
 /* ---- token embedding (gpt_neox.embed_in / OPT embed_tokens+embed_positions) -------------------------------
  * fwd: out[r] = W[ids[r]] (+ P[pos[r]]);  bwd: dW[ids[r]] += dout[r]  (fp32 atomics into dW32, then cast)
@@ -177,6 +181,14 @@ int unimp_focal_ce_fwd(const void* logits, int64_t ldv, const int64_t* labels, c
 int unimp_focal_ce_bwd(const void* logits, int64_t ldv, const int64_t* labels, const float* weights, float gamma,
                        int use_reweight, const float* row_lse, const float* row_zy, const float* out3,
                        const float* gscale, void* dlogits, int B, int L, int V, void* stream);
+/* bwd_rows: the same gradient for a list of scored positions rows[i] = b*L + j (int64, n_rows entries), written compactly:
+ *      dl[i][0..ldd) = dlogits[rows[i]][0..ldd), V <= ldd <= ldv.  The reference (mmrec.py:190-215) materialises the dense
+ *      [B*L][V] gradient, which is zero on every row without a label (~98 % of them); the head's dX / dW GEMMs then run on
+ *      the listed rows only -- same gradients, no zero-row products. */
+int unimp_focal_ce_bwd_rows(const void* logits, int64_t ldv, const int64_t* labels, const float* weights, float gamma,
+                            int use_reweight, const float* row_lse, const float* row_zy, const float* out3,
+                            const float* gscale, const int64_t* rows, int n_rows, void* dl, int64_t ldd, int L, int V,
+                            void* stream);
 
 /* ---- optimizer (mmrec.py:247-256,609-631,671): global-norm clip + AdamW, flat buffers ---------------------
  * sumsq: out[0] += sum(g^2) (fp32; caller zeroes out[0]; out[1..1025) is scratch for the ordered reduction).  adamw: for i in [0,n): g = grad[i]*gscale*clip,

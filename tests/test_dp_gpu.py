@@ -35,7 +35,7 @@ def _worker(rank, world, port, q):
         # local gradient of this rank's batch, no exchange
         hm0 = P.build_hip(cfg, om, layout)
         t0 = Trainer.__new__(Trainer)
-        t0.model, t0.sparse_head, t0.ids, t0.gamma, t0.use_reweight = hm0, False, layout.special(), 2.0, True
+        t0.model, t0.sparse_head, t0.ids, t0.gamma, t0.use_reweight, t0.dense_head_backward = hm0, False, layout.special(), 2.0, True, False
         opt0 = FlatAdamW(hm0.named_parameters())
         loss0, _, _, _ = Trainer.forward_loss(t0, batch)
         loss0.backward()

@@ -182,10 +182,12 @@ def test_beam_search_tokens_match_oracle_beam_search(K):
     """F1 pinned against the oracle, not against itself: HIP ``generate`` (KV cache, beam reorder, HIP-graph step) with
     K beams x K returned sequences (eval_rec.py:100-110 uses K = 10) vs the SAME host beam search (pinned token-for-token
     against transformers' generate in tests/test_generate_cpu.py) driven by the fp32 oracle's logits.  Beam search decides
-    on the ORDER of candidate scores, so bf16 noise may legitimately flip near-ties: step t of a prompt is compared while
-    every step up to t has its first K + 1 oracle candidate scores pairwise >= 0.02 nats apart -- then the K surviving
-    (beam, token) candidates must be identical and their scores within 0.01; a prompt whose every step is clear must return
-    identical sequences.  12 prompts; the compared steps / prompts are counted and a minimum is required."""
+    on the ORDER of candidate scores, so bf16 noise may legitimately flip near-ties.  Per prompt the two searches are walked
+    step by step while their beams coincide: at every such step the K surviving (beam, token) candidates must be the same
+    set in the same order, EXCEPT where the oracle's own scores of the two differing candidates lie within twice the
+    measured HIP-vs-oracle score deviation of that step (a near-tie: the walk of that prompt stops there); the scores of
+    the common candidates must agree within 0.08 nats (measured ~0.04 on logits sharpened x4).  Prompts whose walk reaches
+    the end must return identical sequences.  12 prompts; minimum numbers of identical steps / prompts are required."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     import _parity as P
@@ -196,9 +198,8 @@ def test_beam_search_tokens_match_oracle_beam_search(K):
         p_.data.mul_(4.0)                     # peakier next-token distributions
     om.eval()
     hm = P.build_hip(cfg, om, layout).eval()
-    steps_ok = full_ok = 0
-    new, thr = 5, 0.02
-    worst = 0.0
+    steps_ok = full_ok = ties = 0
+    new, worst = 5, 0.0
     for seed in range(1234, 1246):
         batch = P.make_batch(cfg, layout, seed=seed)
         n = int(batch["attention_mask"][0].sum())
@@ -211,23 +212,28 @@ def test_beam_search_tokens_match_oracle_beam_search(K):
         want = beam_search(oracle_logits, ids, K, new, layout.eos, layout.eos, K, True, trace=tw)
         got = hm.generate(vx.cuda(), ids.cuda(), num_beams=K, num_return_sequences=K, early_stopping=True, max_new_tokens=new,
                           eos_token_id=layout.eos, pad_token_id=layout.eos, trace=tg).cpu()
-        clear = True
+        same = True
         for t, ((sw, iw), (sg, ig)) in enumerate(zip(tw, tg)):
             sw, iw, sg, ig = sw[0], iw[0], sg[0], ig[0]
-            if min(a - b for a, b in zip(sw[:K], sw[1:K + 1])) < thr:
-                clear = False
+            ow = dict(zip(iw, sw))                                   # oracle score by candidate (2K of them)
+            common = [(a, ow[i]) for a, i in zip(sg, ig) if i in ow]
+            dev = max(abs(a - b) for a, b in common)
+            worst = max(worst, dev)
+            assert dev <= 0.08, (seed, t, dev)
+            if ig[:K] != iw[:K]:
+                for cg, cw in zip(ig[:K], iw[:K]):                   # a flip is only legitimate between oracle near-ties
+                    if cg != cw:
+                        assert cg in ow and abs(ow[cg] - ow[cw]) <= 2 * dev + 1e-4, (seed, t, cg, cw, ow.get(cg), ow[cw], dev)
+                same = False
+                ties += 1
                 break
-            assert ig[:K] == iw[:K], (seed, t, ig[:K], iw[:K])
-            d = max(abs(a - b) for a, b in zip(sg[:K], sw[:K]))
-            worst = max(worst, d)
-            assert d <= 0.01, (seed, t, d)
             steps_ok += 1
-        if clear and len(tw) == len(tg):
+        if same and len(tw) == len(tg):
             assert got.shape == want.shape and torch.equal(got, want), (seed, got[:, ids.shape[1]:].tolist(), want[:, ids.shape[1]:].tolist())
             full_ok += 1
-    print(f"\n[beam K={K}] {steps_ok} beam-search steps with clear margins identical (max candidate-score deviation {worst:.2e} nats); "
-          f"{full_ok} prompts identical end to end")
-    assert steps_ok >= (12 if K == 4 else 3) and (full_ok >= 2 or K > 4)
+    print(f"\n[beam K={K}] {steps_ok} beam-search steps identical (max candidate-score deviation {worst:.2e} nats), {ties} prompts left the "
+          f"comparison at an oracle near-tie, {full_ok} of 12 prompts identical end to end")
+    assert steps_ok >= 20 and full_ok >= (3 if K == 4 else 1)
 
 
 @pytest.mark.parametrize("cfg_name", ["TINY", "TINY_OPT", "TINY_PAR"])

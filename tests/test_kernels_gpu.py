@@ -21,6 +21,18 @@ def ops():
     return o
 
 
+@pytest.fixture(params=[1, 2], ids=["gen1", "gen2"])
+def attn_gen(request):
+    """run an attention test on both kernel generations (attention.hip / attention2.hip): two independent implementations
+    of one contract, each checked against the fp32 reference."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from unimp_amd import _lib
+    old = _lib.lib().unimp_attn_set_generation(request.param)
+    yield request.param
+    _lib.lib().unimp_attn_set_generation(old)
+
+
 def rnd(*shape, scale=1.0, seed=0):
     g = torch.Generator().manual_seed(seed)
     return (torch.randn(*shape, generator=g) * scale).to(bf16)
@@ -356,7 +368,7 @@ ATTN_CASES = [
 
 
 @pytest.mark.parametrize("B,H,Sq,Sk,D,mode", ATTN_CASES)
-def test_attention_fwd_bwd(ops, B, H, Sq, Sk, D, mode):
+def test_attention_fwd_bwd(ops, attn_gen, B, H, Sq, Sk, D, mode):
     g = torch.Generator().manual_seed(Sq * 7 + D)
     # packed [B, S, H, 3D] buffer like the fused QKV GEMM output: exercises strided views
     if Sq == Sk:
@@ -406,7 +418,7 @@ def test_attention_fwd_bwd(ops, B, H, Sq, Sk, D, mode):
     close(dv, vr.grad, rel=2 ** -5, name="attn dv")
 
 
-def test_attention_spiked_row_online_softmax(ops):
+def test_attention_spiked_row_online_softmax(ops, attn_gen):
     """force the running-max rescale branch: one key far above the rest in a late tile (cdna guide rule 26)."""
     B, H, S, D = 1, 1, 256, 64
     g = torch.Generator().manual_seed(0)
@@ -574,7 +586,7 @@ def mpt_alibi_slopes(n_heads, alibi_bias_max=8):
 
 @pytest.mark.parametrize("B,H,S,D,kvpad", [(2, 4, 200, 64, True), (1, 6, 512, 128, False), (2, 3, 96, 80, True),
                                            (2, 4, 1024, 128, True)])      # the last: cfg5's img-gen sequence length
-def test_attention_alibi_causal(ops, B, H, S, D, kvpad):
+def test_attention_alibi_causal(ops, attn_gen, B, H, S, D, kvpad):
     """ALiBi as MPT applies it (bias = slope_h * (j - (S - 1)), causal): forward and all three gradients, plus a single
     query row against a longer key cache (the decode shape)."""
     g = torch.Generator().manual_seed(S + D)

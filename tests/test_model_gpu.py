@@ -405,3 +405,29 @@ def test_scheduler_and_accumulation_stepping(P):
     assert all(abs(a - b) <= 1e-12 for a, b in zip(used, want)), (used, want)
     assert all(abs(s - 1.0 / GA) < 1e-12 for s in scales)
     tr.dp.remove()
+
+
+def test_compact_head_backward_equals_dense(P):
+    """The default Trainer restricts the LM head's backward to the labeled positions (functional.DenseHeadLossFn): same dense
+    logits (bitwise), same loss (bitwise), and every gradient equal to the dense path's up to the fp32 summation order of the
+    head's weight gradient (the contraction runs over n labeled rows instead of B*L rows, B*L - n of which are zero)."""
+    from unimp_amd.train import Trainer
+    cfg = P.TINY
+    om, layout = P.build_oracle(cfg)
+    batch = {k: v.cuda() for k, v in P.make_batch(cfg, layout).items()}
+    res = {}
+    for dense in (True, False):
+        hm = P.build_hip(cfg, om, layout)
+        tr = Trainer(hm, layout.special(), lr=1e-3, gamma=2.0, use_reweight=True, dense_head_backward=dense)
+        hm.train()
+        loss, stats, out, labels = tr.forward_loss(batch)
+        loss.backward()
+        res[dense] = (out["logits"].clone(), loss.item(), stats.clone(), {n: p.grad.float().clone() for n, p in hm.named_parameters() if p.grad is not None})
+        tr.dp.remove()
+    assert torch.equal(res[True][0], res[False][0]) and res[True][1] == res[False][1] and torch.equal(res[True][2], res[False][2])
+    assert set(res[True][3]) == set(res[False][3])
+    for n, g in res[True][3].items():
+        if g.abs().max() == 0:
+            assert res[False][3][n].abs().max() == 0, n
+        else:
+            assert P.rel_l2(res[False][3][n], g) <= 4e-3, (n, P.rel_l2(res[False][3][n], g))

@@ -54,8 +54,10 @@ _SIGS = {
     "unimp_bcast_rows": [c_p, c_p, c_l, c_i, c_i, c_i, c_p],
     "unimp_reduce_rows_periodic": [c_p, c_l, c_p, c_i, c_i, c_i, c_p],
     "unimp_label_mask": [c_p, c_p, c_p, c_i, c_i, c_l, c_l, c_l, c_l, c_p],
+    "unimp_attn_set_generation": [c_i],
     "unimp_focal_ce_fwd": [c_p, c_l, c_p, c_p, c_f, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "unimp_focal_ce_bwd": [c_p, c_l, c_p, c_p, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
+    "unimp_focal_ce_bwd_rows": [c_p, c_l, c_p, c_p, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_l, c_i, c_i, c_p],
     "unimp_sumsq_bf16": [c_p, c_l, c_p, c_p],
     "unimp_adamw_flat": [c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_f, c_f, c_f, c_f, c_f, c_i, c_p, c_f, c_f, c_i, c_p],
     "unimp_image_resize_normalize": [c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_p],

@@ -14,6 +14,7 @@
 // The backward uses the same trick for dQ (contraction over keys) and, with S = Q·K^T un-transposed, for
 // dK / dV (contraction over queries, P and dS stay in registers, Q / dO fetched transposed from LDS).
 // dQ and dK/dV are separate kernels: 7 instead of 5 MFMA products, but no atomics and bit-reproducible.
+#include <stdlib.h>
 #include "common.h"
 #include "unimp_hip.h"
 
@@ -21,17 +22,7 @@
 #define LN2 0.6931471805599453f
 #define EXP2(x) __builtin_amdgcn_exp2f(x)
 
-struct AttnP {
-  const bf16* q; const bf16* k; const bf16* v; bf16* o; float* lse;
-  long q_bs, q_ss, q_hs, k_bs, k_ss, k_hs, v_bs, v_ss, v_hs, o_bs, o_ss, o_hs;
-  int B, H, Sq, Sk, D;
-  float scale;
-  int mask_mode;
-  const int* kv_len; const int* seg; int seg_len;
-  const bf16* d_o; bf16* dq; bf16* dk; bf16* dv; float* delta;
-  long do_bs, do_ss, do_hs, dq_bs, dq_ss, dq_hs, dk_bs, dk_ss, dk_hs, dv_bs, dv_ss, dv_hs;
-  const float* alibi;        // per-head slopes or null: raw score += slope / scale * key  (so that score * scale gains slope * key)
-};
+#include "attention_params.h"
 
 // key range [lo, hi) attended by query row `qr` of batch b
 __device__ __forceinline__ void key_range(const AttnP& p, int b, int qr, int& lo, int& hi) {
@@ -636,11 +627,21 @@ static int fill(AttnP& p, const unimp_attn_desc* d, bool bwd) {
   return 0;
 }
 
+// kernel generation knob: 2 (default) = attention2.hip where it has a kernel, 1 = the first-generation kernels of this file
+// everywhere (A/B measurements, tests run both).  Initial value from UNIMP_ATTN_GEN.
+static int g_attn_gen = -1;
+static int attn_generation() {
+  if (g_attn_gen < 0) { const char* e = getenv("UNIMP_ATTN_GEN"); g_attn_gen = e ? atoi(e) : 2; }
+  return g_attn_gen;
+}
+extern "C" int unimp_attn_set_generation(int gen) { int old = attn_generation(); g_attn_gen = gen; return old; }
+
 extern "C" int unimp_attn_fwd(const unimp_attn_desc* d, void* stream) {
   AttnP p;
   int e = fill(p, d, false);
   if (e) return e;
   if (p.B <= 0 || p.H <= 0 || p.Sq <= 0) return UNIMP_OK;
+  if (attn_generation() >= 2) return unimp_attn_fwd2_dispatch(p, stream);
   dim3 grid((p.Sq + 127) / 128, p.H, p.B), block(256);
   hipStream_t s = (hipStream_t)stream;
 #define FWD(A_) do { if (p.D == 64) hipLaunchKernelGGL((attn_fwd_kernel<64, 64, A_>), grid, block, 0, s, p);       \

@@ -145,6 +145,58 @@ __global__ __launch_bounds__(256) void focal_bwd_kernel(const bf16* __restrict__
   }
 }
 
+// the same gradient for a LIST of scored positions, written compactly: block i handles row rows[i] (= b*L + j) and writes
+// dl[i][0..ldd).  Rows without a label never appear in the list: the dense [B*L][ldv] gradient the reference materialises is
+// zero there, and neither dX = dlogits W nor dW = dlogits^T h receives anything from a zero row.
+__global__ __launch_bounds__(256) void focal_bwd_rows_kernel(const bf16* __restrict__ logits, long ldv, const int64_t* __restrict__ labels,
+                                                             const float* __restrict__ weights, float gamma, int use_reweight,
+                                                             const float* __restrict__ row_lse, const float* __restrict__ row_zy,
+                                                             const float* __restrict__ out3, const float* __restrict__ gscale,
+                                                             const int64_t* __restrict__ rows, bf16* __restrict__ dl, long ldd, int L, int V) {
+  long r = rows[blockIdx.x];
+  int j = r % L; int b = r / L;
+  long y = (j < L - 1) ? labels[r + 1] : -100;
+  const bf16* z = logits + r * ldv;
+  bf16* d = dl + (long)blockIdx.x * ldd;
+  int nch = ldd >> 3;
+  if (y < 0 || y >= V) {                                   // a listed row without a label: zeros (the dense kernel's value)
+    bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int c = threadIdx.x; c < nch; c += 256) *(bf16x8*)(d + c * 8) = zero;
+    return;
+  }
+  float lse = row_lse[r], ce = lse - row_zy[r];
+  float coef = 1.f;
+  if (use_reweight && gamma != 0.f) {
+    float pt = __expf(-ce), om = fmaxf(1.f - pt, 0.f);
+    coef = powf(om, gamma) + gamma * pt * powf(om, gamma - 1.f) * ce;
+  }
+  float g = (gscale ? gscale[0] : 1.f) * weights[b] * coef / out3[1];
+  for (int c = threadIdx.x; c < nch; c += 256) {
+    bf16x8 v = *(const bf16x8*)(z + c * 8), o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      int col = c * 8 + k;
+      float p = col < V ? __expf(bf2f(v[k]) - lse) : 0.f;
+      if (col == y) p -= 1.f;
+      o[k] = f2bf(g * p);
+    }
+    *(bf16x8*)(d + c * 8) = o;
+  }
+}
+
+extern "C" int unimp_focal_ce_bwd_rows(const void* logits, int64_t ldv, const int64_t* labels, const float* weights, float gamma,
+                                       int use_reweight, const float* row_lse, const float* row_zy, const float* out3,
+                                       const float* gscale, const int64_t* rows, int n_rows, void* dl, int64_t ldd, int L, int V,
+                                       void* stream) {
+  if (!logits || !labels || !weights || !row_lse || !row_zy || !out3 || !rows || !dl) return unimp_set_error(UNIMP_ERR_ARG, "focal_ce_bwd_rows: null pointer");
+  if ((ldv & 7) || (ldd & 7) || ldv < V || ldd < V || ldd > ldv || ((uintptr_t)logits & 15) || ((uintptr_t)dl & 15))
+    return unimp_set_error(UNIMP_ERR_ALIGN, "focal_ce_bwd_rows: ldv, ldd %% 8 == 0, V <= ldd <= ldv, 16-B aligned");
+  if (n_rows <= 0 || L <= 0) return UNIMP_OK;
+  hipLaunchKernelGGL(focal_bwd_rows_kernel, dim3((unsigned)n_rows), dim3(256), 0, (hipStream_t)stream, (const bf16*)logits, (long)ldv, labels,
+                     weights, gamma, use_reweight, row_lse, row_zy, out3, gscale, rows, (bf16*)dl, (long)ldd, L, V);
+  return unimp_check_launch("focal_ce_bwd_rows");
+}
+
 extern "C" int unimp_focal_ce_fwd(const void* logits, int64_t ldv, const int64_t* labels, const float* weights, float gamma,
                                   int use_reweight, float* row_lse, float* row_zy, float* out3, int B, int L, int V, void* stream) {
   if (!logits || !labels || !weights || !row_lse || !row_zy || !out3) return unimp_set_error(UNIMP_ERR_ARG, "focal_ce_fwd: null pointer");

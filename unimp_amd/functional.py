@@ -642,6 +642,53 @@ class SparseHeadLossFn(Function):
         return dh, dw, None, None, None, None
 
 
+class DenseHeadLossFn(Function):
+    """LM head + weighted focal CE in one node: the FORWARD is the reference's -- dense logits for all B*L positions (returned,
+    non-differentiable, as the model's ``output["logits"]``: mmrec.py:190) and the loss over them (mmrec.py:190-213); the
+    BACKWARD touches the labeled positions only.  d loss / d logits is exactly zero on every row whose next token carries no
+    label (~98 % of the rows: 10 answers in 512 tokens), so the dense [B*L, V] gradient the reference materialises, and the
+    zero rows of its dX = dlogits W and dW = dlogits^T h products, are never formed: ``rows`` (b*L + j of the scored
+    positions, from the label mask) selects the n rows whose gradient is written compactly [n, V]; dX is scattered back
+    into a zero [B*L, H] tensor and dW contracts over the n rows.  Same gradients as LinearFn + FocalCEFn
+    (tests/test_model_gpu.py::test_compact_head_backward_equals_dense)."""
+
+    @staticmethod
+    def forward(ctx, h, w, labels, weights, rows, gamma, use_reweight):
+        B, L, H = h.shape
+        V = w.shape[0]
+        ldv = (V + 7) // 8 * 8
+        h2 = h.reshape(B * L, H)
+        y = ops.gemm(h2, w, ldc=ldv)                                                    # [B*L, V] view, leading dimension ldv
+        logits = y.as_strided((B, L, V), (L * ldv, ldv, 1), y.storage_offset())
+        lse, zy, out3 = ops.focal_ce_fwd(logits, V, labels, weights, gamma, use_reweight)
+        ctx.save_for_backward(h2, w, logits, labels, weights, lse, zy, out3, rows)
+        ctx.cfg = (gamma, use_reweight, B, L, H)
+        ctx.mark_non_differentiable(out3, logits)
+        return out3[0] / out3[1], out3, logits
+
+    @staticmethod
+    def backward(ctx, dloss, _a, _b):
+        h2, w, logits, labels, weights, lse, zy, out3, rows = ctx.saved_tensors
+        gamma, rw, B, L, H = ctx.cfg
+        V = w.shape[0]
+        dh = torch.zeros((B * L, H), dtype=bf16, device=h2.device) if _need(ctx, 0) else None
+        dw = None
+        if rows.numel() > 0:
+            dl = ops.focal_ce_bwd_rows(logits, V, labels, weights, gamma, rw, lse, zy, out3, dloss.float().reshape(1), rows)
+            if dh is not None:
+                dh.index_copy_(0, rows, ops.gemm(dl, w, b_ks=True))                       # rows are distinct positions
+            if _need(ctx, 1):
+                dw = ops.gemm(dl, h2.index_select(0, rows), a_ks=True, b_ks=True)
+        elif _need(ctx, 1):
+            dw = torch.zeros_like(w)
+        return (dh.view(B, L, H) if dh is not None else None), dw, None, None, None, None, None
+
+
+def dense_head_loss(h, w, labels, weights, rows, gamma, use_reweight=True):
+    """returns (loss, stats, logits [B, L, V]); see DenseHeadLossFn."""
+    return DenseHeadLossFn.apply(h, w, labels, weights, rows, float(gamma), bool(use_reweight))
+
+
 def sparse_head_loss(h_rows, w, targets, row_w, gamma, use_reweight=True):
     return SparseHeadLossFn.apply(h_rows, w, targets, row_w, float(gamma), bool(use_reweight))
 

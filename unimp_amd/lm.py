@@ -145,6 +145,8 @@ class _TowerBase(nn.Module):
         if last_index is not None:          # padded prompts: every row's own last valid position
             h = h[torch.arange(h.shape[0], device=h.device), last_index].unsqueeze(1)
             last_only = False
+        if isinstance(head_rows, str):     # "hidden": the caller applies head + loss as one fused node (train.py, functional.DenseHeadLossFn)
+            return LMOutput(None, None, hidden_rows=h)
         if head_rows is not None:          # the caller applies the head itself on these flattened (b*L + j) rows (train.py)
             return LMOutput(None, None, hidden_rows=h.reshape(-1, h.shape[-1]).index_select(0, head_rows))
         w = self.get_output_embeddings().weight

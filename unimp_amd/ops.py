@@ -431,6 +431,19 @@ def focal_ce_bwd(logits, V, labels, weights, gamma, use_reweight, lse, zy, out3,
     return dlogits
 
 
+def focal_ce_bwd_rows(logits, V, labels, weights, gamma, use_reweight, lse, zy, out3, gscale, rows):
+    """compact gradient [n, ldd] (ldd = roundup8(V)) of the scored positions rows[i] = b*L + j; see include/unimp_hip.h."""
+    labels, weights = _focal_args(logits, labels, weights)
+    L, ldv = logits.shape[1], logits.stride(1)
+    assert rows.dtype == torch.int64 and rows.is_contiguous()
+    n, ldd = rows.numel(), (V + 7) // 8 * 8
+    buf = torch.empty((n, ldd), dtype=bf16, device=logits.device)
+    check(_lib.lib().unimp_focal_ce_bwd_rows(logits.data_ptr(), ldv, labels.data_ptr(), weights.data_ptr(), gamma, int(use_reweight),
+                                              lse.data_ptr(), zy.data_ptr(), out3.data_ptr(), _p(gscale), _dev(rows).data_ptr(), n,
+                                              buf.data_ptr(), ldd, L, V, _stream()), "focal_ce_bwd_rows")
+    return buf[:, :V]
+
+
 def sumsq(g, out):
     """out: fp32 [1 + 1024]; out[0] += sum(g^2)."""
     check(_lib.lib().unimp_sumsq_bf16(_dev(g).data_ptr(), g.numel(), out.data_ptr(), _stream()), "sumsq")

@@ -85,11 +85,15 @@ def load_checkpoint(path, model, trainer=None):
 class Trainer:
     def __init__(self, model, special_ids, lr=2e-4, weight_decay=0.1, gamma=2.0, use_reweight=True, max_grad_norm=1.0,
                  lr_scheduler="cosine", warmup_steps=0, total_steps=1000, bucket_bytes=256 << 20, process_group=None,
-                 sparse_head=False, grad_accum=1, mask_lm_head=False, force_dp_hooks=False):
+                 sparse_head=False, grad_accum=1, mask_lm_head=False, force_dp_hooks=False, dense_head_backward=False):
         """sparse_head (off by default): apply the LM head and the loss only to the positions whose next token carries a
         label -- identical loss / gradients / update (unlabeled rows contribute nothing), ~5 % fewer FLOPs at cfg2; the
-        returned model output then has no logits.  Costs one host sync per step (the row count)."""
-        self.model, self.sparse_head = model, sparse_head
+        returned model output then has no logits.  Costs one host sync per step (the row count).
+        dense_head_backward (off by default): form the dense [B*L, V] logit gradient and run the head's dX / dW GEMMs over all
+        B*L rows as the reference does.  The default computes the SAME dense forward logits and loss but restricts the head's
+        backward to the positions that carry a label -- the gradient is exactly zero on the others (functional.DenseHeadLossFn);
+        it needs the number of labeled positions on the host: one sync per step, right after the label-mask kernel."""
+        self.model, self.sparse_head, self.dense_head_backward = model, sparse_head, dense_head_backward
         self.grad_accum, self._micro = grad_accum, 0       # mmrec.py's --gradient_accumulation_steps (accelerator.accumulate)
         self.ids = special_ids                   # dict(answer_id, eoc_id, pad_id, media_id)
         self.gamma, self.use_reweight = gamma, use_reweight
@@ -129,8 +133,16 @@ class Trainer:
                 loss, stats = F_.sparse_head_loss(out.hidden_rows, w, labels[bj[:, 0], bj[:, 1] + 1].contiguous(),
                                                   batch["weights"].float()[bj[:, 0]].contiguous(), self.gamma, self.use_reweight)
                 return loss, stats, out, labels
-        out = self.model(vision_x=vx, lang_x=ids, attention_mask=batch["attention_mask"], labels=None)
-        loss, stats = F_.focal_ce(out["logits"], labels, batch["weights"], self.gamma, self.use_reweight)
+        if self.dense_head_backward:
+            out = self.model(vision_x=vx, lang_x=ids, attention_mask=batch["attention_mask"], labels=None)
+            loss, stats = F_.focal_ce(out["logits"], labels, batch["weights"], self.gamma, self.use_reweight)
+            return loss, stats, out, labels
+        bj = (labels[:, 1:] != -100).nonzero()                           # host sync: how many positions are scored
+        rows = (bj[:, 0] * ids.shape[1] + bj[:, 1]).contiguous()
+        out = self.model(vision_x=vx, lang_x=ids, attention_mask=batch["attention_mask"], labels=None, head_rows="hidden")
+        w = self.model.lang_encoder.get_output_embeddings().weight
+        loss, stats, logits = F_.dense_head_loss(out.hidden_rows, w, labels, batch["weights"], rows, self.gamma, self.use_reweight)
+        out.logits, out.hidden_rows = logits, None                       # the reference's dense output["logits"] (mmrec.py:190)
         return loss, stats, out, labels
 
     def _mask_lm_head_grads(self):
