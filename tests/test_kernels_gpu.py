@@ -21,10 +21,11 @@ def ops():
     return o
 
 
-@pytest.fixture(params=[1, 2], ids=["gen1", "gen2"])
+@pytest.fixture(params=[1, 2, 3], ids=["gen1", "gen2", "gen3"])
 def attn_gen(request):
-    """run an attention test on both kernel generations (attention.hip / attention2.hip): two independent implementations
-    of one contract, each checked against the fp32 reference."""
+    """run an attention test on every kernel generation (1: attention.hip; 2: attention2.hip forward + dQ with the
+    first-generation dK/dV kernel -- the default; 3: attention2.hip throughout): independent implementations of one
+    contract, each checked against the fp32 reference."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from unimp_amd import _lib

@@ -45,7 +45,7 @@ for name in (sys.argv[1:] or SHAPES):
     q, k, v, dq, dk, dv, do, kv_len, seg, seg_len = setup(B, H, Sq, Sk, D, mode)
     fl = 4.0 * B * H * Sq * Sk * D
     res = {}
-    for gen in (1, 2):
+    for gen in (1, 2, 3):
         _lib.lib().unimp_attn_set_generation(gen)
         o, lse = ops.attn_fwd(q, k, v, D ** -0.5, mode, kv_len, seg, seg_len)
         tf = timeit(lambda: ops.attn_fwd(q, k, v, D ** -0.5, mode, kv_len, seg, seg_len))
@@ -53,4 +53,4 @@ for name in (sys.argv[1:] or SHAPES):
         res[gen] = (tf, tb, o.float().clone(), dq.float().clone(), dk.float().clone(), dv.float().clone())
     d = [float((res[1][i] - res[2][i]).abs().max()) for i in range(2, 6)]
     print(f"{name:6s} B{B} H{H} {Sq}x{Sk} D{D} mode{mode}: fwd gen1 {res[1][0]:.3f} ms ({fl / res[1][0] / 1e9:.0f} TF) gen2 {res[2][0]:.3f} ms ({fl / res[2][0] / 1e9:.0f} TF) | "
-          f"bwd gen1 {res[1][1]:.3f} ms ({2.5 * fl / res[1][1] / 1e9:.0f} TF) gen2 {res[2][1]:.3f} ms ({2.5 * fl / res[2][1] / 1e9:.0f} TF) | max|gen1-gen2| o {d[0]:.2e} dq {d[1]:.2e} dk {d[2]:.2e} dv {d[3]:.2e}", flush=True)
+          f"bwd gen1 {res[1][1]:.3f} ms ({2.5 * fl / res[1][1] / 1e9:.0f} TF) gen2 {res[2][1]:.3f} ms gen3 {res[3][1]:.3f} ms | max|gen1-gen2| o {d[0]:.2e} dq {d[1]:.2e} dk {d[2]:.2e} dv {d[3]:.2e}", flush=True)

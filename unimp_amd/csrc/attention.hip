@@ -660,11 +660,19 @@ extern "C" int unimp_attn_bwd(const unimp_attn_desc* d, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   long n = (long)p.B * p.H * p.Sq;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((n * 16 + 255) / 256)), dim3(256), 0, s, p);
+  // generation 2 (default): second-generation dQ kernel + first-generation dK/dV kernel (measured faster at 2 waves per SIMD:
+  // profiles/ r02 attention notes); generation 3: both second generation.  The second-generation kernels store 16-byte chunks:
+  // output strides must be multiples of 8 elements.
+  int gen = attn_generation();
+  bool al16 = !(((p.dq_bs | p.dq_ss | p.dq_hs | p.dk_bs | p.dk_ss | p.dk_hs | p.dv_bs | p.dv_ss | p.dv_hs) & 7) ||
+                (((uintptr_t)p.dq | (uintptr_t)p.dk | (uintptr_t)p.dv) & 15)) && p.Sq >= 4;
+  int which2 = (gen >= 2 && al16) ? (gen >= 3 ? 3 : 1) : 0;
+  if (which2) { int e2 = unimp_attn_bwd2_dispatch(p, which2, stream); if (e2) return e2; }
   dim3 gq((p.Sq + 127) / 128, p.H, p.B), gk((p.Sk + 127) / 128, p.H, p.B), block(256);
 #define BWD(A_) do {                                                                                                   \
-    if (p.D == 64) { hipLaunchKernelGGL((attn_dq_kernel<64, 64, A_>), gq, block, 0, s, p); hipLaunchKernelGGL((attn_dkv_kernel<64, 64, A_>), gk, block, 0, s, p); }            \
-    else if (p.D == 80) { hipLaunchKernelGGL((attn_dq_kernel<96, 80, A_>), gq, block, 0, s, p); hipLaunchKernelGGL((attn_dkv_kernel<96, 80, A_>), gk, block, 0, s, p); }       \
-    else { hipLaunchKernelGGL((attn_dq_kernel<128, 128, A_>), gq, block, 0, s, p); hipLaunchKernelGGL((attn_dkv_kernel<128, 128, A_>), gk, block, 0, s, p); } } while (0)
+    if (p.D == 64) { if (!(which2 & 1)) hipLaunchKernelGGL((attn_dq_kernel<64, 64, A_>), gq, block, 0, s, p); if (!(which2 & 2)) hipLaunchKernelGGL((attn_dkv_kernel<64, 64, A_>), gk, block, 0, s, p); }            \
+    else if (p.D == 80) { if (!(which2 & 1)) hipLaunchKernelGGL((attn_dq_kernel<96, 80, A_>), gq, block, 0, s, p); if (!(which2 & 2)) hipLaunchKernelGGL((attn_dkv_kernel<96, 80, A_>), gk, block, 0, s, p); }       \
+    else { if (!(which2 & 1)) hipLaunchKernelGGL((attn_dq_kernel<128, 128, A_>), gq, block, 0, s, p); if (!(which2 & 2)) hipLaunchKernelGGL((attn_dkv_kernel<128, 128, A_>), gk, block, 0, s, p); } } while (0)
   if (p.alibi) BWD(true); else BWD(false);
 #undef BWD
   return unimp_check_launch("attn_bwd");

@@ -16,3 +16,4 @@ struct AttnP {
 };
 
 int unimp_attn_fwd2_dispatch(const AttnP& p, void* stream);      // attention2.hip
+int unimp_attn_bwd2_dispatch(const AttnP& p, int which, void* stream);      // attention2.hip (after the delta kernel): 1 dQ, 2 dK/dV
