@@ -443,11 +443,15 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(AttnP p) {
 // block = 128 keys: each wave owns 32 keys (two 16-key blocks whose K / V fragments live in registers) and sweeps the
 // query tiles (32 rows, double-buffered Q / dO images + per-row lse / delta / key range); P and dS stay in registers.
 template <int DQK, int DV, bool ALIBI>
-__global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p) {
+__global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p, int nx) {
   constexpr int STR = DQK * 2 + 16, NKS = DQK / 32, ND = DV / 16;
   constexpr int STAGE = 2 * 32 * STR + 32 * 16 + 16;
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
-  int b = blockIdx.z, h = blockIdx.y, kblk = blockIdx.x;
+  // 1-D launch decoded XCD-aware (attention2.hip a2_decode): the key blocks of one (batch, head) share an XCD's L2, first
+  // key block (the one that sees the most query tiles under the causal mask) first
+  int id_ = xcd_remap(blockIdx.x, nx * p.H * p.B);
+  int kblk = id_ % nx, t_ = id_ / nx;
+  int h = t_ % p.H, b = t_ / p.H;
   int wave = threadIdx.x >> 6, l = lane_id(), g = l >> 4;
   int key0 = kblk * 128 + wave * 32;
   const bf16* qb = p.q + b * p.q_bs + h * p.q_hs;
@@ -582,18 +586,47 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p) {
     }
     __syncthreads();
   }
+  // epilogue through a wave-private LDS region (the loop ended with a barrier): accumulator layout (lane: key = l & 15 of
+  // block u, 4 consecutive d) -> whole 16-byte chunks of consecutive key rows; 8-byte stores straight from the accumulators
+  // touched 16 different rows per instruction (store-issue bound: ~80 us of this kernel at the LM shape)
+  constexpr int EP = DV * 2 + 16, ECPR = DV / 8;
+  static_assert(4 * 32 * EP <= 2 * STAGE, "epilogue staging fits");
+  char* ew = smem + wave * (32 * EP);
+  const bool wide = !((p.dk_bs | p.dk_ss | p.dk_hs | p.dv_bs | p.dv_ss | p.dv_hs) & 7) && !(((uintptr_t)p.dk | (uintptr_t)p.dv) & 15);
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    int key = key0 + u * 16 + (l & 15);
-    if (key < p.Sk) {
-      bf16* okb = p.dk + b * p.dk_bs + (long)key * p.dk_ss + h * p.dk_hs;
-      bf16* ovb = p.dv + b * p.dv_bs + (long)key * p.dv_ss + h * p.dv_hs;
+  for (int which = 0; which < 2; ++which) {
+    bf16* gb = (which ? p.dv + b * p.dv_bs + h * p.dv_hs : p.dk + b * p.dk_bs + h * p.dk_hs);
+    long gs = which ? p.dv_ss : p.dk_ss;
+    if (wide) {
 #pragma unroll
-      for (int nd = 0; nd < ND; ++nd) {
-        bf16x4 a = {f2bf(dk[u][nd][0]), f2bf(dk[u][nd][1]), f2bf(dk[u][nd][2]), f2bf(dk[u][nd][3])};
-        bf16x4 c = {f2bf(dv[u][nd][0]), f2bf(dv[u][nd][1]), f2bf(dv[u][nd][2]), f2bf(dv[u][nd][3])};
-        *(bf16x4*)(okb + nd * 16 + g * 4) = a;
-        *(bf16x4*)(ovb + nd * 16 + g * 4) = c;
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int nd = 0; nd < ND; ++nd) {
+          const f32x4& a = which ? dv[u][nd] : dk[u][nd];
+          bf16x4 w = {f2bf(a[0]), f2bf(a[1]), f2bf(a[2]), f2bf(a[3])};
+          *(bf16x4*)(ew + (u * 16 + (l & 15)) * EP + (nd * 16 + g * 4) * 2) = w;
+        }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i = 0; i < (32 * ECPR + 63) / 64; ++i) {
+        int id = l + 64 * i;
+        int r = id / ECPR, c = id - r * ECPR;
+        if (id < 32 * ECPR && key0 + r < p.Sk) *(u32x4*)(gb + (long)(key0 + r) * gs + c * 8) = *(const u32x4*)(ew + r * EP + c * 16);
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+    } else {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        int key = key0 + u * 16 + (l & 15);
+        if (key < p.Sk)
+#pragma unroll
+          for (int nd = 0; nd < ND; ++nd) {
+            const f32x4& a = which ? dv[u][nd] : dk[u][nd];
+            bf16x4 w = {f2bf(a[0]), f2bf(a[1]), f2bf(a[2]), f2bf(a[3])};
+            *(bf16x4*)(gb + (long)key * gs + nd * 16 + g * 4) = w;
+          }
       }
     }
   }
@@ -659,7 +692,6 @@ extern "C" int unimp_attn_bwd(const unimp_attn_desc* d, void* stream) {
   if (p.B <= 0 || p.H <= 0 || p.Sq <= 0) return UNIMP_OK;
   hipStream_t s = (hipStream_t)stream;
   long n = (long)p.B * p.H * p.Sq;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((n * 16 + 255) / 256)), dim3(256), 0, s, p);
   // generation 2 (default): second-generation dQ kernel + first-generation dK/dV kernel (measured faster at 2 waves per SIMD:
   // profiles/ r02 attention notes); generation 3: both second generation.  The second-generation kernels store 16-byte chunks:
   // output strides must be multiples of 8 elements.
@@ -667,12 +699,15 @@ extern "C" int unimp_attn_bwd(const unimp_attn_desc* d, void* stream) {
   bool al16 = !(((p.dq_bs | p.dq_ss | p.dq_hs | p.dk_bs | p.dk_ss | p.dk_hs | p.dv_bs | p.dv_ss | p.dv_hs) & 7) ||
                 (((uintptr_t)p.dq | (uintptr_t)p.dk | (uintptr_t)p.dv) & 15)) && p.Sq >= 4;
   int which2 = (gen >= 2 && al16) ? (gen >= 3 ? 3 : 1) : 0;
+  // delta = rowsum(dO * O): the second-generation dQ kernel computes and publishes it itself
+  if (!(which2 & 1)) hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((n * 16 + 255) / 256)), dim3(256), 0, s, p);
   if (which2) { int e2 = unimp_attn_bwd2_dispatch(p, which2, stream); if (e2) return e2; }
-  dim3 gq((p.Sq + 127) / 128, p.H, p.B), gk((p.Sk + 127) / 128, p.H, p.B), block(256);
+  const int nkb = (p.Sk + 127) / 128;
+  dim3 gq((p.Sq + 127) / 128, p.H, p.B), gk(nkb * p.H * p.B), block(256);
 #define BWD(A_) do {                                                                                                   \
-    if (p.D == 64) { if (!(which2 & 1)) hipLaunchKernelGGL((attn_dq_kernel<64, 64, A_>), gq, block, 0, s, p); if (!(which2 & 2)) hipLaunchKernelGGL((attn_dkv_kernel<64, 64, A_>), gk, block, 0, s, p); }            \
-    else if (p.D == 80) { if (!(which2 & 1)) hipLaunchKernelGGL((attn_dq_kernel<96, 80, A_>), gq, block, 0, s, p); if (!(which2 & 2)) hipLaunchKernelGGL((attn_dkv_kernel<96, 80, A_>), gk, block, 0, s, p); }       \
-    else { if (!(which2 & 1)) hipLaunchKernelGGL((attn_dq_kernel<128, 128, A_>), gq, block, 0, s, p); if (!(which2 & 2)) hipLaunchKernelGGL((attn_dkv_kernel<128, 128, A_>), gk, block, 0, s, p); } } while (0)
+    if (p.D == 64) { if (!(which2 & 1)) hipLaunchKernelGGL((attn_dq_kernel<64, 64, A_>), gq, block, 0, s, p); if (!(which2 & 2)) hipLaunchKernelGGL((attn_dkv_kernel<64, 64, A_>), gk, block, 0, s, p, nkb); }            \
+    else if (p.D == 80) { if (!(which2 & 1)) hipLaunchKernelGGL((attn_dq_kernel<96, 80, A_>), gq, block, 0, s, p); if (!(which2 & 2)) hipLaunchKernelGGL((attn_dkv_kernel<96, 80, A_>), gk, block, 0, s, p, nkb); }       \
+    else { if (!(which2 & 1)) hipLaunchKernelGGL((attn_dq_kernel<128, 128, A_>), gq, block, 0, s, p); if (!(which2 & 2)) hipLaunchKernelGGL((attn_dkv_kernel<128, 128, A_>), gk, block, 0, s, p, nkb); } } while (0)
   if (p.alibi) BWD(true); else BWD(false);
 #undef BWD
   return unimp_check_launch("attn_bwd");

@@ -389,7 +389,19 @@ __global__ __launch_bounds__(256) void attn_dq2_kernel(AttnP p, int nx) {
     for (int ks = 0; ks < KS; ++ks) { qf[ks] = *(const bf16x8*)(qrow + ks * 16 + hi5 * 8); dof[ks] = *(const bf16x8*)(dorow + ks * 16 + hi5 * 8); }
     a2_key_range(p, b, qr, lo, hi);
     long sidx = ((long)b * p.H + h) * p.Sq + qc;
-    lse2 = p.lse[sidx] * LOG2E; dl = p.delta[sidx];
+    lse2 = p.lse[sidx] * LOG2E;
+    // delta = rowsum(dO * O), computed here (the wave holds its dO rows anyway) and published for the dK/dV kernel that
+    // follows on the stream: the separate delta pass over O and dO is gone
+    const bf16* orow = p.o + b * p.o_bs + h * p.o_hs + (long)qc * p.o_ss;
+    float acc = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      bf16x8 of = *(const bf16x8*)(orow + ks * 16 + hi5 * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc += bf2f(of[j]) * bf2f(dof[ks][j]);
+    }
+    dl = acc + __shfl_xor(acc, 32, 64);
+    if (hi5 == 0 && qr < p.Sq) p.delta[sidx] = dl;
   }
   int wlo = lo, whi = hi;
 #pragma unroll
@@ -695,12 +707,12 @@ int unimp_attn_bwd2_dispatch(const AttnP& p, int which, void* stream) {
 
 template <int D, bool ALIBI>
 static void launch_fwd2(const AttnP& p, hipStream_t s) {
-  int full = p.Sq / 128, rem = p.Sq - full * 128;
-  // whole 128-row blocks (plus a ragged one when more than one wave's worth of rows is left) by the 4-wave kernel; a tail of
-  // at most 32 rows (the ViT's 257th token) by one-wave blocks instead of a fourth-empty 128-row block
-  int big = full + (rem > 32 ? 1 : 0);
-  if (big > 0) hipLaunchKernelGGL((attn_fwd2_kernel<D, 4, ALIBI>), dim3(big * p.H * p.B), dim3(256), 0, s, p, 0, big);
-  if (rem > 0 && rem <= 32) hipLaunchKernelGGL((attn_fwd2_kernel<D, 1, ALIBI>), dim3(p.H * p.B), dim3(64), 0, s, p, full * 128, 1);
+  // a wave owns 32 query rows; 4 or 5 waves per block, whichever wastes fewer wave slots: S = 257 (the ViT: 256 patches + CLS)
+  // is 9 waves of rows = 2 blocks of 5 instead of 3 blocks of 4 with a third nearly empty one
+  int w = (p.Sq + 31) / 32;
+  int b4 = (w + 3) / 4, b5 = (w + 4) / 5;
+  if (b5 * 5 < b4 * 4) hipLaunchKernelGGL((attn_fwd2_kernel<D, 5, ALIBI>), dim3(b5 * p.H * p.B), dim3(320), 0, s, p, 0, b5);
+  else hipLaunchKernelGGL((attn_fwd2_kernel<D, 4, ALIBI>), dim3(b4 * p.H * p.B), dim3(256), 0, s, p, 0, b4);
 }
 
 int unimp_attn_fwd2_dispatch(const AttnP& p, void* stream) {
