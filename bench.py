@@ -161,6 +161,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--model", choices=["4b-instruct", "9b"], default="4b-instruct",
                     help="9b = ViT-L/14 + MPT-7B, cross-attention every 4th block (mmrec.py:515-524), bf16 -- NOT the headline configuration")
+    ap.add_argument("--fp8", action="store_true", help="frozen towers (LM + ViT Linear layers, forward and dX) on the MX-fp8 GEMM: OCP e4m3 weights "
+                    "with E8M0 block scales quantised once, activations quantised on the fly (BASELINE config 5; NOT the headline bf16 configuration)")
     ap.add_argument("--sparse-head", action="store_true", help="Trainer(sparse_head=True): head + loss on the labeled rows only "
                     "(same loss / gradients; NOT the default and not the headline configuration)")
     args = ap.parse_args()
@@ -183,8 +185,11 @@ def main():
     torch.cuda.set_device(dev)
 
     from unimp_amd import ops
+    from unimp_amd import functional as F_
     from unimp_amd.synthetic import make_batch
     from unimp_amd.train import Trainer
+    if args.fp8:
+        F_.FP8_FROZEN = True
 
     nine = args.model == "9b"
     if args.batch is None:
@@ -291,7 +296,8 @@ def main():
             cpu = cpu_baseline(T, L, layout, fps, args.cpu_full_steps)
         line = {"metric": "train samples/sec (user sequences) at 4B-instruct", "value": round(value, 3), "unit": "samples/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2),
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "bf16 (trainable blocks, activations, attention) + MX-fp8 e4m3 frozen-tower GEMMs" if args.fp8 else "bf16", "data": "synthetic",
                 "config": {"workload": ("cfg5 model in bf16: 9b Flamingo (ViT-L/14 + MPT-7B dims, xattn every 4), " if nine else
                                         "cfg2: 4b-instruct Flamingo (ViT-L/14 + GPT-NeoX-3B RedPajama dims, xattn every 2), ") +
                                        "single-task rec, full optimizer step" + (", LM head on labeled rows only" if args.sparse_head else ""), "per_gpu_batch": B, "grad_accum": GA, "global_batch": GA * B * world,

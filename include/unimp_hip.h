@@ -28,7 +28,7 @@ enum { UNIMP_ACT_NONE = 0, UNIMP_ACT_GELU = 1, UNIMP_ACT_QUICKGELU = 2, UNIMP_AC
 enum { UNIMP_MASK_NONE = 0, UNIMP_MASK_CAUSAL = 1, UNIMP_MASK_SEGMENT = 2 };
 
 int unimp_abi_version(void);
-int unimp_struct_size(int which);            /* sizeof(unimp_gemm_desc / unimp_attn_desc / unimp_image_desc) for which = 0 / 1 / 2 */
+int unimp_struct_size(int which);            /* sizeof(unimp_gemm_desc / unimp_attn_desc / unimp_image_desc / unimp_mx_gemm_desc) for which = 0 / 1 / 2 / 3 */
 const char* unimp_last_error(void);          /* thread-local, valid until the next failing call */
 /* internal helpers shared by the translation units (exported for the tests' benefit only) */
 int unimp_set_error(int code, const char* msg);
@@ -161,6 +161,23 @@ int unimp_dot_bf16(const void* a, const void* b, int64_t n, float* out, void* st
 /* out[r] = src[r % period] (Perceiver latents repeat "n d -> b T n d") and its adjoint out[j] = sum_{r%period==j} src[r] (bf16) */
 int unimp_bcast_rows(const void* src, void* out, int64_t ldo, int rows, int period, int D, void* stream);
 int unimp_reduce_rows_periodic(const void* src, int64_t lds_, void* out, int rows, int period, int D, void* stream);
+
+/* ---- MX-fp8 path for the frozen towers (reference: the "9b" model of mmrec.py:515-524, BASELINE config 5) ----
+ * mx_quantize: bf16 x[rows][K] (row stride ldx elements) -> OCP e4m3 q[rows][K] (row stride ldq bytes) + one E8M0 scale byte per 32
+ *   consecutive k: scales[rows][K/32] (row stride lds bytes).  MX rule: shared exponent floor(log2 amax) - 8, saturating cast.
+ * gemm_mxfp8:  C[M][N] (bf16) = epi( sum_k A[m][k] B[n][k] ) with both operands quantised along k (k-contiguous rows), fp32
+ *   accumulate on v_mfma_scale_f32_16x16x128_f8f6f4.  Epilogue: + bias[N], act (UNIMP_ACT_*; with `pre` != NULL the derivative
+ *   act'(z) is written there), x aux[M][N], + res[M][N].  K % 128 == 0. */
+typedef struct unimp_mx_gemm_desc {
+  const void* A; const void* B;            /* e4m3 bytes, [M][K] and [N][K] */
+  const void* scale_a; const void* scale_b; /* E8M0 bytes, [M][K/32] and [N][K/32] */
+  void* C;
+  const void* bias; const void* res; const void* aux; void* pre;
+  int64_t lda, ldb, ldsa, ldsb, ldc, ldres, ldaux, ldpre;
+  int32_t M, N, K, act;
+} unimp_mx_gemm_desc;
+int unimp_mx_quantize(const void* x, int64_t ldx, void* q, int64_t ldq, void* scales, int64_t lds, int rows, int K, void* stream);
+int unimp_gemm_mxfp8(const unimp_mx_gemm_desc* d, void* stream);
 
 /* ---- training-step host logic moved to the device ---------------------------------------------------------
  * label mask state machine (mmrec.py:143-168): labels[b][j] = keep ? ids : -100, one thread block per row.

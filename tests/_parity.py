@@ -19,6 +19,10 @@ TINY_PAR = dict(vit=dict(image_size=32, patch_size=8, width=128, layers=1, heads
 TINY_MPT = dict(vit=dict(image_size=32, patch_size=8, width=128, layers=1, heads=2, mlp_dim=256, output_dim=64),
                 lm=dict(kind="mpt", vocab_size=512, d_model=192, n_layers=2, n_heads=3), every=1, T=2, L=40, B=2,
                 n_items=40, base_vocab=300)          # 3 heads of 64: non-power-of-two ALiBi slopes, tied head
+# every frozen Linear has both dimensions % 128 == 0 (the MX-fp8 path's tile contract): 2 heads of 128, ALiBi, tied head
+TINY_MX = dict(vit=dict(image_size=32, patch_size=8, width=128, layers=2, heads=2, mlp_dim=256, output_dim=64),
+               lm=dict(kind="mpt", vocab_size=512, d_model=256, n_layers=2, n_heads=2), every=1, T=2, L=48, B=2,
+               n_items=40, base_vocab=300)
 # BASELINE cfg2 / cfg3 at FULL WIDTH and reduced depth -- the model bench.cpu_baseline's bounded sample uses: ViT-L/14 widths
 # with 3 of 24 blocks, GPT-NeoX-3B widths (H 2560, 32 heads of 80, FFN 10 240) with 4 of 32 layers and 2 of 16 gated
 # cross-attention blocks, Perceiver 1 of 6 layers, V = 74 053, T = 8, L = 512.  The fp32 oracle runs it in tens of seconds.

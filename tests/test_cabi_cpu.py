@@ -50,6 +50,7 @@ def test_ctypes_mirrors_have_the_c_struct_sizes():
     assert lib.unimp_struct_size(0) == C.sizeof(_lib.GemmDesc)
     assert lib.unimp_struct_size(1) == C.sizeof(_lib.AttnDesc)
     assert lib.unimp_struct_size(2) == C.sizeof(_ImageDesc)
+    assert lib.unimp_struct_size(3) == C.sizeof(_lib.MxGemmDesc)
     assert lib.unimp_struct_size(9) == -1
 
 

@@ -622,3 +622,56 @@ def test_attention_alibi_causal(ops, attn_gen, B, H, S, D, kvpad):
     rows = torch.softmax((torch.einsum("bhd,bkhd->bhk", q[:, n - 1].float(), k[:, :n].float()) * scale
                           + slopes[None, :, None] * torch.arange(n)[None, None, :]), -1)
     close(o1[:, 0], torch.einsum("bhk,bkhd->bhd", rows, v[:, :n].float()), rel=2 ** -6, name="alibi decode row")
+
+
+# ------------------------------------------------------------------------------------------------- MX-fp8 (frozen towers, F4)
+def _mx_reference(x):
+    """the MX quantisation rule on the host: per 32 consecutive k, shared exponent floor(log2 amax) - 8 (E8M0 byte = exponent
+    + 127), elements x / 2^e saturated to +-448 and rounded to e4m3 (torch's float8_e4m3fn cast rounds to nearest even)."""
+    R, K = x.shape
+    xb = x.float().view(R, K // 32, 32)
+    amax = xb.abs().amax(-1)
+    e = torch.where(amax > 0, torch.floor(torch.log2(amax.clamp_min(1e-38))), torch.full_like(amax, -127.0))
+    sb = (e - 8 + 127).clamp(0, 254)
+    scale = torch.pow(2.0, sb - 127.0)
+    q = (xb / scale[..., None]).clamp(-448, 448).to(torch.float8_e4m3fn)
+    return q.view(R, K), sb.to(torch.uint8)
+
+
+@pytest.mark.parametrize("R,K", [(7, 64), (300, 2560), (64, 4096)])
+def test_mx_quantize(ops, R, K):
+    x = rnd(R, K, scale=3.0, seed=R)
+    x[0, :32] = 0                                   # an all-zero block
+    x[1, 5] = 1000.0                                # a block dominated by one large element
+    got = ops.mx_quantize(x.cuda())
+    q_ref, s_ref = _mx_reference(x)
+    assert torch.equal(got.scales.cpu(), s_ref)
+    assert torch.equal(got.q.cpu().view(torch.float8_e4m3fn).float(), q_ref.float())
+    # round trip error of the format: relative to each block's amax, at most 2^-3 / 2 of the top binade
+    back = got.dequantize().cpu()
+    blk = x.float().view(R, K // 32, 32).abs().amax(-1).repeat_interleave(32, 1)
+    assert ((back - x.float()).abs() <= blk * 2 ** -3).all()
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (200, 300, 256), (1024, 2560, 2560 // 128 * 128), (64, 8, 384), (520, 4104, 1024)])
+def test_gemm_mxfp8_vs_dequantised_reference(ops, M, N, K):
+    """the block-scaled MFMA path against fp32 matmul of the DEQUANTISED operands: the same products, fp32 accumulation in a
+    different order -> 1e-5-level agreement (this pins the operand / scale layout found by tools/micro/mx_probe.hip)."""
+    a = ops.mx_quantize(rnd(M, K, seed=1).cuda())
+    b = ops.mx_quantize(rnd(N, K, scale=0.5, seed=2).cuda())
+    want = a.dequantize().double().cpu() @ b.dequantize().double().cpu().t()
+    got = ops.gemm_mx(a, b).float().cpu()
+    err = (got.double() - want).abs().max() / want.abs().max()
+    assert err <= 2 ** -8, err                       # bf16 output rounding dominates (2^-9 relative per element)
+    # epilogue: bias + GELU with the derivative as a second output, then aux multiply + residual
+    bias = rnd(N, seed=3).cuda()
+    pre = torch.empty((M, N), dtype=bf16, device="cuda")
+    y = ops.gemm_mx(a, b, bias=bias, act="gelu", pre=pre).float().cpu()
+    z = (want + bias.float().cpu().double()).float()
+    close(y, torch.nn.functional.gelu(z), rel=2 ** -6, name="mx gelu")
+    zt = z.clone().requires_grad_(True)
+    torch.nn.functional.gelu(zt).sum().backward()
+    close(pre.float().cpu(), zt.grad, rel=2 ** -6, name="mx gelu'")
+    aux, res = rnd(M, N, seed=4).cuda(), rnd(M, N, seed=5).cuda()
+    y2 = ops.gemm_mx(a, b, aux=aux, res=res).float().cpu()
+    close(y2, want.float() * aux.float().cpu() + res.float().cpu(), rel=2 ** -6, name="mx aux+res")

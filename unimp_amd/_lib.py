@@ -31,6 +31,13 @@ class AttnDesc(C.Structure):
                                    "dv_bs", "dv_ss", "dv_hs")] + [("alibi_slopes", c_p)]
 
 
+class MxGemmDesc(C.Structure):
+    _fields_ = [("A", c_p), ("B", c_p), ("scale_a", c_p), ("scale_b", c_p), ("C", c_p),
+                ("bias", c_p), ("res", c_p), ("aux", c_p), ("pre", c_p)] + \
+               [(n, c_l) for n in ("lda", "ldb", "ldsa", "ldsb", "ldc", "ldres", "ldaux", "ldpre")] + \
+               [("M", c_i), ("N", c_i), ("K", c_i), ("act", c_i)]
+
+
 # name -> argtypes (every entry point returns int status)
 _SIGS = {
     "unimp_gemm_bf16": [C.POINTER(GemmDesc), c_p],
@@ -55,6 +62,8 @@ _SIGS = {
     "unimp_reduce_rows_periodic": [c_p, c_l, c_p, c_i, c_i, c_i, c_p],
     "unimp_label_mask": [c_p, c_p, c_p, c_i, c_i, c_l, c_l, c_l, c_l, c_p],
     "unimp_attn_set_generation": [c_i],
+    "unimp_mx_quantize": [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_p],
+    "unimp_gemm_mxfp8": [C.POINTER(MxGemmDesc), c_p],
     "unimp_focal_ce_fwd": [c_p, c_l, c_p, c_p, c_f, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "unimp_focal_ce_bwd": [c_p, c_l, c_p, c_p, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "unimp_focal_ce_bwd_rows": [c_p, c_l, c_p, c_p, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_l, c_i, c_i, c_p],

@@ -27,6 +27,7 @@ extern "C" int unimp_struct_size(int which) {
     case 0: return (int)sizeof(unimp_gemm_desc);
     case 1: return (int)sizeof(unimp_attn_desc);
     case 2: return (int)sizeof(unimp_image_desc);
+    case 3: return (int)sizeof(unimp_mx_gemm_desc);
     default: return -1;
   }
 }

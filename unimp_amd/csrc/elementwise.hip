@@ -7,34 +7,62 @@
 #define GRID1D(n, per) dim3((unsigned)std::min<long>(((n) + (per) - 1) / (per), 65535L * 16))
 
 // ------------------------------------------------------------------------------------------- RoPE (half-split)
+// One block per group of rows; the (head, vector, chunk) decomposition of a thread's items is the same in every row, so it
+// is done ONCE per thread (32-bit arithmetic) and the row loop only adds the row base and looks the position up -- the
+// first version decomposed a flat 64-bit index per item (four 64-bit divisions: 4.2 TB/s; this one streams).
 template <int CH>
-__global__ void rope_kernel(bf16* __restrict__ x, long row_stride, long head_stride, int rows, int L, int heads, int half,
-                            int nvec, int off0, int off1, const float* __restrict__ cs, const float* __restrict__ sn, int inverse) {
-  int cpr = half / CH;
-  long total = (long)rows * heads * nvec * cpr;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    int c = i % cpr; long t = i / cpr;
-    int vsel = t % nvec; t /= nvec;
-    int h = t % heads; long r = t / heads;
-    int pos = r % L;
-    bf16* p = x + r * row_stride + h * head_stride + (vsel ? off1 : off0) + c * CH;
-    const float* cp = cs + (long)pos * half + c * CH;
-    const float* sp = sn + (long)pos * half + c * CH;
-    if (CH == 8) {
-      bf16x8 a = *(bf16x8*)p, b = *(bf16x8*)(p + half), oa, ob;
+__global__ __launch_bounds__(256) void rope_kernel(bf16* __restrict__ x, long row_stride, long head_stride, int rows, int L, int heads,
+                                                   int half, int nvec, int off0, int off1, const float* __restrict__ cs,
+                                                   const float* __restrict__ sn, int inverse) {
+  constexpr int MAXI = 4;                                   // items per thread and row (a row has heads * nvec * half / CH items)
+  const int cpr = half / CH, per_head = nvec * cpr, items = heads * per_head;
+  int eoff[MAXI], toff[MAXI];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float co = cp[j], si = inverse ? -sp[j] : sp[j];
-        float x1 = bf2f(a[j]), x2 = bf2f(b[j]);
-        oa[j] = f2bf(x1 * co - x2 * si);
-        ob[j] = f2bf(x2 * co + x1 * si);
+  for (int k = 0; k < MAXI; ++k) {
+    int t = threadIdx.x + 256 * k;
+    int h = t / per_head, rem = t - h * per_head;
+    int vsel = rem / cpr, c = rem - vsel * cpr;
+    eoff[k] = t < items ? (int)(h * head_stride + (vsel ? off1 : off0) + c * CH) : -1;
+    toff[k] = c * CH;
+  }
+  const float sgn = inverse ? -1.f : 1.f;
+  for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+    int pos = r % L;
+    bf16* xr = x + (long)r * row_stride;
+    const float* cr = cs + (long)pos * half;
+    const float* sr = sn + (long)pos * half;
+    for (int k0 = 0; k0 * 256 < items; k0 += MAXI) {       // rows with more than MAXI * 256 items: further passes (not the LM shapes)
+#pragma unroll
+      for (int k = 0; k < MAXI; ++k) {
+        int eo = eoff[k], to = toff[k];
+        if (k0 > 0) {                                       // recompute for the later passes
+          int t = threadIdx.x + 256 * (k0 + k);
+          int h = t / per_head, rem = t - h * per_head;
+          int vsel = rem / cpr, c = rem - vsel * cpr;
+          eo = t < items ? (int)(h * head_stride + (vsel ? off1 : off0) + c * CH) : -1;
+          to = c * CH;
+        }
+        if (eo < 0) continue;
+        bf16* p = xr + eo;
+        if (CH == 8) {
+          bf16x8 a = *(bf16x8*)p, b = *(bf16x8*)(p + half), oa, ob;
+          f32x4 c0 = *(const f32x4*)(cr + to), c1 = *(const f32x4*)(cr + to + 4);
+          f32x4 s0 = *(const f32x4*)(sr + to), s1 = *(const f32x4*)(sr + to + 4);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float co = j < 4 ? c0[j & 3] : c1[j & 3], si = sgn * (j < 4 ? s0[j & 3] : s1[j & 3]);
+            float x1 = bf2f(a[j]), x2 = bf2f(b[j]);
+            oa[j] = f2bf(x1 * co - x2 * si);
+            ob[j] = f2bf(x2 * co + x1 * si);
+          }
+          *(bf16x8*)p = oa; *(bf16x8*)(p + half) = ob;
+        } else {
+          float co = cr[to], si = sgn * sr[to];
+          float x1 = bf2f(p[0]), x2 = bf2f(p[half]);
+          p[0] = f2bf(x1 * co - x2 * si);
+          p[half] = f2bf(x2 * co + x1 * si);
+        }
       }
-      *(bf16x8*)p = oa; *(bf16x8*)(p + half) = ob;
-    } else {
-      float co = cp[0], si = inverse ? -sp[0] : sp[0];
-      float x1 = bf2f(p[0]), x2 = bf2f(p[half]);
-      p[0] = f2bf(x1 * co - x2 * si);
-      p[half] = f2bf(x2 * co + x1 * si);
     }
   }
 }
@@ -49,15 +77,16 @@ extern "C" int unimp_rope_halfsplit(void* x, int64_t row_stride, int64_t head_st
   bool vec = (half % 8 == 0) && (row_stride % 8 == 0) && (head_stride % 8 == 0) && (vec_off0 % 8 == 0) && (vec_off1 % 8 == 0) &&
              (((uintptr_t)x & 15) == 0);
   hipStream_t s = (hipStream_t)stream;
-  if (vec) {
-    long total = (long)rows * heads * nvec * (half / 8);
-    hipLaunchKernelGGL((rope_kernel<8>), GRID1D(total, 256), dim3(256), 0, s, (bf16*)x, (long)row_stride, (long)head_stride, rows, L,
+  // cos / sin rows are read as float4: the table's row length (half) is a multiple of 8 in the vector form, so every chunk is
+  // 16-byte aligned when the table itself is (torch allocations are)
+  if ((long)heads * head_stride + rot > (1L << 30)) return unimp_set_error(UNIMP_ERR_SHAPE, "rope: row too long");
+  int grid = rows < 16384 ? rows : 16384;
+  if (vec && (((uintptr_t)cos_t | (uintptr_t)sin_t) & 15) == 0)
+    hipLaunchKernelGGL((rope_kernel<8>), dim3(grid), dim3(256), 0, s, (bf16*)x, (long)row_stride, (long)head_stride, rows, L,
                        heads, half, nvec, vec_off0, vec_off1, cos_t, sin_t, inverse);
-  } else {
-    long total = (long)rows * heads * nvec * half;
-    hipLaunchKernelGGL((rope_kernel<1>), GRID1D(total, 256), dim3(256), 0, s, (bf16*)x, (long)row_stride, (long)head_stride, rows, L,
+  else
+    hipLaunchKernelGGL((rope_kernel<1>), dim3(grid), dim3(256), 0, s, (bf16*)x, (long)row_stride, (long)head_stride, rows, L,
                        heads, half, nvec, vec_off0, vec_off1, cos_t, sin_t, inverse);
-  }
   return unimp_check_launch("rope");
 }
 

@@ -1,0 +1,254 @@
+// MX-fp8 path for the FROZEN towers (BASELINE config 5 "9B ... fp8 MFMA weights"): OCP e4m3 elements with one
+// E8M0 scale per 32 consecutive elements of the contraction dimension, multiplied on the block-scaled matrix instruction
+// v_mfma_scale_f32_16x16x128_f8f6f4 (fp32 accumulate; twice the bf16 MFMA rate per clock).
+//
+// Operand layout of that instruction, measured with exact integer data (tools/micro/mx_probe.hip; the guides give none):
+//   lane l (r = l & 15, g = l >> 4) supplies 32 bytes of row r:  bytes 0..15 = k 16 g .. 16 g + 15,  bytes 16..31 = k 64 + 16 g ..;
+//   the scale operand's lane (r, t = l >> 4) carries, in the byte chosen by op_sel, the E8M0 scale of row r's block k 32 t .. 32 t + 31;
+//   B likewise with r = column; C / D as every 16x16 MFMA (col = l & 15, row = 4 (l >> 4) + reg).
+// So a lane reads two 16-byte chunks (g and 4 + g) of its row's 128-byte K-step, and shifts its row's scale word by 8 t.
+//
+// unimp_mx_quantize : bf16 [R, K] -> e4m3 [R, K] + E8M0 [R, K / 32] (MX rule: shared exponent = floor(log2 amax) - 8, saturating cast)
+// unimp_gemm_mxfp8  : C[M, N] = epi(A[M, K] B[N, K]^T), both operands quantised along K and k-contiguous.  The frozen weights are
+//                     quantised ONCE in both orientations (W along K for y = x W^T; W^T along N for dx = dy W), so this one form
+//                     serves forward and dX.  128 x 128 tile, 4 waves (64 x 64 each), 128-byte K-steps, two LDS stages filled by
+//                     LDS-DMA (data + scale words; the XOR swizzle of the 128-byte rows is applied to the DMA's source address),
+//                     epilogue through LDS in 16-byte row chunks: + bias, GELU / ReLU with the derivative as a second output,
+//                     x aux (activation backward), + residual, bf16 out.
+// First version of this path: correct and measured (tools/bench_mx.py), not yet schedule-tuned like the bf16 GEMMs.
+#include "common.h"
+#include "unimp_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+
+// ------------------------------------------------------------------------------------------- quantiser
+// one thread per 32-element block: 64 bytes in, 32 + 1 bytes out
+__global__ __launch_bounds__(256) void mx_quantize_kernel(const bf16* __restrict__ x, long ldx, uint8_t* __restrict__ q, long ldq,
+                                                          uint8_t* __restrict__ sc, long lds_, int rows, int kblocks) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = (long)rows * kblocks;
+  if (i >= total) return;
+  int kb = i % kblocks; long r = i / kblocks;
+  const bf16* p = x + r * ldx + kb * 32;
+  float v[32];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    bf16x8 t = *(const bf16x8*)(p + c * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[c * 8 + j] = bf2f(t[j]);
+  }
+  float amax = 0.f;
+#pragma unroll
+  for (int j = 0; j < 32; ++j) amax = fmaxf(amax, fabsf(v[j]));
+  // shared exponent e = floor(log2 amax) - emax(e4m3 = 8), E8M0 byte = e + 127 in [0, 254]
+  int eb = (int)((__float_as_uint(amax) >> 23) & 0xff);          // biased exponent of amax (0 for zero / subnormal bf16 magnitudes)
+  int sbyte = max(eb - 8, 0);
+  if (!(amax == amax) || eb == 255) sbyte = 254;                // NaN / inf in the block: largest finite scale; elements saturate / NaN
+  float inv = __uint_as_float((uint32_t)(254 - sbyte) << 23);   // 2^-(sbyte - 127); sbyte = 0 -> 2^127
+  if (sbyte == 254) inv = 1.17549435e-38f;
+  uint32_t out[8];
+#pragma unroll
+  for (int w = 0; w < 8; ++w) {
+    float a = fminf(fmaxf(v[4 * w] * inv, -448.f), 448.f), b = fminf(fmaxf(v[4 * w + 1] * inv, -448.f), 448.f);
+    float c = fminf(fmaxf(v[4 * w + 2] * inv, -448.f), 448.f), d = fminf(fmaxf(v[4 * w + 3] * inv, -448.f), 448.f);
+    int pk = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    pk = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, pk, true);
+    out[w] = (uint32_t)pk;
+  }
+  uint8_t* qo = q + r * ldq + kb * 32;
+  *(u32x4*)qo = u32x4{out[0], out[1], out[2], out[3]};
+  *(u32x4*)(qo + 16) = u32x4{out[4], out[5], out[6], out[7]};
+  sc[r * lds_ + kb] = (uint8_t)sbyte;
+}
+
+extern "C" int unimp_mx_quantize(const void* x, int64_t ldx, void* q, int64_t ldq, void* scales, int64_t lds_, int rows, int K,
+                                 void* stream) {
+  if (!x || !q || !scales) return unimp_set_error(UNIMP_ERR_ARG, "mx_quantize: null pointer");
+  if (rows <= 0 || K <= 0) return UNIMP_OK;
+  if ((K & 31) || (ldx & 7) || (ldq & 15) || ((uintptr_t)x & 15) || ((uintptr_t)q & 15))
+    return unimp_set_error(UNIMP_ERR_SHAPE, "mx_quantize: K %% 32 == 0, ldx %% 8 == 0, ldq %% 16 == 0, 16-byte aligned pointers");
+  long total = (long)rows * (K / 32);
+  hipLaunchKernelGGL(mx_quantize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (long)ldx,
+                     (uint8_t*)q, (long)ldq, (uint8_t*)scales, (long)lds_, rows, K / 32);
+  return unimp_check_launch("mx_quantize");
+}
+
+// ------------------------------------------------------------------------------------------- GEMM
+struct MxP {
+  const uint8_t* A; const uint8_t* B; const uint8_t* sA; const uint8_t* sB;
+  long lda, ldb, ldsa, ldsb;
+  bf16* C; long ldc;
+  const bf16* bias; const bf16* res; long ldres; const bf16* aux; long ldaux; bf16* pre; long ldpre;
+  int M, N, K, act, nbm, nbn;
+};
+
+__device__ __forceinline__ void mx_glds16(const void* sbase, uint32_t voff, uint32_t lds_dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
+}
+__device__ __forceinline__ void mx_glds4(const void* sbase, uint32_t voff, uint32_t lds_dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
+}
+
+#define MX_BM 128
+#define MX_BN 128
+// stage: A data 16 KiB | B data 16 KiB | A scale words 512 B | B scale words 512 B
+#define MX_STAGE (2 * MX_BM * 128 + 2 * 512)
+
+__global__ __launch_bounds__(256) void gemm_mx_kernel(MxP p) {
+  __shared__ __attribute__((aligned(1024))) char smem[2 * MX_STAGE];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = lane_id(), r16 = l & 15, g = l >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  // tile mapping: XCD-aware, groups of 8 row tiles share their column sweep
+  int nwg = p.nbm * p.nbn;
+  int id = xcd_remap(blockIdx.x, nwg);
+  constexpr int GM = 8;
+  int per_group = GM * p.nbn, grp = id / per_group, first_m = grp * GM, gsz = min(p.nbm - first_m, GM);
+  int in_g = id - grp * per_group;
+  const int tm = first_m + in_g % gsz, tn = in_g / gsz;
+  const int m0 = tm * MX_BM, n0 = tn * MX_BN;
+
+  // ---- DMA plan.  Data: 2 x 128 rows x 8 chunks = 2048 slots of 16 B = 32 wave-instructions, 8 per wave; slot s of an operand
+  // holds (row s >> 3, chunk (s & 7) ^ ((row >> 1) & 7)).  Scales: one dword per row and K-step, 2 wave-instructions per operand.
+  uint32_t d_off[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    int i = wave * 8 + t;                     // 0..15: A, 16..31: B
+    bool isb = i >= 16;
+    int s = 64 * (i & 15) + l;
+    int row = s >> 3, c = (s & 7) ^ ((row >> 1) & 7);
+    int gr = isb ? min(n0 + row, p.N - 1) : min(m0 + row, p.M - 1);
+    d_off[t] = (uint32_t)((long)gr * (isb ? p.ldb : p.lda) + c * 16);
+  }
+  // scale words: wave 0/1 -> A rows 0..63 / 64..127, wave 2/3 -> B
+  uint32_t s_off;
+  {
+    int row = (wave & 1) * 64 + l;
+    bool isb = wave >= 2;
+    int gr = isb ? min(n0 + row, p.N - 1) : min(m0 + row, p.M - 1);
+    s_off = (uint32_t)((long)gr * (isb ? p.ldsb : p.ldsa));
+  }
+  const uint32_t smem_lds = (uint32_t)(uintptr_t)LDS_PTR(char, smem);
+  auto dma_step = [&](int ks, int stage) {
+    const uint8_t* ab = p.A + (long)ks * 128;
+    const uint8_t* bb = p.B + (long)ks * 128;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      int i = wave * 8 + t;
+      bool isb = i >= 16;
+      uint32_t dst = smem_lds + stage * MX_STAGE + (isb ? MX_BM * 128 : 0) + (i & 15) * 1024;
+      mx_glds16(isb ? bb : ab, d_off[t], __builtin_amdgcn_readfirstlane(dst));
+    }
+    const uint8_t* sb_ = (wave >= 2 ? p.sB : p.sA) + (long)ks * 4;
+    uint32_t dst = smem_lds + stage * MX_STAGE + 2 * MX_BM * 128 + (wave >= 2 ? 512 : 0) + (wave & 1) * 256;
+    mx_glds4(sb_, s_off, __builtin_amdgcn_readfirstlane(dst));
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K >> 7;
+  dma_step(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int ks = 0; ks < nk; ++ks) {
+    const int st = ks & 1;
+    const char* sb = smem + st * MX_STAGE;
+    if (ks + 1 < nk) dma_step(ks + 1, st ^ 1);
+    i32x8 af[4], bfr[4];
+    int sa[4], sbv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int ra = wm * 64 + i * 16 + r16, rb = wn * 64 + i * 16 + r16;
+      u32x4 a0 = *(const u32x4*)(sb + kc_off(ra, g)), a1 = *(const u32x4*)(sb + kc_off(ra, 4 + g));
+      u32x4 b0 = *(const u32x4*)(sb + MX_BM * 128 + kc_off(rb, g)), b1 = *(const u32x4*)(sb + MX_BM * 128 + kc_off(rb, 4 + g));
+      af[i] = i32x8{(int)a0[0], (int)a0[1], (int)a0[2], (int)a0[3], (int)a1[0], (int)a1[1], (int)a1[2], (int)a1[3]};
+      bfr[i] = i32x8{(int)b0[0], (int)b0[1], (int)b0[2], (int)b0[3], (int)b1[0], (int)b1[1], (int)b1[2], (int)b1[3]};
+      sa[i] = (int)(*(const uint32_t*)(sb + 2 * MX_BM * 128 + ra * 4) >> (8 * g));
+      sbv[i] = (int)(*(const uint32_t*)(sb + 2 * MX_BM * 128 + 512 + rb * 4) >> (8 * g));
+    }
+    // D = B_frag x A_frag (operands swapped, as in the bf16 kernels): a lane then owns 4 consecutive n of one m
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bfr[j], af[i], acc[i][j], 0, 0, 0, sbv[j], 0, sa[i]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- epilogue through a wave-private f32 staging area, 32 rows per pass, then 16-byte chunks of 8 consecutive columns.
+  // acc[i][j]: row m = 16 i + r16 (the swapped product puts A's row on the lane), columns n = 16 j + 4 g + e
+  constexpr int FP = 64 + 4;                                        // row pitch in floats
+  static_assert(4 * 32 * FP * 4 <= 2 * MX_STAGE, "epilogue staging fits");
+  float* ewf = (float*)(smem + wave * (32 * FP * 4));
+  const int em = m0 + wm * 64, en = n0 + wn * 64;
+  const bool vec = !((p.ldc | p.ldres | p.ldaux | p.ldpre) & 7);
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+    for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *(f32x4*)(ewf + (16 * i2 + r16) * FP + 16 * j + 4 * g) = acc[2 * pass + i2][j];
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      int idx = l + 64 * it;                    // 32 rows x 8 chunks of 8 columns
+      int r = idx >> 3, c = idx & 7;
+      int gm = em + 32 * pass + r, gn = en + c * 8;
+      if (gm >= p.M || gn >= p.N) continue;
+      float v[8], d[8];
+      f32x4 x0 = *(const f32x4*)(ewf + r * FP + c * 8), x1 = *(const f32x4*)(ewf + r * FP + c * 8 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] = x0[e]; v[4 + e] = x1[e]; }
+      bool full = vec && gn + 8 <= p.N;
+      if (p.bias) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) if (gn + e < p.N) v[e] += bf2f(p.bias[gn + e]);
+      }
+      if (p.act) {
+        if (p.pre) {
+          act_fwd_deriv_n<8>(p.act, v, d);
+          if (full) { bf16x8 o; for (int e = 0; e < 8; ++e) o[e] = f2bf(d[e]); *(bf16x8*)(p.pre + (long)gm * p.ldpre + gn) = o; }
+          else for (int e = 0; e < 8; ++e) if (gn + e < p.N) p.pre[(long)gm * p.ldpre + gn + e] = f2bf(d[e]);
+        } else act_fwd_n<8>(p.act, v);
+      }
+      if (p.aux) {
+        if (full) { bf16x8 a = *(const bf16x8*)(p.aux + (long)gm * p.ldaux + gn); for (int e = 0; e < 8; ++e) v[e] *= bf2f(a[e]); }
+        else for (int e = 0; e < 8; ++e) if (gn + e < p.N) v[e] *= bf2f(p.aux[(long)gm * p.ldaux + gn + e]);
+      }
+      if (p.res) {
+        if (full) { bf16x8 a = *(const bf16x8*)(p.res + (long)gm * p.ldres + gn); for (int e = 0; e < 8; ++e) v[e] += bf2f(a[e]); }
+        else for (int e = 0; e < 8; ++e) if (gn + e < p.N) v[e] += bf2f(p.res[(long)gm * p.ldres + gn + e]);
+      }
+      if (full) { bf16x8 o; for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]); *(bf16x8*)(p.C + (long)gm * p.ldc + gn) = o; }
+      else for (int e = 0; e < 8; ++e) if (gn + e < p.N) p.C[(long)gm * p.ldc + gn + e] = f2bf(v[e]);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+extern "C" int unimp_gemm_mxfp8(const unimp_mx_gemm_desc* d, void* stream) {
+  if (!d || !d->A || !d->B || !d->scale_a || !d->scale_b || !d->C) return unimp_set_error(UNIMP_ERR_ARG, "gemm_mxfp8: null pointer");
+  if (d->M <= 0 || d->N <= 0) return UNIMP_OK;
+  if (d->K <= 0 || (d->K & 127)) return unimp_set_error(UNIMP_ERR_SHAPE, "gemm_mxfp8: K must be a positive multiple of 128");
+  if ((d->lda & 15) || (d->ldb & 15) || (d->ldsa & 3) || (d->ldsb & 3) || ((uintptr_t)d->A & 15) || ((uintptr_t)d->B & 15) ||
+      ((uintptr_t)d->scale_a & 3) || ((uintptr_t)d->scale_b & 3) || ((uintptr_t)d->C & 15))
+    return unimp_set_error(UNIMP_ERR_ALIGN, "gemm_mxfp8: lda, ldb %% 16, scale strides %% 4, 16-byte aligned data / output, 4-byte aligned scales");
+  if ((long)d->M * d->lda >= (1L << 32) || (long)d->N * d->ldb >= (1L << 32))
+    return unimp_set_error(UNIMP_ERR_SHAPE, "gemm_mxfp8: operand larger than 4 GiB");
+  MxP p;
+  p.A = (const uint8_t*)d->A; p.B = (const uint8_t*)d->B; p.sA = (const uint8_t*)d->scale_a; p.sB = (const uint8_t*)d->scale_b;
+  p.lda = d->lda; p.ldb = d->ldb; p.ldsa = d->ldsa; p.ldsb = d->ldsb;
+  p.C = (bf16*)d->C; p.ldc = d->ldc;
+  p.bias = (const bf16*)d->bias; p.res = (const bf16*)d->res; p.ldres = d->ldres; p.aux = (const bf16*)d->aux; p.ldaux = d->ldaux;
+  p.pre = (bf16*)d->pre; p.ldpre = d->ldpre;
+  p.M = d->M; p.N = d->N; p.K = d->K; p.act = d->act;
+  p.nbm = (d->M + MX_BM - 1) / MX_BM; p.nbn = (d->N + MX_BN - 1) / MX_BN;
+  hipLaunchKernelGGL(gemm_mx_kernel, dim3(p.nbm * p.nbn), dim3(256), 0, (hipStream_t)stream, p);
+  return unimp_check_launch("gemm_mxfp8");
+}

@@ -197,9 +197,11 @@ __global__ __launch_bounds__(256) void ln_wgrad_reduce_kernel(const float* __res
   }
 }
 
+#include <stdlib.h>
 static inline int ln_grid(int rows) {
+  static const int cap = [] { const char* e = getenv("UNIMP_LN_GRID"); return e ? atoi(e) : 8192; }();
   int blocks = (rows + 3) / 4;
-  return blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+  return blocks < 1 ? 1 : (blocks > cap ? cap : blocks);
 }
 
 extern "C" int unimp_layernorm_fwd(const void* x, int64_t ldx, const void* gamma, const void* beta, void* y, int64_t ldy,

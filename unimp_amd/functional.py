@@ -139,6 +139,29 @@ FROZEN_WT = _FW >= 1      # use the transposed copy for frozen MLP weights (cost
 FROZEN_WT_ATTN = _FW >= 2    # same for the frozen qkv / attention-out projections
 
 
+# ----------------------------------------------------------------------------------------------- MX-fp8 frozen towers (F4)
+FP8_FROZEN = _os.environ.get("UNIMP_FP8", "0") == "1"   # opt-in (bench.py --fp8): frozen Linear layers of the towers run on the MX-fp8 GEMM
+
+
+def _mx_ok(w, M):
+    """the MX path serves a FROZEN weight whose two dimensions are multiples of 128 (contraction of the forward and of dX), for
+    row counts the decode kernel does not take"""
+    return FP8_FROZEN and not w.requires_grad and M > 64 and w.shape[0] % 128 == 0 and w.shape[1] % 128 == 0
+
+
+def _frozen_mx(w, transposed=False):
+    """e4m3 + E8M0 copy of a frozen weight, quantised ONCE along the contraction dimension of the product it serves:
+    W [out, in] along `in` for y = x W^T; W^T [in, out] along `out` for dx = dy W.  Cached on the parameter, rebuilt when the
+    weight is written to (like _frozen_t)."""
+    key = "_unimp_mx_t" if transposed else "_unimp_mx"
+    c = getattr(w, key, None)
+    if c is None or c[0] != w._version:
+        src = w.detach().t().contiguous() if transposed else w.detach()
+        c = (w._version, ops.mx_quantize(src))
+        setattr(w, key, c)
+    return c[1]
+
+
 # ----------------------------------------------------------------------------------------------- MLP sub-block
 class MLPBlockFn(Function):
     """out = res + tanh(gate) * (act(LN(x) W1^T + b1) W2^T + b2);  res defaults to x, gate to 1."""
@@ -154,12 +177,18 @@ class MLPBlockFn(Function):
         bwd = any(ctx.needs_input_grad)            # frozen tower on constant inputs (the ViT): no act'(z) output, nothing saved
         pre = torch.empty((M, F), dtype=bf16, device=x.device) if bwd else None
         t1, t2 = FROZEN_WT and not w1g and M > 64, FROZEN_WT and not w2g and M > 64      # M <= 64: the weight-streaming decode kernel
-        a = ops.gemm(h, _frozen_t(w1) if t1 else w1, b_ks=t1, bias=b1, act=act, pre=pre, pre_deriv=bwd)   # pre <- act'(z): backward needs no transcendental
-        raw = torch.empty_like(x2) if gate is not None and bwd else None
-        out = ops.gemm(a, _frozen_t(w2) if t2 else w2, b_ks=t2, bias=b2, gate=gate, res=r2, pre=raw)
+        mx = gate is None and _mx_ok(w1, M) and _mx_ok(w2, M)
+        if mx:      # frozen tower on the MX-fp8 path: activations quantised on the fly (e4m3 + E8M0 per 32), fp32 accumulate
+            a = ops.gemm_mx(ops.mx_quantize(h), _frozen_mx(w1), bias=b1, act=act, pre=pre)
+            raw = None
+            out = ops.gemm_mx(ops.mx_quantize(a), _frozen_mx(w2), bias=b2, res=r2)
+        else:
+            a = ops.gemm(h, _frozen_t(w1) if t1 else w1, b_ks=t1, bias=b1, act=act, pre=pre, pre_deriv=bwd)   # pre <- act'(z): backward needs no transcendental
+            raw = torch.empty_like(x2) if gate is not None and bwd else None
+            out = ops.gemm(a, _frozen_t(w2) if t2 else w2, b_ks=t2, bias=b2, gate=gate, res=r2, pre=raw)
         if bwd:
             ctx.save_for_backward(x2, ln_w, mean, rstd, w1, w2, gate, pre, h if w1g else None, a if w2g else None, raw)
-        ctx.act, ctx.shp, ctx.res_is_x, ctx.has_lnb = act, shp, res is None, ln_b is not None
+        ctx.act, ctx.shp, ctx.res_is_x, ctx.has_lnb, ctx.mx = act, shp, res is None, ln_b is not None, mx
         return out.view(shp)
 
     @staticmethod
@@ -171,10 +200,15 @@ class MLPBlockFn(Function):
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
         dgate = _gate_grad(dy2, raw, gate) if gate is not None and _need(ctx, 8) else None
-        dpre = ops.gemm(dy2, w2, b_ks=True, gate=gate, aux=pre, dact="deriv")          # [M,F]  (dy tanh(g) W2) * act'(z)
-        dw2 = ops.gemm(dy2, a, a_ks=True, b_ks=True, gate=gate) if _need(ctx, 6) else None
-        dw1 = ops.gemm(dpre, h, a_ks=True, b_ks=True) if _need(ctx, 4) else None
-        dh = ops.gemm(dpre, w1, b_ks=True)
+        if ctx.mx:      # dX through the frozen MLP on the MX path: the same e4m3 weights, quantised along the other dimension
+            dpre = ops.gemm_mx(ops.mx_quantize(dy2), _frozen_mx(w2, True), aux=pre)
+            dw1 = dw2 = None
+            dh = ops.gemm_mx(ops.mx_quantize(dpre), _frozen_mx(w1, True))
+        else:
+            dpre = ops.gemm(dy2, w2, b_ks=True, gate=gate, aux=pre, dact="deriv")          # [M,F]  (dy tanh(g) W2) * act'(z)
+            dw2 = ops.gemm(dy2, a, a_ks=True, b_ks=True, gate=gate) if _need(ctx, 6) else None
+            dw1 = ops.gemm(dpre, h, a_ks=True, b_ks=True) if _need(ctx, 4) else None
+            dh = ops.gemm(dpre, w1, b_ks=True)
         del dpre
         wg = _need(ctx, 2) or (ctx.has_lnb and _need(ctx, 3))
         dx, dg, db = ops.layernorm_bwd(dh, x2, ln_w, mean, rstd, dres=dy2 if ctx.res_is_x else None, want_wgrad=wg,
@@ -237,18 +271,22 @@ class SelfAttnBlockFn(Function):
         h, mean, rstd = ops.layernorm_fwd(x2, ln_w, ln_b, eps, rms=rms)
         tq = FROZEN_WT_ATTN and not wqkv.requires_grad and B * L >= 1024
         td = FROZEN_WT_ATTN and not wd.requires_grad and B * L >= 1024
-        qkv = ops.gemm(h, _frozen_t(wqkv) if tq else wqkv, b_ks=tq, bias=bqkv)
+        mx = _mx_ok(wqkv, B * L) and _mx_ok(wd, B * L)
+        qkv = ops.gemm_mx(ops.mx_quantize(h), _frozen_mx(wqkv), bias=bqkv) if mx else \
+            ops.gemm(h, _frozen_t(wqkv) if tq else wqkv, b_ks=tq, bias=bqkv)
         q, k, v, hs, offs = _split_qkv(qkv, B, L, nh, hd, interleaved)
         if rope is not None:
             cos, sin, rot = rope
             ops.rope_(qkv, L, nh, hs, rot, offs, cos, sin)
         o, lse = ops.attn_fwd(q, k, v, q_scale, ops.MASK_CAUSAL if causal else ops.MASK_NONE, kv_len, alibi=alibi)
         o2 = o.view(B * L, H)
-        out = ops.gemm(o2, _frozen_t(wd) if td else wd, b_ks=td, bias=bd, res=r2)
+        out = ops.gemm_mx(ops.mx_quantize(o2), _frozen_mx(wd), bias=bd, res=r2) if mx else \
+            ops.gemm(o2, _frozen_t(wd) if td else wd, b_ks=td, bias=bd, res=r2)
         ctx.save_for_backward(x2, ln_w, mean, rstd, wqkv, wd, qkv, o, lse, kv_len, h if wqkv.requires_grad else None,
                               rope[0] if rope is not None else None, rope[1] if rope is not None else None, alibi)
         ctx.cfg = (B, L, H, nh, hd, interleaved, causal, rms, q_scale, rope[2] if rope is not None else 0, res is None,
                    ln_b is not None)
+        ctx.mx = mx
         return out.view(B, L, H)
 
     @staticmethod
@@ -261,7 +299,7 @@ class SelfAttnBlockFn(Function):
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
         o2 = o.view(B * L, H)
-        do = ops.gemm(dy2, wd, b_ks=True).view(B, L, nh, hd)
+        do = (ops.gemm_mx(ops.mx_quantize(dy2), _frozen_mx(wd, True)) if ctx.mx else ops.gemm(dy2, wd, b_ks=True)).view(B, L, nh, hd)
         dwd = ops.gemm(dy2, o2, a_ks=True, b_ks=True) if _need(ctx, 6) else None
         q, k, v, hs, offs = _split_qkv(qkv, B, L, nh, hd, interleaved)
         dqkv = torch.empty_like(qkv)
@@ -270,7 +308,7 @@ class SelfAttnBlockFn(Function):
         if cos is not None:
             ops.rope_(dqkv, L, nh, hs, rot, offs, cos, sin, inverse=True)
         dwqkv = ops.gemm(dqkv, h, a_ks=True, b_ks=True) if _need(ctx, 4) else None
-        dh = ops.gemm(dqkv, wqkv, b_ks=True)
+        dh = ops.gemm_mx(ops.mx_quantize(dqkv), _frozen_mx(wqkv, True)) if ctx.mx else ops.gemm(dqkv, wqkv, b_ks=True)
         wg = _need(ctx, 2) or (has_lnb and _need(ctx, 3))
         dx, dg, db = ops.layernorm_bwd(dh, x2, ln_w, mean, rstd, dres=dy2 if res_is_x else None, want_wgrad=wg,
                                        has_beta=has_lnb, rms=rms)

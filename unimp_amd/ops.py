@@ -8,7 +8,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import GemmDesc, AttnDesc, check
+from ._lib import GemmDesc, AttnDesc, MxGemmDesc, check
 
 ACT = {None: 0, "none": 0, "gelu": 1, "quick_gelu": 2, "relu": 3, "silu": 4, "deriv": 5}
 MASK_NONE, MASK_CAUSAL, MASK_SEGMENT = 0, 1, 2
@@ -453,3 +453,55 @@ def adamw_flat(master, m, v, p16, g16, n_decay, lr, beta1, beta2, eps, wd, step,
     check(_lib.lib().unimp_adamw_flat(_dev(master).data_ptr(), m.data_ptr(), v.data_ptr(), p16.data_ptr(), g16.data_ptr(),
                                        master.numel(), n_decay, lr, beta1, beta2, eps, wd, step, _p(sumsq_buf), gscale, max_norm,
                                        int(zero_grad), _stream()), "adamw")
+
+
+# ------------------------------------------------------------------------------------------------- MX-fp8 (frozen towers, F4)
+class MxTensor:
+    """OCP e4m3 elements [R, K] (uint8) + one E8M0 scale byte per 32 consecutive k: scales [R, K / 32] (uint8)."""
+    __slots__ = ("q", "scales", "K")
+
+    def __init__(self, q, scales):
+        self.q, self.scales, self.K = q, scales, q.shape[1]
+
+    def dequantize(self):
+        """fp32 [R, K]: element * 2^(scale - 127) (tests; the GEMM never materialises this)."""
+        e = self.q.view(torch.float8_e4m3fn).float()
+        s = torch.pow(2.0, self.scales.float() - 127.0).repeat_interleave(32, dim=1)
+        return e * s
+
+
+def mx_quantize(x):
+    """bf16 [R, K] (unit inner stride, K % 32 == 0) -> MxTensor, quantised along K (include/unimp_hip.h)."""
+    x, ldx = _mat(x)
+    R, K = x.shape
+    q = torch.empty((R, K), dtype=torch.uint8, device=x.device)
+    sc = torch.empty((R, K // 32), dtype=torch.uint8, device=x.device)
+    check(_lib.lib().unimp_mx_quantize(x.data_ptr(), ldx, q.data_ptr(), K, sc.data_ptr(), K // 32, R, K, _stream()), "mx_quantize")
+    return MxTensor(q, sc)
+
+
+def gemm_mx(a, b, *, bias=None, act=None, pre=None, aux=None, res=None, out=None):
+    """C[M, N] (bf16) = epi(A B^T) for MxTensors a [M, K], b [N, K]; epilogue as unimp_gemm_mxfp8."""
+    M, N, K = a.q.shape[0], b.q.shape[0], a.K
+    assert b.K == K, (a.q.shape, b.q.shape)
+    if out is None:
+        out = torch.empty((M, N), dtype=bf16, device=a.q.device)
+    d = MxGemmDesc()
+    d.A, d.B, d.scale_a, d.scale_b, d.C = a.q.data_ptr(), b.q.data_ptr(), a.scales.data_ptr(), b.scales.data_ptr(), _dev(out).data_ptr()
+    d.lda, d.ldb, d.ldsa, d.ldsb, d.ldc = a.q.stride(0), b.q.stride(0), a.scales.stride(0), b.scales.stride(0), out.stride(0)
+    d.bias = _p(bias)
+    if res is not None:
+        d.res, d.ldres = res.data_ptr(), res.stride(0)
+    if aux is not None:
+        d.aux, d.ldaux = aux.data_ptr(), aux.stride(0)
+    if pre is not None:
+        d.pre, d.ldpre = pre.data_ptr(), pre.stride(0)
+    d.M, d.N, d.K, d.act = M, N, K, ACT[act]
+    if GEMM_PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(_lib.lib().unimp_gemm_mxfp8(C.byref(d), _stream()), "gemm_mxfp8")
+    if GEMM_PROFILE is not None:
+        e1.record()
+        GEMM_PROFILE.append((e0, e1, 2.0 * M * N * K, (M, N, K, 0, 0, "mxfp8")))
+    return out
