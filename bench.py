@@ -148,7 +148,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=None, help="samples per GPU per step (default 48; 24 for --model 9b; env UNIMP_BENCH_BATCH)")
+    ap.add_argument("--batch", type=int, default=None, help="samples per GPU per step (default 64; 24 for --model 9b; env UNIMP_BENCH_BATCH)")
     ap.add_argument("--images", type=int, default=8)
     ap.add_argument("--seq", type=int, default=512)
     ap.add_argument("--grad-accum", type=int, default=1, help="micro-batches per optimizer step (mmrec.py --gradient_accumulation_steps; "
@@ -193,7 +193,7 @@ def main():
 
     nine = args.model == "9b"
     if args.batch is None:
-        args.batch = int(os.environ.get("UNIMP_BENCH_BATCH", 24 if nine else 48))
+        args.batch = int(os.environ.get("UNIMP_BENCH_BATCH", 24 if nine else 64))
     model, layout = build_cfg2(dev, lang="anas-awadalla/mpt-7b", every=4) if nine else build_cfg2(dev)
     trainer = Trainer(model, layout.special(), lr=2e-4, weight_decay=0.1, gamma=2.0, use_reweight=True,
                       lr_scheduler="cosine", warmup_steps=10, total_steps=10000, sparse_head=args.sparse_head,
