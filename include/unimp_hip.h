@@ -57,6 +57,13 @@ typedef struct {
   int out_f32, accumulate;
   int pre_deriv;   /* pre receives act'(v) instead of v: the backward multiply then needs no transcendental (dact = DERIV) */
 } unimp_gemm_desc;
+/* Pre-packed B operand for FROZEN weights (b_kstrided = 2 in the descriptor; ping-pong variants only): every MFMA B fragment
+ * of the 16x16x32 instruction -- (n-tile of 16, 32-k step) -- stored as one contiguous 1-KiB block in lane order, so a wave
+ * fetches it with one coalesced global_load_dwordx4 and the B operand bypasses the LDS.  pack_b_bytes gives the image size
+ * (N rounded up to 256 columns, K to 32); `kstrided` describes the SOURCE (0: X[n*ld + k], 1: X[k*ld + n]).  Results are
+ * bit-identical to the unpacked ping-pong kernel (same k grouping inside the MFMAs). */
+int64_t unimp_pack_b_bytes(int N, int K);
+int unimp_pack_b_bf16(const void* X, int64_t ld, int N, int K, int kstrided, void* out, void* stream);
 int unimp_gemm_bf16(const unimp_gemm_desc* d, void* stream);
 /* same, with an explicit kernel variant (all compute identical results up to fp32 summation order):
  *   V1      128x128x64 tiles, 4 waves, register-staged double buffer, 2 workgroups / CU (small or ragged problems)

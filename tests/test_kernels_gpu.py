@@ -675,3 +675,26 @@ def test_gemm_mxfp8_vs_dequantised_reference(ops, M, N, K):
     aux, res = rnd(M, N, seed=4).cuda(), rnd(M, N, seed=5).cuda()
     y2 = ops.gemm_mx(a, b, aux=aux, res=res).float().cpu()
     close(y2, want.float() * aux.float().cpu() + res.float().cpu(), rel=2 ** -6, name="mx aux+res")
+
+
+# ------------------------------------------------------------------------------------------------- packed-B ping-pong GEMM
+@pytest.mark.parametrize("M,N,K", [(1024, 2560, 2560), (1096, 520, 1000), (2048, 10240, 2560), (1304, 2560, 10240 + 40), (1024, 264, 96)])
+@pytest.mark.parametrize("b_ks", [False, True])
+@pytest.mark.parametrize("a_ks", [False, True])
+def test_gemm_packed_b_is_bit_identical(ops, M, N, K, b_ks, a_ks):
+    """frozen weights pre-packed in MFMA fragment order (unimp_pack_b_bf16): the B operand bypasses the LDS; same k grouping
+    inside the MFMAs, so the result must equal the unpacked ping-pong kernel's bit for bit -- both tile widths, every operand
+    form, ragged M / N / K, with an epilogue, repeated launches (the packed fragments fly across a barrier: race screen)."""
+    a = rnd(K, M, seed=1).cuda() if a_ks else rnd(M, K, seed=1).cuda()
+    w = rnd(K, N, seed=2).cuda() if b_ks else rnd(N, K, seed=2).cuda()
+    pk = ops.pack_b(w, b_ks)
+    bias, res = rnd(N, seed=3).cuda(), rnd(M, N, seed=4).cuda()
+    for var, pvar in (("pp256", "pk256"), ("pp128", "pk128")):
+        if N < 256 and var == "pp256":
+            continue
+        want = ops.gemm(a, w, a_ks=a_ks, b_ks=b_ks, bias=bias, act="gelu", res=res, variant=var)
+        for rep in range(4):
+            got = ops.gemm(a, w, a_ks=a_ks, b_ks=b_ks, bias=bias, act="gelu", res=res, variant=pvar, b_pk=pk)
+            assert torch.equal(got, want), (var, rep, (got.float() - want.float()).abs().max().item())
+    ref = (a.float().t() if a_ks else a.float()) @ (w.float() if b_ks else w.float().t())
+    close(ops.gemm(a, w, a_ks=a_ks, b_ks=b_ks, variant="pk256" if N >= 256 else "pk128", b_pk=pk), ref.cpu(), rel=2 ** -6, name="packed gemm")

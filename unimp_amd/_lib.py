@@ -62,6 +62,7 @@ _SIGS = {
     "unimp_reduce_rows_periodic": [c_p, c_l, c_p, c_i, c_i, c_i, c_p],
     "unimp_label_mask": [c_p, c_p, c_p, c_i, c_i, c_l, c_l, c_l, c_l, c_p],
     "unimp_attn_set_generation": [c_i],
+    "unimp_pack_b_bf16": [c_p, c_l, c_i, c_i, c_i, c_p, c_p],
     "unimp_mx_quantize": [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_p],
     "unimp_gemm_mxfp8": [C.POINTER(MxGemmDesc), c_p],
     "unimp_focal_ce_fwd": [c_p, c_l, c_p, c_p, c_f, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
@@ -92,6 +93,7 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.unimp_last_error.restype = C.c_char_p
         L.unimp_abi_version.restype = c_i
+        L.unimp_pack_b_bytes.restype, L.unimp_pack_b_bytes.argtypes = c_l, [c_i, c_i]
         for name, args in _SIGS.items():
             fn = getattr(L, name)
             fn.argtypes, fn.restype = args, c_i
@@ -107,4 +109,4 @@ def check(rc, what):
 
 
 def declared_symbols():
-    return ["unimp_abi_version", "unimp_struct_size", "unimp_last_error", "unimp_set_error", "unimp_check_launch"] + list(_SIGS)
+    return ["unimp_abi_version", "unimp_struct_size", "unimp_last_error", "unimp_set_error", "unimp_check_launch", "unimp_pack_b_bytes"] + list(_SIGS)

@@ -356,11 +356,51 @@ static int validate(const unimp_gemm_desc* d) {
   if (!d || !d->A || !d->B || !d->C) return unimp_set_error(UNIMP_ERR_ARG, "gemm: null pointer");
   if (d->M <= 0 || d->N <= 0 || d->K <= 0) return unimp_set_error(UNIMP_ERR_SHAPE, "gemm: empty shape");
   int e;
-  if ((e = check_operand(d->A, d->lda, d->a_kstrided, d->M)) || (e = check_operand(d->B, d->ldb, d->b_kstrided, d->N)))
+  if ((e = check_operand(d->A, d->lda, d->a_kstrided, d->M)))
+    return unimp_set_error(e, "gemm: operand base must be 16-B aligned, ld %% 8 == 0, k-strided ld >= roundup8(rows)");
+  if (d->b_kstrided == 2) {                 // pre-packed B image (unimp_pack_b_bf16): no ld, 16-byte aligned
+    if ((uintptr_t)d->B & 15) return unimp_set_error(UNIMP_ERR_ALIGN, "gemm: packed B must be 16-B aligned");
+  } else if ((e = check_operand(d->B, d->ldb, d->b_kstrided, d->N)))
     return unimp_set_error(e, "gemm: operand base must be 16-B aligned, ld %% 8 == 0, k-strided ld >= roundup8(rows)");
   if (!d->a_kstrided && d->lda < ((d->K + 7) & ~7)) return unimp_set_error(UNIMP_ERR_SHAPE, "gemm: lda < roundup8(K)");
   if (!d->b_kstrided && d->ldb < ((d->K + 7) & ~7)) return unimp_set_error(UNIMP_ERR_SHAPE, "gemm: ldb < roundup8(K)");
   return 0;
+}
+
+// ---- B operand pre-packed for the ping-pong kernels (frozen weights): out[(nt * nh + h) * 64 + lane][j] = B[n = 16 nt + (lane & 15)]
+// [k = 32 h + 8 (lane >> 4) + j], zero beyond (N, K); nt < ceil(N / 16) rounded up to a multiple of 16 tiles (a 256-column block),
+// nh = ceil(K / 32).  B[n][k] = X[n * ld + k] (k-contiguous source) or X[k * ld + n] (k-strided source).
+__global__ void pack_b_kernel(const bf16* __restrict__ X, long ld, int N, int K, int ks, bf16* __restrict__ out, long ntiles, long nh) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ntiles * nh * 64) return;
+  int lane = i & 63; long t = i >> 6;
+  long h = t % nh, nt = t / nh;
+  int n = (int)(nt * 16 + (lane & 15)), k0 = (int)(h * 32 + 8 * (lane >> 4));
+  bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (n < N) {
+    if (!ks && k0 + 8 <= K) v = *(const bf16x8*)(X + (long)n * ld + k0);
+    else
+#pragma unroll
+      for (int j = 0; j < 8; ++j) if (k0 + j < K) v[j] = ks ? X[(long)(k0 + j) * ld + n] : X[(long)n * ld + k0 + j];
+  }
+  *(bf16x8*)(out + i * 8) = v;
+}
+
+extern "C" int64_t unimp_pack_b_bytes(int N, int K) {
+  long ntiles = (((long)N + 255) / 256) * 16, nh = ((long)K + 31) / 32;
+  return ntiles * nh * 1024;
+}
+
+extern "C" int unimp_pack_b_bf16(const void* X, int64_t ld, int N, int K, int kstrided, void* out, void* stream) {
+  if (!X || !out) return unimp_set_error(UNIMP_ERR_ARG, "pack_b: null pointer");
+  if (N <= 0 || K <= 0) return unimp_set_error(UNIMP_ERR_SHAPE, "pack_b: empty shape");
+  int e = check_operand(X, ld, kstrided, N);
+  if (e || ((uintptr_t)out & 15)) return unimp_set_error(UNIMP_ERR_ALIGN, "pack_b: 16-B aligned pointers, ld %% 8 == 0");
+  long ntiles = (((long)N + 255) / 256) * 16, nh = ((long)K + 31) / 32;
+  long total = ntiles * nh * 64;
+  hipLaunchKernelGGL(pack_b_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)X, (long)ld, N, K, kstrided,
+                     (bf16*)out, ntiles, nh);
+  return unimp_check_launch("pack_b");
 }
 
 static void launch_v1(const unimp_gemm_desc* d, void* stream, int splits = 1, float* slabs = nullptr) {
@@ -390,6 +430,7 @@ static void launch_v1(const unimp_gemm_desc* d, void* stream, int splits = 1, fl
 // default choice when the caller does not autotune: the ping-pong kernel once there are enough rows for 256-row tiles,
 // tile width by round quantisation over the 256 CUs; the 128x128 kernel otherwise.
 static int auto_variant(const unimp_gemm_desc* d) {
+  if (d->b_kstrided == 2) return d->N >= 256 ? UNIMP_GEMM_PP256 : UNIMP_GEMM_PP128;
   if (skinny_ok(d)) return UNIMP_GEMM_SKINNY;
   if (d->M < 1024 || d->N < 128 || d->K < 128) return UNIMP_GEMM_V1;
   long nbm = (d->M + 255) / 256;
@@ -403,6 +444,8 @@ extern "C" int unimp_gemm_bf16_variant(const unimp_gemm_desc* d, int variant, vo
   int e = validate(d);
   if (e) return e;
   if (variant == UNIMP_GEMM_AUTO) variant = auto_variant(d);
+  if (d->b_kstrided == 2 && variant != UNIMP_GEMM_PP256 && variant != UNIMP_GEMM_PP128)
+    return unimp_set_error(UNIMP_ERR_UNSUPPORTED, "gemm: a pre-packed B operand is served by the ping-pong kernels only (variants pp256 / pp128)");
   switch (variant) {
     case UNIMP_GEMM_V1: launch_v1(d, stream); break;
     case UNIMP_GEMM_DMA256: unimp_gemm2_launch(d, 256, stream); break;

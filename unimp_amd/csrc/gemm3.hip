@@ -19,6 +19,13 @@
 // ds_read_b128); k-strided operands as [32][rows] read by ds_read_b64_tr_b16 (granule swizzle of common.h).  The DMA
 // destination is lane-linear, so both swizzles are applied to the per-lane SOURCE address; out-of-range chunks come
 // from a zero constant (no predication).  Epilogue: gemm_tile.h (through LDS, 16-byte row-major accesses).
+// BPK form (b_kstrided == 2): the B operand is a PRE-PACKED image of a frozen weight -- [n-tile of 16][32-k step][lane][8 bf16],
+// i.e. every MFMA B fragment is one contiguous, coalesced 1-KiB block (unimp_pack_b_bf16) -- and bypasses the LDS: each wave
+// loads its NJ fragments of half-step h+1 with NJ global_load_dwordx4 during the L phase of half-step h (one phase pair of
+// latency cover, served by L2: a B tile is shared by all row tiles).  Per half-step the LDS then carries 64 KiB of A-fragment
+// reads + 16 KiB of DMA writes instead of 96 + 32 KiB: with B through the LDS the LDS pipe (128 B/clk) is as busy as the matrix
+// pipe (128 KiB per 1024 MFMA cycles), which is what held every schedule of this family at 52-57 % MFMA utilisation.
+// Same k grouping inside the MFMAs as the unpacked kernel: bit-identical results.
 #include "gemm_half.h"
 
 #define G3_BM 256
@@ -41,7 +48,13 @@ extern "C" int unimp_debug_g3_stamps(void* out) { return (int)hipMemcpyFromSymbo
 #define G3_FENCE() do { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); } while (0)
 #define G3_BARRIER() do { G3_FENCE(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); G3_FENCE(); } while (0)
 
-template <bool AKS, bool BKS, int BN>
+// one fragment of the packed B image: 64 lanes x 16 B contiguous.  Inline asm: the result registers are only touched after
+// the counted vmcnt + barrier of the L phase (same discipline as frag_ks32_asm).
+__device__ __forceinline__ void frag_packed_asm(const void* sbase, uint32_t voff, bf16x8& out) {
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(out) : "v"(voff), "s"(sbase) : "memory");
+}
+
+template <bool AKS, bool BKS, int BN, bool BPK = false>
 __global__ __launch_bounds__(512, 2) void gemm3_bf16_kernel(Gemm2Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   G3_T(0);
@@ -52,10 +65,10 @@ __global__ __launch_bounds__(512, 2) void gemm3_bf16_kernel(Gemm2Params p) {
   }
 #endif
   constexpr int NJ = BN / 64, WN = BN / 4;
-  constexpr int A_SUB = G3_BM * 64, B_SUB = BN * 64, SUB = A_SUB + B_SUB;
-  constexpr int NEW = G3_BM / 128 + BN / 128;          // LDS-DMA instructions a wave issues per half-step
+  constexpr int A_SUB = G3_BM * 64, B_SUB = BPK ? 0 : BN * 64, SUB = A_SUB + B_SUB;
+  constexpr int NEW = G3_BM / 128 + (BPK ? NJ : BN / 128);   // vector-memory instructions a wave issues per half-step (DMA + packed-B loads)
 
-  if (p.ksplit > 0) {               // split-K: this block reduces one K slice into its own f32 slab (summed by splitk_reduce)
+  if (!BPK && p.ksplit > 0) {       // split-K: this block reduces one K slice into its own f32 slab (summed by splitk_reduce)
     int k_off = blockIdx.y * p.ksplit;
     p.A += AKS ? (long)k_off * p.lda : (long)k_off;
     p.B += BKS ? (long)k_off * p.ldb : (long)k_off;
@@ -88,23 +101,28 @@ __global__ __launch_bounds__(512, 2) void gemm3_bf16_kernel(Gemm2Params p) {
 
   uint32_t aoff[G3_BM / 128], boff[BN / 128];
   dma_setup<AKS, G3_BM>(p.lda, m0, p.M, wave, aoff);
-  dma_setup<BKS, BN>(p.ldb, n0, p.N, wave, boff);
+  if (!BPK) dma_setup<BKS, BN>(p.ldb, n0, p.N, wave, boff);
+  // packed B: fragment (n-tile nt, half-step h) sits at ((nt * nh + h) * 64 + lane) * 16 bytes; n-tiles beyond N exist (zero padded)
+  const long pk_nh = (p.K + 31) >> 5;
+  const char* pk_base = BPK ? (const char*)p.B + ((long)((n0 + wn * WN) >> 4) * pk_nh) * 1024 : nullptr;
+  const uint32_t pk_lane = (uint32_t)lane * 16u;
 #define DMA(H) do { char* b_ = smem + ((H) % G3_NST) * SUB;                                                             \
     dma_issue<AKS, G3_BM>(p.A, p.lda, (H), p.K, b_, wave, aoff);                                                   \
-    dma_issue<BKS, BN>(p.B, p.ldb, (H), p.K, b_ + A_SUB, wave, boff); } while (0)
+    if (!BPK) dma_issue<BKS, BN>(p.B, p.ldb, (H), p.K, b_ + A_SUB, wave, boff); } while (0)
   const uint32_t smem_lds = (uint32_t)(uintptr_t)LDS_PTR(char, smem);
-  const uint32_t lbA = AKS ? ks32_lane_base<G3_BM>(wm * 128) : 0u, lbB = BKS ? ks32_lane_base<BN>(wn * WN) : 0u;
+  const uint32_t lbA = AKS ? ks32_lane_base<G3_BM>(wm * 128) : 0u, lbB = (BKS && !BPK) ? ks32_lane_base<BN>(wn * WN) : 0u;
 #define LOADF(S, H) do { const char* b_ = smem + ((H) % G3_NST) * SUB;                                                  \
     uint32_t ub_ = smem_lds + ((H) % G3_NST) * SUB;                                                                     \
     _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                               \
-      if (BKS) frag_ks32_asm<BN>(lbB + ub_ + A_SUB, j, lb##S[j], hb##S[j]);                                        \
+      if (BPK) frag_packed_asm(pk_base + ((long)j * pk_nh + (H)) * 1024, pk_lane, rb##S[j]);                       \
+      else if (BKS) frag_ks32_asm<BN>(lbB + ub_ + A_SUB, j, lb##S[j], hb##S[j]);                                   \
       else rb##S[j] = frag_kc32(b_ + A_SUB, wn * WN + j * 16); }                                                   \
     _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                \
       if (AKS) frag_ks32_asm<G3_BM>(lbA + ub_, i, la##S[i], ha##S[i]);                                             \
       else ra##S[i] = frag_kc32(b_, wm * 128 + i * 16); } } while (0)
 #define MFMAS(S) do { G3_PRIO(1);                                                                                  \
     bf16x8 fb_[NJ];                                                                                                \
-    _Pragma("unroll") for (int j = 0; j < NJ; ++j) fb_[j] = BKS ? join_halves(lb##S[j], hb##S[j]) : rb##S[j];      \
+    _Pragma("unroll") for (int j = 0; j < NJ; ++j) fb_[j] = (BKS && !BPK) ? join_halves(lb##S[j], hb##S[j]) : rb##S[j];      \
     _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                \
       bf16x8 fa_ = AKS ? join_halves(la##S[i], ha##S[i]) : ra##S[i];                                               \
       _Pragma("unroll") for (int j = 0; j < NJ; ++j) acc[i][j] = MFMA16(fb_[j], fa_, acc[i][j]); }                 \
@@ -175,11 +193,13 @@ __global__ __launch_bounds__(512, 2) void gemm3_bf16_kernel(Gemm2Params p) {
   G3_T(3);
 }
 
-template <bool AKS, bool BKS, int BN>
+template <bool AKS, bool BKS, int BN, bool BPK = false>
 static void launch3(const Gemm2Params& p, hipStream_t s, int slices = 1) {
   static bool attr_set = false;
-  constexpr size_t lds = G3_NST * (G3_BM * 64 + BN * 64);
-  auto kern = gemm3_bf16_kernel<AKS, BKS, BN>;
+  // the epilogue stages the tile through wave-private LDS regions: 8 waves x 64 rows x (BN / 4) floats
+  constexpr size_t lds_ring = G3_NST * (G3_BM * 64 + (BPK ? 0 : BN * 64)), lds_epi = 8 * 64 * (BN / 4) * 4;
+  constexpr size_t lds = lds_ring > lds_epi ? lds_ring : lds_epi;
+  auto kern = gemm3_bf16_kernel<AKS, BKS, BN, BPK>;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
   hipLaunchKernelGGL(kern, dim3(p.nbm * p.nbn, slices), dim3(512), lds, s, p);
 }
@@ -211,7 +231,10 @@ extern "C" int unimp_gemm3_launch_splitk(const unimp_gemm_desc* d, int bn, int s
   hipStream_t s = (hipStream_t)stream;
   int a = d->a_kstrided, b = d->b_kstrided;
 #define L3(AK, BK_) do { if (bn == 256) launch3<AK, BK_, 256>(p, s, slices); else launch3<AK, BK_, 128>(p, s, slices); } while (0)
-  if (!a && !b) L3(false, false); else if (!a && b) L3(false, true); else if (a && b) L3(true, true); else L3(true, false);
+#define L3P(AK) do { if (bn == 256) launch3<AK, false, 256, true>(p, s, 1); else launch3<AK, false, 128, true>(p, s, 1); } while (0)
+  if (b == 2) { if (a) L3P(true); else L3P(false); }
+  else if (!a && !b) L3(false, false); else if (!a && b) L3(false, true); else if (a && b) L3(true, true); else L3(true, false);
 #undef L3
+#undef L3P
   return 1;
 }

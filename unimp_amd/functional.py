@@ -132,7 +132,26 @@ def _frozen_t(w):
     return c[1]
 
 
+def _frozen_pk(w, b_ks=False):
+    """fragment-ordered image of a FROZEN weight for the packed-B ping-pong GEMM (ops.pack_b), one per orientation: b_ks=False
+    serves y = x W^T, b_ks=True serves dx = dy W.  Cached on the parameter like _frozen_t; costs one extra copy of the frozen
+    weights per orientation in HBM (4b-instruct: 2 x 5 GB)."""
+    if not FROZEN_PK or w.requires_grad:
+        return None
+    key = "_unimp_pk_t" if b_ks else "_unimp_pk"
+    c = getattr(w, key, None)
+    if c is None or c[0] != w._version:
+        c = (w._version, ops.pack_b(w.detach(), b_ks))
+        setattr(w, key, c)
+    return c[1]
+
+
 import os as _os
+# opt-in: frozen weights also kept as packed-B images (the B operand bypasses the LDS).  Measured (tools/bench_packed.py, b = 64): +3 %
+# over the best unpacked variant on the MLP up-projection, equal or slower on the other seven tower shapes -- the fragment loads
+# wait on L2 latency every half-step where the LDS-DMA ring does not -- so it is NOT the default (it also costs a second copy
+# of the frozen weights per orientation)
+FROZEN_PK = _os.environ.get("UNIMP_FROZEN_PK", "0") == "1"
 _FW = int(_os.environ.get("UNIMP_FROZEN_WT", "0"))   # opt-in: +0.8 % on the step, but a k-strided weight operand is summed in a different
 # order inside the MFMA by the 128x128 and the 256-row kernels, so a sample's bits would depend on which variant its batch size tuned to
 FROZEN_WT = _FW >= 1      # use the transposed copy for frozen MLP weights (costs one extra copy of them in HBM)
@@ -183,9 +202,11 @@ class MLPBlockFn(Function):
             raw = None
             out = ops.gemm_mx(ops.mx_quantize(a), _frozen_mx(w2), bias=b2, res=r2)
         else:
-            a = ops.gemm(h, _frozen_t(w1) if t1 else w1, b_ks=t1, bias=b1, act=act, pre=pre, pre_deriv=bwd)   # pre <- act'(z): backward needs no transcendental
+            a = ops.gemm(h, _frozen_t(w1) if t1 else w1, b_ks=t1, bias=b1, act=act, pre=pre, pre_deriv=bwd,   # pre <- act'(z): backward needs no transcendental
+                         b_pk=None if t1 or M <= 64 else _frozen_pk(w1))
             raw = torch.empty_like(x2) if gate is not None and bwd else None
-            out = ops.gemm(a, _frozen_t(w2) if t2 else w2, b_ks=t2, bias=b2, gate=gate, res=r2, pre=raw)
+            out = ops.gemm(a, _frozen_t(w2) if t2 else w2, b_ks=t2, bias=b2, gate=gate, res=r2, pre=raw,
+                           b_pk=None if t2 or M <= 64 else _frozen_pk(w2))
         if bwd:
             ctx.save_for_backward(x2, ln_w, mean, rstd, w1, w2, gate, pre, h if w1g else None, a if w2g else None, raw)
         ctx.act, ctx.shp, ctx.res_is_x, ctx.has_lnb, ctx.mx = act, shp, res is None, ln_b is not None, mx
@@ -205,10 +226,10 @@ class MLPBlockFn(Function):
             dw1 = dw2 = None
             dh = ops.gemm_mx(ops.mx_quantize(dpre), _frozen_mx(w1, True))
         else:
-            dpre = ops.gemm(dy2, w2, b_ks=True, gate=gate, aux=pre, dact="deriv")          # [M,F]  (dy tanh(g) W2) * act'(z)
+            dpre = ops.gemm(dy2, w2, b_ks=True, gate=gate, aux=pre, dact="deriv", b_pk=_frozen_pk(w2, True))   # [M,F]  (dy tanh(g) W2) * act'(z)
             dw2 = ops.gemm(dy2, a, a_ks=True, b_ks=True, gate=gate) if _need(ctx, 6) else None
             dw1 = ops.gemm(dpre, h, a_ks=True, b_ks=True) if _need(ctx, 4) else None
-            dh = ops.gemm(dpre, w1, b_ks=True)
+            dh = ops.gemm(dpre, w1, b_ks=True, b_pk=_frozen_pk(w1, True))
         del dpre
         wg = _need(ctx, 2) or (ctx.has_lnb and _need(ctx, 3))
         dx, dg, db = ops.layernorm_bwd(dh, x2, ln_w, mean, rstd, dres=dy2 if ctx.res_is_x else None, want_wgrad=wg,
@@ -273,7 +294,7 @@ class SelfAttnBlockFn(Function):
         td = FROZEN_WT_ATTN and not wd.requires_grad and B * L >= 1024
         mx = _mx_ok(wqkv, B * L) and _mx_ok(wd, B * L)
         qkv = ops.gemm_mx(ops.mx_quantize(h), _frozen_mx(wqkv), bias=bqkv) if mx else \
-            ops.gemm(h, _frozen_t(wqkv) if tq else wqkv, b_ks=tq, bias=bqkv)
+            ops.gemm(h, _frozen_t(wqkv) if tq else wqkv, b_ks=tq, bias=bqkv, b_pk=None if tq else _frozen_pk(wqkv))
         q, k, v, hs, offs = _split_qkv(qkv, B, L, nh, hd, interleaved)
         if rope is not None:
             cos, sin, rot = rope
@@ -281,7 +302,7 @@ class SelfAttnBlockFn(Function):
         o, lse = ops.attn_fwd(q, k, v, q_scale, ops.MASK_CAUSAL if causal else ops.MASK_NONE, kv_len, alibi=alibi)
         o2 = o.view(B * L, H)
         out = ops.gemm_mx(ops.mx_quantize(o2), _frozen_mx(wd), bias=bd, res=r2) if mx else \
-            ops.gemm(o2, _frozen_t(wd) if td else wd, b_ks=td, bias=bd, res=r2)
+            ops.gemm(o2, _frozen_t(wd) if td else wd, b_ks=td, bias=bd, res=r2, b_pk=None if td else _frozen_pk(wd))
         ctx.save_for_backward(x2, ln_w, mean, rstd, wqkv, wd, qkv, o, lse, kv_len, h if wqkv.requires_grad else None,
                               rope[0] if rope is not None else None, rope[1] if rope is not None else None, alibi)
         ctx.cfg = (B, L, H, nh, hd, interleaved, causal, rms, q_scale, rope[2] if rope is not None else 0, res is None,
@@ -299,7 +320,7 @@ class SelfAttnBlockFn(Function):
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
         o2 = o.view(B * L, H)
-        do = (ops.gemm_mx(ops.mx_quantize(dy2), _frozen_mx(wd, True)) if ctx.mx else ops.gemm(dy2, wd, b_ks=True)).view(B, L, nh, hd)
+        do = (ops.gemm_mx(ops.mx_quantize(dy2), _frozen_mx(wd, True)) if ctx.mx else ops.gemm(dy2, wd, b_ks=True, b_pk=_frozen_pk(wd, True))).view(B, L, nh, hd)
         dwd = ops.gemm(dy2, o2, a_ks=True, b_ks=True) if _need(ctx, 6) else None
         q, k, v, hs, offs = _split_qkv(qkv, B, L, nh, hd, interleaved)
         dqkv = torch.empty_like(qkv)
@@ -308,7 +329,7 @@ class SelfAttnBlockFn(Function):
         if cos is not None:
             ops.rope_(dqkv, L, nh, hs, rot, offs, cos, sin, inverse=True)
         dwqkv = ops.gemm(dqkv, h, a_ks=True, b_ks=True) if _need(ctx, 4) else None
-        dh = ops.gemm_mx(ops.mx_quantize(dqkv), _frozen_mx(wqkv, True)) if ctx.mx else ops.gemm(dqkv, wqkv, b_ks=True)
+        dh = ops.gemm_mx(ops.mx_quantize(dqkv), _frozen_mx(wqkv, True)) if ctx.mx else ops.gemm(dqkv, wqkv, b_ks=True, b_pk=_frozen_pk(wqkv, True))
         wg = _need(ctx, 2) or (has_lnb and _need(ctx, 3))
         dx, dg, db = ops.layernorm_bwd(dh, x2, ln_w, mean, rstd, dres=dy2 if res_is_x else None, want_wgrad=wg,
                                        has_beta=has_lnb, rms=rms)

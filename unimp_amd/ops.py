@@ -36,7 +36,7 @@ def _load_tune_table(path):
     try:
         with open(path) as f:
             raw = json.load(f)
-        return {tuple(json.loads(k)): int(v) for k, v in raw.items()}
+        return {tuple(json.loads(k)): int(v) for k, v in raw.items()}      # key[4] is bool (b k-strided) or "pk" (packed-B decision)
     except (ValueError, OSError, TypeError) as e:          # a truncated / corrupt table is not fatal: tune live
         import warnings
         warnings.warn(f"ignoring unreadable GEMM autotune table {path!r}: {e}")
@@ -48,8 +48,8 @@ def _save_tune_table(path):
         return
     tmp = f"{path}.tmp.{os.getpid()}"
     with open(tmp, "w") as f:
-        json.dump({json.dumps([int(k[0]), int(k[1]), int(k[2]), bool(k[3]), bool(k[4]), bool(k[5])]): v
-                   for k, v in sorted(_GEMM_CHOICE.items()) if len(k) == 6}, f, indent=0)
+        json.dump({json.dumps([int(k[0]), int(k[1]), int(k[2]), bool(k[3]), k[4] if k[4] == "pk" else bool(k[4]), bool(k[5])]): v
+                   for k, v in sorted(_GEMM_CHOICE.items(), key=lambda kv: str(kv[0])) if len(k) == 6}, f, indent=0)
     os.replace(tmp, path)
 
 
@@ -126,9 +126,78 @@ def _mat(t):
     return t, (t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1]))
 
 
+class PackedB:
+    """pre-packed B operand of a frozen weight (include/unimp_hip.h: unimp_pack_b_bf16): fragment-ordered image + logical (N, K)."""
+    __slots__ = ("buf", "N", "K")
+
+    def __init__(self, buf, N, K):
+        self.buf, self.N, self.K = buf, N, K
+
+
+def pack_b(b, b_ks=False):
+    """b: [N, K] (or [K, N] if b_ks) bf16 -> PackedB."""
+    b, ldb = _mat(b)
+    (K, N) = b.shape if b_ks else b.shape[::-1]
+    nbytes = _lib.lib().unimp_pack_b_bytes(N, K)
+    buf = torch.empty(nbytes // 2, dtype=bf16, device=b.device)
+    check(_lib.lib().unimp_pack_b_bf16(b.data_ptr(), ldb, N, K, int(b_ks), buf.data_ptr(), _stream()), "pack_b")
+    return PackedB(buf, N, K)
+
+
+PACKED_MIN_M = 1024       # a packed B operand is only tried on problems the ping-pong kernels serve
+
+
+def _tune_packed(M, N, K, a_ks, device, reads_mn, unpacked_variant, b_ks):
+    """packed-B ping-pong (pp256 / pp128) against the table's choice for the SAME problem with B through the LDS; returns the
+    packed variant to use or 0 (keep the unpacked kernel).  Key: (M, N, K, a_ks, "pk", reads_mn)."""
+    key = (M, N, K, a_ks, "pk", bool(reads_mn))
+    v = _GEMM_CHOICE.get(key)
+    if v is not None:
+        return v
+    if not GEMM_AUTOTUNE or torch.cuda.is_current_stream_capturing():
+        return 4 if N >= 256 else 5
+    r8 = lambda n: (n + 7) // 8 * 8
+    a = torch.randn((K, r8(M)) if a_ks else (M, r8(K)), device=device, dtype=torch.float32).to(bf16)
+    b = torch.randn((K, r8(N)) if b_ks else (N, r8(K)), device=device, dtype=torch.float32).to(bf16)
+    pk = pack_b(b[:, :N] if b_ks else b[:, :K], b_ks)
+    ldc = r8(N)
+    c = torch.empty((M, ldc), dtype=bf16, device=device)
+    d = GemmDesc()
+    d.A, d.C, d.M, d.N, d.K = a.data_ptr(), c.data_ptr(), M, N, K
+    d.lda, d.ldc, d.a_kstrided, d.alpha = a.stride(0), ldc, int(a_ks), 1.0
+    if reads_mn:
+        r = torch.randn((M, ldc), device=device, dtype=torch.float32).to(bf16)
+        d.res, d.ldres = r.data_ptr(), ldc
+
+    def run(v, packed):
+        if packed:
+            d.B, d.ldb, d.b_kstrided = pk.buf.data_ptr(), 0, 2
+        else:
+            d.B, d.ldb, d.b_kstrided = b.data_ptr(), b.stride(0), int(b_ks)
+        _launch_gemm(d, v)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            _launch_gemm(d, v)
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1)
+    best, best_t = 0, run(unpacked_variant, False)
+    for v in ([4, 5] if N >= 256 else [5]):
+        t = run(v, True)
+        if t < best_t * 0.99:
+            best, best_t = v, t
+    _GEMM_CHOICE[key] = best
+    TUNE_MISSES.append(key)
+    if _TUNE_FILE and _TUNE_WRITE:
+        _save_tune_table(_TUNE_FILE)
+    return best
+
+
 def gemm(a, b, *, a_ks=False, b_ks=False, bias=None, act=None, res=None, aux=None, dact=None, pre=None,
-         gate=None, alpha=1.0, out=None, out_f32=False, accumulate=False, ldc=None, variant=None, pre_deriv=False):
-    """C[M,N] = epi(alpha * A B^T).  a: [M,K] (or [K,M] if a_ks); b: [N,K] (or [K,N] if b_ks)."""
+         gate=None, alpha=1.0, out=None, out_f32=False, accumulate=False, ldc=None, variant=None, pre_deriv=False, b_pk=None):
+    """C[M,N] = epi(alpha * A B^T).  a: [M,K] (or [K,M] if a_ks); b: [N,K] (or [K,N] if b_ks).
+    b_pk: optional PackedB image of the same b (frozen weights): used when the packed ping-pong kernel measured faster."""
     a, lda = _mat(a)
     b, ldb = _mat(b)
     if a_ks:
@@ -181,15 +250,24 @@ def gemm(a, b, *, a_ks=False, b_ks=False, bias=None, act=None, res=None, aux=Non
             e1.record()
             GEMM_PROFILE.append((e0, e1, 2.0 * M * N * K, (M, N, K, int(a_ks), int(b_ks), -splits)))
         return out
-    v = GEMM_VARIANTS[variant] if isinstance(variant, str) else (variant if variant is not None else
-                                                                  _tune_gemm(M, N, K, bool(a_ks), bool(b_ks), a.device,
-                                                                             res is not None or aux is not None))
+    forced_pk = {"pk256": 4, "pk128": 5}.get(variant) if isinstance(variant, str) else None
+    if forced_pk is not None:
+        v = forced_pk
+    else:
+        v = GEMM_VARIANTS[variant] if isinstance(variant, str) else (variant if variant is not None else
+                                                                      _tune_gemm(M, N, K, bool(a_ks), bool(b_ks), a.device,
+                                                                                 res is not None or aux is not None))
+    if b_pk is not None and (forced_pk is not None or (variant is None and M >= PACKED_MIN_M and N >= 128 and K >= 128)):
+        assert b_pk.N == N and b_pk.K == K, (b_pk.N, b_pk.K, N, K)
+        vp = forced_pk or _tune_packed(M, N, K, bool(a_ks), a.device, res is not None or aux is not None, v, bool(b_ks))
+        if vp:
+            d.B, d.ldb, d.b_kstrided, v = b_pk.buf.data_ptr(), 0, 2, vp
     if GEMM_PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         _launch_gemm(d, v)
         e1.record()
-        GEMM_PROFILE.append((e0, e1, 2.0 * M * N * K, (M, N, K, int(a_ks), int(b_ks), v)))
+        GEMM_PROFILE.append((e0, e1, 2.0 * M * N * K, (M, N, K, int(a_ks), int(d.b_kstrided), v)))
         return out
     _launch_gemm(d, v)
     return out

@@ -51,7 +51,7 @@ class ResidualAttentionBlock(nn.Module):
         mx = all(F_._mx_ok(w, h.shape[0]) for w in ws)          # opt-in MX-fp8 path for the frozen tower (functional.FP8_FROZEN)
 
         def lin(x, w, **kw):
-            return ops.gemm_mx(ops.mx_quantize(x), F_._frozen_mx(w), **kw) if mx else ops.gemm(x, w, **kw)
+            return ops.gemm_mx(ops.mx_quantize(x), F_._frozen_mx(w), **kw) if mx else ops.gemm(x, w, b_pk=F_._frozen_pk(w), **kw)
         a, _, _ = ops.layernorm_fwd(h, self.ln_1.weight, self.ln_1.bias, self.ln_1.eps)
         qkv = lin(a, self.attn.in_proj_weight, bias=self.attn.in_proj_bias).view(N, S, 3, self.heads, hd)
         o, _ = ops.attn_fwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], hd ** -0.5, ops.MASK_NONE)
