@@ -157,6 +157,8 @@ def main():
     ap.add_argument("--cpu-full-steps", type=int, default=2, help="timed full-depth oracle steps of the cpu_baseline leg (0: 1/8-depth sample only)")
     ap.add_argument("--dense-head-backward", action="store_true", help="form the dense [B*L, V] logit gradient and run the head's dX / dW "
                     "GEMMs over all rows (the reference's arithmetic incl. its ~98 %% zero rows); default: labeled rows only, same gradients")
+    ap.add_argument("--shard-optimizer", action="store_true", help="ZeRO-2-style optimizer-state sharding over the ranks (N > 1): fp32 master / m / v "
+                    "for 1/N of every bucket, reduce-scatter + all-gather instead of all-reduce (the reference's DeepSpeed ZeRO-2 layout)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--model", choices=["4b-instruct", "9b"], default="4b-instruct",
@@ -197,7 +199,8 @@ def main():
     model, layout = build_cfg2(dev, lang="anas-awadalla/mpt-7b", every=4) if nine else build_cfg2(dev)
     trainer = Trainer(model, layout.special(), lr=2e-4, weight_decay=0.1, gamma=2.0, use_reweight=True,
                       lr_scheduler="cosine", warmup_steps=10, total_steps=10000, sparse_head=args.sparse_head,
-                      grad_accum=args.grad_accum, dense_head_backward=args.dense_head_backward)
+                      grad_accum=args.grad_accum, dense_head_backward=args.dense_head_backward,
+                      shard_optimizer=args.shard_optimizer and world > 1)
     trainer.dp.record_exposed = world > 1
     n_train = sum(p.numel() for p in model.parameters() if p.requires_grad)
     T, L, B, GA = args.images, args.seq, args.batch, args.grad_accum
@@ -250,6 +253,7 @@ def main():
     rccl = None
     if world > 1:
         rccl = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "buckets": len(trainer.dp.buckets),
+                "optimizer_state": "sharded (reduce-scatter + all-gather)" if trainer.opt.shard else "replicated (all-reduce)",
                 "bucket_bytes": [int((b[1] - b[0]) * 2) for b in trainer.dp.buckets][:4],
                 "exposed_allreduce_ms_per_step": round(sum(exposed) / max(1, len(exposed)), 3),
                 "note": "exposed = time the compute stream waits in GradBucketer.finish() for collectives that backward did not hide (HIP events)"}

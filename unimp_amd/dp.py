@@ -31,21 +31,32 @@ class GradBucketer:
         self._late = {id(p) for p in late_params}
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        self.active = self.world > 1 or (force_hooks and dist.is_initialized())
+        self.active = self.world > 1 or ((force_hooks or getattr(optimizer, "shard", None) is not None) and dist.is_initialized())
         self.buckets = []        # [start, end, n_params]
         elems = max(1, bucket_bytes // optimizer.flat_g.element_size())
         cur = None
         self.param_bucket = {}
         self._slot = {}          # id(param) -> (offset, numel) of its view in the flat gradient buffer
-        for n, p, o, k in optimizer.layout:
-            end = o + (k + optimizer.ALIGN - 1) // optimizer.ALIGN * optimizer.ALIGN
-            if cur is None or (end - cur[0]) > elems and cur[2] > 0:
-                cur = [o, end, 0]
-                self.buckets.append(cur)
-            cur[1] = end
-            cur[2] += 1
-            self.param_bucket[id(p)] = len(self.buckets) - 1
-            self._slot[id(p)] = (o, k)
+        self.sharded = getattr(optimizer, "shard", None) is not None
+        if self.sharded:         # the optimizer cut (and padded) the buckets itself: rank r owns the r-th 1/world of each
+            self.buckets = [[s_, e_, 0] for s_, e_ in optimizer.buckets]
+            bi = 0
+            for n, p, o, k in optimizer.layout:
+                while o >= self.buckets[bi][1]:
+                    bi += 1
+                self.buckets[bi][2] += 1
+                self.param_bucket[id(p)] = bi
+                self._slot[id(p)] = (o, k)
+        else:
+            for n, p, o, k in optimizer.layout:
+                end = o + (k + optimizer.ALIGN - 1) // optimizer.ALIGN * optimizer.ALIGN
+                if cur is None or (end - cur[0]) > elems and cur[2] > 0:
+                    cur = [o, end, 0]
+                    self.buckets.append(cur)
+                cur[1] = end
+                cur[2] += 1
+                self.param_bucket[id(p)] = len(self.buckets) - 1
+                self._slot[id(p)] = (o, k)
         self._late_buckets = sorted({self.param_bucket[i] for i in self._late if i in self.param_bucket})
         self._order = [bi for bi in range(len(self.buckets)) if bi not in self._late_buckets]     # issue order during backward
         self._reset()
@@ -87,7 +98,13 @@ class GradBucketer:
         s, e, _ = self.buckets[bi]
         self._issued.add(bi)
         self.launch_log.append(bi)
-        self._handles.append(dist.all_reduce(self.opt.flat_g[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        g = self.opt.flat_g
+        if self.sharded and dist.get_backend(self.pg) == "nccl":
+            # ZeRO-2: the rank only needs the sum over its own 1/world of the bucket (in place: output = its slice of the input)
+            lo, hi, _ = self.opt.owned[bi]
+            self._handles.append(dist.reduce_scatter_tensor(g[lo:hi], g[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        else:       # replicated state, or a backend without reduce-scatter (gloo in the tests): the owned slice of the sum is what is used
+            self._handles.append(dist.all_reduce(g[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
     def finish(self):
         """call after backward: issue, in index order, the buckets that did not go out during backward (parameters

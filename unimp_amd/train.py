@@ -70,8 +70,7 @@ def load_checkpoint(path, model, trainer=None):
     epoch = 0
     if trainer is not None:
         # parameters are views of the flat bf16 buffer: refresh the fp32 master copy from what was just loaded
-        for n, p, o, k in trainer.opt.layout:
-            trainer.opt.master[o:o + k].copy_(p.detach().reshape(-1))
+        trainer.opt.refresh_master()
         if os.path.exists(path + ".resume"):
             r = torch.load(path + ".resume", map_location="cpu")
             trainer.opt.load_state_dict(r["optimizer"])
@@ -85,7 +84,8 @@ def load_checkpoint(path, model, trainer=None):
 class Trainer:
     def __init__(self, model, special_ids, lr=2e-4, weight_decay=0.1, gamma=2.0, use_reweight=True, max_grad_norm=1.0,
                  lr_scheduler="cosine", warmup_steps=0, total_steps=1000, bucket_bytes=256 << 20, process_group=None,
-                 sparse_head=False, grad_accum=1, mask_lm_head=False, force_dp_hooks=False, dense_head_backward=False):
+                 sparse_head=False, grad_accum=1, mask_lm_head=False, force_dp_hooks=False, dense_head_backward=False,
+                 shard_optimizer=False):
         """sparse_head (off by default): apply the LM head and the loss only to the positions whose next token carries a
         label -- identical loss / gradients / update (unlabeled rows contribute nothing), ~5 % fewer FLOPs at cfg2; the
         returned model output then has no logits.  Costs one host sync per step (the row count).
@@ -97,7 +97,13 @@ class Trainer:
         self.grad_accum, self._micro = grad_accum, 0       # mmrec.py's --gradient_accumulation_steps (accelerator.accumulate)
         self.ids = special_ids                   # dict(answer_id, eoc_id, pad_id, media_id)
         self.gamma, self.use_reweight = gamma, use_reweight
-        self.opt = FlatAdamW(model.named_parameters(), lr=lr, weight_decay=weight_decay, max_grad_norm=max_grad_norm)
+        shard = None
+        if shard_optimizer:       # ZeRO-2-style optimizer-state sharding over the data-parallel group (optim.FlatAdamW)
+            import torch.distributed as dist
+            if not dist.is_initialized():
+                raise RuntimeError("shard_optimizer needs an initialised process group")
+            shard = (dist.get_rank(process_group), dist.get_world_size(process_group), max(1, bucket_bytes // 2), process_group)
+        self.opt = FlatAdamW(model.named_parameters(), lr=lr, weight_decay=weight_decay, max_grad_norm=max_grad_norm, shard=shard)
         le = model.lang_encoder
         late = [le.get_input_embeddings().weight] if getattr(le, "tied", False) else []
         # --mask_lm_head (mmrec.py:218-229): only the <answer> row of the embedding / head gradients survives.  The rows are
