@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/all; mkdir -p $O
-timeout 3000 python -m pytest tests -q -m gpu -x > $O/tests.log 2>&1; echo "tests rc=$?" >> $O/rc.txt
+timeout 3000 python -m pytest tests -q -m gpu > $O/tests.log 2>&1; echo "tests rc=$?" >> $O/rc.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/rc.txt
