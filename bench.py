@@ -23,6 +23,7 @@ import torch
 import torch.distributed as dist
 
 PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA peak, MI355X_MICROARCH.md §Chip-level parameters
+PEAK_MXFP8_TFLOPS = 5000.0         # dense MX-fp8 peak (block-scaled v_mfma_scale_f32_16x16x128_f8f6f4), same guide, Matrix cores table
 PROF_STEPS = 4            # timed steps whose GEMM launches are bracketed by HIP events (roofline.achieved)
 
 
@@ -260,7 +261,16 @@ def main():
 
     if rank == 0:
         roofline = None
+        mx_roof = None
         if prof:
+            mxp = [r for r in prof if r[3][-1] == "mxfp8"]
+            if mxp:       # --fp8: the MX GEMMs get their own roofline (5 PF peak); the main object keeps the bf16 GEMMs
+                mx_ms, mx_fl = sum(r[0].elapsed_time(r[1]) for r in mxp), sum(r[2] for r in mxp)
+                mx_ach = mx_fl / (mx_ms * 1e-3) / 1e12
+                mx_roof = {"bound": "mfma", "kernel": "gemm_mx_kernel (MX-fp8 e4m3 + E8M0, frozen-tower GEMMs, forward + dX)", "achieved": round(mx_ach, 2),
+                           "peak": PEAK_MXFP8_TFLOPS, "unit": "TFLOP/s", "frac": round(mx_ach / PEAK_MXFP8_TFLOPS, 4),
+                           "launches_per_step": len(mxp) // prof_steps, "ms_per_step": round(mx_ms / prof_steps, 2)}
+                prof = [r for r in prof if r[3][-1] != "mxfp8"]
             tot_ms = sum(r[0].elapsed_time(r[1]) for r in prof)
             tot_fl = sum(r[2] for r in prof)
             if os.environ.get("UNIMP_BENCH_SHAPES"):
@@ -294,7 +304,7 @@ def main():
                         "lm_xattn_gemms": {"achieved": round(lm_ach, 2), "frac": round(lm_ach / PEAK_BF16_TFLOPS, 4),
                                            "ms_per_step": round(lm_ms / prof_steps, 2)},
                         "launches_per_step": len(prof) // prof_steps, "gemm_ms_per_step": round(tot_ms / prof_steps, 2), "profiled_steps": prof_steps,
-                        "gemm_flop_per_step": tot_fl / prof_steps}
+                        "gemm_flop_per_step": tot_fl / prof_steps, **({"mx_gemms": mx_roof} if mx_roof else {})}
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(T, L, layout, fps, args.cpu_full_steps)

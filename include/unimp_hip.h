@@ -163,7 +163,8 @@ int unimp_cast_f32_to_bf16(const float* src, void* dst, int64_t n, float scale, 
 int unimp_swiglu_fwd(const void* gate_up, int64_t ld, void* out, int64_t ldo, int rows, int F, void* stream);
 int unimp_swiglu_bwd(const void* gate_up, int64_t ld, const void* dout, int64_t lddo, void* dgate_up, int64_t ldd,
                      int rows, int F, void* stream);
-/* out[0] += sum(a*b) over n elements (fp32, out zeroed by the caller): d tanh-gate = dot(dy, y_pre_gate) */
+/* out[0] += sum(a*b) over n elements (fp32; out is fp32[1 + 1024]: out[0] zeroed by the caller, out[1..1025) scratch for the ordered
+ * two-stage reduction -- no float atomics): d tanh-gate = dot(dy, y_pre_gate) */
 int unimp_dot_bf16(const void* a, const void* b, int64_t n, float* out, void* stream);
 /* out[r] = src[r % period] (Perceiver latents repeat "n d -> b T n d") and its adjoint out[j] = sum_{r%period==j} src[r] (bf16) */
 int unimp_bcast_rows(const void* src, void* out, int64_t ldo, int rows, int period, int D, void* stream);

@@ -287,6 +287,17 @@ extern "C" int unimp_swiglu_bwd(const void* gate_up, int64_t ld, const void* dou
   return unimp_check_launch("swiglu_bwd");
 }
 
+// ordered two-stage reduction (like sumsq): per-block partials into out[1 + block], then one block adds them in a fixed order --
+// the tanh-gate gradients are bit-reproducible from run to run (round 1 used one fp32 atomicAdd per block)
+__global__ void dot_final_kernel(const float* __restrict__ part, int nb, float* __restrict__ out) {
+  __shared__ float sh[256];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 256) a += part[i];
+  sh[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) out[0] += sh[0];
+}
 __global__ void dot_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b, long n, float* __restrict__ out) {
   __shared__ float sh[4];
   float acc = 0.f;
@@ -300,13 +311,14 @@ __global__ void dot_kernel(const bf16* __restrict__ a, const bf16* __restrict__ 
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, sh[0] + sh[1] + sh[2] + sh[3]);
+  if (threadIdx.x == 0) out[1 + blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 extern "C" int unimp_dot_bf16(const void* a, const void* b, int64_t n, float* out, void* stream) {
   if (!a || !b || !out) return unimp_set_error(UNIMP_ERR_ARG, "dot: null pointer");
   if (n <= 0) return UNIMP_OK;
   long blocks = std::min<long>(((n >> 3) + 255) / 256 + 1, 1024);
   hipLaunchKernelGGL(dot_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)a, (const bf16*)b, (long)n, out);
+  hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, out + 1, (int)blocks, out);
   return unimp_check_launch("dot");
 }
 

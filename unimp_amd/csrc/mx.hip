@@ -16,6 +16,7 @@
 //                     epilogue through LDS in 16-byte row chunks: + bias, GELU / ReLU with the derivative as a second output,
 //                     x aux (activation backward), + residual, bf16 out.
 // First version of this path: correct and measured (tools/bench_mx.py), not yet schedule-tuned like the bf16 GEMMs.
+#include <stdlib.h>
 #include "common.h"
 #include "unimp_hip.h"
 
@@ -89,15 +90,20 @@ __device__ __forceinline__ void mx_glds4(const void* sbase, uint32_t voff, uint3
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
 }
 
-#define MX_BM 128
-#define MX_BN 128
-// stage: A data 16 KiB | B data 16 KiB | A scale words 512 B | B scale words 512 B
-#define MX_STAGE (2 * MX_BM * 128 + 2 * 512)
-
-__global__ __launch_bounds__(256) void gemm_mx_kernel(MxP p) {
-  __shared__ __attribute__((aligned(1024))) char smem[2 * MX_STAGE];
+// Tile configurations: WMW x WNW waves, each owning (16 MI) x (16 NJ) outputs.
+//   <2, 2, 4, 4>: 128 x 128 tile, 4 waves, 66 KiB of LDS (2 workgroups per CU) -- few-tile problems
+//   <2, 4, 8, 4>: 256 x 256 tile, 8 waves (128 x 64 each, 2 per SIMD), 132 KiB of LDS -- the tower shapes: per K-step a wave reads
+//                 12 fragments for 32 MFMAs instead of 8 for 16 (LDS bytes per MFMA: 0.75 vs 1.0)
+template <int WMW, int WNW, int MI, int NJ>
+__global__ __launch_bounds__(64 * WMW * WNW) void gemm_mx_kernel(MxP p) {
+  constexpr int BM = WMW * 16 * MI, BN = WNW * 16 * NJ, NWAVE = WMW * WNW;
+  constexpr int STAGE = (BM + BN) * 128 + (BM + BN) * 4;                 // data rows of 128 B, then one scale word per row
+  constexpr int ND = (BM + BN) * 8 / 64 / NWAVE;                        // data DMA instructions per wave and K-step
+  constexpr int NS = (BM + BN + 64 * NWAVE - 1) / (64 * NWAVE);         // scale DMA instructions per wave and K-step
+  static_assert((BM + BN) * 8 % (64 * NWAVE) == 0, "data slots divide evenly over the waves");
+  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = lane_id(), r16 = l & 15, g = l >> 4;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WNW, wn = wave % WNW;
   // tile mapping: XCD-aware, groups of 8 row tiles share their column sweep
   int nwg = p.nbm * p.nbn;
   int id = xcd_remap(blockIdx.x, nwg);
@@ -105,49 +111,52 @@ __global__ __launch_bounds__(256) void gemm_mx_kernel(MxP p) {
   int per_group = GM * p.nbn, grp = id / per_group, first_m = grp * GM, gsz = min(p.nbm - first_m, GM);
   int in_g = id - grp * per_group;
   const int tm = first_m + in_g % gsz, tn = in_g / gsz;
-  const int m0 = tm * MX_BM, n0 = tn * MX_BN;
+  const int m0 = tm * BM, n0 = tn * BN;
 
-  // ---- DMA plan.  Data: 2 x 128 rows x 8 chunks = 2048 slots of 16 B = 32 wave-instructions, 8 per wave; slot s of an operand
-  // holds (row s >> 3, chunk (s & 7) ^ ((row >> 1) & 7)).  Scales: one dword per row and K-step, 2 wave-instructions per operand.
-  uint32_t d_off[8];
+  // ---- DMA plan.  The stage holds the rows [A rows 0..BM) ; B rows 0..BN)], 8 slots of 16 B each; slot s holds
+  // (row s >> 3, chunk (s & 7) ^ ((row >> 1) & 7)).  Scales: one dword per row and K-step.
+  uint32_t d_off[ND];
 #pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    int i = wave * 8 + t;                     // 0..15: A, 16..31: B
-    bool isb = i >= 16;
-    int s = 64 * (i & 15) + l;
+  for (int t = 0; t < ND; ++t) {
+    int s = 64 * (wave * ND + t) + l;
     int row = s >> 3, c = (s & 7) ^ ((row >> 1) & 7);
-    int gr = isb ? min(n0 + row, p.N - 1) : min(m0 + row, p.M - 1);
+    bool isb = row >= BM;
+    int gr = isb ? min(n0 + row - BM, p.N - 1) : min(m0 + row, p.M - 1);
     d_off[t] = (uint32_t)((long)gr * (isb ? p.ldb : p.lda) + c * 16);
   }
-  // scale words: wave 0/1 -> A rows 0..63 / 64..127, wave 2/3 -> B
-  uint32_t s_off;
-  {
-    int row = (wave & 1) * 64 + l;
-    bool isb = wave >= 2;
-    int gr = isb ? min(n0 + row, p.N - 1) : min(m0 + row, p.M - 1);
-    s_off = (uint32_t)((long)gr * (isb ? p.ldsb : p.ldsa));
+  uint32_t s_off[NS];
+#pragma unroll
+  for (int t = 0; t < NS; ++t) {
+    int row = min(64 * (wave * NS + t) + l, BM + BN - 1);
+    bool isb = row >= BM;
+    int gr = isb ? min(n0 + row - BM, p.N - 1) : min(m0 + row, p.M - 1);
+    s_off[t] = (uint32_t)((long)gr * (isb ? p.ldsb : p.ldsa));
   }
   const uint32_t smem_lds = (uint32_t)(uintptr_t)LDS_PTR(char, smem);
   auto dma_step = [&](int ks, int stage) {
     const uint8_t* ab = p.A + (long)ks * 128;
     const uint8_t* bb = p.B + (long)ks * 128;
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      int i = wave * 8 + t;
-      bool isb = i >= 16;
-      uint32_t dst = smem_lds + stage * MX_STAGE + (isb ? MX_BM * 128 : 0) + (i & 15) * 1024;
-      mx_glds16(isb ? bb : ab, d_off[t], __builtin_amdgcn_readfirstlane(dst));
+    for (int t = 0; t < ND; ++t) {
+      int i = wave * ND + t;                                  // wave-uniform; 64 slots = 8 rows per instruction
+      bool isb = i * 8 >= BM;
+      mx_glds16(isb ? bb : ab, d_off[t], __builtin_amdgcn_readfirstlane(smem_lds + stage * STAGE + i * 1024));
     }
-    const uint8_t* sb_ = (wave >= 2 ? p.sB : p.sA) + (long)ks * 4;
-    uint32_t dst = smem_lds + stage * MX_STAGE + 2 * MX_BM * 128 + (wave >= 2 ? 512 : 0) + (wave & 1) * 256;
-    mx_glds4(sb_, s_off, __builtin_amdgcn_readfirstlane(dst));
+#pragma unroll
+    for (int t = 0; t < NS; ++t) {
+      int i = wave * NS + t;                                  // 64 rows per instruction; BM is a multiple of 64
+      if (i * 64 < BM + BN) {
+        bool isb = i * 64 >= BM;
+        mx_glds4((isb ? p.sB : p.sA) + (long)ks * 4, s_off[t], __builtin_amdgcn_readfirstlane(smem_lds + stage * STAGE + (BM + BN) * 128 + i * 256));
+      }
+    }
   };
 
-  f32x4 acc[4][4];
+  f32x4 acc[MI][NJ];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = p.K >> 7;
   dma_step(0, 0);
@@ -155,49 +164,52 @@ __global__ __launch_bounds__(256) void gemm_mx_kernel(MxP p) {
   __syncthreads();
   for (int ks = 0; ks < nk; ++ks) {
     const int st = ks & 1;
-    const char* sb = smem + st * MX_STAGE;
+    const char* sb = smem + st * STAGE;
+    const char* ssc = sb + (BM + BN) * 128;
     if (ks + 1 < nk) dma_step(ks + 1, st ^ 1);
-    i32x8 af[4], bfr[4];
-    int sa[4], sbv[4];
+    i32x8 bfr[NJ];
+    int sbv[NJ];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int ra = wm * 64 + i * 16 + r16, rb = wn * 64 + i * 16 + r16;
-      u32x4 a0 = *(const u32x4*)(sb + kc_off(ra, g)), a1 = *(const u32x4*)(sb + kc_off(ra, 4 + g));
-      u32x4 b0 = *(const u32x4*)(sb + MX_BM * 128 + kc_off(rb, g)), b1 = *(const u32x4*)(sb + MX_BM * 128 + kc_off(rb, 4 + g));
-      af[i] = i32x8{(int)a0[0], (int)a0[1], (int)a0[2], (int)a0[3], (int)a1[0], (int)a1[1], (int)a1[2], (int)a1[3]};
-      bfr[i] = i32x8{(int)b0[0], (int)b0[1], (int)b0[2], (int)b0[3], (int)b1[0], (int)b1[1], (int)b1[2], (int)b1[3]};
-      sa[i] = (int)(*(const uint32_t*)(sb + 2 * MX_BM * 128 + ra * 4) >> (8 * g));
-      sbv[i] = (int)(*(const uint32_t*)(sb + 2 * MX_BM * 128 + 512 + rb * 4) >> (8 * g));
+    for (int j = 0; j < NJ; ++j) {
+      int rb = BM + wn * 16 * NJ + j * 16 + r16;
+      u32x4 b0 = *(const u32x4*)(sb + kc_off(rb, g)), b1 = *(const u32x4*)(sb + kc_off(rb, 4 + g));
+      bfr[j] = i32x8{(int)b0[0], (int)b0[1], (int)b0[2], (int)b0[3], (int)b1[0], (int)b1[1], (int)b1[2], (int)b1[3]};
+      sbv[j] = (int)(*(const uint32_t*)(ssc + rb * 4) >> (8 * g));
     }
     // D = B_frag x A_frag (operands swapped, as in the bf16 kernels): a lane then owns 4 consecutive n of one m
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i) {
+      int ra = wm * 16 * MI + i * 16 + r16;
+      u32x4 a0 = *(const u32x4*)(sb + kc_off(ra, g)), a1 = *(const u32x4*)(sb + kc_off(ra, 4 + g));
+      i32x8 af = i32x8{(int)a0[0], (int)a0[1], (int)a0[2], (int)a0[3], (int)a1[0], (int)a1[1], (int)a1[2], (int)a1[3]};
+      int sa = (int)(*(const uint32_t*)(ssc + ra * 4) >> (8 * g));
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bfr[j], af[i], acc[i][j], 0, 0, 0, sbv[j], 0, sa[i]);
+      for (int j = 0; j < NJ; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bfr[j], af, acc[i][j], 0, 0, 0, sbv[j], 0, sa);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
 
   // ---- epilogue through a wave-private f32 staging area, 32 rows per pass, then 16-byte chunks of 8 consecutive columns.
   // acc[i][j]: row m = 16 i + r16 (the swapped product puts A's row on the lane), columns n = 16 j + 4 g + e
-  constexpr int FP = 64 + 4;                                        // row pitch in floats
-  static_assert(4 * 32 * FP * 4 <= 2 * MX_STAGE, "epilogue staging fits");
+  constexpr int WNC = 16 * NJ, FP = WNC + 4, CPRW = WNC / 8;          // wave tile width, row pitch in floats, 8-column chunks per row
+  static_assert(NWAVE * 32 * FP * 4 <= 2 * STAGE, "epilogue staging fits");
   float* ewf = (float*)(smem + wave * (32 * FP * 4));
-  const int em = m0 + wm * 64, en = n0 + wn * 64;
+  const int em = m0 + wm * 16 * MI, en = n0 + wn * WNC;
   const bool vec = !((p.ldc | p.ldres | p.ldaux | p.ldpre) & 7);
 #pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
+  for (int pass = 0; pass < MI / 2; ++pass) {
 #pragma unroll
     for (int i2 = 0; i2 < 2; ++i2)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) *(f32x4*)(ewf + (16 * i2 + r16) * FP + 16 * j + 4 * g) = acc[2 * pass + i2][j];
+      for (int j = 0; j < NJ; ++j) *(f32x4*)(ewf + (16 * i2 + r16) * FP + 16 * j + 4 * g) = acc[2 * pass + i2][j];
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      int idx = l + 64 * it;                    // 32 rows x 8 chunks of 8 columns
-      int r = idx >> 3, c = idx & 7;
+    for (int it = 0; it < 32 * CPRW / 64; ++it) {
+      int idx = l + 64 * it;                    // 32 rows x CPRW chunks of 8 columns
+      int r = idx / CPRW, c = idx - r * CPRW;
       int gm = em + 32 * pass + r, gn = en + c * 8;
       if (gm >= p.M || gn >= p.N) continue;
       float v[8], d[8];
@@ -248,7 +260,16 @@ extern "C" int unimp_gemm_mxfp8(const unimp_mx_gemm_desc* d, void* stream) {
   p.bias = (const bf16*)d->bias; p.res = (const bf16*)d->res; p.ldres = d->ldres; p.aux = (const bf16*)d->aux; p.ldaux = d->ldaux;
   p.pre = (bf16*)d->pre; p.ldpre = d->ldpre;
   p.M = d->M; p.N = d->N; p.K = d->K; p.act = d->act;
-  p.nbm = (d->M + MX_BM - 1) / MX_BM; p.nbn = (d->N + MX_BN - 1) / MX_BN;
-  hipLaunchKernelGGL(gemm_mx_kernel, dim3(p.nbm * p.nbn), dim3(256), 0, (hipStream_t)stream, p);
+  // 256 x 256 tiles once they fill the chip (>= 2 rounds of 256 CUs), 128 x 128 otherwise; env UNIMP_MX_TILE=128|256 forces one (A/B)
+  static const int force = [] { const char* e = getenv("UNIMP_MX_TILE"); return e ? atoi(e) : 0; }();
+  long t256 = (long)((d->M + 255) / 256) * ((d->N + 255) / 256);
+  bool big = force ? force == 256 : t256 >= 512;
+  if (big) {
+    p.nbm = (d->M + 255) / 256; p.nbn = (d->N + 255) / 256;
+    hipLaunchKernelGGL((gemm_mx_kernel<2, 4, 8, 4>), dim3(p.nbm * p.nbn), dim3(512), 0, (hipStream_t)stream, p);
+  } else {
+    p.nbm = (d->M + 127) / 128; p.nbn = (d->N + 127) / 128;
+    hipLaunchKernelGGL((gemm_mx_kernel<2, 2, 4, 4>), dim3(p.nbm * p.nbn), dim3(256), 0, (hipStream_t)stream, p);
+  }
   return unimp_check_launch("gemm_mxfp8");
 }

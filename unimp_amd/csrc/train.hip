@@ -1,7 +1,9 @@
 // Training-step kernels: label mask + media_time scan, fused weighted focal cross-entropy (fwd / bwd),
 // global grad-norm, fused flat AdamW.  All HBM-bound; 16-byte accesses; reductions are two-stage and
-// ordered (no float atomics) so the loss, the clip coefficient and therefore every rank's parameters are
-// bit-reproducible from run to run.
+// ordered (no float atomics) so the loss and the clip coefficient are bit-reproducible from run to run for given
+// gradients.  (The one float-atomic left on the training path is the embedding-table scatter-add,
+// elementwise.hip::embedding_bwd_kernel: its fp32 sums may differ in the last bit between runs before they are
+// rounded to bf16; replicas still agree because gradients are all-reduced.)
 #include <algorithm>
 #include "common.h"
 #include "unimp_hip.h"

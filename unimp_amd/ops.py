@@ -405,9 +405,9 @@ def add(a, b, out=None):
 def dot(a, b):
     """fp32 scalar tensor sum(a*b)."""
     assert a.is_contiguous() and b.is_contiguous() and a.numel() == b.numel()
-    out = torch.zeros(1, dtype=torch.float32, device=a.device)
+    out = torch.zeros(1 + 1024, dtype=torch.float32, device=a.device)      # [0]: result, [1:]: scratch of the ordered reduction
     check(_lib.lib().unimp_dot_bf16(_dev(a).data_ptr(), b.data_ptr(), a.numel(), out.data_ptr(), _stream()), "dot")
-    return out
+    return out[:1]
 
 
 def vit_patchify(pixels, P, ldc):
