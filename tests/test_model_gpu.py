@@ -472,3 +472,41 @@ def test_fp8_frozen_towers_track_the_bf16_path(P, monkeypatch):
           f"({worst1[1]}); {res[True][3]} MX GEMMs")
     # the scalar tanh-gate gradients are single, heavily cancelling dot products (see test_forward_backward_parity): looser bound
     assert e_log <= 8e-2 and e_loss <= 2e-2 and e_or <= 2e-2 and worst[0] <= 0.25 and worst1[0] <= 0.6
+
+
+def test_mask_lm_head_keeps_only_the_answer_row(P):
+    """mmrec.py:218-229 (--mask_lm_head): after backward the embedding / head gradients are multiplied by a mask that is 1 on the
+    <answer> token's row only.  Trainer(mask_lm_head=True): after an optimizer step every other row of the input embedding and
+    of the head is unchanged (AdamW without weight decay on these tensors: a zero gradient with zero moments moves nothing),
+    the <answer> row moved."""
+    from unimp_amd.train import Trainer
+    cfg = P.TINY
+    om, layout = P.build_oracle(cfg)
+    hm = P.build_hip(cfg, om, layout)
+    emb, head = hm.lang_encoder.get_input_embeddings().weight, hm.lang_encoder.get_output_embeddings().weight
+    e0, h0 = emb.detach().clone(), head.detach().clone()
+    tr = Trainer(hm, layout.special(), lr=1e-2, mask_lm_head=True)
+    tr.step({k: v.cuda() for k, v in P.make_batch(cfg, layout).items()})
+    a = layout.answer
+    for w, w0 in ((emb, e0), (head, h0)):
+        d = (w.detach().float() - w0.float()).abs().sum(1)
+        assert d[a] > 0, "the <answer> row must train"
+        d[a] = 0
+        assert float(d.max()) == 0.0, "rows other than <answer> must not move"
+    tr.dp.remove()
+
+
+def test_precision_choice_is_bf16_not_the_reference_default(P):
+    """the reference's default --precision amp is torch.cuda.amp fp16 autocast (train_utils.py:17-19)
+    layered on a DeepSpeed bf16 engine; every shipped script keeps that default.  BASELINE names bf16, and this build computes in
+    bf16 throughout (parameters, activations, logits) with fp32 accumulation / statistics / master weights -- asserted here so
+    the deviation is explicit."""
+    from unimp_amd.train import Trainer
+    cfg = P.TINY
+    om, layout = P.build_oracle(cfg)
+    hm = P.build_hip(cfg, om, layout)
+    assert all(p.dtype == torch.bfloat16 for p in hm.parameters())
+    tr = Trainer(hm, layout.special())
+    loss, stats, out, _ = tr.forward_loss({k: v.cuda() for k, v in P.make_batch(cfg, layout).items()})
+    assert out["logits"].dtype == torch.bfloat16 and loss.dtype == torch.float32 and tr.opt.master.dtype == torch.float32
+    tr.dp.remove()
