@@ -84,7 +84,7 @@ def test_kernel_register_budgets():
         return res
     vg = ("-mllvm", "-amdgpu-mfma-vgpr-form")
     g3 = remarks("gemm3.hip", vg)
-    assert len(g3) == 8
+    assert len(g3) == 12                # 4 operand forms x 2 tile widths + the packed-B form (2 A layouts x 2 widths)
     for k, r in g3.items():
         assert r["ScratchSize"] == 0 and r["VGPRs"] + r.get("AGPRs", 0) <= 256 and r["Occupancy"] >= 2, (k, r)
     at = remarks("attention.hip", vg)
@@ -94,6 +94,21 @@ def test_kernel_register_budgets():
         assert r["ScratchSize"] == 0, (k, r)
         if "attn_dq" not in k:                                  # dQ holds two 32-row blocks of q, dO, dq: one wave per SIMD by design
             assert r["Occupancy"] >= 2, (k, r)
+    # second-generation attention (the default forward and dQ): three waves per SIMD at head dim 80 / 64 is what the design buys
+    a2 = remarks("attention2.hip", vg)
+    hot = {k: r for k, r in a2.items() if ("fwd2_kernelILi80ELi4ELb0" in k or "fwd2_kernelILi64ELi5ELb0" in k or "dq2_kernelILi80ELb0" in k)}
+    assert len(hot) == 3, sorted(a2)
+    for k, r in hot.items():
+        if "dq2" in k:       # 70 KiB of LDS (three images per tile) hold dQ at two workgroups per CU; registers must not lower that
+            assert r["ScratchSize"] == 0 and r["VGPRs"] + r.get("AGPRs", 0) <= 256 and r["Occupancy"] >= 2, (k, r)
+        else:
+            assert r["ScratchSize"] == 0 and r["VGPRs"] + r.get("AGPRs", 0) <= 168 and r["Occupancy"] >= 3, (k, r)
+    for k, r in a2.items():
+        if "dkv2" not in k or "Li128" not in k:                  # the experimental dK/dV kernel at head dim 128 runs one wave per SIMD
+            assert r["ScratchSize"] == 0, (k, r)
+    mx = remarks("mx.hip", vg)
+    big = [r for k, r in mx.items() if "gemm_mx_kernelILi2ELi4ELi8ELi4" in k]
+    assert len(big) == 1 and big[0]["ScratchSize"] == 0 and big[0]["VGPRs"] + big[0].get("AGPRs", 0) <= 256, big
 
 
 def test_gemm_kernel_code_fits_the_instruction_cache():
