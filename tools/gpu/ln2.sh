@@ -1,0 +1,7 @@
+cd /tmp && export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/ln2; mkdir -p $O
+timeout 600 python -m pytest tests/test_kernels_gpu.py -q -m gpu -k "layernorm" > $O/tests.log 2>&1; echo "tests rc=$?" > $O/rc.txt
+timeout 300 python tools/bench_ln.py --rotate 3 > $O/new.log 2>&1
+timeout 900 python bench.py --steps 10 --warmup 3 --cpu-full-steps 0 > $O/bench.json 2> $O/bench.err; echo "bench rc=$?" >> $O/rc.txt
+timeout 900 python -m pytest tests/test_model_gpu.py -q -m gpu -x > $O/model.log 2>&1; echo "model rc=$?" >> $O/rc.txt
