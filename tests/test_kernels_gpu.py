@@ -287,6 +287,14 @@ def test_gemm_splitk_weight_grad(ops, M, N, K, gate):
     if K % 8 == 0:                                   # the same product from k-contiguous operands (kc x kc split-K)
         got_kc = ops.gemm(dy.t().contiguous().cuda(), x.t().contiguous().cuda(), gate=g.cuda() if gate else None)
         close(got_kc, want, name="splitk kc")
+    # accumulate: the reduction pass adds into C (the weight-gradient sink of train.Trainer), bf16 and fp32 outputs
+    c0 = rnd(M, N, seed=3)
+    acc = c0.cuda().clone()
+    ops.gemm(dy.cuda(), x.cuda(), a_ks=True, b_ks=True, gate=g.cuda() if gate else None, out=acc, accumulate=True)
+    close(acc, want + c0.float(), name="splitk dW accumulate")
+    acc32 = c0.float().cuda()
+    ops.gemm(dy.cuda(), x.cuda(), a_ks=True, b_ks=True, gate=g.cuda() if gate else None, out=acc32, accumulate=True)
+    close(acc32, want + c0.float(), name="splitk dW accumulate f32")
 
 
 def test_gemm_rejects_bad_args(ops):

@@ -51,7 +51,7 @@ def test_forward_backward_parity(P, cfgname):
     print(f"\n[{cfgname}] argmax agreement {ag['rate']:.4f} over {ag['n']} valid positions; {ag['n_sure']} with HIP margin > 8 sigma "
           f"({ag['sigma']:.2e}): identical = {ag['sure_equal']}")
     assert ag["sure_equal"] and ag["rate"] >= 0.9, ag
-    loss.backward()
+    tr._backward(loss)              # the production backward: weight-gradient GEMMs add straight into the flat gradient buffer
     noise = P.bf16_noise_floor(om, layout, batch, want_labels, want_grads)
     named = dict(hm.named_parameters())
     checked = 0
@@ -431,6 +431,46 @@ def test_compact_head_backward_equals_dense(P):
             assert res[False][3][n].abs().max() == 0, n
         else:
             assert P.rel_l2(res[False][3][n], g) <= 4e-3, (n, P.rel_l2(res[False][3][n], g))
+
+
+def test_direct_weight_gradients_equal_autograd_path(P):
+    """Single rank: the dW GEMMs accumulate into the flat gradient buffer themselves (functional.WGRAD_SINK, epilogue
+    ``accumulate``) instead of returning a temporary for autograd's ``.grad +=``.  Same gradients up to one bf16 rounding
+    (the direct path rounds acc + grad once, autograd rounds the GEMM output and then the sum), also when two micro-batches
+    accumulate; the sink is really used (every 2-D trainable weight of the gated blocks and the Perceiver), and split-K
+    weight gradients (narrow projections) take the same route."""
+    from unimp_amd.train import Trainer
+    from unimp_amd import functional as Fn
+    cfg = P.TINY
+    om, layout = P.build_oracle(cfg)
+    batch = {k: v.cuda() for k, v in P.make_batch(cfg, layout).items()}
+    res, hits = {}, 0
+    for direct in (False, True):
+        hm = P.build_hip(cfg, om, layout)
+        tr = Trainer(hm, layout.special(), lr=1e-3, gamma=2.0, use_reweight=True, direct_wgrad=direct)
+        assert (tr._sink is not None) == direct
+        hm.train()
+        if direct:
+            orig = tr._sink.view_of
+            def counted(w, orig=orig):
+                nonlocal hits
+                v = orig(w)
+                hits += v is not None
+                return v
+            tr._sink.view_of = counted
+        for _ in range(2):                      # two micro-batches add up in the buffer
+            loss, stats, out, labels = tr.forward_loss(batch)
+            tr._backward(loss)
+        assert Fn.WGRAD_SINK is None
+        res[direct] = {n: p.grad.float().clone() for n, p in hm.named_parameters() if p.grad is not None}
+        tr.dp.remove()
+    assert hits >= 2 * 10, hits
+    assert set(res[True]) == set(res[False])
+    for n, g in res[False].items():
+        if g.abs().max() == 0:
+            assert res[True][n].abs().max() == 0, n
+        else:
+            assert P.rel_l2(res[True][n], g) <= 6e-3, (n, P.rel_l2(res[True][n], g))
 
 
 def test_fp8_frozen_towers_track_the_bf16_path(P, monkeypatch):

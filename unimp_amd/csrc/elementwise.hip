@@ -67,6 +67,63 @@ __global__ __launch_bounds__(256) void rope_kernel(bf16* __restrict__ x, long ro
   }
 }
 
+// Streaming form for the vectorisable case: a block takes G rows at a time and spreads their G * items 16-byte items evenly over its
+// 256 threads (NS slots per thread, the last one partly empty), and all 6 * NS loads of a thread - both halves of the pair, cos
+// and sin - are issued before the first one is waited for (a lane without an item reads item 0 of the first row instead of
+// branching: with a branch per item the compiler waited for every item's loads separately, 4.4 TB/s).
+template <int NS>
+__global__ __launch_bounds__(256) void rope_rows_kernel(bf16* __restrict__ x, long row_stride, long head_stride, int rows, int L, int heads,
+                                                        int half, int nvec, int off0, int off1, const float* __restrict__ cs,
+                                                        const float* __restrict__ sn, int inverse, int G) {
+  const int cpr = half >> 3, per_head = nvec * cpr, items = heads * per_head;
+  int eoff[NS], toff[NS], rg[NS];
+  bool has[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    int t = threadIdx.x + 256 * k;
+    has[k] = t < G * items;
+    int tt = has[k] ? t : 0;
+    rg[k] = tt / items;
+    int it = tt - rg[k] * items;
+    int h = it / per_head, rem = it - h * per_head;
+    int vsel = rem / cpr, c = rem - vsel * cpr;
+    eoff[k] = (int)(h * head_stride + (vsel ? off1 : off0) + c * 8);
+    toff[k] = c * 8;
+  }
+  const float sgn = inverse ? -1.f : 1.f;
+  for (int r0 = blockIdx.x * G; r0 < rows; r0 += gridDim.x * G) {
+    bf16x8 a[NS], b[NS];
+    f32x4 c0[NS], c1[NS], s0[NS], s1[NS];
+    bf16* p[NS];
+    bool ok[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      int r = r0 + rg[k];
+      ok[k] = has[k] && r < rows;
+      if (!ok[k]) r = r0;
+      int pos = r % L;
+      p[k] = x + (long)r * row_stride + eoff[k];
+      const float* cr = cs + (long)pos * half + toff[k];
+      const float* sr = sn + (long)pos * half + toff[k];
+      a[k] = *(const bf16x8*)p[k]; b[k] = *(const bf16x8*)(p[k] + half);
+      c0[k] = *(const f32x4*)cr; c1[k] = *(const f32x4*)(cr + 4);
+      s0[k] = *(const f32x4*)sr; s1[k] = *(const f32x4*)(sr + 4);
+    }
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      bf16x8 oa, ob;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float co = j < 4 ? c0[k][j & 3] : c1[k][j & 3], si = sgn * (j < 4 ? s0[k][j & 3] : s1[k][j & 3]);
+        float x1 = bf2f(a[k][j]), x2 = bf2f(b[k][j]);
+        oa[j] = f2bf(x1 * co - x2 * si);
+        ob[j] = f2bf(x2 * co + x1 * si);
+      }
+      if (ok[k]) { *(bf16x8*)p[k] = oa; *(bf16x8*)(p[k] + half) = ob; }
+    }
+  }
+}
+
 extern "C" int unimp_rope_halfsplit(void* x, int64_t row_stride, int64_t head_stride, int rows, int L, int heads, int rot,
                                     int nvec, int vec_off0, int vec_off1, const float* cos_t, const float* sin_t, int inverse,
                                     void* stream) {
@@ -81,7 +138,26 @@ extern "C" int unimp_rope_halfsplit(void* x, int64_t row_stride, int64_t head_st
   // 16-byte aligned when the table itself is (torch allocations are)
   if ((long)heads * head_stride + rot > (1L << 30)) return unimp_set_error(UNIMP_ERR_SHAPE, "rope: row too long");
   int grid = rows < 16384 ? rows : 16384;
-  if (vec && (((uintptr_t)cos_t | (uintptr_t)sin_t) & 15) == 0)
+  const bool vec16 = vec && (((uintptr_t)cos_t | (uintptr_t)sin_t) & 15) == 0;
+  const int items = vec16 ? heads * nvec * (half / 8) : 0;
+  if (vec16 && items <= 6 * 256) {
+    // rows per block pass: the smallest G in {1, 2, 4, 8} that fills the threads' slots best (G * items close below a multiple of 256)
+    int G = 1, best_waste = 1 << 30;
+    for (int g = 1; g <= 8; g *= 2) {
+      int ns = (g * items + 255) / 256;
+      if (ns > 6 || g > rows) break;
+      int waste = (ns * 256 - g * items) * (8 / g);           // idle slots per 8 rows
+      if (waste < best_waste) { best_waste = waste; G = g; }
+    }
+    int ns = (G * items + 255) / 256;
+    int g2 = (rows + G - 1) / G; if (g2 > 16384) g2 = 16384;
+#define ROPE_NS(N) case N: hipLaunchKernelGGL((rope_rows_kernel<N>), dim3(g2), dim3(256), 0, s, (bf16*)x, (long)row_stride, (long)head_stride, rows, L, \
+                       heads, half, nvec, vec_off0, vec_off1, cos_t, sin_t, inverse, G); break
+    switch (ns) { ROPE_NS(1); ROPE_NS(2); ROPE_NS(3); ROPE_NS(4); ROPE_NS(5); ROPE_NS(6); default: break; }
+#undef ROPE_NS
+    return unimp_check_launch("rope");
+  }
+  if (vec16)
     hipLaunchKernelGGL((rope_kernel<8>), dim3(grid), dim3(256), 0, s, (bf16*)x, (long)row_stride, (long)head_stride, rows, L,
                        heads, half, nvec, vec_off0, vec_off1, cos_t, sin_t, inverse);
   else

@@ -467,23 +467,32 @@ extern "C" int unimp_gemm_bf16_variant(const unimp_gemm_desc* d, int variant, vo
 // with K = all tokens): K slices -> f32 slabs [S][M][N] (plain stores), then one ordered reduction pass (reproducible,
 // no atomics) that applies alpha * tanh(gate) and writes bf16 / f32.
 __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int S, long MN, int N, void* __restrict__ C, long ldc,
-                                     int out_f32, float alpha, const bf16* __restrict__ gate) {
+                                     int out_f32, float alpha, const bf16* __restrict__ gate, int accumulate) {
   long i4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i4 >= MN) return;
   float g = alpha * (gate ? tanhf(bf2f(*gate)) : 1.f);
   f32x4 a = {0.f, 0.f, 0.f, 0.f};
   for (int s = 0; s < S; ++s) a += *(const f32x4*)(slabs + (long)s * MN + i4);
+  a *= g;
   long m = i4 / N; int n = (int)(i4 - m * N);
-  if (out_f32) { *(f32x4*)((float*)C + m * ldc + n) = a * g; }
-  else { bf16x4 o = {f2bf(a[0] * g), f2bf(a[1] * g), f2bf(a[2] * g), f2bf(a[3] * g)}; *(bf16x4*)((bf16*)C + m * ldc + n) = o; }
+  if (out_f32) {
+    float* d = (float*)C + m * ldc + n;
+    if (accumulate) a += *(const f32x4*)d;
+    *(f32x4*)d = a;
+  } else {
+    bf16* d = (bf16*)C + m * ldc + n;
+    if (accumulate) { bf16x4 c = *(const bf16x4*)d; a += f32x4{bf2f(c[0]), bf2f(c[1]), bf2f(c[2]), bf2f(c[3])}; }
+    bf16x4 o = {f2bf(a[0]), f2bf(a[1]), f2bf(a[2]), f2bf(a[3])};
+    *(bf16x4*)d = o;
+  }
 }
 
 extern "C" int unimp_gemm_bf16_splitk(const unimp_gemm_desc* d, int splits, float* slabs, void* stream) {
   int e = validate(d);
   if (e) return e;
   if (splits < 2 || !slabs) return unimp_set_error(UNIMP_ERR_ARG, "gemm_splitk: need splits >= 2 and a slab workspace");
-  if (d->bias || d->res || d->aux || d->pre || d->act || d->dact || d->accumulate)
-    return unimp_set_error(UNIMP_ERR_UNSUPPORTED, "gemm_splitk: only alpha / gate epilogues");
+  if (d->bias || d->res || d->aux || d->pre || d->act || d->dact)
+    return unimp_set_error(UNIMP_ERR_UNSUPPORTED, "gemm_splitk: only alpha / gate (/ accumulate) epilogues");
   if ((d->N & 3) || (d->ldc & 3)) return unimp_set_error(UNIMP_ERR_SHAPE, "gemm_splitk: N and ldc must be multiples of 4");
   // 256 x 256 ping-pong tiles once the output holds a few of them (twice the 128 x 128 kernel's rate); 128 x 128 tiles otherwise
   if (d->M >= 256 && d->N >= 256) unimp_gemm3_launch_splitk(d, 256, splits, slabs, stream);
@@ -492,7 +501,7 @@ extern "C" int unimp_gemm_bf16_splitk(const unimp_gemm_desc* d, int splits, floa
   int S = (d->K + ks - 1) / ks;
   long MN = (long)d->M * d->N;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((MN / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, slabs, S, MN, d->N,
-                     d->C, (long)d->ldc, d->out_f32, d->alpha, (const bf16*)d->gate);
+                     d->C, (long)d->ldc, d->out_f32, d->alpha, (const bf16*)d->gate, d->accumulate);
   return unimp_check_launch("gemm_splitk");
 }
 

@@ -25,6 +25,27 @@ def _need(ctx, i):
     return ctx.needs_input_grad[i]
 
 
+# Weight-gradient sink (train.Trainer installs one around backward on a single rank): an object with ``view_of(weight)`` ->
+# the weight's [out, in] view of the flat bf16 gradient buffer, or None.  With a sink the dW GEMM adds its fp32 accumulators
+# straight into that view (epilogue ``accumulate``) and autograd gets no gradient for the weight -- no temporary, no
+# ``.grad +=`` pass, one bf16 rounding instead of two.  Without one (tests, the data-parallel path, whose bucket launches
+# hang on autograd's post-accumulate hooks) the gradient is returned as usual.
+WGRAD_SINK = None
+
+
+def _dw(ctx, idx, w, a, b, gate=None):
+    """weight gradient a^T b ([out, tokens] x [tokens, in], both token-major) of forward input ``idx``."""
+    if not _need(ctx, idx):
+        return None
+    sink = WGRAD_SINK
+    if sink is not None:
+        out = sink.view_of(w)
+        if out is not None:
+            ops.gemm(a, b, a_ks=True, b_ks=True, gate=gate, out=out, accumulate=True)
+            return None
+    return ops.gemm(a, b, a_ks=True, b_ks=True, gate=gate)
+
+
 def _gate_grad(dy, raw, gate):
     """d/d gate of tanh(gate) * raw contracted with dy."""
     d = ops.dot(dy, raw)
@@ -85,7 +106,7 @@ class LinearFn(Function):
         N = w.shape[0]
         dy2 = _as_matrix(dy, N)
         dx = ops.gemm(dy2, w, b_ks=True).view(ctx.shp) if _need(ctx, 0) else None
-        dw = ops.gemm(dy2, x2, a_ks=True, b_ks=True) if _need(ctx, 1) else None
+        dw = _dw(ctx, 1, w, dy2, x2)
         return dx, dw, None, None
 
 
@@ -227,8 +248,8 @@ class MLPBlockFn(Function):
             dh = ops.gemm_mx(ops.mx_quantize(dpre), _frozen_mx(w1, True))
         else:
             dpre = ops.gemm(dy2, w2, b_ks=True, gate=gate, aux=pre, dact="deriv", b_pk=_frozen_pk(w2, True))   # [M,F]  (dy tanh(g) W2) * act'(z)
-            dw2 = ops.gemm(dy2, a, a_ks=True, b_ks=True, gate=gate) if _need(ctx, 6) else None
-            dw1 = ops.gemm(dpre, h, a_ks=True, b_ks=True) if _need(ctx, 4) else None
+            dw2 = _dw(ctx, 6, w2, dy2, a, gate=gate)
+            dw1 = _dw(ctx, 4, w1, dpre, h)
             dh = ops.gemm(dpre, w1, b_ks=True, b_pk=_frozen_pk(w1, True))
         del dpre
         wg = _need(ctx, 2) or (ctx.has_lnb and _need(ctx, 3))
@@ -523,15 +544,15 @@ class GatedXAttnFn(Function):
         dgate = _gate_grad(dy2, raw, gate) if _need(ctx, 8) else None
         o2 = o.view(B * L, inner)
         do = ops.gemm(dy2, wo, b_ks=True, gate=gate).view(B, L, heads, dh)
-        dwo = ops.gemm(dy2, o2, a_ks=True, b_ks=True, gate=gate) if _need(ctx, 7) else None
+        dwo = _dw(ctx, 7, wo, dy2, o2, gate=gate)
         dq = torch.empty_like(q)
         dkv = torch.empty_like(kv)
         kv5, dkv5 = kv.view(B, Sk, 2, heads, dh), dkv.view(B, Sk, 2, heads, dh)
         ops.attn_bwd(q.view(B, L, heads, dh), kv5[:, :, 0], kv5[:, :, 1], o, lse, do, dq.view(B, L, heads, dh),
                      dkv5[:, :, 0], dkv5[:, :, 1], dh ** -0.5, ops.MASK_SEGMENT, None, seg, n_lat)
-        dwq = ops.gemm(dq, h, a_ks=True, b_ks=True) if _need(ctx, 5) else None
+        dwq = _dw(ctx, 5, wq, dq, h)
         dh_ = ops.gemm(dq, wq, b_ks=True)
-        dwkv = ops.gemm(dkv, m2, a_ks=True, b_ks=True) if _need(ctx, 6) else None
+        dwkv = _dw(ctx, 6, wkv, dkv, m2)
         dmedia = ops.gemm(dkv, wkv, b_ks=True).view(B, Sk, -1) if _need(ctx, 1) else None
         wg = _need(ctx, 3) or _need(ctx, 4)
         dx, dg, db = ops.layernorm_bwd(dh_, x2, ln_w, mean, rstd, dres=dy2, want_wgrad=wg)
@@ -578,14 +599,14 @@ class PerceiverAttnFn(Function):
             dy2 = dy2.contiguous()
         o2 = o.view(G * n2, inner)
         do = ops.gemm(dy2, wo, b_ks=True).view(G, n2, heads, dh)
-        dwo = ops.gemm(dy2, o2, a_ks=True, b_ks=True) if _need(ctx, 8) else None
+        dwo = _dw(ctx, 8, wo, dy2, o2)
         dq, dkv = torch.empty_like(q), torch.empty_like(kv)
         kv5, dkv5 = kv.view(G, S, 2, heads, dh), dkv.view(G, S, 2, heads, dh)
         ops.attn_bwd(q.view(G, n2, heads, dh), kv5[:, :, 0], kv5[:, :, 1], o, lse, do, dq.view(G, n2, heads, dh),
                      dkv5[:, :, 0], dkv5[:, :, 1], dh ** -0.5, ops.MASK_NONE)
-        dwq = ops.gemm(dq, hl, a_ks=True, b_ks=True) if _need(ctx, 6) else None
+        dwq = _dw(ctx, 6, wq, dq, hl)
         dhl = ops.gemm(dq, wq, b_ks=True)
-        dwkv = ops.gemm(dkv, kvin, a_ks=True, b_ks=True) if _need(ctx, 7) else None
+        dwkv = _dw(ctx, 7, wkv, dkv, kvin)
         dkvin = ops.gemm(dkv, wkv, b_ks=True)                                   # [G*S, D]
         dxm = dgm = dbm = None
         if _need(ctx, 0) or _need(ctx, 2) or _need(ctx, 3):

@@ -231,7 +231,7 @@ def gemm(a, b, *, a_ks=False, b_ks=False, bias=None, act=None, res=None, aux=Non
     d.act, d.dact = ACT[act], ACT[dact]
     d.out_f32, d.accumulate = int(out.dtype == torch.float32), int(accumulate)
     d.pre_deriv = int(pre_deriv)
-    plain = bias is None and res is None and aux is None and pre is None and act is None and dact is None and not accumulate
+    plain = bias is None and res is None and aux is None and pre is None and act is None and dact is None   # alpha / gate / accumulate only
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     tiles256 = ((M + 255) // 256) * ((N + 255) // 256)
     if variant is None and M <= 64 and not a_ks and not b_ks and K % 64 == 0:

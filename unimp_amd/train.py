@@ -81,11 +81,33 @@ def load_checkpoint(path, model, trainer=None):
     return epoch
 
 
+class _WgradSink:
+    """functional.WGRAD_SINK of a single-rank Trainer: 2-D parameters -> their views of the optimizer's flat bf16 gradient buffer."""
+
+    def __init__(self, opt, exclude=()):
+        ex = {id(p) for p in exclude}
+        self.views = {}
+        if opt.flat_g.dtype == torch.bfloat16:
+            for n, p, o, k in opt.layout:
+                if p.dim() == 2 and id(p) not in ex:
+                    self.views[p.data_ptr()] = (p, opt.flat_g[o:o + k].view(p.shape))
+
+    def view_of(self, w):
+        e = self.views.get(w.data_ptr())
+        if e is None or e[0].shape != w.shape:
+            return None
+        p, v = e
+        g = p.grad
+        if g is None or g.data_ptr() != v.data_ptr():     # foreign code replaced .grad: autograd's path, folded back by _reattach
+            return None
+        return v
+
+
 class Trainer:
     def __init__(self, model, special_ids, lr=2e-4, weight_decay=0.1, gamma=2.0, use_reweight=True, max_grad_norm=1.0,
                  lr_scheduler="cosine", warmup_steps=0, total_steps=1000, bucket_bytes=256 << 20, process_group=None,
                  sparse_head=False, grad_accum=1, mask_lm_head=False, force_dp_hooks=False, dense_head_backward=False,
-                 shard_optimizer=False):
+                 shard_optimizer=False, direct_wgrad=True):
         """sparse_head (off by default): apply the LM head and the loss only to the positions whose next token carries a
         label -- identical loss / gradients / update (unlabeled rows contribute nothing), ~5 % fewer FLOPs at cfg2; the
         returned model output then has no logits.  Costs one host sync per step (the row count).
@@ -117,6 +139,9 @@ class Trainer:
                                force_hooks=force_dp_hooks)
         self.sched, self.base_lr, self.warmup, self.total = lr_scheduler, lr, warmup_steps, total_steps
         self.sched_step = 0
+        # single rank: the weight-gradient GEMMs add straight into the flat gradient buffer (functional.WGRAD_SINK).  The
+        # data-parallel path keeps autograd's accumulation: its bucket launches hang on the post-accumulate hooks.
+        self._sink = _WgradSink(self.opt, exclude=late) if direct_wgrad and not self.dp.active else None
 
     def current_lr(self):
         if self.sched == "cosine":
@@ -159,6 +184,13 @@ class Trainer:
             g.zero_()
             g[a].copy_(keep)
 
+    def _backward(self, loss):
+        F_.WGRAD_SINK = self._sink
+        try:
+            loss.backward()
+        finally:
+            F_.WGRAD_SINK = None
+
     def step(self, batch):
         """returns (loss, stats) device tensors; no host synchronisation."""
         self.model.train()
@@ -169,7 +201,7 @@ class Trainer:
             # advances once per optimizer step (mmrec.py:691-692 sizes its schedule in optimizer steps).
             self._micro += 1
             self.dp.sync = False
-            loss.backward()
+            self._backward(loss)
             if self._micro % self.grad_accum == 0:
                 self._mask_lm_head_grads()
                 gscale = self.dp.finish() / self.grad_accum
@@ -177,7 +209,7 @@ class Trainer:
                 self.opt.step(lr=self.current_lr(), grad_scale=gscale)
                 self.sched_step += 1
             return loss.detach(), stats
-        loss.backward()
+        self._backward(loss)
         self._mask_lm_head_grads()
         gscale = self.dp.finish()
         self.opt.step(lr=self.current_lr(), grad_scale=gscale)
