@@ -297,6 +297,29 @@ def test_gemm_splitk_weight_grad(ops, M, N, K, gate):
     close(acc32, want + c0.float(), name="splitk dW accumulate f32")
 
 
+@pytest.mark.parametrize("M,N", [(4352, 4096), (4096, 4608)])
+def test_gemm_tail_split_weight_grad(ops, M, N):
+    """Weight-gradient GEMM with 257..511 tiles (one full round of the 256 CUs + a mostly idle second one): ops.gemm cuts the
+    output into a <= 256-tile part and a split-K remainder (ops._tail_split_plan).  Same result as the single-launch kernel,
+    reproducible, with gate and with accumulation into an existing gradient."""
+    K = 8192 + 64
+    plan = ops._tail_split_plan(M, N, K)
+    assert plan is not None, plan
+    dy, x = rnd(K, M, seed=1, scale=0.1).cuda(), rnd(K, N, seed=2).cuda()
+    g = torch.tensor([0.4]).to(bf16).cuda()
+    want = ops.gemm(dy, x, a_ks=True, b_ks=True, gate=g, variant="pp256")        # a forced variant bypasses the split
+    got = ops.gemm(dy, x, a_ks=True, b_ks=True, gate=g)
+    close(got, want.float(), name="tail-split dW")
+    assert torch.equal(got, ops.gemm(dy, x, a_ks=True, b_ks=True, gate=g))
+    spot = torch.randint(0, M, (64,)), torch.randint(0, N, (64,))
+    ref = (dy[:, spot[0].cuda()].float() * x[:, spot[1].cuda()].float()).sum(0) * math.tanh(0.4)
+    close(got[spot[0].cuda(), spot[1].cuda()], ref, name="tail-split dW vs fp32 spot check")
+    c0 = rnd(M, N, seed=3).cuda()
+    acc = c0.clone()
+    ops.gemm(dy, x, a_ks=True, b_ks=True, gate=g, out=acc, accumulate=True)
+    close(acc, want.float() + c0.float(), name="tail-split dW accumulate")
+
+
 def test_gemm_rejects_bad_args(ops):
     from unimp_amd._lib import UnimpHipError
     a = rnd(16, 12).cuda()      # K = 12: ld not a multiple of 8

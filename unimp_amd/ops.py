@@ -194,8 +194,42 @@ def _tune_packed(M, N, K, a_ks, device, reads_mn, unpacked_variant, b_ks):
     return best
 
 
+TAIL_SPLIT = os.environ.get("UNIMP_GEMM_TAIL_SPLIT", "1") != "0"
+
+
+def _tail_split_plan(M, N, K):
+    """Weight-gradient GEMM whose 256 x 256 tiles fill the 256 CUs once and then leave a mostly empty second round (400 tiles:
+    the second round is 44 % idle): cut the output along the dimension with the finer tile granularity into a part of <= 256
+    tiles (one full round, ordinary kernel) and a remainder that runs under split-K, its slices sized to fill whole rounds.
+    Returns (axis, cut_elements, splits) or None.  Model: a tile costs T = its FLOPs at the deep-K main-loop rate, a split-K
+    slice T / S, the slabs one write + one read at 4 TB/s."""
+    nbm, nbn = (M + 255) // 256, (N + 255) // 256
+    tiles = nbm * nbn
+    if not (256 < tiles < 512) or K < 8192:
+        return None
+    T = 2.0 * 256 * 256 * K / 5.4e12
+    base = 2.0 * T
+    best = None
+    for axis, step, n_line in (("m", nbn, nbm), ("n", nbm, nbn)):
+        k = min(256 // step, n_line - 1)
+        if k < 1:
+            continue
+        ta, tb = k * step, tiles - k * step
+        for S in range(2, 9):
+            if K // S < 1024:
+                break
+            rounds = -(-tb * S // 256)
+            cost = T + rounds * T / S + tb * S * 262144 * 2 / 4e12
+            if best is None or cost < best[0]:
+                best = (cost, axis, k * 256, S)
+    if best is None or best[0] > 0.92 * base:
+        return None
+    return best[1], best[2], best[3]
+
+
 def gemm(a, b, *, a_ks=False, b_ks=False, bias=None, act=None, res=None, aux=None, dact=None, pre=None,
-         gate=None, alpha=1.0, out=None, out_f32=False, accumulate=False, ldc=None, variant=None, pre_deriv=False, b_pk=None):
+         gate=None, alpha=1.0, out=None, out_f32=False, accumulate=False, ldc=None, variant=None, pre_deriv=False, b_pk=None,
+         _splits=None):
     """C[M,N] = epi(alpha * A B^T).  a: [M,K] (or [K,M] if a_ks); b: [N,K] (or [K,N] if b_ks).
     b_pk: optional PackedB image of the same b (frozen weights): used when the packed ping-pong kernel measured faster."""
     a, lda = _mat(a)
@@ -214,6 +248,19 @@ def gemm(a, b, *, a_ks=False, b_ks=False, bias=None, act=None, res=None, aux=Non
         out = torch.empty((M, ldc), dtype=torch.float32 if out_f32 else bf16, device=a.device)
         if ldc != N:
             out = out[:, :N]
+    if (TAIL_SPLIT and variant is None and _splits is None and a_ks and b_ks and bias is None and res is None and aux is None
+            and pre is None and act is None and dact is None and N % 4 == 0 and out.stride(0) % 4 == 0):
+        plan = _tail_split_plan(M, N, K)
+        if plan is not None:
+            axis, cut, S = plan
+            kw = dict(a_ks=True, b_ks=True, gate=gate, alpha=alpha, accumulate=accumulate)
+            if axis == "m":
+                gemm(a[:, :cut], b, out=out[:cut], _splits=0, **kw)
+                gemm(a[:, cut:], b, out=out[cut:], _splits=S, **kw)
+            else:
+                gemm(a, b[:, :cut], out=out[:, :cut], _splits=0, **kw)
+                gemm(a, b[:, cut:], out=out[:, cut:], _splits=S, **kw)
+            return out
     d = GemmDesc()
     d.A, d.B, d.C = a.data_ptr(), b.data_ptr(), _dev(out).data_ptr()
     d.M, d.N, d.K = M, N, K
@@ -238,9 +285,10 @@ def gemm(a, b, *, a_ks=False, b_ks=False, bias=None, act=None, res=None, aux=Non
         variant = 6                      # decode rows: the weight-streaming kernel, any epilogue
     wide = M >= 256 and N >= 256 and a_ks and b_ks   # weight-gradient form only (a forward GEMM of a small batch must not change
     #                                                  its summation order with the batch size); 256 x 256 ping-pong tiles under split-K
-    if variant is None and plain and (tiles256 <= 128 if wide else tiles <= 96) and K >= 2048 and N % 4 == 0 and out.stride(0) % 4 == 0:
+    if (variant is None and plain and _splits != 0 and ((tiles256 <= 128 if wide else tiles <= 96) or _splits) and K >= 2048 and N % 4 == 0
+            and out.stride(0) % 4 == 0):
         # weight gradient of a narrow projection: far fewer tiles than CUs, very deep K -> split-K over the chip
-        splits = max(2, min(32, 512 // tiles256, K // 1024)) if wide else max(2, min(32, 320 // tiles, K // 512))
+        splits = _splits or (max(2, min(32, 512 // tiles256, K // 1024)) if wide else max(2, min(32, 320 // tiles, K // 512)))
         slabs = torch.empty((splits, M, N), dtype=torch.float32, device=a.device)
         if GEMM_PROFILE is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
