@@ -297,6 +297,20 @@ def test_gemm_splitk_weight_grad(ops, M, N, K, gate):
     close(acc32, want + c0.float(), name="splitk dW accumulate f32")
 
 
+def test_gemm_splitk_head_dx_shape(ops):
+    """The LM head's dX over the labeled rows only: [~640, V] x [V, 2560] with V = 74 053 (odd, the logit-gradient rows padded to a
+    multiple of 8): k-contiguous A, k-strided B, 100 tiles of 128 x 128 and a very deep K -> split-K (was one 170 TFLOP/s launch)."""
+    M, N, K = 640, 2560, 20000 + 5
+    ld = (K + 7) // 8 * 8
+    dl = torch.zeros(M, ld, dtype=bf16)
+    dl[:, :K] = rnd(M, K, seed=1, scale=0.05)
+    w = rnd(K, N, seed=2)
+    got = ops.gemm(dl.cuda()[:, :K], w.cuda(), b_ks=True)
+    close(got, dl[:, :K].float() @ w.float(), name="head dX split-K")
+    assert torch.equal(got, ops.gemm(dl.cuda()[:, :K], w.cuda(), b_ks=True))
+    close(ops.gemm(dl.cuda()[:, :K], w.cuda(), b_ks=True, variant="v1"), dl[:, :K].float() @ w.float(), name="head dX v1")
+
+
 @pytest.mark.parametrize("M,N", [(4352, 4096), (4096, 4608)])
 def test_gemm_tail_split_weight_grad(ops, M, N):
     """Weight-gradient GEMM with 257..511 tiles (one full round of the 256 CUs + a mostly idle second one): ops.gemm cuts the

@@ -285,10 +285,12 @@ def gemm(a, b, *, a_ks=False, b_ks=False, bias=None, act=None, res=None, aux=Non
         variant = 6                      # decode rows: the weight-streaming kernel, any epilogue
     wide = M >= 256 and N >= 256 and a_ks and b_ks   # weight-gradient form only (a forward GEMM of a small batch must not change
     #                                                  its summation order with the batch size); 256 x 256 ping-pong tiles under split-K
-    if (variant is None and plain and _splits != 0 and ((tiles256 <= 128 if wide else tiles <= 96) or _splits) and K >= 2048 and N % 4 == 0
-            and out.stride(0) % 4 == 0):
+    # (K >= 16384 with up to 160 tiles: the LM head's dX over the labeled rows only, [~640, 74 053] x [74 053, 2560] -- 100 tiles, 170 TFLOP/s unsplit)
+    if (variant is None and plain and _splits != 0 and ((tiles256 <= 128 if wide else (tiles <= 96 or (tiles <= 160 and K >= 16384))) or _splits)
+            and K >= 2048 and N % 4 == 0 and out.stride(0) % 4 == 0):
         # weight gradient of a narrow projection: far fewer tiles than CUs, very deep K -> split-K over the chip
-        splits = _splits or (max(2, min(32, 512 // tiles256, K // 1024)) if wide else max(2, min(32, 320 // tiles, K // 512)))
+        big = wide or (K >= 16384 and M >= 256 and N >= 256)        # the C side runs 256 x 256 tiles whenever M, N >= 256
+        splits = _splits or (max(2, min(32, 512 // tiles256, K // 1024)) if big else max(2, min(32, 320 // tiles, K // 512)))
         slabs = torch.empty((splits, M, N), dtype=torch.float32, device=a.device)
         if GEMM_PROFILE is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
