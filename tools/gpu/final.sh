@@ -3,6 +3,7 @@ cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/final; mkdir -p $O
 T=$PWD/$O/gemm_autotune_gfx950.json
+cp profiles/gemm_autotune_gfx950.json $T        # keep the committed choices; only shapes / epilogue classes that are missing get tuned
 # 1. autotune table for the shapes of the default bench (b = 64), the reference's shipped shape (b = 3, GA 2) and the 9b model
 UNIMP_GEMM_TUNE_FILE=$T UNIMP_GEMM_TUNE_WRITE=1 timeout 900 python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline > $O/tune1.json 2> $O/tune1.err
 UNIMP_GEMM_TUNE_FILE=$T UNIMP_GEMM_TUNE_WRITE=1 timeout 900 python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --batch 3 --grad-accum 2 > $O/tune2.json 2> $O/tune2.err
@@ -17,6 +18,11 @@ timeout 900 python bench.py --no-cpu-baseline --model 9b --fp8 > $O/bench_9b_fp8
 timeout 900 python bench.py --no-cpu-baseline --batch 48 > $O/bench_b48.json 2> $O/bench_b48.err
 # 3. kernel stats of the default bench command
 timeout 900 rocprofv3 --kernel-trace --stats -d $O/stats -o st --output-format csv -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-roofline > $O/prof.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats -d $O/stats48 -o st --output-format csv -- python3 bench.py --batch 48 --steps 6 --warmup 2 --no-cpu-baseline --no-roofline > $O/prof48.log 2>&1
+# 3b. micro-benchmarks of the HBM-bound kernels, streaming from HBM
+timeout 300 python tools/bench_ln.py --rotate 3 > $O/bench_ln.log 2>&1
+timeout 300 python tools/bench_rope.py > $O/bench_rope.log 2>&1
+timeout 300 python tools/bench_adamw.py > $O/bench_adamw.log 2>&1
 # 4. PMC passes: dominant GEMM shapes, attention kernels (both generations)
 for pm in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   tag=$(echo $pm | cut -d' ' -f1)

@@ -48,7 +48,8 @@ def _save_tune_table(path):
         return
     tmp = f"{path}.tmp.{os.getpid()}"
     with open(tmp, "w") as f:
-        json.dump({json.dumps([int(k[0]), int(k[1]), int(k[2]), bool(k[3]), k[4] if k[4] == "pk" else bool(k[4]), bool(k[5])]): v
+        json.dump({json.dumps([int(k[0]), int(k[1]), int(k[2]), bool(k[3]), k[4] if k[4] == "pk" else bool(k[4]),
+                               k[5] if k[5] == "out2" else bool(k[5])]): v
                    for k, v in sorted(_GEMM_CHOICE.items(), key=lambda kv: str(kv[0])) if len(k) == 6}, f, indent=0)
     os.replace(tmp, path)
 
@@ -61,10 +62,11 @@ def _launch_gemm(d, variant):
 
 
 def _tune_gemm(M, N, K, a_ks, b_ks, device, reads_mn=False):
-    """pick the fastest variant for this problem class, on scratch data.  Two epilogue classes per shape: without and with a
-    per-element [M, N] input (residual / stored act'(z)) -- the persistent kernel hides a tile's prologue under its epilogue
-    and wins or loses by 10-20 % depending on which epilogue that is.  Runs once per key, outside graph capture."""
-    key = (M, N, K, a_ks, b_ks, bool(reads_mn))
+    """pick the fastest variant for this problem class, on scratch data.  Three epilogue classes per shape: plain (False), with a
+    per-element [M, N] input (True: residual / stored act'(z)) and with a second [M, N] output ("out2": the up-projection's
+    GELU + stored GELU') -- the persistent kernel hides a tile's prologue under its epilogue and wins or loses by 10-20 %
+    depending on which epilogue that is.  Runs once per key, outside graph capture."""
+    key = (M, N, K, a_ks, b_ks, "out2" if reads_mn == "out2" else bool(reads_mn))
     v = _GEMM_CHOICE.get(key)
     if v is not None:
         return v
@@ -82,7 +84,11 @@ def _tune_gemm(M, N, K, a_ks, b_ks, device, reads_mn=False):
     d = GemmDesc()
     d.A, d.B, d.C, d.M, d.N, d.K = a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K
     d.lda, d.ldb, d.ldc, d.a_kstrided, d.b_kstrided, d.alpha = a.stride(0), b.stride(0), ldc, int(a_ks), int(b_ks), 1.0
-    if reads_mn:
+    if reads_mn == "out2":
+        r = torch.empty((M, ldc), dtype=bf16, device=device)
+        bias = torch.zeros(r8(N), dtype=bf16, device=device)
+        d.pre, d.ldpre, d.pre_deriv, d.act, d.bias = r.data_ptr(), ldc, 1, ACT["gelu"], bias.data_ptr()
+    elif reads_mn:
         r = torch.randn((M, ldc), device=device, dtype=torch.float32).to(bf16)
         d.res, d.ldres = r.data_ptr(), ldc
     best, best_t = 0, float("inf")
@@ -306,7 +312,8 @@ def gemm(a, b, *, a_ks=False, b_ks=False, bias=None, act=None, res=None, aux=Non
     else:
         v = GEMM_VARIANTS[variant] if isinstance(variant, str) else (variant if variant is not None else
                                                                       _tune_gemm(M, N, K, bool(a_ks), bool(b_ks), a.device,
-                                                                                 res is not None or aux is not None))
+                                                                                 True if (res is not None or aux is not None) else
+                                                                                 ("out2" if pre is not None else False)))
     if b_pk is not None and (forced_pk is not None or (variant is None and M >= PACKED_MIN_M and N >= 128 and K >= 128)):
         assert b_pk.N == N and b_pk.K == K, (b_pk.N, b_pk.K, N, K)
         vp = forced_pk or _tune_packed(M, N, K, bool(a_ks), a.device, res is not None or aux is not None, v, bool(b_ks))
