@@ -106,6 +106,17 @@ def test_kernel_register_budgets():
     for k, r in a2.items():
         if "dkv2" not in k or "Li128" not in k:                  # the experimental dK/dV kernel at head dim 128 runs one wave per SIMD
             assert r["ScratchSize"] == 0, (k, r)
+    # LayerNorm: HBM-bound, lives on waves in flight.  The forward and the plain backward at the LM width (5 chunks of 512) keep
+    # three waves per SIMD (the scheduler widens gamma / beta or both passes' operands to fp32 if allowed to: 180-255 registers),
+    # the weight-gradient form two (its partial sums are in LDS, not in 80 more registers); nothing spills at the widths in use
+    ln = remarks("norm.hip")
+    for k, r in ln.items():
+        if "ILi5E" in k or "ILi2E" in k:
+            assert r["ScratchSize"] == 0, (k, r)
+        if "ln_fwd_kernelILi5ELb1E" in k or "ln_bwd_kernelILi5ELb0ELb1E" in k:
+            assert r["Occupancy"] >= 3, (k, r)
+        if "ln_bwd_kernelILi5ELb1ELb1E" in k:
+            assert r["Occupancy"] >= 2, (k, r)
     mx = remarks("mx.hip", vg)
     big = [r for k, r in mx.items() if "gemm_mx_kernelILi2ELi4ELi8ELi4" in k]
     assert len(big) == 1 and big[0]["ScratchSize"] == 0 and big[0]["VGPRs"] + big[0].get("AGPRs", 0) <= 256, big
