@@ -48,7 +48,8 @@ def _worker(rank, world, port, q):
         tr = Trainer(hm, layout.special(), lr=1e-3, lr_scheduler="constant", bucket_bytes=1 << 16)       # several buckets
         assert tr.dp.world == world and len(tr.dp.buckets) > 3
         loss, _, _, _ = tr.forward_loss(batch)
-        loss.backward()
+        assert tr._sink is not None and tr._sink.dp is tr.dp
+        tr._backward(loss)       # production backward: dW GEMMs add into the flat buffer and notify the bucketer themselves
         gscale = tr.dp.finish()
         red = tr.opt.flat_g.float() * gscale
         err = float((red - mean).norm() / mean.norm())

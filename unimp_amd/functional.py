@@ -25,11 +25,12 @@ def _need(ctx, i):
     return ctx.needs_input_grad[i]
 
 
-# Weight-gradient sink (train.Trainer installs one around backward on a single rank): an object with ``view_of(weight)`` ->
-# the weight's [out, in] view of the flat bf16 gradient buffer, or None.  With a sink the dW GEMM adds its fp32 accumulators
-# straight into that view (epilogue ``accumulate``) and autograd gets no gradient for the weight -- no temporary, no
-# ``.grad +=`` pass, one bf16 rounding instead of two.  Without one (tests, the data-parallel path, whose bucket launches
-# hang on autograd's post-accumulate hooks) the gradient is returned as usual.
+# Weight-gradient sink (train.Trainer installs one around backward): an object with ``view_of(weight)`` -> the weight's
+# [out, in] view of the flat bf16 gradient buffer, or None, and ``done(weight)``.  With a sink the dW GEMM adds its fp32
+# accumulators straight into that view (epilogue ``accumulate``) and autograd gets no gradient for the weight -- no temporary,
+# no ``.grad +=`` pass, one bf16 rounding instead of two; ``done`` then plays the post-accumulate hook for the data-parallel
+# bucketer (the weight's gradient is complete: every weight routed here is used once per step).  Without a sink (tests that
+# call ``loss.backward()`` themselves) the gradient is returned as usual.
 WGRAD_SINK = None
 
 
@@ -42,6 +43,7 @@ def _dw(ctx, idx, w, a, b, gate=None):
         out = sink.view_of(w)
         if out is not None:
             ops.gemm(a, b, a_ks=True, b_ks=True, gate=gate, out=out, accumulate=True)
+            sink.done(w)
             return None
     return ops.gemm(a, b, a_ks=True, b_ks=True, gate=gate)
 

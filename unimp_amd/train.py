@@ -82,11 +82,17 @@ def load_checkpoint(path, model, trainer=None):
 
 
 class _WgradSink:
-    """functional.WGRAD_SINK of a single-rank Trainer: 2-D parameters -> their views of the optimizer's flat bf16 gradient buffer."""
+    """functional.WGRAD_SINK of a Trainer: 2-D parameters -> their views of the optimizer's flat bf16 gradient buffer.
+    Every weight that reaches the sink (the dense layers of the gated blocks and the Perceiver: LinearFn, MLPBlockFn,
+    GatedXAttnFn, PerceiverAttnFn) is used ONCE per forward, so its gradient is complete after its one dW GEMM and ``done`` can
+    tell the data-parallel bucketer so, exactly as autograd's post-accumulate hook would; a second use inside one backward is
+    refused loudly instead of being reduced half-summed.  Tied / masked embeddings (``exclude``) never come here."""
 
-    def __init__(self, opt, exclude=()):
+    def __init__(self, opt, exclude=(), dp=None):
         ex = {id(p) for p in exclude}
         self.views = {}
+        self.dp = dp
+        self.seen = set()
         if opt.flat_g.dtype == torch.bfloat16:
             for n, p, o, k in opt.layout:
                 if p.dim() == 2 and id(p) not in ex:
@@ -100,7 +106,16 @@ class _WgradSink:
         g = p.grad
         if g is None or g.data_ptr() != v.data_ptr():     # foreign code replaced .grad: autograd's path, folded back by _reattach
             return None
+        if self.dp is not None and self.dp.sync:
+            if id(p) in self.seen:
+                raise RuntimeError("a weight routed through the weight-gradient sink was used twice in one backward under data "
+                                   "parallelism: its bucket may already be on the wire (Trainer(direct_wgrad=False) disables the sink)")
+            self.seen.add(id(p))
         return v
+
+    def done(self, w):
+        if self.dp is not None:
+            self.dp._on_grad(self.views[w.data_ptr()][0])
 
 
 class Trainer:
@@ -139,9 +154,9 @@ class Trainer:
                                force_hooks=force_dp_hooks)
         self.sched, self.base_lr, self.warmup, self.total = lr_scheduler, lr, warmup_steps, total_steps
         self.sched_step = 0
-        # single rank: the weight-gradient GEMMs add straight into the flat gradient buffer (functional.WGRAD_SINK).  The
-        # data-parallel path keeps autograd's accumulation: its bucket launches hang on the post-accumulate hooks.
-        self._sink = _WgradSink(self.opt, exclude=late) if direct_wgrad and not self.dp.active else None
+        # the weight-gradient GEMMs add straight into the flat gradient buffer (functional.WGRAD_SINK); under data parallelism
+        # the sink plays the post-accumulate hook for the bucketer
+        self._sink = _WgradSink(self.opt, exclude=late, dp=self.dp if self.dp.active else None) if direct_wgrad else None
 
     def current_lr(self):
         if self.sched == "cosine":
@@ -186,6 +201,8 @@ class Trainer:
 
     def _backward(self, loss):
         F_.WGRAD_SINK = self._sink
+        if self._sink is not None:
+            self._sink.seen.clear()
         try:
             loss.backward()
         finally:
