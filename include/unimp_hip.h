@@ -132,6 +132,13 @@ typedef struct {
   int64_t do_bs, do_ss, do_hs, dq_bs, dq_ss, dq_hs, dk_bs, dk_ss, dk_hs, dv_bs, dv_ss, dv_hs;
   const float* alibi_slopes;   /* NULL, or fp32 [H]: score(i, j) += slope[h] * j (MPT's key-position ALiBi: softmax is shift-invariant
                                   per row, so this equals slope * (j - i) and transformers' slope * (j - (Sk - 1))) */
+  /* backward only, optional: q and k entered the forward rotated (unimp_rope_halfsplit); with rope_cos / rope_sin set
+   * (fp32 [>= max(Sq, Sk)][rope_half], row = position = sequence index) unimp_attn_bwd applies the transpose rotation to
+   * the first 2 * rope_half dims of every dq and dk row on their way out -- the same arithmetic as
+   * unimp_rope_halfsplit(inverse = 1) on the stored gradients, without that pass over HBM.  rope_half % 8 == 0,
+   * 2 * rope_half <= D; needs 16-byte aligned dq / dk / dv views (UNIMP_ERR_UNSUPPORTED otherwise, and under kernel
+   * generations other than 2). */
+  const float* rope_cos; const float* rope_sin; int rope_half;
 } unimp_attn_desc;
 int unimp_attn_fwd(const unimp_attn_desc* d, void* stream);
 int unimp_attn_bwd(const unimp_attn_desc* d, void* stream);
@@ -139,6 +146,7 @@ int unimp_attn_bwd(const unimp_attn_desc* d, void* stream);
  * the 32x32x16-MFMA / LDS-DMA kernels of attention2.hip; 1: the first-generation kernels (kept for A/B measurements and
  * run by the tests as a second implementation of the same contract).  Returns the previous value. */
 int unimp_attn_set_generation(int generation);
+int unimp_attn_get_generation(void);
 
 /* ---- token embedding (gpt_neox.embed_in / OPT embed_tokens+embed_positions) -------------------------------
  * fwd: out[r] = W[ids[r]] (+ P[pos[r]]);  bwd: dW[ids[r]] += dout[r]  (fp32 atomics into dW32, then cast)

@@ -464,6 +464,54 @@ def test_attention_fwd_bwd(ops, attn_gen, B, H, Sq, Sk, D, mode):
     close(dv, vr.grad, rel=2 ** -5, name="attn dv")
 
 
+@pytest.mark.parametrize("B,H,S,D,rot,interleaved", [(2, 4, 200, 80, 80, True), (1, 2, 512, 80, 80, True), (2, 2, 130, 128, 128, False),
+                                                     (2, 3, 96, 64, 16, True), (1, 2, 257, 64, 64, False)])
+def test_attention_bwd_fused_inverse_rope(ops, attn_gen, B, H, S, D, rot, interleaved):
+    """unimp_attn_bwd with rope tables: dq / dk leave the kernels rotated back.  Bit-identical to the separate pass
+    (unimp_rope_halfsplit(inverse) over the stored bf16 gradients) for both layouts of the fused projection, full and partial
+    rotary; dv untouched.  Generation 1 has no fused form: the binding says so (attn_rope_fusable) and the C entry refuses."""
+    from unimp_amd._lib import UnimpHipError
+    from oracle.lm import neox_rope_tables
+    g = torch.Generator().manual_seed(S + D)
+    if interleaved:
+        qkv = torch.randn(B, S, H, 3 * D, generator=g).to(bf16).cuda()
+        q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+        hs, offs = 3 * D, (0, D)
+    else:
+        qkv = torch.randn(B, S, 3, H, D, generator=g).to(bf16).cuda()
+        q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+        hs, offs = D, (0, H * D)
+    cos, sin = neox_rope_tables(S, rot, 10000.0)
+    half = rot // 2
+    ct, st = cos[:, :half].contiguous().cuda(), sin[:, :half].contiguous().cuda()
+    scale = D ** -0.5
+    out, lse = ops.attn_fwd(q, k, v, scale, 1)
+    do = torch.randn(B, S, H, D, generator=g).to(bf16).cuda()
+
+    def grads(rope):
+        dqkv = torch.full_like(qkv, float("nan"))
+        if interleaved:
+            dq, dk, dv = dqkv[..., :D], dqkv[..., D:2 * D], dqkv[..., 2 * D:]
+        else:
+            dq, dk, dv = dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2]
+        ops.attn_bwd(q, k, v, out, lse, do, dq, dk, dv, scale, 1, rope=rope)
+        return dqkv, (dq, dk, dv)
+    two, (dq, dk, dv) = grads(None)
+    ops.rope_(two.view(B * S, -1), S, H, hs, rot, offs, ct, st, inverse=True)
+    if attn_gen == 1:
+        assert not ops.attn_rope_fusable(dq, dk, dv, half, D)
+        with pytest.raises(UnimpHipError):
+            grads((ct, st))
+        return
+    assert ops.attn_rope_fusable(dq, dk, dv, half, D)
+    one, _ = grads((ct, st))
+    assert not torch.isnan(one.float()).any()
+    diff = (one.float() - two.float()).abs()
+    # same inputs, same formula; the compiler may contract a*b - c*d differently in the two kernels: allow isolated 1-ulp cases
+    bad = diff > 2 ** -7 * two.float().abs().clamp_min(1e-3)
+    assert bad.float().mean() < 1e-3 and diff.max() <= 2 ** -6 * two.float().abs().max(), (bad.float().mean(), diff.max())
+
+
 def test_attention_spiked_row_online_softmax(ops, attn_gen):
     """force the running-max rescale branch: one key far above the rest in a late tile (cdna guide rule 26)."""
     B, H, S, D = 1, 1, 256, 64

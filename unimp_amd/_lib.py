@@ -28,7 +28,7 @@ class AttnDesc(C.Structure):
                 ("kv_len", c_p), ("seg", c_p), ("seg_len", c_i),
                 ("d_o", c_p), ("dq", c_p), ("dk", c_p), ("dv", c_p), ("delta", c_p)] + \
                [(n, c_l) for n in ("do_bs", "do_ss", "do_hs", "dq_bs", "dq_ss", "dq_hs", "dk_bs", "dk_ss", "dk_hs",
-                                   "dv_bs", "dv_ss", "dv_hs")] + [("alibi_slopes", c_p)]
+                                   "dv_bs", "dv_ss", "dv_hs")] + [("alibi_slopes", c_p), ("rope_cos", c_p), ("rope_sin", c_p), ("rope_half", c_i)]
 
 
 class MxGemmDesc(C.Structure):
@@ -62,6 +62,7 @@ _SIGS = {
     "unimp_reduce_rows_periodic": [c_p, c_l, c_p, c_i, c_i, c_i, c_p],
     "unimp_label_mask": [c_p, c_p, c_p, c_i, c_i, c_l, c_l, c_l, c_l, c_p],
     "unimp_attn_set_generation": [c_i],
+    "unimp_attn_get_generation": [],
     "unimp_pack_b_bf16": [c_p, c_l, c_i, c_i, c_i, c_p, c_p],
     "unimp_mx_quantize": [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_p],
     "unimp_gemm_mxfp8": [C.POINTER(MxGemmDesc), c_p],

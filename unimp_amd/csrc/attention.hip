@@ -612,7 +612,13 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p, int nx) {
       for (int i = 0; i < (32 * ECPR + 63) / 64; ++i) {
         int id = l + 64 * i;
         int r = id / ECPR, c = id - r * ECPR;
-        if (id < 32 * ECPR && key0 + r < p.Sk) *(u32x4*)(gb + (long)(key0 + r) * gs + c * 8) = *(const u32x4*)(ew + r * EP + c * 16);
+        if (id < 32 * ECPR && key0 + r < p.Sk) {
+          u32x4 v;
+          if (which == 0 && p.rope_cos) v = attn_rope_inv_chunk(ew + r * EP, c, p.rope_half, p.rope_cos + (long)(key0 + r) * p.rope_half,
+                                                                p.rope_sin + (long)(key0 + r) * p.rope_half);
+          else v = *(const u32x4*)(ew + r * EP + c * 16);
+          *(u32x4*)(gb + (long)(key0 + r) * gs + c * 8) = v;
+        }
       }
       __builtin_amdgcn_s_waitcnt(0xc07f);
       __builtin_amdgcn_wave_barrier();
@@ -648,6 +654,13 @@ static int fill(AttnP& p, const unimp_attn_desc* d, bool bwd) {
   p.B = d->B; p.H = d->H; p.Sq = d->Sq; p.Sk = d->Sk; p.D = d->D; p.scale = d->scale; p.mask_mode = d->mask_mode;
   p.kv_len = d->kv_len; p.seg = d->seg; p.seg_len = d->seg_len; p.alibi = d->alibi_slopes;
   p.d_o = nullptr; p.dq = p.dk = p.dv = nullptr; p.delta = nullptr;
+  p.rope_cos = p.rope_sin = nullptr; p.rope_half = 0;
+  if (bwd && (d->rope_cos || d->rope_sin)) {
+    if (!d->rope_cos || !d->rope_sin || d->rope_half <= 0 || (d->rope_half & 7) || 2 * d->rope_half > d->D)
+      return unimp_set_error(UNIMP_ERR_ARG, "attn_bwd: rope needs cos and sin tables, rope_half % 8 == 0, 2 * rope_half <= D");
+    if (((uintptr_t)d->rope_cos | (uintptr_t)d->rope_sin) & 15) return unimp_set_error(UNIMP_ERR_ALIGN, "attn_bwd: rope tables must be 16-B aligned");
+    p.rope_cos = d->rope_cos; p.rope_sin = d->rope_sin; p.rope_half = d->rope_half;
+  }
   if (bwd) {
     if (!d->d_o || !d->dq || !d->dk || !d->dv || !d->delta || !d->lse) return unimp_set_error(UNIMP_ERR_ARG, "attn_bwd: null pointer");
     int64_t s2[] = {d->do_bs, d->do_ss, d->do_hs, d->dq_bs, d->dq_ss, d->dq_hs, d->dk_bs, d->dk_ss, d->dk_hs, d->dv_bs, d->dv_ss, d->dv_hs};
@@ -668,6 +681,7 @@ static int attn_generation() {
   return g_attn_gen;
 }
 extern "C" int unimp_attn_set_generation(int gen) { int old = attn_generation(); g_attn_gen = gen; return old; }
+extern "C" int unimp_attn_get_generation(void) { return attn_generation(); }
 
 extern "C" int unimp_attn_fwd(const unimp_attn_desc* d, void* stream) {
   AttnP p;
@@ -699,6 +713,8 @@ extern "C" int unimp_attn_bwd(const unimp_attn_desc* d, void* stream) {
   bool al16 = !(((p.dq_bs | p.dq_ss | p.dq_hs | p.dk_bs | p.dk_ss | p.dk_hs | p.dv_bs | p.dv_ss | p.dv_hs) & 7) ||
                 (((uintptr_t)p.dq | (uintptr_t)p.dk | (uintptr_t)p.dv) & 15)) && p.Sq >= 4;
   int which2 = (gen >= 2 && al16) ? (gen >= 3 ? 3 : 1) : 0;
+  if (p.rope_cos && !(which2 & 1))
+    return unimp_set_error(UNIMP_ERR_UNSUPPORTED, "attn_bwd: fused rope needs kernel generation >= 2 and 16-byte aligned dq / dk / dv views");
   // delta = rowsum(dO * O): the second-generation dQ kernel computes and publishes it itself
   if (!(which2 & 1)) hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((n * 16 + 255) / 256)), dim3(256), 0, s, p);
   if (which2) { int e2 = unimp_attn_bwd2_dispatch(p, which2, stream); if (e2) return e2; }

@@ -80,7 +80,8 @@ template <int D> struct A2Cfg {
 // have passed a barrier after the last LDS read of the tile loop; the region is [32][D * 2 + 16] bytes per wave.
 template <int D, int ND>
 __device__ __forceinline__ void a2_store_rows(char* lds_wave, const f32x16 (&acc)[ND], float mul, bf16* __restrict__ gbase, long row_stride,
-                                              int row0, int nrows) {
+                                              int row0, int nrows, const float* rope_cos = nullptr, const float* rope_sin = nullptr,
+                                              int rope_half = 0) {
   constexpr int PITCH = D * 2 + 16, CPR = D / 8;
   const int l = lane_id(), hi5 = l >> 5, rl = l & 31;
 #pragma unroll
@@ -100,7 +101,10 @@ __device__ __forceinline__ void a2_store_rows(char* lds_wave, const f32x16 (&acc
     int id = l + 64 * i;
     int r = id / CPR, c = id - r * CPR;
     if (id < 32 * CPR && row0 + r < nrows) {
-      u32x4 v = *(const u32x4*)(lds_wave + r * PITCH + c * 16);
+      u32x4 v;
+      if (rope_cos) v = attn_rope_inv_chunk(lds_wave + r * PITCH, c, rope_half, rope_cos + (long)(row0 + r) * rope_half,
+                                            rope_sin + (long)(row0 + r) * rope_half);
+      else v = *(const u32x4*)(lds_wave + r * PITCH + c * 16);
       *(u32x4*)(gbase + (long)(row0 + r) * row_stride + c * 8) = v;
     }
   }
@@ -471,7 +475,8 @@ __global__ __launch_bounds__(256) void attn_dq2_kernel(AttnP p, int nx) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
-  a2_store_rows<D, ND>(smem + wave * (32 * (D * 2 + 16)), dq, 1.f, p.dq + b * p.dq_bs + h * p.dq_hs, p.dq_ss, q0, p.Sq);
+  a2_store_rows<D, ND>(smem + wave * (32 * (D * 2 + 16)), dq, 1.f, p.dq + b * p.dq_bs + h * p.dq_hs, p.dq_ss, q0, p.Sq,
+                       p.rope_cos, p.rope_sin, p.rope_half);
 }
 
 // ------------------------------------------------------------------------------------------- dK, dV
@@ -674,7 +679,7 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void attn_dkv2_kernel(AttnP 
   }
   if (!(dbg & 8)) {
     char* ew = smem + wave * (32 * (D * 2 + 16));
-    a2_store_rows<D, ND>(ew, dk, 1.f, p.dk + b * p.dk_bs + h * p.dk_hs, p.dk_ss, key0, p.Sk);
+    a2_store_rows<D, ND>(ew, dk, 1.f, p.dk + b * p.dk_bs + h * p.dk_hs, p.dk_ss, key0, p.Sk, p.rope_cos, p.rope_sin, p.rope_half);
     __builtin_amdgcn_wave_barrier();
     a2_store_rows<D, ND>(ew, dv, 1.f, p.dv + b * p.dv_bs + h * p.dv_hs, p.dv_ss, key0, p.Sk);
   }

@@ -12,6 +12,7 @@ Arithmetic restated (reference file:line):
   perceiver_attn     open_flamingo PerceiverAttention (A.2)
   focal_ce           UniMP/mmrec.py:190-213
 """
+import os as _os
 import weakref
 import torch
 from torch.autograd import Function
@@ -32,6 +33,7 @@ def _need(ctx, i):
 # bucketer (the weight's gradient is complete: every weight routed here is used once per step).  Without a sink (tests that
 # call ``loss.backward()`` themselves) the gradient is returned as usual.
 WGRAD_SINK = None
+ROPE_FUSE = _os.environ.get("UNIMP_ROPE_FUSE", "1") != "0"      # backward: dq / dk rotated back inside the attention kernels' epilogues
 
 
 def _dw(ctx, idx, w, a, b, gate=None):
@@ -169,7 +171,6 @@ def _frozen_pk(w, b_ks=False):
     return c[1]
 
 
-import os as _os
 # opt-in: frozen weights also kept as packed-B images (the B operand bypasses the LDS).  Measured (tools/bench_packed.py, b = 64): +3 %
 # over the best unpacked variant on the MLP up-projection, equal or slower on the other seven tower shapes -- the fragment loads
 # wait on L2 latency every half-step where the LDS-DMA ring does not -- so it is NOT the default (it also costs a second copy
@@ -348,8 +349,11 @@ class SelfAttnBlockFn(Function):
         q, k, v, hs, offs = _split_qkv(qkv, B, L, nh, hd, interleaved)
         dqkv = torch.empty_like(qkv)
         dq, dk, dv, _, _ = _split_qkv(dqkv, B, L, nh, hd, interleaved)
-        ops.attn_bwd(q, k, v, o, lse, do, dq, dk, dv, q_scale, ops.MASK_CAUSAL if causal else ops.MASK_NONE, kv_len, alibi=alibi)
-        if cos is not None:
+        # the backward kernels rotate dq / dk back on their way out (same arithmetic as the separate pass, no trip through HBM)
+        fuse = ROPE_FUSE and cos is not None and cos.shape[0] >= L and cos.shape[1] * 2 == rot and ops.attn_rope_fusable(dq, dk, dv, rot // 2, hd)
+        ops.attn_bwd(q, k, v, o, lse, do, dq, dk, dv, q_scale, ops.MASK_CAUSAL if causal else ops.MASK_NONE, kv_len, alibi=alibi,
+                     rope=(cos, sin) if fuse else None)
+        if cos is not None and not fuse:
             ops.rope_(dqkv, L, nh, hs, rot, offs, cos, sin, inverse=True)
         dwqkv = ops.gemm(dqkv, h, a_ks=True, b_ks=True) if _need(ctx, 4) else None
         dh = ops.gemm_mx(ops.mx_quantize(dqkv), _frozen_mx(wqkv, True)) if ctx.mx else ops.gemm(dqkv, wqkv, b_ks=True, b_pk=_frozen_pk(wqkv, True))

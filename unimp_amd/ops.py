@@ -410,8 +410,24 @@ def attn_fwd(q, k, v, scale, mask_mode=MASK_NONE, kv_len=None, seg=None, seg_len
     return out, lse
 
 
-def attn_bwd(q, k, v, o, lse, do, dq, dk, dv, scale, mask_mode=MASK_NONE, kv_len=None, seg=None, seg_len=0, alibi=None):
-    """writes dq/dk/dv (strided [B,S,H,D] views, every element of the views is overwritten)."""
+def attn_rope_fusable(dq, dk, dv, rope_half, D):
+    """can unimp_attn_bwd apply the transpose rotation to dq / dk itself?  (second-generation kernels, 16-byte aligned views)"""
+    if attn_generation() < 2 or rope_half <= 0 or rope_half % 8 or 2 * rope_half > D or dq.shape[1] < 4:
+        return False
+    for t in (dq, dk, dv):
+        if t.data_ptr() % 16 or any(s_ % 8 for s_ in t.stride()[:3]):
+            return False
+    return True
+
+
+def attn_generation():
+    return _lib.lib().unimp_attn_get_generation()
+
+
+def attn_bwd(q, k, v, o, lse, do, dq, dk, dv, scale, mask_mode=MASK_NONE, kv_len=None, seg=None, seg_len=0, alibi=None, rope=None):
+    """writes dq/dk/dv (strided [B,S,H,D] views, every element of the views is overwritten).
+    rope = (cos, sin) fp32 [positions][half] tables: dq and dk leave the kernels already rotated back (the transpose of the
+    forward's rotation) -- only when attn_rope_fusable(); otherwise the caller runs rope_(inverse=True) itself."""
     B, Sq, H, D = q.shape
     Sk = k.shape[1]
     delta = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device)
@@ -423,6 +439,11 @@ def attn_bwd(q, k, v, o, lse, do, dq, dk, dv, scale, mask_mode=MASK_NONE, kv_len
     d.dk, (d.dk_bs, d.dk_ss, d.dk_hs) = _view4(dk)
     d.dv, (d.dv_bs, d.dv_ss, d.dv_hs) = _view4(dv)
     d.delta = delta.data_ptr()
+    if rope is not None:
+        cos, sin = rope
+        assert cos.dtype == torch.float32 and sin.dtype == torch.float32 and cos.is_contiguous() and sin.is_contiguous()
+        assert cos.shape == sin.shape and cos.shape[0] >= max(Sq, Sk), (cos.shape, Sq, Sk)
+        d.rope_cos, d.rope_sin, d.rope_half = cos.data_ptr(), sin.data_ptr(), cos.shape[1]
     check(_lib.lib().unimp_attn_bwd(C.byref(d), _stream()), "attn_bwd")
 
 
