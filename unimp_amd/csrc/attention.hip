@@ -608,16 +608,29 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p, int nx) {
         }
       __builtin_amdgcn_s_waitcnt(0xc07f);
       __builtin_amdgcn_wave_barrier();
+      constexpr int NCH = (32 * ECPR + 63) / 64;
+      if (which == 0 && p.rope_cos) {                         // dk leaves rotated back (attention_params.h): all table loads first
+        AttnRopeChunk ch[NCH];
 #pragma unroll
-      for (int i = 0; i < (32 * ECPR + 63) / 64; ++i) {
-        int id = l + 64 * i;
-        int r = id / ECPR, c = id - r * ECPR;
-        if (id < 32 * ECPR && key0 + r < p.Sk) {
-          u32x4 v;
-          if (which == 0 && p.rope_cos) v = attn_rope_inv_chunk(ew + r * EP, c, p.rope_half, p.rope_cos + (long)(key0 + r) * p.rope_half,
-                                                                p.rope_sin + (long)(key0 + r) * p.rope_half);
-          else v = *(const u32x4*)(ew + r * EP + c * 16);
-          *(u32x4*)(gb + (long)(key0 + r) * gs + c * 8) = v;
+        for (int i = 0; i < NCH; ++i) {
+          int id = min(l + 64 * i, 32 * ECPR - 1);
+          int r = id / ECPR, c = id - r * ECPR;
+          long pos = min(key0 + r, p.Sk - 1);
+          attn_rope_inv_load(ch[i], ew + r * EP, c, p.rope_half, p.rope_cos + pos * p.rope_half, p.rope_sin + pos * p.rope_half);
+        }
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+          int id = l + 64 * i;
+          int r = id / ECPR, c = id - r * ECPR;
+          u32x4 v = attn_rope_inv_apply(ch[i]);
+          if (id < 32 * ECPR && key0 + r < p.Sk) *(u32x4*)(gb + (long)(key0 + r) * gs + c * 8) = v;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+          int id = l + 64 * i;
+          int r = id / ECPR, c = id - r * ECPR;
+          if (id < 32 * ECPR && key0 + r < p.Sk) *(u32x4*)(gb + (long)(key0 + r) * gs + c * 8) = *(const u32x4*)(ew + r * EP + c * 16);
         }
       }
       __builtin_amdgcn_s_waitcnt(0xc07f);

@@ -96,15 +96,31 @@ __device__ __forceinline__ void a2_store_rows(char* lds_wave, const f32x16 (&acc
     }
   __builtin_amdgcn_s_waitcnt(0xc07f);                         // lgkmcnt(0): the wave's own LDS writes have landed (wave-private region)
   __builtin_amdgcn_wave_barrier();
+  constexpr int NCH = (32 * CPR + 63) / 64;
+  if (rope_cos) {
+    AttnRopeChunk ch[NCH];
 #pragma unroll
-  for (int i = 0; i < (32 * CPR + 63) / 64; ++i) {
+    for (int i = 0; i < NCH; ++i) {                            // branch-free: a lane without a chunk / row re-reads a valid one
+      int id = min(l + 64 * i, 32 * CPR - 1);
+      int r = id / CPR, c = id - r * CPR;
+      long pos = min(row0 + r, nrows - 1);
+      attn_rope_inv_load(ch[i], lds_wave + r * PITCH, c, rope_half, rope_cos + pos * rope_half, rope_sin + pos * rope_half);
+    }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      int id = l + 64 * i;
+      int r = id / CPR, c = id - r * CPR;
+      u32x4 v = attn_rope_inv_apply(ch[i]);
+      if (id < 32 * CPR && row0 + r < nrows) *(u32x4*)(gbase + (long)(row0 + r) * row_stride + c * 8) = v;
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
     int id = l + 64 * i;
     int r = id / CPR, c = id - r * CPR;
     if (id < 32 * CPR && row0 + r < nrows) {
-      u32x4 v;
-      if (rope_cos) v = attn_rope_inv_chunk(lds_wave + r * PITCH, c, rope_half, rope_cos + (long)(row0 + r) * rope_half,
-                                            rope_sin + (long)(row0 + r) * rope_half);
-      else v = *(const u32x4*)(lds_wave + r * PITCH + c * 16);
+      u32x4 v = *(const u32x4*)(lds_wave + r * PITCH + c * 16);
       *(u32x4*)(gbase + (long)(row0 + r) * row_stride + c * 8) = v;
     }
   }

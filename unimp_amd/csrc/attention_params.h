@@ -16,29 +16,37 @@ struct AttnP {
   const float* rope_cos; const float* rope_sin; int rope_half;     // backward: transpose half-split rotation of dq / dk rows (null: none)
 };
 
-// Inverse (transpose) half-split rotation of one 16-byte chunk of a gradient row that is staged in LDS as bf16 [D]:
+// Inverse (transpose) half-split rotation of the 16-byte chunks of gradient rows that are staged in LDS as bf16 [D]:
 // chunk c holds dims 8c .. 8c + 7; its partner (dims +- half) is chunk c +- half / 8 of the same row.  Same arithmetic
 // as rope_kernel<8>(inverse) on the stored bf16 values (elementwise.hip), so fusing it here changes no bits.
-__device__ __forceinline__ u32x4 attn_rope_inv_chunk(const char* row, int c, int half, const float* __restrict__ cosr,
-                                                     const float* __restrict__ sinr) {
+// Two phases so that a lane's table loads for ALL its chunks are in flight together (a load inside the per-chunk bounds
+// branch gets its own s_waitcnt vmcnt(0): one L2 round trip per chunk, +30 us on a 450 us kernel).
+struct AttnRopeChunk { bf16x8 x, y; f32x4 c0, c1, s0, s1; int mode; };       // mode 0: pass through, 1: first half, 2: second half
+
+__device__ __forceinline__ void attn_rope_inv_load(AttnRopeChunk& k, const char* row, int c, int half, const float* __restrict__ cosr,
+                                                   const float* __restrict__ sinr) {
   const int hc = half >> 3;
-  bf16x8 x = *(const bf16x8*)(row + c * 16);
-  if (c < 2 * hc) {
-    const bool first = c < hc;
-    bf16x8 y = *(const bf16x8*)(row + (first ? c + hc : c - hc) * 16);
-    const int t = (first ? c : c - hc) * 8;
-    f32x4 c0 = *(const f32x4*)(cosr + t), c1 = *(const f32x4*)(cosr + t + 4);
-    f32x4 s0 = *(const f32x4*)(sinr + t), s1 = *(const f32x4*)(sinr + t + 4);
-    bf16x8 o;
+  k.mode = c < hc ? 1 : (c < 2 * hc ? 2 : 0);
+  const int pc = k.mode == 1 ? c + hc : (k.mode == 2 ? c - hc : c);
+  const int t = (k.mode == 2 ? c - hc : (k.mode == 1 ? c : 0)) * 8;          // mode 0 reads the row's first table entries (unused)
+  k.x = *(const bf16x8*)(row + c * 16);
+  k.y = *(const bf16x8*)(row + pc * 16);
+  k.c0 = *(const f32x4*)(cosr + t); k.c1 = *(const f32x4*)(cosr + t + 4);
+  k.s0 = *(const f32x4*)(sinr + t); k.s1 = *(const f32x4*)(sinr + t + 4);
+}
+
+__device__ __forceinline__ u32x4 attn_rope_inv_apply(const AttnRopeChunk& k) {
+  bf16x8 o = k.x;
+  if (k.mode) {
+    const bool first = k.mode == 1;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float co = j < 4 ? c0[j & 3] : c1[j & 3], si = -(j < 4 ? s0[j & 3] : s1[j & 3]);
-      float x1 = bf2f(first ? x[j] : y[j]), x2 = bf2f(first ? y[j] : x[j]);
+      float co = j < 4 ? k.c0[j & 3] : k.c1[j & 3], si = -(j < 4 ? k.s0[j & 3] : k.s1[j & 3]);
+      float x1 = bf2f(first ? k.x[j] : k.y[j]), x2 = bf2f(first ? k.y[j] : k.x[j]);
       o[j] = first ? f2bf(x1 * co - x2 * si) : f2bf(x2 * co + x1 * si);
     }
-    x = o;
   }
-  union { bf16x8 b; u32x4 u; } cv; cv.b = x;
+  union { bf16x8 b; u32x4 u; } cv; cv.b = o;
   return cv.u;
 }
 
