@@ -29,6 +29,11 @@
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 #define EXP2(x) __builtin_amdgcn_exp2f(x)
+__device__ __forceinline__ float a2_max3(float a, float b, float c) {
+  float d;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
 #define LOG2E 1.4426950408889634f
 #define LN2 0.6931471805599453f
 
@@ -272,10 +277,14 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd2_kernel(AttnP p, int row_bas
           s1[r] = (key + 32 >= lo && key + 32 < hi) ? s1[r] : -INFINITY;
         }
       }
-      float mloc = fmaxf(s0[0], s1[0]);
+      // row maximum of the lane's 32 scores as 16 v_max3_f32 (asm: fmaxf on MFMA outputs makes the compiler canonicalise every
+      // operand first -- 49 v_max_f32 per tile instead of 16; the scores are finite or -inf, never signalling)
+      float mloc = a2_max3(s0[0], s1[0], s0[1]);
+      mloc = a2_max3(mloc, s1[1], s0[2]);
 #pragma unroll
-      for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, fmaxf(s0[r], s1[r]));
-      mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+      for (int r = 2; r < 15; ++r) mloc = a2_max3(mloc, s1[r], s0[r + 1]);
+      mloc = a2_max3(mloc, s1[15], s1[15]);
+      mloc = a2_max3(mloc, __shfl_xor(mloc, 32, 64), mloc);
       float mnew = fmaxf(m, mloc * sc2);                     // running max in the scaled (log2) domain; sc2 > 0
       float muse = (mnew == -INFINITY) ? 0.f : mnew;
       if (__any(mnew != m)) {                                // some row's max moved: rescale (rare after the first tiles)
