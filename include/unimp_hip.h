@@ -56,6 +56,16 @@ typedef struct {
   int act, dact;
   int out_f32, accumulate;
   int pre_deriv;   /* pre receives act'(v) instead of v: the backward multiply then needs no transcendental (dact = DERIV) */
+  /* optional rotary epilogue (rope_rot > 0; the fused QKV projection of a GPT-NeoX / Llama block): C is [tokens][N] with
+   * position = row % rope_L; column n belongs to a rotated vector iff (n % rope_period) < rope_span, its index inside the
+   * head vector is n % rope_hd, and the first rope_rot indices are rotated.  The rotation pairs are ADJACENT in memory:
+   * index 8g + j pairs with 8g + 4 + j (j < 4) at frequency i = 4g + j, theta_i = base^(-2i / rope_rot) -- i.e. the caller
+   * permuted the projection's rows from the half-split order (i, i + rope_rot / 2) once (attention is invariant to a common
+   * permutation of q and k).  cos / sin of position * theta_i are computed in the epilogue (v_sin / v_cos on the fractional
+   * number of turns; |error| <= 6e-5 against fp32 tables at position 2048).  Plain epilogue (alpha, bias) only, N % 8 == 0,
+   * ldc % 8 == 0, k-contiguous A and B, variants PP256 / PP256P (UNIMP_ERR_UNSUPPORTED otherwise).  rope_log2_base = log2(base). */
+  int rope_rot, rope_hd, rope_period, rope_span, rope_L;
+  float rope_log2_base;
 } unimp_gemm_desc;
 /* Pre-packed B operand for FROZEN weights (b_kstrided = 2 in the descriptor; ping-pong variants only): every MFMA B fragment
  * of the 16x16x32 instruction -- (n-tile of 16, 32-k step) -- stored as one contiguous 1-KiB block in lane order, so a wave
@@ -139,6 +149,10 @@ typedef struct {
    * 2 * rope_half <= D; needs 16-byte aligned dq / dk / dv views (UNIMP_ERR_UNSUPPORTED otherwise, and under kernel
    * generations other than 2). */
   const float* rope_cos; const float* rope_sin; int rope_half;
+  /* rope_log2_base != 0 (and rope_cos / rope_sin NULL, rope_half set): the ADJACENT-pair layout of the GEMM's rotary epilogue
+   * (unimp_gemm_desc.rope_*): dims 8g + j and 8g + 4 + j of every dq / dk row are rotated back at frequency 4g + j, cos / sin
+   * computed in the epilogue -- no tables, no partner chunk. */
+  float rope_log2_base;
 } unimp_attn_desc;
 int unimp_attn_fwd(const unimp_attn_desc* d, void* stream);
 int unimp_attn_bwd(const unimp_attn_desc* d, void* stream);

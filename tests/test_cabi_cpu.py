@@ -84,7 +84,7 @@ def test_kernel_register_budgets():
         return res
     vg = ("-mllvm", "-amdgpu-mfma-vgpr-form")
     g3 = remarks("gemm3.hip", vg)
-    assert len(g3) == 12                # 4 operand forms x 2 tile widths + the packed-B form (2 A layouts x 2 widths)
+    assert len(g3) == 13                # 4 operand forms x 2 tile widths + the packed-B form (2 A layouts x 2 widths) + the rotary-epilogue one
     for k, r in g3.items():
         assert r["ScratchSize"] == 0 and r["VGPRs"] + r.get("AGPRs", 0) <= 256 and r["Occupancy"] >= 2, (k, r)
     vg_a = vg + ("-fno-slp-vectorize",)             # the Makefile's flags for the attention kernels

@@ -544,6 +544,76 @@ def test_rope(ops, hd, rot):
     close(d, qkv.float(), rel=2 ** -6, name="rope inverse")
 
 
+def _adjacent_perm(hd, rot):
+    """new -> old index inside one head vector for the pair-adjacent rotary layout (functional._rope_perm_index)"""
+    p = torch.arange(hd)
+    g, j = p // 8, p % 8
+    d = torch.where(j < 4, 4 * g + j, rot // 2 + 4 * g + (j - 4))
+    return torch.where(p < rot, d, p)
+
+
+@pytest.mark.parametrize("variant", ["pp256", "pp256p"])
+@pytest.mark.parametrize("nh,hd,rot,interleaved,L", [(4, 80, 80, True, 200), (6, 64, 16, True, 128), (3, 128, 128, False, 300)])
+def test_gemm_rotary_epilogue(ops, variant, nh, hd, rot, interleaved, L):
+    """QKV projection with the rotary epilogue (rows of W permuted to the pair-adjacent order, cos / sin computed in the
+    epilogue) = plain projection + half-split RoPE from fp32 tables, dims permuted: q, k rotated, v untouched, every position."""
+    from unimp_amd import functional as Fn
+    from oracle.lm import neox_rope_tables, rotate_half
+    B, H = 3, nh * hd
+    M, K = B * L, 256
+    x, w, b = rnd(M, K, seed=1), rnd(3 * H, K, seed=2, scale=0.08), rnd(3 * H, seed=3)
+    idx = Fn._rope_perm_index(nh, hd, rot, interleaved, "cpu")
+    rope = dict(rot=rot, hd=hd, period=3 * hd if interleaved else 3 * H, span=2 * hd if interleaved else 2 * H, L=L, log2_base=math.log2(10000.0))
+    got = ops.gemm(x.cuda(), w[idx].contiguous().cuda(), bias=b[idx].contiguous().cuda(), rope=rope, variant=variant).float().cpu()
+    y = (x.float() @ w.float().t() + b.float())
+    y = y.view(B, L, nh, 3, hd) if interleaved else y.view(B, L, 3, nh, hd).permute(0, 1, 3, 2, 4)      # [B, L, nh, 3, hd]
+    cos, sin = neox_rope_tables(L, rot, 10000.0)
+    want = y.clone()
+    for part in (0, 1):
+        r = y[..., part, :rot]
+        want[..., part, :rot] = r * cos[None, :, None] + rotate_half(r) * sin[None, :, None]
+    perm = _adjacent_perm(hd, rot)
+    want[..., 0, :] = want[..., 0, :][..., perm]
+    want[..., 1, :] = want[..., 1, :][..., perm]
+    g = got.view(B, L, nh, 3, hd) if interleaved else got.view(B, L, 3, nh, hd).permute(0, 1, 3, 2, 4)
+    close(g, want, name="rotary epilogue")
+    assert float((g[..., 2, :] - want[..., 2, :]).abs().max()) <= 2 ** -7 * float(want.abs().max())          # v: plain projection
+    with pytest.raises(ops._lib.UnimpHipError):
+        ops.gemm(x.cuda(), w.cuda(), rope=rope, variant="w8")
+
+
+@pytest.mark.parametrize("B,H,S,D,rot", [(2, 4, 200, 80, 80), (1, 2, 512, 80, 80), (2, 3, 130, 128, 128), (2, 3, 96, 64, 16)])
+def test_attention_bwd_adjacent_inverse_rope(ops, attn_gen, B, H, S, D, rot):
+    """adjacent-pair form of the fused inverse rotation (the layout of the GEMM's rotary epilogue): dq / dk of the plain
+    backward, rotated back in fp32 with table cos / sin, against the kernels' on-the-fly version; dv untouched."""
+    if attn_gen == 1:
+        pytest.skip("generation 1 has no fused form")
+    from oracle.lm import neox_rope_tables
+    g = torch.Generator().manual_seed(S + D)
+    qkv = torch.randn(B, S, H, 3 * D, generator=g).to(bf16).cuda()
+    q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+    scale = D ** -0.5
+    out, lse = ops.attn_fwd(q, k, v, scale, 1)
+    do = torch.randn(B, S, H, D, generator=g).to(bf16).cuda()
+
+    def grads(rope):
+        dqkv = torch.full_like(qkv, float("nan"))
+        ops.attn_bwd(q, k, v, out, lse, do, dqkv[..., :D], dqkv[..., D:2 * D], dqkv[..., 2 * D:], scale, 1, rope=rope)
+        return dqkv
+    plain = grads(None).float().cpu().view(B, S, H, 3, D)
+    fused = grads((rot // 2, math.log2(10000.0))).float().cpu().view(B, S, H, 3, D)
+    cos, sin = neox_rope_tables(S, rot, 10000.0)
+    c, s_ = cos[:, :rot // 2], sin[:, :rot // 2]                       # [S, half], frequency i
+    want = plain.clone()
+    for part in (0, 1):
+        x = plain[..., part, :rot].reshape(B, S, H, rot // 8, 2, 4)      # chunk g: pairs (j, j + 4) at frequency 4 g + j
+        x1, x2 = x[..., 0, :], x[..., 1, :]
+        cc, ss = c.view(S, rot // 8, 4)[None, :, None], s_.view(S, rot // 8, 4)[None, :, None]
+        want[..., part, :rot] = torch.stack([x1 * cc + x2 * ss, x2 * cc - x1 * ss], -2).reshape(B, S, H, rot)
+    close(fused, want, rel=2 ** -7, name="adjacent inverse rope")
+    assert torch.equal(fused[..., 2, :], plain[..., 2, :])
+
+
 # ------------------------------------------------------------------------------------------------- embedding / misc
 def test_embedding_fwd_bwd(ops):
     V, D, n = 50, 64, 300

@@ -473,6 +473,37 @@ def test_direct_weight_gradients_equal_autograd_path(P):
             assert P.rel_l2(res[True][n], g) <= 6e-3, (n, P.rel_l2(res[True][n], g))
 
 
+@pytest.mark.parametrize("interleaved,rotary_pct", [(True, 1.0), (True, 0.25), (False, 1.0)])
+def test_rotary_epilogue_block_equals_separate_rope_pass(monkeypatch, interleaved, rotary_pct):
+    """A frozen self-attention block at the LM's head size: the QKV GEMM rotates q / k in its epilogue (permuted projection
+    rows, adjacent pairs, on-the-fly cos / sin) and the attention backward rotates dq / dk back in the same layout --
+    output and input gradient equal the path with the two rope_ passes up to bf16 rounding."""
+    from unimp_amd import functional as Fn, ops
+    nh, hd, B, L = 4, 80, 2, 256
+    H, rot = nh * hd, int(80 * rotary_pct) // 8 * 8
+    g = torch.Generator().manual_seed(5)
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(torch.bfloat16).cuda()
+    x = r(B, L, H)
+    ln_w, ln_b = (1 + 0.1 * torch.randn(H, generator=g)).to(torch.bfloat16).cuda(), r(H, sc=0.1)
+    wqkv, bqkv, wd, bd = r(3 * H, H, sc=H ** -0.5), r(3 * H, sc=0.1), r(H, H, sc=H ** -0.5), r(H, sc=0.1)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, rot, 2, dtype=torch.float32) / rot))
+    fr = torch.arange(L, dtype=torch.float32)[:, None] * inv[None]
+    rope = (fr.cos().contiguous().cuda(), fr.sin().contiguous().cuda(), rot, 10000.0)
+    dy = r(B, L, H)
+    monkeypatch.setattr(ops, "gemm_rope_variant", lambda M, N, K, b_ks, dev: None if b_ks else 4)
+    res = {}
+    for fused in (False, True):
+        monkeypatch.setattr(Fn, "ROPE_EPILOGUE", fused)
+        xr = x.clone().requires_grad_(True)
+        out = Fn.self_attn_block(xr, ln_w, ln_b, wqkv, bqkv, wd, bd, nh, rope=rope, interleaved=interleaved)
+        out.backward(dy)
+        res[fused] = (out.detach().float(), xr.grad.float())
+    assert hasattr(wqkv, "_unimp_rope_perm")                      # the fused path really ran
+    for a, b_, name in zip(res[True], res[False], ("out", "dx")):
+        e = float((a - b_).norm() / b_.norm())
+        assert e <= 6e-3, (name, e)
+
+
 def test_fp8_frozen_towers_track_the_bf16_path(P, monkeypatch):
     """F4 (BASELINE config 5: "fp8 MFMA weights"): with functional.FP8_FROZEN the frozen Linear layers of the LM and the ViT
     run on the MX-fp8 GEMM (e4m3 elements, E8M0 scale per 32 k, activations quantised on the fly, fp32 accumulate), forward

@@ -17,7 +17,8 @@ class GemmDesc(C.Structure):
                 ("lda", c_l), ("ldb", c_l), ("ldc", c_l), ("a_kstrided", c_i), ("b_kstrided", c_i),
                 ("bias", c_p), ("res", c_p), ("ldres", c_l), ("aux", c_p), ("ldaux", c_l),
                 ("pre", c_p), ("ldpre", c_l), ("gate", c_p), ("alpha", c_f), ("act", c_i), ("dact", c_i),
-                ("out_f32", c_i), ("accumulate", c_i), ("pre_deriv", c_i)]
+                ("out_f32", c_i), ("accumulate", c_i), ("pre_deriv", c_i),
+                ("rope_rot", c_i), ("rope_hd", c_i), ("rope_period", c_i), ("rope_span", c_i), ("rope_L", c_i), ("rope_log2_base", c_f)]
 
 
 class AttnDesc(C.Structure):
@@ -28,7 +29,7 @@ class AttnDesc(C.Structure):
                 ("kv_len", c_p), ("seg", c_p), ("seg_len", c_i),
                 ("d_o", c_p), ("dq", c_p), ("dk", c_p), ("dv", c_p), ("delta", c_p)] + \
                [(n, c_l) for n in ("do_bs", "do_ss", "do_hs", "dq_bs", "dq_ss", "dq_hs", "dk_bs", "dk_ss", "dk_hs",
-                                   "dv_bs", "dv_ss", "dv_hs")] + [("alibi_slopes", c_p), ("rope_cos", c_p), ("rope_sin", c_p), ("rope_half", c_i)]
+                                   "dv_bs", "dv_ss", "dv_hs")] + [("alibi_slopes", c_p), ("rope_cos", c_p), ("rope_sin", c_p), ("rope_half", c_i), ("rope_log2_base", c_f)]
 
 
 class MxGemmDesc(C.Structure):

@@ -609,7 +609,15 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p, int nx) {
       __builtin_amdgcn_s_waitcnt(0xc07f);
       __builtin_amdgcn_wave_barrier();
       constexpr int NCH = (32 * ECPR + 63) / 64;
-      if (which == 0 && p.rope_cos) {                         // dk leaves rotated back (attention_params.h): all table loads first
+      if (which == 0 && p.rope_step != 0.f) {                // adjacent-pair layout: no tables, no partner chunk
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+          int id = l + 64 * i;
+          int r = id / ECPR, c = id - r * ECPR;
+          if (id < 32 * ECPR && key0 + r < p.Sk)
+            *(u32x4*)(gb + (long)(key0 + r) * gs + c * 8) = attn_rope_inv_adjacent(ew + r * EP, c, p.rope_half, (float)(key0 + r), p.rope_step);
+        }
+      } else if (which == 0 && p.rope_cos) {                  // dk leaves rotated back (attention_params.h): all table loads first
         AttnRopeChunk ch[NCH];
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
@@ -667,8 +675,12 @@ static int fill(AttnP& p, const unimp_attn_desc* d, bool bwd) {
   p.B = d->B; p.H = d->H; p.Sq = d->Sq; p.Sk = d->Sk; p.D = d->D; p.scale = d->scale; p.mask_mode = d->mask_mode;
   p.kv_len = d->kv_len; p.seg = d->seg; p.seg_len = d->seg_len; p.alibi = d->alibi_slopes;
   p.d_o = nullptr; p.dq = p.dk = p.dv = nullptr; p.delta = nullptr;
-  p.rope_cos = p.rope_sin = nullptr; p.rope_half = 0;
-  if (bwd && (d->rope_cos || d->rope_sin)) {
+  p.rope_cos = p.rope_sin = nullptr; p.rope_half = 0; p.rope_step = 0.f;
+  if (bwd && d->rope_log2_base != 0.f) {
+    if (d->rope_cos || d->rope_sin || d->rope_half <= 0 || (d->rope_half & 3) || 2 * d->rope_half > d->D || !(d->rope_log2_base > 0.f))
+      return unimp_set_error(UNIMP_ERR_ARG, "attn_bwd: adjacent-pair rope needs rope_half % 4 == 0, 2 * rope_half <= D, log2(base) > 0 and no tables");
+    p.rope_half = d->rope_half; p.rope_step = d->rope_log2_base / (float)d->rope_half;
+  } else if (bwd && (d->rope_cos || d->rope_sin)) {
     if (!d->rope_cos || !d->rope_sin || d->rope_half <= 0 || (d->rope_half & 7) || 2 * d->rope_half > d->D)
       return unimp_set_error(UNIMP_ERR_ARG, "attn_bwd: rope needs cos and sin tables, rope_half % 8 == 0, 2 * rope_half <= D");
     if (((uintptr_t)d->rope_cos | (uintptr_t)d->rope_sin) & 15) return unimp_set_error(UNIMP_ERR_ALIGN, "attn_bwd: rope tables must be 16-B aligned");
@@ -726,7 +738,7 @@ extern "C" int unimp_attn_bwd(const unimp_attn_desc* d, void* stream) {
   bool al16 = !(((p.dq_bs | p.dq_ss | p.dq_hs | p.dk_bs | p.dk_ss | p.dk_hs | p.dv_bs | p.dv_ss | p.dv_hs) & 7) ||
                 (((uintptr_t)p.dq | (uintptr_t)p.dk | (uintptr_t)p.dv) & 15)) && p.Sq >= 4;
   int which2 = (gen >= 2 && al16) ? (gen >= 3 ? 3 : 1) : 0;
-  if (p.rope_cos && !(which2 & 1))
+  if ((p.rope_cos || p.rope_step != 0.f) && !(which2 & 1))
     return unimp_set_error(UNIMP_ERR_UNSUPPORTED, "attn_bwd: fused rope needs kernel generation >= 2 and 16-byte aligned dq / dk / dv views");
   // delta = rowsum(dO * O): the second-generation dQ kernel computes and publishes it itself
   if (!(which2 & 1)) hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((n * 16 + 255) / 256)), dim3(256), 0, s, p);

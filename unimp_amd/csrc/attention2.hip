@@ -86,7 +86,7 @@ template <int D> struct A2Cfg {
 template <int D, int ND>
 __device__ __forceinline__ void a2_store_rows(char* lds_wave, const f32x16 (&acc)[ND], float mul, bf16* __restrict__ gbase, long row_stride,
                                               int row0, int nrows, const float* rope_cos = nullptr, const float* rope_sin = nullptr,
-                                              int rope_half = 0) {
+                                              int rope_half = 0, float rope_step = 0.f) {
   constexpr int PITCH = D * 2 + 16, CPR = D / 8;
   const int l = lane_id(), hi5 = l >> 5, rl = l & 31;
 #pragma unroll
@@ -102,6 +102,16 @@ __device__ __forceinline__ void a2_store_rows(char* lds_wave, const f32x16 (&acc
   __builtin_amdgcn_s_waitcnt(0xc07f);                         // lgkmcnt(0): the wave's own LDS writes have landed (wave-private region)
   __builtin_amdgcn_wave_barrier();
   constexpr int NCH = (32 * CPR + 63) / 64;
+  if (rope_step != 0.f) {                                      // adjacent-pair layout: no tables, no partner chunk
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      int id = l + 64 * i;
+      int r = id / CPR, c = id - r * CPR;
+      if (id < 32 * CPR && row0 + r < nrows)
+        *(u32x4*)(gbase + (long)(row0 + r) * row_stride + c * 8) = attn_rope_inv_adjacent(lds_wave + r * PITCH, c, rope_half, (float)(row0 + r), rope_step);
+    }
+    return;
+  }
   if (rope_cos) {
     AttnRopeChunk ch[NCH];
 #pragma unroll
@@ -501,7 +511,7 @@ __global__ __launch_bounds__(256) void attn_dq2_kernel(AttnP p, int nx) {
     __syncthreads();
   }
   a2_store_rows<D, ND>(smem + wave * (32 * (D * 2 + 16)), dq, 1.f, p.dq + b * p.dq_bs + h * p.dq_hs, p.dq_ss, q0, p.Sq,
-                       p.rope_cos, p.rope_sin, p.rope_half);
+                       p.rope_cos, p.rope_sin, p.rope_half, p.rope_step);
 }
 
 // ------------------------------------------------------------------------------------------- dK, dV
@@ -704,7 +714,7 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void attn_dkv2_kernel(AttnP 
   }
   if (!(dbg & 8)) {
     char* ew = smem + wave * (32 * (D * 2 + 16));
-    a2_store_rows<D, ND>(ew, dk, 1.f, p.dk + b * p.dk_bs + h * p.dk_hs, p.dk_ss, key0, p.Sk, p.rope_cos, p.rope_sin, p.rope_half);
+    a2_store_rows<D, ND>(ew, dk, 1.f, p.dk + b * p.dk_bs + h * p.dk_hs, p.dk_ss, key0, p.Sk, p.rope_cos, p.rope_sin, p.rope_half, p.rope_step);
     __builtin_amdgcn_wave_barrier();
     a2_store_rows<D, ND>(ew, dv, 1.f, p.dv + b * p.dv_bs + h * p.dv_hs, p.dv_ss, key0, p.Sk);
   }

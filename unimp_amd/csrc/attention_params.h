@@ -14,7 +14,28 @@ struct AttnP {
   long do_bs, do_ss, do_hs, dq_bs, dq_ss, dq_hs, dk_bs, dk_ss, dk_hs, dv_bs, dv_ss, dv_hs;
   const float* alibi;        // per-head slopes or null: raw score += slope / scale * key  (so that score * scale gains slope * key)
   const float* rope_cos; const float* rope_sin; int rope_half;     // backward: transpose half-split rotation of dq / dk rows (null: none)
+  float rope_step;           // != 0: adjacent-pair layout, cos / sin computed in the epilogue (2 log2(base) / (2 rope_half)); tables unused
 };
+
+// Adjacent-pair form (the layout the GEMM's rotary epilogue writes, gemm_tile.h): chunk c holds the pairs (j, j + 4), j < 4, at
+// frequencies 4c + j; the transpose rotation needs neither a partner chunk nor a table.
+__device__ __forceinline__ u32x4 attn_rope_inv_adjacent(const char* row, int c, int half, float pos, float step) {
+  bf16x8 x = *(const bf16x8*)(row + c * 16);
+  if (c * 4 < half) {
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float turns = __builtin_amdgcn_fractf(pos * (__builtin_amdgcn_exp2f(-(float)(4 * c + j) * step) * 0.15915494309189535f));
+      float co = __builtin_amdgcn_cosf(turns), si = __builtin_amdgcn_sinf(turns);
+      float x1 = bf2f(x[j]), x2 = bf2f(x[j + 4]);
+      o[j] = f2bf(x1 * co + x2 * si);
+      o[j + 4] = f2bf(x2 * co - x1 * si);
+    }
+    x = o;
+  }
+  union { bf16x8 b; u32x4 u; } cv; cv.b = x;
+  return cv.u;
+}
 
 // Inverse (transpose) half-split rotation of the 16-byte chunks of gradient rows that are staged in LDS as bf16 [D]:
 // chunk c holds dims 8c .. 8c + 7; its partner (dims +- half) is chunk c +- half / 8 of the same row.  Same arithmetic

@@ -446,6 +446,15 @@ extern "C" int unimp_gemm_bf16_variant(const unimp_gemm_desc* d, int variant, vo
   if (variant == UNIMP_GEMM_AUTO) variant = auto_variant(d);
   if (d->b_kstrided == 2 && variant != UNIMP_GEMM_PP256 && variant != UNIMP_GEMM_PP128)
     return unimp_set_error(UNIMP_ERR_UNSUPPORTED, "gemm: a pre-packed B operand is served by the ping-pong kernels only (variants pp256 / pp128)");
+  if (d->rope_rot) {
+    if (d->rope_rot < 0 || (d->rope_rot & 7) || d->rope_hd <= 0 || (d->rope_hd & 7) || d->rope_rot > d->rope_hd || d->rope_L <= 0 ||
+        d->rope_period <= 0 || d->rope_period % d->rope_hd || d->rope_span % d->rope_hd || d->rope_span > d->rope_period || !(d->rope_log2_base > 0.f))
+      return unimp_set_error(UNIMP_ERR_ARG, "gemm: rotary epilogue needs rot % 8 == 0 <= hd, hd % 8 == 0, period / span multiples of hd, L > 0, base > 1");
+    if (d->M >= (1 << 24)) return unimp_set_error(UNIMP_ERR_SHAPE, "gemm: rotary epilogue needs M < 2^24");
+    bool kern = (variant == UNIMP_GEMM_PP256 || variant == UNIMP_GEMM_PP256P) && !d->a_kstrided && !d->b_kstrided;
+    if (!kern || d->res || d->aux || d->pre || d->act || d->dact || d->accumulate || d->gate || d->out_f32 || (d->N & 7) || (d->ldc & 7) || d->M < 256 || d->N < 128)
+      return unimp_set_error(UNIMP_ERR_UNSUPPORTED, "gemm: the rotary epilogue is served by variants pp256 / pp256p on k-contiguous operands with a plain (alpha, bias) bf16 epilogue, N % 8 == 0, ldc % 8 == 0");
+  }
   switch (variant) {
     case UNIMP_GEMM_V1: launch_v1(d, stream); break;
     case UNIMP_GEMM_DMA256: unimp_gemm2_launch(d, 256, stream); break;
@@ -491,7 +500,7 @@ extern "C" int unimp_gemm_bf16_splitk(const unimp_gemm_desc* d, int splits, floa
   int e = validate(d);
   if (e) return e;
   if (splits < 2 || !slabs) return unimp_set_error(UNIMP_ERR_ARG, "gemm_splitk: need splits >= 2 and a slab workspace");
-  if (d->bias || d->res || d->aux || d->pre || d->act || d->dact)
+  if (d->bias || d->res || d->aux || d->pre || d->act || d->dact || d->rope_rot)
     return unimp_set_error(UNIMP_ERR_UNSUPPORTED, "gemm_splitk: only alpha / gate (/ accumulate) epilogues");
   if ((d->N & 3) || (d->ldc & 3)) return unimp_set_error(UNIMP_ERR_SHAPE, "gemm_splitk: N and ldc must be multiples of 4");
   // 256 x 256 ping-pong tiles once the output holds a few of them (twice the 128 x 128 kernel's rate); 128 x 128 tiles otherwise

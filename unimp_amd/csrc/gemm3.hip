@@ -54,7 +54,7 @@ __device__ __forceinline__ void frag_packed_asm(const void* sbase, uint32_t voff
   asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(out) : "v"(voff), "s"(sbase) : "memory");
 }
 
-template <bool AKS, bool BKS, int BN, bool BPK = false>
+template <bool AKS, bool BKS, int BN, bool BPK = false, bool ROPE = false>
 __global__ __launch_bounds__(512, 2) void gemm3_bf16_kernel(Gemm2Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   G3_T(0);
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_bf16_kernel(Gemm2Params p) {
     __builtin_amdgcn_s_waitcnt(0xc07f); } while (0)
   // the epilogue kind is chosen once per tile; every global load goes out before the first store (see gemm_tile.h)
   const int em = m0 + wm * 128, en = n0 + wn * WN;
-  const int kind = epi_kind(p, fast);
+  const int kind = ROPE ? EK_ROPE : epi_kind(p, fast);
   EpiPre<WN> pre0, pre1;
   bf16x8 biasv = epi_bias<WN>(p, lane, en, kind);
   epi_fetch<WN>(p, lane, em, en, kind, pre0);
@@ -183,23 +183,23 @@ __global__ __launch_bounds__(512, 2) void gemm3_bf16_kernel(Gemm2Params p) {
   G3_T(5);
   epi_fetch<WN>(p, lane, em + 64, en, kind, pre1);
   if (kind != EK_GENERIC) epi_inputs_ready();
-  epi_pass_kind<WN>(p, er, lane, em, en, gate, fast, kind, pre0, biasv);
+  epi_pass_kind<WN, 64, ROPE>(p, er, lane, em, en, gate, fast, kind, pre0, biasv);
   __builtin_amdgcn_s_waitcnt(0xc07f);
   G3_T(6);
   EPI_STAGE(1);
   G3_T(7);
-  epi_pass_kind<WN>(p, er, lane, em + 64, en, gate, fast, kind, pre1, biasv);
+  epi_pass_kind<WN, 64, ROPE>(p, er, lane, em + 64, en, gate, fast, kind, pre1, biasv);
 #undef EPI_STAGE
   G3_T(3);
 }
 
-template <bool AKS, bool BKS, int BN, bool BPK = false>
+template <bool AKS, bool BKS, int BN, bool BPK = false, bool ROPE = false>
 static void launch3(const Gemm2Params& p, hipStream_t s, int slices = 1) {
   static bool attr_set = false;
   // the epilogue stages the tile through wave-private LDS regions: 8 waves x 64 rows x (BN / 4) floats
   constexpr size_t lds_ring = G3_NST * (G3_BM * 64 + (BPK ? 0 : BN * 64)), lds_epi = 8 * 64 * (BN / 4) * 4;
   constexpr size_t lds = lds_ring > lds_epi ? lds_ring : lds_epi;
-  auto kern = gemm3_bf16_kernel<AKS, BKS, BN, BPK>;
+  auto kern = gemm3_bf16_kernel<AKS, BKS, BN, BPK, ROPE>;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
   hipLaunchKernelGGL(kern, dim3(p.nbm * p.nbn, slices), dim3(512), lds, s, p);
 }
@@ -217,7 +217,7 @@ extern "C" int unimp_gemm3_launch_splitk(const unimp_gemm_desc* d, int bn, int s
   p.bias = (const bf16*)d->bias; p.res = (const bf16*)d->res; p.ldres = d->ldres;
   p.aux = (const bf16*)d->aux; p.ldaux = d->ldaux; p.pre = (bf16*)d->pre; p.ldpre = d->ldpre;
   p.gate = (const bf16*)d->gate; p.alpha = d->alpha; p.act = d->act; p.dact = d->dact;
-  p.out_f32 = d->out_f32; p.accumulate = d->accumulate; p.pre_deriv = d->pre_deriv;
+  p.out_f32 = d->out_f32; p.accumulate = d->accumulate; p.pre_deriv = d->pre_deriv; GEMM2_FILL_ROPE(p, d);
   p.nbm = (d->M + G3_BM - 1) / G3_BM;
   p.nbn = (d->N + bn - 1) / bn;
   p.ksplit = 0;
@@ -232,6 +232,7 @@ extern "C" int unimp_gemm3_launch_splitk(const unimp_gemm_desc* d, int bn, int s
   int a = d->a_kstrided, b = d->b_kstrided;
 #define L3(AK, BK_) do { if (bn == 256) launch3<AK, BK_, 256>(p, s, slices); else launch3<AK, BK_, 128>(p, s, slices); } while (0)
 #define L3P(AK) do { if (bn == 256) launch3<AK, false, 256, true>(p, s, 1); else launch3<AK, false, 128, true>(p, s, 1); } while (0)
+  if (p.rope_rot) { launch3<false, false, 256, false, true>(p, s, 1); return 1; }      // host-validated: k-contiguous operands, 256-wide tiles
   if (b == 2) { if (a) L3P(true); else L3P(false); }
   else if (!a && !b) L3(false, false); else if (!a && b) L3(false, true); else if (a && b) L3(true, true); else L3(true, false);
 #undef L3

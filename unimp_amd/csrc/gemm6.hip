@@ -19,7 +19,7 @@
 #define G3_BARRIER() do { G3_FENCE(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); G3_FENCE(); } while (0)
 
 
-template <bool AKS, bool BKS>
+template <bool AKS, bool BKS, bool ROPE = false>
 __global__ __launch_bounds__(512, 2) void gemm6_bf16_kernel(Gemm2Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BN = 256, NJ = BN / 64, WN = BN / 4;
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(512, 2) void gemm6_bf16_kernel(Gemm2Params p) {
         *(f32x4*)(er + row * ESTR + ((u ^ (row & (UNITS - 1))) << 4)) = acc[(SP) * 2 + i2][j];                     \
       }                                                                                                            \
     __builtin_amdgcn_s_waitcnt(0xc07f); } while (0)
-    const int kind = epi_kind(p, fast);
+    const int kind = ROPE ? EK_ROPE : epi_kind(p, fast);
     EpiPre<WN, 32> q0, q1, q2, q3;
     bf16x8 biasv = epi_bias<WN>(p, el, en, kind);
     epi_fetch<WN, 32>(p, el, em, en, kind, q0);
@@ -131,16 +131,16 @@ __global__ __launch_bounds__(512, 2) void gemm6_bf16_kernel(Gemm2Params p) {
       TILE(t);
       for (int h0 = 0; h0 < PD && h0 < nh; ++h0) DMA(h0);
     }
-    epi_pass_kind<WN, 32>(p, er, el, em, en, gate, fast, kind, q0, biasv);
+    epi_pass_kind<WN, 32, ROPE>(p, er, el, em, en, gate, fast, kind, q0, biasv);
     __builtin_amdgcn_s_waitcnt(0xc07f);
     EPI_STAGE(1);
-    epi_pass_kind<WN, 32>(p, er, el, em + 32, en, gate, fast, kind, q1, biasv);
+    epi_pass_kind<WN, 32, ROPE>(p, er, el, em + 32, en, gate, fast, kind, q1, biasv);
     __builtin_amdgcn_s_waitcnt(0xc07f);
     EPI_STAGE(2);
-    epi_pass_kind<WN, 32>(p, er, el, em + 64, en, gate, fast, kind, q2, biasv);
+    epi_pass_kind<WN, 32, ROPE>(p, er, el, em + 64, en, gate, fast, kind, q2, biasv);
     __builtin_amdgcn_s_waitcnt(0xc07f);
     EPI_STAGE(3);
-    epi_pass_kind<WN, 32>(p, er, el, em + 96, en, gate, fast, kind, q3, biasv);
+    epi_pass_kind<WN, 32, ROPE>(p, er, el, em + 96, en, gate, fast, kind, q3, biasv);
     __builtin_amdgcn_s_waitcnt(0xc07f);
 #undef EPI_STAGE
     if (!more) break;
@@ -152,12 +152,12 @@ __global__ __launch_bounds__(512, 2) void gemm6_bf16_kernel(Gemm2Params p) {
 #undef TILE
 }
 
-template <bool AKS, bool BKS>
+template <bool AKS, bool BKS, bool ROPE = false>
 static void launch6(const Gemm2Params& p, hipStream_t s) {
   static bool attr_set = false;
   static int ncu = 0;
   constexpr size_t lds = G3_NST * (G3_BM * 64 + 256 * 64) + 32768;
-  auto kern = gemm6_bf16_kernel<AKS, BKS>;
+  auto kern = gemm6_bf16_kernel<AKS, BKS, ROPE>;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
   if (!ncu) { int dev = 0; hipDeviceProp_t pr; (void)hipGetDevice(&dev); (void)hipGetDeviceProperties(&pr, dev); ncu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
   int ntiles = p.nbm * p.nbn;
@@ -171,11 +171,12 @@ extern "C" int unimp_gemm6_launch(const unimp_gemm_desc* d, void* stream) {
   p.bias = (const bf16*)d->bias; p.res = (const bf16*)d->res; p.ldres = d->ldres;
   p.aux = (const bf16*)d->aux; p.ldaux = d->ldaux; p.pre = (bf16*)d->pre; p.ldpre = d->ldpre;
   p.gate = (const bf16*)d->gate; p.alpha = d->alpha; p.act = d->act; p.dact = d->dact;
-  p.out_f32 = d->out_f32; p.accumulate = d->accumulate; p.pre_deriv = d->pre_deriv; p.ksplit = 0;
+  p.out_f32 = d->out_f32; p.accumulate = d->accumulate; p.pre_deriv = d->pre_deriv; GEMM2_FILL_ROPE(p, d); p.ksplit = 0;
   p.nbm = (d->M + G3_BM - 1) / G3_BM;
   p.nbn = (d->N + 255) / 256;
   hipStream_t s = (hipStream_t)stream;
   int a = d->a_kstrided, b = d->b_kstrided;
+  if (p.rope_rot) { launch6<false, false, true>(p, s); return 1; }       // host-validated: k-contiguous operands
   if (!a && !b) launch6<false, false>(p, s); else if (!a && b) launch6<false, true>(p, s);
   else if (a && b) launch6<true, true>(p, s); else launch6<true, false>(p, s);
   return 1;

@@ -16,7 +16,32 @@ struct Gemm2Params {
   int act, dact, out_f32, accumulate, pre_deriv;
   int nbm, nbn;
   int ksplit;                       // > 0 (gemm3 only): blockIdx.y reduces k in [y*ksplit, (y+1)*ksplit) into f32 slab y of C
+  int rope_rot, rope_hd, rope_period, rope_span, rope_L;      // rotary epilogue (EK_PLAIN only; include/unimp_hip.h), rope_rot == 0: none
+  float rope_step, rope_invL;       // 2 log2(base) / rope_rot;  1 / rope_L
 };
+
+#define GEMM2_FILL_ROPE(P_, D_) do { (P_).rope_rot = (D_)->rope_rot; (P_).rope_hd = (D_)->rope_hd; (P_).rope_period = (D_)->rope_period;   \
+    (P_).rope_span = (D_)->rope_span; (P_).rope_L = (D_)->rope_L;                                                                      \
+    (P_).rope_step = (D_)->rope_rot > 0 ? 2.f * (D_)->rope_log2_base / (float)(D_)->rope_rot : 0.f;                                     \
+    (P_).rope_invL = (D_)->rope_L > 0 ? 1.f / (float)(D_)->rope_L : 0.f; } while (0)
+
+// cos / sin of position * base^(-2 i / rot) for the 4 frequencies i0 .. i0 + 3, from the fractional number of turns
+__device__ __forceinline__ void rope_cs4(float pos, int i0, float step, float (&co)[4], float (&si)[4]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float turns = pos * (__builtin_amdgcn_exp2f(-(float)(i0 + j) * step) * 0.15915494309189535f);
+    turns = __builtin_amdgcn_fractf(turns);
+    co[j] = __builtin_amdgcn_cosf(turns); si[j] = __builtin_amdgcn_sinf(turns);
+  }
+}
+// m % L for 0 <= m < 2^24 without an integer division
+__device__ __forceinline__ int rope_pos(int m, int L, float invL) {
+  int q = (int)((float)m * invL);
+  int r = m - q * L;
+  r += r < 0 ? L : 0;
+  r -= r >= L ? L : 0;
+  return r;
+}
 
 static __device__ uint4 g_zero16[4];      // zero-initialised: source of every out-of-range LDS-DMA chunk
 
@@ -133,7 +158,7 @@ __device__ __forceinline__ void epi_pass(const Gemm2Params& p, const char* er, i
 // there (it cannot count in-flight stores across branches), which also waits for the previous row group's store to be
 // acknowledged.  EK_PLAIN / EK_ACT have no per-row-group input and run as a rolled loop; EK_AUX / EK_RES unroll their <= 8
 // row groups around the prefetched registers.
-enum { EK_PLAIN = 0, EK_ACT = 1, EK_AUX = 2, EK_RES = 3, EK_GENERIC = 4 };
+enum { EK_PLAIN = 0, EK_ACT = 1, EK_AUX = 2, EK_RES = 3, EK_GENERIC = 4, EK_ROPE = 5 /* EK_PLAIN + rotary pairs (QKV projection) */ };
 __device__ __forceinline__ int epi_kind(const Gemm2Params& p, bool fast) {
   if (!fast || p.accumulate || (p.aux && p.res)) return EK_GENERIC;
   if (p.aux) return (p.dact == ACT_DERIV && !p.act && !p.pre) ? EK_AUX : EK_GENERIC;
@@ -175,6 +200,19 @@ __device__ __forceinline__ void epi8k(const Gemm2Params& p, float (&v)[8], int m
   if (p.bias) {
 #pragma unroll
     for (int r = 0; r < 8; ++r) v[r] = __fadd_rn(v[r], bf2f(biasv[r]));
+  }
+  if (KIND == EK_ROPE) {                      // rotary epilogue: the 8 columns are 4 adjacent pairs (j, j + 4)
+    int pp = n % p.rope_hd;
+    if (n % p.rope_period < p.rope_span && pp < p.rope_rot) {
+      float co[4], si[4];
+      rope_cs4((float)rope_pos(m, p.rope_L, p.rope_invL), (pp >> 3) * 4, p.rope_step, co, si);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float x1 = v[j], x2 = v[j + 4];
+        v[j] = x1 * co[j] - x2 * si[j];
+        v[j + 4] = x2 * co[j] + x1 * si[j];
+      }
+    }
   }
   if (KIND == EK_ACT) {
     if (p.pre) {
@@ -240,6 +278,9 @@ __device__ __forceinline__ void epi_groups(const Gemm2Params& p, const char* er,
   } else if (KIND == EK_PLAIN) {          // small body: 4 row groups per trip so their LDS reads overlap
 #pragma unroll 4
     for (int u = 0; u < NIT; ++u) EPI_GROUP(u, bf16x8{});
+  } else if (KIND == EK_ROPE) {           // one rolled copy: the kernels must stay inside the instruction cache
+#pragma unroll 1
+    for (int u = 0; u < NIT; ++u) EPI_GROUP(u, bf16x8{});
   } else {
 #pragma unroll 2
     for (int u = 0; u < NIT; ++u) EPI_GROUP(u, bf16x8{});
@@ -247,9 +288,12 @@ __device__ __forceinline__ void epi_groups(const Gemm2Params& p, const char* er,
 #undef EPI_GROUP
 }
 // one pass of the chosen kind
-template <int WN, int ROWS = 64>
+// ROPE: the kernel instantiation that serves the rotary epilogue (and nothing else: the host validated a plain alpha / bias
+// epilogue, N % 8 == 0) -- a separate instantiation because the ordinary kernels sit within 1 KiB of the instruction cache.
+template <int WN, int ROWS = 64, bool ROPE = false>
 __device__ __forceinline__ void epi_pass_kind(const Gemm2Params& p, const char* er, int lane, int mbase, int nbase, float gate, bool fast,
                                               int kind, const EpiPre<WN, ROWS>& e, bf16x8 biasv) {
+  if (ROPE) { epi_groups<WN, EK_ROPE, ROWS>(p, er, lane, mbase, nbase, gate, e, biasv); return; }
   // generic form: the whole wave for EK_GENERIC; otherwise only the lanes that own the partial last 8-column group of a ragged N
   // (the 74 053-column LM head) -- one copy of the general code serves both
   const int n_ = nbase + (lane % (WN / 8)) * 8;

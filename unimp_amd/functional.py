@@ -12,6 +12,7 @@ Arithmetic restated (reference file:line):
   perceiver_attn     open_flamingo PerceiverAttention (A.2)
   focal_ce           UniMP/mmrec.py:190-213
 """
+import math
 import os as _os
 import weakref
 import torch
@@ -154,6 +155,42 @@ def _frozen_t(w):
     if c is None or c[0] != w._version or c[1].data_ptr() == 0:
         c = (w._version, w.detach().t().contiguous())
         w._unimp_wt = c
+    return c[1]
+
+
+# Rotary epilogue of the fused QKV projection (frozen towers, training path): the projection's rows are permuted ONCE so that
+# the rotation pairs (i, i + rot/2) of every q and k head vector become adjacent -- index 8g + j pairs with 8g + 4 + j -- and the
+# QKV GEMM rotates them in its epilogue (ops.gemm(rope=...), csrc/gemm_tile.h): the read + write pass of rope_ over the fused
+# [B L, 3H] buffer is gone, and the backward kernels rotate dq / dk back in the same layout without tables.  Attention only ever
+# takes q . k, which a common permutation of their dims leaves unchanged; v keeps its order.  UNIMP_ROPE_EPILOGUE=0 disables it.
+ROPE_EPILOGUE = _os.environ.get("UNIMP_ROPE_EPILOGUE", "1") != "0"
+
+
+def _rope_perm_index(nh, hd, rot, interleaved, device):
+    """row index map new -> old of the fused projection [3H, H] for the adjacent-pair layout"""
+    half = rot // 2
+    p = torch.arange(hd)
+    g, j = p // 8, p % 8
+    d = torch.where(j < 4, 4 * g + j, half + 4 * g + (j - 4))
+    d = torch.where(p < rot, d, p)                               # dims beyond the rotary part keep their place
+    ident = torch.arange(hd)
+    if interleaved:            # rows [nh][q | k | v][hd]
+        per_head = torch.cat([d, hd + d, 2 * hd + ident])
+        idx = (torch.arange(nh)[:, None] * 3 * hd + per_head[None]).reshape(-1)
+    else:                      # rows [q | k | v][nh][hd]
+        H = nh * hd
+        qk = (torch.arange(nh)[:, None] * hd + d[None]).reshape(-1)
+        idx = torch.cat([qk, H + qk, 2 * H + torch.arange(H)])
+    return idx.to(device)
+
+
+def _frozen_rope_perm(t, nh, hd, rot, interleaved):
+    """rows of a FROZEN fused QKV projection weight [3H, H] (or bias [3H]) in the adjacent-pair order; cached on the tensor like _frozen_t"""
+    key = (t._version, nh, hd, rot, interleaved)
+    c = getattr(t, "_unimp_rope_perm", None)
+    if c is None or c[0] != key:
+        c = (key, t.detach().index_select(0, _rope_perm_index(nh, hd, rot, interleaved, t.device)).contiguous())
+        t._unimp_rope_perm = c
     return c[1]
 
 
@@ -317,11 +354,24 @@ class SelfAttnBlockFn(Function):
         tq = FROZEN_WT_ATTN and not wqkv.requires_grad and B * L >= 1024
         td = FROZEN_WT_ATTN and not wd.requires_grad and B * L >= 1024
         mx = _mx_ok(wqkv, B * L) and _mx_ok(wd, B * L)
-        qkv = ops.gemm_mx(ops.mx_quantize(h), _frozen_mx(wqkv), bias=bqkv) if mx else \
-            ops.gemm(h, _frozen_t(wqkv) if tq else wqkv, b_ks=tq, bias=bqkv, b_pk=None if tq else _frozen_pk(wqkv))
+        # rotary epilogue: frozen projection, bf16 path, a kernel variant that serves it, positions 0 .. L-1 per sequence
+        fused = None
+        if (ROPE_EPILOGUE and rope is not None and len(rope) > 3 and not mx and not tq and not wqkv.requires_grad and not FROZEN_PK
+                and (bqkv is None or not bqkv.requires_grad) and rope[2] % 8 == 0 and hd % 8 == 0 and B * L < (1 << 24)
+                and ops.attn_generation() >= 2 and ops.gemm_rope_variant(B * L, 3 * H, H, False, x.device) is not None):
+            rot = rope[2]
+            fused = dict(rot=rot, hd=hd, period=3 * hd if interleaved else 3 * H, span=2 * hd if interleaved else 2 * H, L=L,
+                         log2_base=math.log2(rope[3]))
+        if fused is not None:
+            wp = _frozen_rope_perm(wqkv, nh, hd, fused["rot"], interleaved)
+            bp = _frozen_rope_perm(bqkv, nh, hd, fused["rot"], interleaved) if bqkv is not None else None
+            qkv = ops.gemm(h, wp, bias=bp, rope=fused)
+        else:
+            qkv = ops.gemm_mx(ops.mx_quantize(h), _frozen_mx(wqkv), bias=bqkv) if mx else \
+                ops.gemm(h, _frozen_t(wqkv) if tq else wqkv, b_ks=tq, bias=bqkv, b_pk=None if tq else _frozen_pk(wqkv))
         q, k, v, hs, offs = _split_qkv(qkv, B, L, nh, hd, interleaved)
-        if rope is not None:
-            cos, sin, rot = rope
+        if rope is not None and fused is None:
+            cos, sin, rot = rope[:3]
             ops.rope_(qkv, L, nh, hs, rot, offs, cos, sin)
         o, lse = ops.attn_fwd(q, k, v, q_scale, ops.MASK_CAUSAL if causal else ops.MASK_NONE, kv_len, alibi=alibi)
         o2 = o.view(B * L, H)
@@ -332,6 +382,7 @@ class SelfAttnBlockFn(Function):
         ctx.cfg = (B, L, H, nh, hd, interleaved, causal, rms, q_scale, rope[2] if rope is not None else 0, res is None,
                    ln_b is not None)
         ctx.mx = mx
+        ctx.rope_fused = fused
         return out.view(B, L, H)
 
     @staticmethod
@@ -350,13 +401,23 @@ class SelfAttnBlockFn(Function):
         dqkv = torch.empty_like(qkv)
         dq, dk, dv, _, _ = _split_qkv(dqkv, B, L, nh, hd, interleaved)
         # the backward kernels rotate dq / dk back on their way out (same arithmetic as the separate pass, no trip through HBM)
-        fuse = ROPE_FUSE and cos is not None and cos.shape[0] >= L and cos.shape[1] * 2 == rot and ops.attn_rope_fusable(dq, dk, dv, rot // 2, hd)
-        ops.attn_bwd(q, k, v, o, lse, do, dq, dk, dv, q_scale, ops.MASK_CAUSAL if causal else ops.MASK_NONE, kv_len, alibi=alibi,
-                     rope=(cos, sin) if fuse else None)
-        if cos is not None and not fuse:
-            ops.rope_(dqkv, L, nh, hs, rot, offs, cos, sin, inverse=True)
-        dwqkv = ops.gemm(dqkv, h, a_ks=True, b_ks=True) if _need(ctx, 4) else None
-        dh = ops.gemm_mx(ops.mx_quantize(dqkv), _frozen_mx(wqkv, True)) if ctx.mx else ops.gemm(dqkv, wqkv, b_ks=True, b_pk=_frozen_pk(wqkv, True))
+        if ctx.rope_fused is not None:
+            # q, k were rotated by the QKV GEMM in the adjacent-pair order of the permuted projection: dq / dk come back in that
+            # order, rotated back by the attention kernels, and meet the same permuted rows in the dX GEMM
+            if not ops.attn_rope_fusable(dq, dk, dv, rot // 2, hd, adjacent=True):
+                raise RuntimeError("rotary epilogue: the attention backward cannot rotate dq / dk (kernel generation changed after the forward?)")
+            ops.attn_bwd(q, k, v, o, lse, do, dq, dk, dv, q_scale, ops.MASK_CAUSAL if causal else ops.MASK_NONE, kv_len, alibi=alibi,
+                         rope=(rot // 2, ctx.rope_fused["log2_base"]))
+            dh = ops.gemm(dqkv, _frozen_rope_perm(wqkv, nh, hd, rot, interleaved), b_ks=True)
+            dwqkv = None
+        else:
+            fuse = ROPE_FUSE and cos is not None and cos.shape[0] >= L and cos.shape[1] * 2 == rot and ops.attn_rope_fusable(dq, dk, dv, rot // 2, hd)
+            ops.attn_bwd(q, k, v, o, lse, do, dq, dk, dv, q_scale, ops.MASK_CAUSAL if causal else ops.MASK_NONE, kv_len, alibi=alibi,
+                         rope=(cos, sin) if fuse else None)
+            if cos is not None and not fuse:
+                ops.rope_(dqkv, L, nh, hs, rot, offs, cos, sin, inverse=True)
+            dwqkv = ops.gemm(dqkv, h, a_ks=True, b_ks=True) if _need(ctx, 4) else None
+            dh = ops.gemm_mx(ops.mx_quantize(dqkv), _frozen_mx(wqkv, True)) if ctx.mx else ops.gemm(dqkv, wqkv, b_ks=True, b_pk=_frozen_pk(wqkv, True))
         wg = _need(ctx, 2) or (has_lnb and _need(ctx, 3))
         dx, dg, db = ops.layernorm_bwd(dh, x2, ln_w, mean, rstd, dres=dy2 if res_is_x else None, want_wgrad=wg,
                                        has_beta=has_lnb, rms=rms)

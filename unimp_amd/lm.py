@@ -233,7 +233,7 @@ class GPTNeoXForCausalLM(_TowerBase):
             n = max(L, 512)
             inv = 1.0 / (c.rotary_emb_base ** (torch.arange(0, rot, 2, dtype=torch.float32) / rot))
             fr = torch.arange(n, dtype=torch.float32)[:, None] * inv[None]
-            self._rope = (fr.cos().contiguous().to(device), fr.sin().contiguous().to(device), rot)
+            self._rope = (fr.cos().contiguous().to(device), fr.sin().contiguous().to(device), rot, float(c.rotary_emb_base))
         return self._rope
 
     def forward(self, input_ids, attention_mask=None, labels=None, past_key_values=None, use_cache=False, **kw):
@@ -448,7 +448,7 @@ class LlamaForCausalLM(_TowerBase):
             n = max(L, 512)
             inv = 1.0 / (c.rope_base ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
             fr = torch.arange(n, dtype=torch.float32)[:, None] * inv[None]
-            self._rope = (fr.cos().contiguous().to(device), fr.sin().contiguous().to(device), hd)
+            self._rope = (fr.cos().contiguous().to(device), fr.sin().contiguous().to(device), hd, float(c.rope_base))
         return self._rope
 
     def forward(self, input_ids, attention_mask=None, labels=None, past_key_values=None, use_cache=False, **kw):

@@ -203,6 +203,19 @@ def _tune_packed(M, N, K, a_ks, device, reads_mn, unpacked_variant, b_ks):
 TAIL_SPLIT = os.environ.get("UNIMP_GEMM_TAIL_SPLIT", "1") != "0"
 
 
+ROPE_VARIANTS = (4, 9)          # pp256 / pp256p: the kernels with a rotary-epilogue instantiation (gemm3.hip, gemm6.hip)
+
+
+def gemm_rope_variant(M, N, K, b_ks, device):
+    """the tuned variant for a plain-epilogue [M, N, K] GEMM if it is one that serves the rotary epilogue, else None"""
+    if M < 256 or N < 128 or N % 8 or M >= 1 << 24:
+        return None
+    if b_ks:
+        return None
+    v = _tune_gemm(M, N, K, False, False, device, False)
+    return v if v in ROPE_VARIANTS else None
+
+
 def _tail_split_plan(M, N, K):
     """Weight-gradient GEMM whose 256 x 256 tiles fill the 256 CUs once and then leave a mostly empty second round (400 tiles:
     the second round is 44 % idle): cut the output along the dimension with the finer tile granularity into a part of <= 256
@@ -235,7 +248,7 @@ def _tail_split_plan(M, N, K):
 
 def gemm(a, b, *, a_ks=False, b_ks=False, bias=None, act=None, res=None, aux=None, dact=None, pre=None,
          gate=None, alpha=1.0, out=None, out_f32=False, accumulate=False, ldc=None, variant=None, pre_deriv=False, b_pk=None,
-         _splits=None):
+         _splits=None, rope=None):
     """C[M,N] = epi(alpha * A B^T).  a: [M,K] (or [K,M] if a_ks); b: [N,K] (or [K,N] if b_ks).
     b_pk: optional PackedB image of the same b (frozen weights): used when the packed ping-pong kernel measured faster."""
     a, lda = _mat(a)
@@ -284,6 +297,14 @@ def gemm(a, b, *, a_ks=False, b_ks=False, bias=None, act=None, res=None, aux=Non
     d.act, d.dact = ACT[act], ACT[dact]
     d.out_f32, d.accumulate = int(out.dtype == torch.float32), int(accumulate)
     d.pre_deriv = int(pre_deriv)
+    if rope is not None:             # rotary epilogue (include/unimp_hip.h): dict(rot, hd, period, span, L, log2_base); see gemm_rope_variant()
+        d.rope_rot, d.rope_hd, d.rope_period, d.rope_span, d.rope_L = rope["rot"], rope["hd"], rope["period"], rope["span"], rope["L"]
+        d.rope_log2_base = rope["log2_base"]
+        _splits = 0
+        if variant is None:
+            variant = gemm_rope_variant(M, N, K, b_ks, a.device)
+            if variant is None:
+                raise _lib.UnimpHipError("gemm: no rotary-epilogue kernel for this problem (ops.gemm_rope_variant); run rope_ as a separate pass")
     plain = bias is None and res is None and aux is None and pre is None and act is None and dact is None   # alpha / gate / accumulate only
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     tiles256 = ((M + 255) // 256) * ((N + 255) // 256)
@@ -410,9 +431,10 @@ def attn_fwd(q, k, v, scale, mask_mode=MASK_NONE, kv_len=None, seg=None, seg_len
     return out, lse
 
 
-def attn_rope_fusable(dq, dk, dv, rope_half, D):
-    """can unimp_attn_bwd apply the transpose rotation to dq / dk itself?  (second-generation kernels, 16-byte aligned views)"""
-    if attn_generation() < 2 or rope_half <= 0 or rope_half % 8 or 2 * rope_half > D or dq.shape[1] < 4:
+def attn_rope_fusable(dq, dk, dv, rope_half, D, adjacent=False):
+    """can unimp_attn_bwd apply the transpose rotation to dq / dk itself?  (second-generation kernels, 16-byte aligned views;
+    adjacent: the pair-adjacent layout of the GEMM's rotary epilogue instead of the half-split one)"""
+    if attn_generation() < 2 or rope_half <= 0 or rope_half % (4 if adjacent else 8) or 2 * rope_half > D or dq.shape[1] < 4:
         return False
     for t in (dq, dk, dv):
         if t.data_ptr() % 16 or any(s_ % 8 for s_ in t.stride()[:3]):
@@ -439,7 +461,9 @@ def attn_bwd(q, k, v, o, lse, do, dq, dk, dv, scale, mask_mode=MASK_NONE, kv_len
     d.dk, (d.dk_bs, d.dk_ss, d.dk_hs) = _view4(dk)
     d.dv, (d.dv_bs, d.dv_ss, d.dv_hs) = _view4(dv)
     d.delta = delta.data_ptr()
-    if rope is not None:
+    if rope is not None and not torch.is_tensor(rope[0]):      # (half, log2 base): adjacent-pair layout, cos / sin computed in the kernels
+        d.rope_half, d.rope_log2_base = int(rope[0]), float(rope[1])
+    elif rope is not None:
         cos, sin = rope
         assert cos.dtype == torch.float32 and sin.dtype == torch.float32 and cos.is_contiguous() and sin.is_contiguous()
         assert cos.shape == sin.shape and cos.shape[0] >= max(Sq, Sk), (cos.shape, Sq, Sk)
