@@ -548,7 +548,7 @@ def self_attn_block_cached(x, ln_w, ln_b, wqkv, bqkv, wd, bd, nh, lc, pos0, *, r
         o, _ = ops.attn_fwd(q, lc.k, lc.v, scale, ops.MASK_NONE, step.kv_len, alibi=alibi)
         return ops.gemm(o.view(R, H), wd, bias=bd, res=r2).view(R, 1, H)
     if rope is not None:
-        cos, sin, rot = rope
+        cos, sin, rot = rope[:3]
         ops.rope_(qkv, Ln, nh, hs, rot, offs, cos[pos0:], sin[pos0:])
     kc, vc = _kv_append(lc, k, v, pos0)
     if pos0 == 0:
