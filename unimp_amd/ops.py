@@ -216,6 +216,23 @@ def gemm_rope_variant(M, N, K, b_ks, device):
     return v if v in ROPE_VARIANTS else None
 
 
+def _splitk_count(M, N, K, tiles256):
+    """slices for a split-K GEMM on 256 x 256 tiles.  More slices fill the 256 CUs better and shorten each block, but every
+    slice writes and re-reads an fp32 [M, N] slab: a block costs ~6 us + 0.8 us per 32 k, the slabs move at ~4 TB/s (measured:
+    [2560, 512, 32768] with 25 slices 129 us, of which 65 us slab traffic)."""
+    best, best_t = 2, float("inf")
+    for S in range(2, 33):
+        ks = (-(-K // S) + 63) // 64 * 64
+        n = -(-K // ks)
+        if n != S or ks < 512:
+            continue
+        rounds = -(-tiles256 * S // 256)
+        t = rounds * (6.0 + 0.8 * ks / 32) + S * M * N * 4 * 2 / 4e6 + 5.0
+        if t < best_t:
+            best, best_t = S, t
+    return best
+
+
 def _tail_split_plan(M, N, K):
     """Weight-gradient GEMM whose 256 x 256 tiles fill the 256 CUs once and then leave a mostly empty second round (400 tiles:
     the second round is 44 % idle): cut the output along the dimension with the finer tile granularity into a part of <= 256
@@ -317,7 +334,7 @@ def gemm(a, b, *, a_ks=False, b_ks=False, bias=None, act=None, res=None, aux=Non
             and K >= 2048 and N % 4 == 0 and out.stride(0) % 4 == 0):
         # weight gradient of a narrow projection: far fewer tiles than CUs, very deep K -> split-K over the chip
         big = wide or (K >= 16384 and M >= 256 and N >= 256)        # the C side runs 256 x 256 tiles whenever M, N >= 256
-        splits = _splits or (max(2, min(32, 512 // tiles256, K // 1024)) if big else max(2, min(32, 320 // tiles, K // 512)))
+        splits = _splits or (_splitk_count(M, N, K, tiles256) if big else max(2, min(32, 320 // tiles, K // 512)))
         slabs = torch.empty((splits, M, N), dtype=torch.float32, device=a.device)
         if GEMM_PROFILE is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
