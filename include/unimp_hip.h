@@ -97,7 +97,8 @@ int unimp_gemm_bf16_splitk(const unimp_gemm_desc* d, int splits, float* slabs, v
  * and LlamaRMSNorm (llama.py:101-118).  rows x D, one wave per row, statistics in fp32.
  * Output row r goes to row (r / grp) * grp_stride + (r % grp) + grp_off of y (grp = 0: identity) so the
  * Perceiver's cat(x, latents) (open_flamingo PerceiverAttention) is written in place.
- * bwd: dx = LN'(dy) (+ dres if given); dgamma/dbeta (bf16 [D], overwritten) through `partial` (fp32
+ * bwd: dx = LN'(dy) (+ dres if given); dgamma/dbeta (bf16 [D]; overwritten, or added to when wgrad_accumulate != 0: the
+ * parameter's slot of a gradient buffer) through `partial` (fp32
  * [partial_blocks*2*D]) when gamma grads are wanted (dgamma != NULL); dy rows are read through the same row map;
  * dy2 (optional, plain row layout) is added to dy first (the Perceiver's norm_latents output feeds both q and kv).
  */
@@ -107,7 +108,7 @@ int unimp_layernorm_fwd(const void* x, int64_t ldx, const void* gamma, const voi
 int unimp_layernorm_bwd(const void* dy, int64_t lddy, const void* dy2, int64_t lddy2, const void* x, int64_t ldx, const void* gamma,
                         const float* mean, const float* rstd, const void* dres, int64_t lddres,
                         void* dx, int64_t lddx, void* dgamma, void* dbeta, float* partial, int partial_blocks,
-                        int rows, int D, int rms, int grp, int grp_stride, int grp_off, void* stream);
+                        int rows, int D, int rms, int grp, int grp_stride, int grp_off, int wgrad_accumulate, void* stream);
 
 /* ---- rotary embedding, GPT-NeoX / Llama half-split (gpt_neox modelling :107-160; llama.py:121-182) ------
  * in place on x viewed as [rows = B*L][heads][head_stride]; rotates the first `rot` dims of the `nvec`

@@ -51,6 +51,12 @@ def _worker(rank, world, port, q):
         assert tr._sink is not None and tr._sink.dp is tr.dp
         tr._backward(loss)       # production backward: dW GEMMs add into the flat buffer and notify the bucketer themselves
         gscale = tr.dp.finish()
+        # every rank must hold the SAME summed gradient, parameter by parameter (a bucket reduced before its last gradient was
+        # written shows up here and nowhere else: a scalar gate does not move the norm-based check below)
+        flats = [torch.empty_like(tr.opt.flat_g) for _ in range(world)]
+        dist.all_gather(flats, tr.opt.flat_g)
+        for n, p, o, k in tr.opt.layout:
+            assert all(torch.equal(flats[0][o:o + k], f[o:o + k]) for f in flats[1:]), f"gradient of {n} differs across ranks after the exchange"
         red = tr.opt.flat_g.float() * gscale
         err = float((red - mean).norm() / mean.norm())
         assert err < 1e-2, err

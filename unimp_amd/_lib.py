@@ -46,7 +46,7 @@ _SIGS = {
     "unimp_gemm_bf16_splitk": [C.POINTER(GemmDesc), c_i, c_p, c_p],
     "unimp_layernorm_fwd": [c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_p, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_p],
     "unimp_layernorm_bwd": [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_i,
-                            c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+                            c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "unimp_rope_halfsplit": [c_p, c_l, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p],
     "unimp_attn_fwd": [C.POINTER(AttnDesc), c_p],
     "unimp_attn_bwd": [C.POINTER(AttnDesc), c_p],

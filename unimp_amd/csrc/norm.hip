@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
 // bytes of a partial row), its 8 waves take every 8th row with 8 independent loads in flight, LDS combines the 8 waves in a
 // fixed order.
 __global__ __launch_bounds__(512) void ln_wgrad_reduce_kernel(const float* __restrict__ partial, int nblk, int D, bf16* __restrict__ dgamma,
-                                                              bf16* __restrict__ dbeta) {
+                                                              bf16* __restrict__ dbeta, int accumulate) {
   __shared__ float sh[8][64];
   int which = blockIdx.y;
   int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
@@ -239,8 +239,8 @@ __global__ __launch_bounds__(512) void ln_wgrad_reduce_kernel(const float* __res
     float a = 0.f;
 #pragma unroll
     for (int g = 0; g < 8; ++g) a += sh[g][cl];
-    if (which == 0) dgamma[col] = f2bf(a);
-    else if (dbeta) dbeta[col] = f2bf(a);
+    bf16* d = which == 0 ? dgamma : dbeta;           // accumulate: the destination is the parameter's slot of the gradient buffer
+    if (d) d[col] = f2bf(accumulate ? a + bf2f(d[col]) : a);
   }
 }
 
@@ -271,7 +271,7 @@ extern "C" int unimp_layernorm_fwd(const void* x, int64_t ldx, const void* gamma
 extern "C" int unimp_layernorm_bwd(const void* dy, int64_t lddy, const void* dy2, int64_t lddy2, const void* x, int64_t ldx, const void* gamma,
                                    const float* mean, const float* rstd, const void* dres, int64_t lddres, void* dx,
                                    int64_t lddx, void* dgamma, void* dbeta, float* partial, int partial_blocks, int rows,
-                                   int D, int rms, int grp, int grp_stride, int grp_off, void* stream) {
+                                   int D, int rms, int grp, int grp_stride, int grp_off, int wgrad_accumulate, void* stream) {
   if (!dy || !x || !gamma || !rstd || !dx) return unimp_set_error(UNIMP_ERR_ARG, "layernorm_bwd: null pointer");
   if (rows <= 0) return UNIMP_OK;
   if ((D & 7) || D > 4096 || (ldx & 7) || (lddy & 7) || (lddx & 7)) return unimp_set_error(UNIMP_ERR_SHAPE, "layernorm_bwd: need D%8==0, D<=4096, ld%8==0");
@@ -297,7 +297,7 @@ extern "C" int unimp_layernorm_bwd(const void* dy, int64_t lddy, const void* dy2
   int e = unimp_check_launch("layernorm_bwd");
   if (e) return e;
   if (wg) {
-    hipLaunchKernelGGL(ln_wgrad_reduce_kernel, dim3((D + 63) / 64, 2), dim3(512), 0, s, partial, nb, D, (bf16*)dgamma, (bf16*)dbeta);
+    hipLaunchKernelGGL(ln_wgrad_reduce_kernel, dim3((D + 63) / 64, 2), dim3(512), 0, s, partial, nb, D, (bf16*)dgamma, (bf16*)dbeta, wgrad_accumulate);
     return unimp_check_launch("layernorm_wgrad_reduce");
   }
   return UNIMP_OK;

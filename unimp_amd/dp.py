@@ -74,6 +74,7 @@ class GradBucketer:
         self._next = 0            # position in self._order of the next bucket to issue
         self._issued = set()
         self._handles = []
+        self._counted = set()     # parameters whose completion has been counted this step
 
     def _on_grad(self, p):
         o, k = self._slot[id(p)]
@@ -84,6 +85,12 @@ class GradBucketer:
             p.grad = view.view(p.shape)
         if id(p) in self._late or not self.sync:
             return
+        # once per parameter and step.  A weight whose gradient the dW GEMM added straight into the flat buffer is reported by the
+        # Trainer's sink (functional.WGRAD_SINK -> done()) AND, in the torch version this was written against, by autograd's
+        # post-accumulate hook, which fires for the parameter although the Function returned no gradient for it
+        if id(p) in self._counted:
+            return
+        self._counted.add(id(p))
         bi = self.param_bucket[id(p)]
         self._pending[bi] -= 1
         self._drain()

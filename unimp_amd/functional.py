@@ -51,6 +51,22 @@ def _dw(ctx, idx, w, a, b, gate=None):
     return ops.gemm(a, b, a_ks=True, b_ks=True, gate=gate)
 
 
+def _ln_bwd(dy, x2, w, b, mean, rstd, need_w, need_b, has_beta=True, **kw):
+    """ops.layernorm_bwd with the weight gradients routed through the sink (added straight into gamma's / beta's slots of the
+    flat gradient buffer) when there is one; returns (dx, dgamma, dbeta) with None for what went to the sink."""
+    want = need_w or (has_beta and need_b)
+    sink = WGRAD_SINK
+    if (want and sink is not None and need_w and (need_b or not has_beta) and sink.has(w) and (not has_beta or (b is not None and sink.has(b)))):
+        vg = sink.view_of(w)
+        vb = sink.view_of(b) if has_beta else None
+        dx, _, _ = ops.layernorm_bwd(dy, x2, w, mean, rstd, want_wgrad=True, has_beta=has_beta, dg_out=vg, db_out=vb, **kw)
+        sink.done(w)
+        if has_beta:
+            sink.done(b)
+        return dx, None, None
+    return ops.layernorm_bwd(dy, x2, w, mean, rstd, want_wgrad=want, has_beta=has_beta, **kw)
+
+
 def _gate_grad(dy, raw, gate):
     """d/d gate of tanh(gate) * raw contracted with dy."""
     d = ops.dot(dy, raw)
@@ -72,7 +88,7 @@ class LayerNormFn(Function):
         x2 = x.reshape(-1, shp[-1])
         y, mean, rstd = ops.layernorm_fwd(x2, w, b, eps, rms=rms)
         ctx.save_for_backward(x2, w, mean, rstd)
-        ctx.rms, ctx.has_b, ctx.shp = rms, b is not None, shp
+        ctx.rms, ctx.has_b, ctx.shp, ctx.b_ref = rms, b is not None, shp, b
         return y.view(shp)
 
     @staticmethod
@@ -81,8 +97,7 @@ class LayerNormFn(Function):
         dy2 = dy.reshape(-1, ctx.shp[-1])
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
-        wg = _need(ctx, 1) or (ctx.has_b and _need(ctx, 2))
-        dx, dg, db = ops.layernorm_bwd(dy2, x2, w, mean, rstd, want_wgrad=wg, has_beta=ctx.has_b, rms=ctx.rms)
+        dx, dg, db = _ln_bwd(dy2, x2, w, ctx.b_ref, mean, rstd, _need(ctx, 1), ctx.has_b and _need(ctx, 2), has_beta=ctx.has_b, rms=ctx.rms)
         return dx.view(ctx.shp), dg, db, None, None
 
 
@@ -270,7 +285,7 @@ class MLPBlockFn(Function):
                            b_pk=None if t2 or M <= 64 else _frozen_pk(w2))
         if bwd:
             ctx.save_for_backward(x2, ln_w, mean, rstd, w1, w2, gate, pre, h if w1g else None, a if w2g else None, raw)
-        ctx.act, ctx.shp, ctx.res_is_x, ctx.has_lnb, ctx.mx = act, shp, res is None, ln_b is not None, mx
+        ctx.act, ctx.shp, ctx.res_is_x, ctx.has_lnb, ctx.mx, ctx.ln_b_ref = act, shp, res is None, ln_b is not None, mx, ln_b
         return out.view(shp)
 
     @staticmethod
@@ -292,9 +307,8 @@ class MLPBlockFn(Function):
             dw1 = _dw(ctx, 4, w1, dpre, h)
             dh = ops.gemm(dpre, w1, b_ks=True, b_pk=_frozen_pk(w1, True))
         del dpre
-        wg = _need(ctx, 2) or (ctx.has_lnb and _need(ctx, 3))
-        dx, dg, db = ops.layernorm_bwd(dh, x2, ln_w, mean, rstd, dres=dy2 if ctx.res_is_x else None, want_wgrad=wg,
-                                       has_beta=ctx.has_lnb)
+        dx, dg, db = _ln_bwd(dh, x2, ln_w, ctx.ln_b_ref, mean, rstd, _need(ctx, 2), ctx.has_lnb and _need(ctx, 3), has_beta=ctx.has_lnb,
+                             dres=dy2 if ctx.res_is_x else None)
         dres = None if ctx.res_is_x else dy
         return dx.view(ctx.shp), dres, dg, db, dw1, None, dw2, None, dgate, None, None
 
@@ -598,6 +612,7 @@ class GatedXAttnFn(Function):
         out = ops.gemm(o.view(B * L, inner), wo, gate=gate, res=x2, pre=raw)
         ctx.save_for_backward(x2, m2, seg, ln_w, mean, rstd, wq, wkv, wo, gate, h, q, kv, o, lse, raw)
         ctx.cfg = (B, L, D, Sk, heads, dh, n_lat)
+        ctx.ln_b_ref = ln_b
         return out.view(B, L, D)
 
     @staticmethod
@@ -621,8 +636,7 @@ class GatedXAttnFn(Function):
         dh_ = ops.gemm(dq, wq, b_ks=True)
         dwkv = _dw(ctx, 6, wkv, dkv, m2)
         dmedia = ops.gemm(dkv, wkv, b_ks=True).view(B, Sk, -1) if _need(ctx, 1) else None
-        wg = _need(ctx, 3) or _need(ctx, 4)
-        dx, dg, db = ops.layernorm_bwd(dh_, x2, ln_w, mean, rstd, dres=dy2, want_wgrad=wg)
+        dx, dg, db = _ln_bwd(dh_, x2, ln_w, ctx.ln_b_ref, mean, rstd, _need(ctx, 3), _need(ctx, 4), dres=dy2)
         return dx.view(B, L, D), dmedia, None, dg, db, dwq, dwkv, dwo, dgate, None, None, None
 
 
@@ -654,6 +668,7 @@ class PerceiverAttnFn(Function):
         out = ops.gemm(o.view(G * n2, inner), wo, res=l2)
         ctx.save_for_backward(x2, l2, nm_w, nl_w, mean_m, rstd_m, mean_l, rstd_l, wq, wkv, wo, kvin, hl, q, kv, o, lse)
         ctx.cfg = (G, n1, n2, D, heads, dh)
+        ctx.nm_b_ref, ctx.nl_b_ref = nm_b, nl_b
         return out.view(G, n2, D)
 
     @staticmethod
@@ -677,11 +692,11 @@ class PerceiverAttnFn(Function):
         dkvin = ops.gemm(dkv, wkv, b_ks=True)                                   # [G*S, D]
         dxm = dgm = dbm = None
         if _need(ctx, 0) or _need(ctx, 2) or _need(ctx, 3):
-            dxm, dgm, dbm = ops.layernorm_bwd(dkvin, x2, nm_w, mean_m, rstd_m, want_wgrad=_need(ctx, 2) or _need(ctx, 3),
-                                              grp=n1, grp_stride=S, grp_off=0)
+            dxm, dgm, dbm = _ln_bwd(dkvin, x2, nm_w, ctx.nm_b_ref, mean_m, rstd_m, _need(ctx, 2), _need(ctx, 3),
+                                    grp=n1, grp_stride=S, grp_off=0)
             dxm = dxm.view(G, n1, D) if _need(ctx, 0) else None
-        dl, dgl, dbl = ops.layernorm_bwd(dkvin, l2, nl_w, mean_l, rstd_l, dres=dy2, dy2=dhl,
-                                         want_wgrad=_need(ctx, 4) or _need(ctx, 5), grp=n2, grp_stride=S, grp_off=n1)
+        dl, dgl, dbl = _ln_bwd(dkvin, l2, nl_w, ctx.nl_b_ref, mean_l, rstd_l, _need(ctx, 4), _need(ctx, 5), dres=dy2, dy2=dhl,
+                               grp=n2, grp_stride=S, grp_off=n1)
         return dxm, dl.view(G, n2, D), dgm, dbm, dgl, dbl, dwq, dwkv, dwo, None, None
 
 

@@ -385,22 +385,30 @@ _PARTIAL_BLOCKS = 512       # 2 blocks per CU: the wgrad variant holds 244 VGPRs
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, *, dres=None, dy2=None, want_wgrad=False, has_beta=True, rms=False, grp=0,
-                  grp_stride=0, grp_off=0):
-    """returns dx, dgamma, dbeta (bf16; None when not wanted).  dy may be the grouped (concat) buffer."""
+                  grp_stride=0, grp_off=0, dg_out=None, db_out=None):
+    """returns dx, dgamma, dbeta (bf16; None when not wanted).  dy may be the grouped (concat) buffer.
+    dg_out / db_out (bf16 [D] views of a gradient buffer, both or -- without beta -- dg_out alone): the weight gradients are
+    ADDED there and None is returned for them."""
     x, ldx = _mat(x)
     rows, D = x.shape
     assert dy.stride(-1) == 1
     dx = torch.empty((rows, D), dtype=bf16, device=x.device)
     dg = db = part = None
+    acc = 0
     if want_wgrad:
-        dg = torch.empty(D, dtype=bf16, device=x.device)
-        db = torch.empty(D, dtype=bf16, device=x.device) if has_beta else None
+        if dg_out is not None and (db_out is not None or not has_beta):
+            dg, db, acc = dg_out, db_out, 1
+        else:
+            dg = torch.empty(D, dtype=bf16, device=x.device)
+            db = torch.empty(D, dtype=bf16, device=x.device) if has_beta else None
         part = torch.empty(_PARTIAL_BLOCKS * 2 * D, dtype=torch.float32, device=x.device)
     check(_lib.lib().unimp_layernorm_bwd(dy.data_ptr(), dy.stride(-2), _p(dy2), dy2.stride(0) if dy2 is not None else 0,
                                           x.data_ptr(), ldx, _p(gamma), _p(mean), _p(rstd),
                                           _p(dres), dres.stride(0) if dres is not None else 0, dx.data_ptr(), D,
                                           _p(dg), _p(db), _p(part), _PARTIAL_BLOCKS, rows, D, int(rms), grp, grp_stride,
-                                          grp_off, _stream()), "layernorm_bwd")
+                                          grp_off, acc, _stream()), "layernorm_bwd")
+    if acc:
+        return dx, None, None
     return dx, dg, db
 
 

@@ -95,8 +95,16 @@ class _WgradSink:
         self.seen = set()
         if opt.flat_g.dtype == torch.bfloat16:
             for n, p, o, k in opt.layout:
-                if p.dim() == 2 and id(p) not in ex:
+                if p.dim() in (1, 2) and p.numel() >= 8 and id(p) not in ex:      # dense weights; LayerNorm gamma / beta (functional._ln_bwd)
                     self.views[p.data_ptr()] = (p, opt.flat_g[o:o + k].view(p.shape))
+
+    def has(self, w):
+        """would view_of(w) hand out a view?  (no bookkeeping)"""
+        e = None if w is None else self.views.get(w.data_ptr())
+        if e is None or e[0].shape != w.shape:
+            return False
+        g = e[0].grad
+        return g is not None and g.data_ptr() == e[1].data_ptr()
 
     def view_of(self, w):
         e = self.views.get(w.data_ptr())
