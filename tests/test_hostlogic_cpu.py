@@ -1,0 +1,64 @@
+"""Host-side decisions of the GEMM / RoPE routing (pure functions, no GPU): the plans the bench's shapes get, and the
+pair-adjacent row permutation of the rotary epilogue against the half-split rotation it replaces (oracle/lm.py)."""
+import math
+import torch
+
+
+def test_tail_split_plan_for_the_step_shapes():
+    from unimp_amd.ops import _tail_split_plan
+    # the gated blocks' two big weight gradients at b = 64 (400 tiles): one full round + a split-K remainder in whole rounds
+    for M, N in ((10240, 2560), (2560, 10240)):
+        axis, cut, S = _tail_split_plan(M, N, 32768)
+        assert axis == ("m" if M > N else "n") and cut % 256 == 0
+        ta = (cut // 256) * ((min(M, N) + 255) // 256)
+        tb = 400 - ta
+        assert ta <= 256 and tb > 0 and (tb * S) % 256 >= 200 or (tb * S) % 256 == 0, (ta, tb, S)
+    assert _tail_split_plan(16384, 4096, 24576) is None          # 1024 tiles: whole rounds already
+    assert _tail_split_plan(4096, 4096, 24576) is None           # exactly one round
+    assert _tail_split_plan(10240, 2560, 4096) is None           # shallow K: a slab round trip costs more than the idle half round
+
+
+def test_splitk_count_balances_rounds_and_slab_traffic():
+    from unimp_amd.ops import _splitk_count
+    for M, N, K in ((2560, 512, 32768), (1024, 1024, 32768), (1024, 4096, 32768), (640, 2560, 74053), (512, 1024, 2120)):
+        tiles = ((M + 255) // 256) * ((N + 255) // 256)
+        S = _splitk_count(M, N, K, tiles)
+        ks = (-(-K // S) + 63) // 64 * 64
+        assert 2 <= S <= 32 and -(-K // ks) == S and ks >= 512, (M, N, K, S)
+        assert tiles * S <= 2 * 256 + 64, (M, N, K, S)            # never more than ~two rounds of ever shorter blocks
+    assert _splitk_count(2560, 512, 32768, 20) == 12             # one round of 240 blocks instead of two of 250 (measured 129 -> 109 us)
+
+
+def test_rope_adjacent_permutation_is_the_half_split_rotation():
+    """rotating adjacent pairs (8g + j, 8g + 4 + j) at frequency 4g + j of the permuted vector == permuting the half-split
+    rotation of the original vector: the identity the rotary epilogue rests on (both QKV layouts, partial rotary)."""
+    from unimp_amd.functional import _rope_perm_index
+    from oracle.lm import neox_rope_tables, rotate_half
+    for nh, hd, rot, inter in ((4, 80, 80, True), (3, 64, 16, True), (2, 128, 128, False)):
+        H = nh * hd
+        idx = _rope_perm_index(nh, hd, rot, inter, "cpu")
+        assert sorted(idx.tolist()) == list(range(3 * H))
+        v_rows = idx.view(nh, 3, hd)[:, 2] if inter else idx[2 * H:]
+        want_v = (torch.arange(nh)[:, None] * 3 * hd + 2 * hd + torch.arange(hd)[None]) if inter else torch.arange(2 * H, 3 * H)
+        assert torch.equal(v_rows.reshape(-1), want_v.reshape(-1))           # v keeps its order
+        L = 7
+        y = torch.randn(L, 3 * H)
+        cos, sin = neox_rope_tables(L, rot, 10000.0)
+        yv = y.view(L, nh, 3, hd) if inter else y.view(L, 3, nh, hd).permute(0, 2, 1, 3)
+        want = yv.clone()
+        for part in (0, 1):
+            r = yv[:, :, part, :rot]
+            want[:, :, part, :rot] = r * cos[:, None] + rotate_half(r) * sin[:, None]
+        want = want.reshape(L, 3 * H) if inter else want.permute(0, 2, 1, 3).reshape(L, 3 * H)
+        yp = y[:, idx]                                                       # what the permuted projection produces
+        gv = yp.view(L, nh, 3, hd) if inter else yp.view(L, 3, nh, hd).permute(0, 2, 1, 3)
+        got = gv.clone()
+        theta = 10000.0 ** (-2.0 * torch.arange(rot // 2) / rot)
+        ang = torch.arange(L)[:, None] * theta[None]                         # [L, rot / 2]
+        for part in (0, 1):
+            x = gv[:, :, part, :rot].reshape(L, nh, rot // 8, 2, 4)
+            c, s_ = ang.cos().view(L, 1, rot // 8, 4), ang.sin().view(L, 1, rot // 8, 4)
+            x1, x2 = x[..., 0, :], x[..., 1, :]
+            got[:, :, part, :rot] = torch.stack([x1 * c - x2 * s_, x2 * c + x1 * s_], -2).reshape(L, nh, rot)
+        got = got.reshape(L, 3 * H) if inter else got.permute(0, 2, 1, 3).reshape(L, 3 * H)
+        assert torch.allclose(got, want[:, idx], atol=1e-5), (nh, hd, rot, inter)
