@@ -184,6 +184,31 @@ def _worker_shard(rank, world, port, q, backend):
         flat = [torch.empty_like(shd.opt.flat_p) for _ in range(world)]
         dist.all_gather(flat, shd.opt.flat_p)
         assert all(torch.equal(flat[0], f) for f in flat)
+        # checkpoint of the sharded state: gathered per parameter (a collective), written by rank 0, loaded by every rank into a
+        # fresh SHARDED trainer and into a REPLICATED one -- both continue exactly like the trainer that was never interrupted
+        import tempfile
+        from unimp_amd.train import save_checkpoint, load_checkpoint
+        obj = [tempfile.mkdtemp() if rank == 0 else None]
+        dist.broadcast_object_list(obj, src=0)
+        path = os.path.join(obj[0], "ck.pt")
+        save_checkpoint(path, shd.model, shd, epoch=3)
+        fresh_s = Trainer(P.build_hip(cfg, om, layout), layout.special(), lr=1e-3, lr_scheduler="constant", bucket_bytes=1 << 16,
+                          shard_optimizer=True)
+        fresh_r = Trainer(P.build_hip(cfg, om, layout), layout.special(), lr=1e-3, lr_scheduler="constant", bucket_bytes=1 << 16)
+        assert load_checkpoint(path, fresh_s.model, fresh_s) == 4 and load_checkpoint(path, fresh_r.model, fresh_r) == 4
+        assert fresh_s.opt.step_count == shd.opt.step_count == fresh_r.opt.step_count
+        assert torch.equal(fresh_s.opt.master, shd.opt.master) and torch.equal(fresh_s.opt.m, shd.opt.m) and torch.equal(fresh_s.opt.v, shd.opt.v)
+        assert torch.equal(fresh_s.opt.flat_p, shd.opt.flat_p)
+        extra = {k: v.cuda() for k, v in P.make_batch(cfg, layout, seed=900 + rank).items()}
+        la, _ = shd.step(extra)
+        lb, _ = fresh_s.step(extra)
+        lc, _ = fresh_r.step(extra)
+        assert la.item() == lb.item() and torch.equal(fresh_s.opt.flat_p, shd.opt.flat_p)          # sharded -> sharded: bit-identical resume
+        assert abs(lc.item() - la.item()) <= 2e-3 * abs(la.item())
+        for (n, p1), (_, p2) in zip(shd.model.named_parameters(), fresh_r.model.named_parameters()):
+            if p1.requires_grad:
+                d = (p1.detach().float() - p2.detach().float()).abs().max().item()
+                assert d <= 2e-5 + 2 ** -7 * p1.detach().float().abs().max().item(), (n, d)          # sharded -> replicated: clip-norm order only
         q.put((rank, "ok", worst))
     except Exception:                                                      # noqa: BLE001
         import traceback

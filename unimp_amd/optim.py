@@ -185,14 +185,56 @@ class FlatAdamW:
         self.m.zero_(); self.v.zero_()
         self.step_count = 0
 
+    def _gather_state(self, buf):
+        """full fp32 flat buffer (this optimizer's layout) of a sharded state buffer: every rank's owned slices, bucket by bucket.
+        Collective: every rank of the group must call it."""
+        import torch.distributed as dist
+        pg, w = self.shard[3], self.shard[1]
+        full = torch.zeros(self.total, dtype=torch.float32, device=buf.device)
+        nccl = dist.get_backend(pg) == "nccl"
+        for (s_, e_), (lo, hi, so) in zip(self.buckets, self.owned):
+            mine = buf[so:so + hi - lo].contiguous()
+            if nccl:
+                dist.all_gather_into_tensor(full[s_:e_], mine, group=pg)
+            else:
+                parts = [torch.empty_like(mine) for _ in range(w)]
+                dist.all_gather(parts, mine, group=pg)
+                full[s_:e_].copy_(torch.cat(parts))
+        return full
+
     def state_dict(self):
-        if self.shard is not None:
-            raise NotImplementedError("checkpointing a sharded optimizer state is not built (gather it, or resume replicated)")
-        return {"step": self.step_count, "master": self.master, "m": self.m, "v": self.v,
-                "names": [n for n, _, _, _ in self.layout], "lr": self.lr}
+        """{"step", "lr", "names", "master" / "m" / "v": {parameter name: fp32 tensor}} -- per parameter, so a state saved by a
+        replicated optimizer loads into a sharded one and back, whatever the bucket padding.  With a sharded state this is a
+        COLLECTIVE (every rank gathers every slice, one state buffer at a time: a transient fp32 copy of the flat buffer)."""
+        out = {"step": self.step_count, "lr": self.lr, "names": [n for n, _, _, _ in self.layout]}
+        for key, buf in (("master", self.master), ("m", self.m), ("v", self.v)):
+            full = buf if self.shard is None else self._gather_state(buf)
+            out[key] = {n: full[o:o + k].detach().to("cpu", copy=True) for n, _, o, k in self.layout}
+            del full
+        return out
 
     def load_state_dict(self, sd):
         assert sd["names"] == [n for n, _, _, _ in self.layout], "parameter layout changed"
         self.step_count = sd["step"]
-        self.master.copy_(sd["master"]); self.m.copy_(sd["m"]); self.v.copy_(sd["v"])
+        for key, buf in (("master", self.master), ("m", self.m), ("v", self.v)):
+            src = sd[key]
+            if torch.is_tensor(src):                      # round-1 files: one flat tensor in the replicated layout
+                if self.shard is not None:
+                    raise ValueError("a flat (round-1) optimizer state cannot be loaded into a sharded optimizer")
+                buf.copy_(src)
+                continue
+            if self.shard is None:
+                for n, _, o, k in self.layout:
+                    buf[o:o + k].copy_(src[n].reshape(-1))
+            else:                                         # every rank reads the whole file and keeps its slices
+                full = torch.zeros(self.total, dtype=torch.float32, device=buf.device)
+                for n, _, o, k in self.layout:
+                    full[o:o + k].copy_(src[n].reshape(-1))
+                for lo, hi, so in self.owned:
+                    buf[so:so + hi - lo].copy_(full[lo:hi])
+                del full
+        if self.shard is not None:                        # bf16 parameters of every slice from the file's masters (identical on all ranks)
+            for n, p, o, k in self.layout:
+                self.flat_p[o:o + k].copy_(sd["master"][n].reshape(-1).to(self.flat_p.device))
+            return
         self.flat_p.copy_(self.master.to(torch.bfloat16))

@@ -48,13 +48,16 @@ def save_checkpoint(path, model, trainer=None, epoch=0):
     resume path is broken.  Same file format for the weights -- a flat ``{name: tensor}`` dict that
     ``model.load_state_dict(sd, strict=False)`` consumes -- plus, optionally, a side file with the fp32 optimizer state
     and the scheduler position so a run can actually resume."""
+    import torch.distributed as dist
+    rank0 = not dist.is_initialized() or dist.get_rank() == 0
     sd = {k: v.detach().to("cpu") for k, v in get_checkpoint(model).items()}
-    torch.save(sd, path)
-    if trainer is not None:
-        o = trainer.opt.state_dict()
-        torch.save({"epoch": epoch, "sched_step": trainer.sched_step,
-                    "optimizer": {k: (v.detach().to("cpu") if torch.is_tensor(v) else v) for k, v in o.items()}},
-                   path + ".resume")
+    o = trainer.opt.state_dict() if trainer is not None else None      # a collective when the optimizer state is sharded: every rank calls
+    if rank0:                                                          # replicas hold identical weights: one writer
+        torch.save(sd, path)
+        if o is not None:
+            torch.save({"epoch": epoch, "sched_step": trainer.sched_step, "optimizer": o}, path + ".resume")
+    if dist.is_initialized():
+        dist.barrier()
 
 
 def load_checkpoint(path, model, trainer=None):
