@@ -100,8 +100,8 @@ def test_kernel_register_budgets():
     hot = {k: r for k, r in a2.items() if ("fwd2_kernelILi80ELi4ELb0" in k or "fwd2_kernelILi64ELi5ELb0" in k or "dq2_kernelILi80ELb0" in k)}
     assert len(hot) == 3, sorted(a2)
     for k, r in hot.items():
-        if "dq2" in k:       # 70 KiB of LDS (three images per tile) hold dQ at two workgroups per CU; registers must not lower that
-            assert r["ScratchSize"] == 0 and r["VGPRs"] + r.get("AGPRs", 0) <= 256 and r["Occupancy"] >= 2, (k, r)
+        if "dq2" in k:       # 44 KiB of LDS (K-row and V-row images, two stages): three workgroups per CU, three waves per SIMD
+            assert r["ScratchSize"] == 0 and r["VGPRs"] + r.get("AGPRs", 0) <= 168 and r["Occupancy"] >= 3, (k, r)
         else:
             assert r["ScratchSize"] == 0 and r["VGPRs"] + r.get("AGPRs", 0) <= 168 and r["Occupancy"] >= 3, (k, r)
     for k, r in a2.items():

@@ -357,13 +357,18 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd2_kernel(AttnP p, int row_bas
 template <int NIMG> struct A2Img { int first[NIMG + 1]; int pitch[NIMG]; int lds[NIMG]; };
 
 // ------------------------------------------------------------------------------------------- dQ
-// wave = 32 query rows (Q, dO fragments, lse, delta in registers); per 64-key tile: images K-row, K-tr, V-row.
+// wave = 32 query rows (Q, dO fragments, lse, delta in registers); per 64-key tile: images K-row, V-row.
 template <int D, bool ALIBI>
 __global__ __launch_bounds__(256) void attn_dq2_kernel(AttnP p, int nx) {
   using C = A2Cfg<D>;
-  constexpr int CPR = C::CPR, PK = C::PK, PV = C::PV, KS = C::KS, ND = C::ND;
-  constexpr int NW = 4, NI = PK + PV + PK, NT = (NI + NW - 1) / NW;
-  constexpr int OFF_KT = 64 * PK * 16, OFF_V = OFF_KT + 64 * PV * 16, STAGE = OFF_V + 64 * PK * 16;
+  constexpr int CPR = C::CPR, PK = C::PK, KS = C::KS, ND = C::ND;
+  // Two images per tile, K-row and V-row (odd pitch PK: conflict-free ds_read_b128 row reads for S and dP).  The dQ product
+  // reads K TRANSPOSED from the same row image: at the odd pitch the ds_read_b64_tr_b16 half-waves overlap on a few banks
+  // (~1.5x on a third of the LDS reads of a kernel whose LDS pipe is 5-7 % busy), but without a third, transposed-pitch image
+  // a stage is 22.5 KiB instead of 35: three workgroups per CU instead of two and a third less DMA -- measured -18 % on this
+  // kernel (LM shape 0.34 -> 0.28 ms, MPT hd 128 -18 % on the whole backward).
+  constexpr int NW = 4, NI = PK + PK, NT = (NI + NW - 1) / NW;
+  constexpr int OFF_KT = 0, OFF_V = 64 * PK * 16, STAGE = OFF_V + 64 * PK * 16, PT = PK;
   __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
   int bx, h, b;
   a2_decode(nx, p.H, p.B, bx, h, b);
@@ -389,9 +394,9 @@ __global__ __launch_bounds__(256) void attn_dq2_kernel(AttnP p, int nx) {
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     int i = wave + NW * t;
-    int img = i < PK ? 0 : (i < PK + PV ? 1 : 2);
-    int ii = i - (img == 0 ? 0 : (img == 1 ? PK : PK + PV));
-    int pitch = img == 1 ? PV : PK;
+    int img = i < PK ? 0 : 2;
+    int ii = i - (img == 0 ? 0 : PK);
+    int pitch = PK;
     int s_ = 64 * ii + l;
     int row = s_ / pitch, cs = s_ - row * pitch;
     d_row[t] = row;
@@ -407,11 +412,11 @@ __global__ __launch_bounds__(256) void attn_dq2_kernel(AttnP p, int nx) {
     for (int t = 0; t < NT; ++t) {
       int i = wave + NW * t;
       if (i < NI) {
-        int img = i < PK ? 0 : (i < PK + PV ? 1 : 2);
-        int ii = i - (img == 0 ? 0 : (img == 1 ? PK : PK + PV));
+        int img = i < PK ? 0 : 2;
+        int ii = i - (img == 0 ? 0 : PK);
         int rc = min(d_row[t], rows_left - 1);
         uint32_t off = (uint32_t)(rc * (img == 2 ? v_sb : k_sb)) + d_col[t];
-        uint32_t dst = smem_lds + stage * STAGE + (img == 0 ? 0 : (img == 1 ? OFF_KT : OFF_V)) + ii * 1024;
+        uint32_t dst = smem_lds + stage * STAGE + (img == 0 ? 0 : OFF_V) + ii * 1024;
         a2_glds(img == 2 ? vt_base : kt_base, off, __builtin_amdgcn_readfirstlane(dst));
       }
     }
@@ -462,7 +467,7 @@ __global__ __launch_bounds__(256) void attn_dq2_kernel(AttnP p, int nx) {
   __syncthreads();
   const int k_rd = (ql * PK + hi5) * 16;
   const int g16 = (l >> 4) & 1, i16 = l & 15;
-  const int t_rd = ((4 * hi5 + (i16 >> 2)) * PV) * 16 + (16 * g16 + 4 * (i16 & 3)) * 2;
+  const int t_rd = ((4 * hi5 + (i16 >> 2)) * PT) * 16 + (16 * g16 + 4 * (i16 & 3)) * 2;
 
   for (int kt = kt_lo; kt < kt_hi; ++kt) {
     const int st = (kt - kt_lo) & 1;
@@ -498,9 +503,9 @@ __global__ __launch_bounds__(256) void attn_dq2_kernel(AttnP p, int nx) {
         for (int nd = 0; nd < ND; ++nd)
 #pragma unroll
           for (int half = 0; half < 2; ++half) {
-            const char* a = sb + OFF_KT + t_rd + (kb2 * 32 + half * 16) * PV * 16 + nd * 64;
+            const char* a = sb + OFF_KT + t_rd + (kb2 * 32 + half * 16) * PT * 16 + nd * 64;
             s16x4 tlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a));
-            s16x4 thi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a + 8 * PV * 16));
+            s16x4 thi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, a + 8 * PT * 16));
             union { struct { s16x4 a, b; } s; bf16x8 v; } u;
             u.s.a = tlo; u.s.b = thi;
             dq[nd] = MFMA32(u.v, dsf[half], dq[nd]);
