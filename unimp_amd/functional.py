@@ -608,34 +608,38 @@ class GatedXAttnFn(Function):
         kv = ops.gemm(m2, wkv)
         kv5 = kv.view(B, Sk, 2, heads, dh)
         o, lse = ops.attn_fwd(q.view(B, L, heads, dh), kv5[:, :, 0], kv5[:, :, 1], dh ** -0.5, ops.MASK_SEGMENT, None, seg, n_lat)
-        raw = torch.empty_like(x2)
-        out = ops.gemm(o.view(B * L, inner), wo, gate=gate, res=x2, pre=raw)
-        ctx.save_for_backward(x2, m2, seg, ln_w, mean, rstd, wq, wkv, wo, gate, h, q, kv, o, lse, raw)
+        out = ops.gemm(o.view(B * L, inner), wo, gate=gate, res=x2)
+        ctx.save_for_backward(x2, m2, seg, ln_w, mean, rstd, wq, wkv, wo, gate, h, q, kv, o, lse)
         ctx.cfg = (B, L, D, Sk, heads, dh, n_lat)
         ctx.ln_b_ref = ln_b
         return out.view(B, L, D)
 
     @staticmethod
     def backward(ctx, dy):
-        x2, m2, seg, ln_w, mean, rstd, wq, wkv, wo, gate, h, q, kv, o, lse, raw = ctx.saved_tensors
+        x2, m2, seg, ln_w, mean, rstd, wq, wkv, wo, gate, h, q, kv, o, lse = ctx.saved_tensors
         B, L, D, Sk, heads, dh, n_lat = ctx.cfg
         inner = heads * dh
         dy2 = dy.reshape(B * L, D)
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
-        dgate = _gate_grad(dy2, raw, gate) if _need(ctx, 8) else None
         o2 = o.view(B * L, inner)
-        do = ops.gemm(dy2, wo, b_ks=True, gate=gate).view(B, L, heads, dh)
+        # do is kept UN-gated: d/d gate of tanh(gate) * (o Wo^T) contracted with dy is <dy Wo, o> -- a dot over [B L, inner] instead
+        # of one over dy and a saved copy of the un-gated block output (both [B L, D], D = 5 inner: the copy and its store in the
+        # forward's epilogue are gone) -- and everything downstream of do is linear in it, so tanh(gate) moves into the epilogues
+        # of the four GEMMs that consume dq / dkv (0 at initialisation there exactly as it was here)
+        do2 = ops.gemm(dy2, wo, b_ks=True)
+        dgate = _gate_grad(do2, o2, gate) if _need(ctx, 8) else None
+        do = do2.view(B, L, heads, dh)
         dwo = _dw(ctx, 7, wo, dy2, o2, gate=gate)
         dq = torch.empty_like(q)
         dkv = torch.empty_like(kv)
         kv5, dkv5 = kv.view(B, Sk, 2, heads, dh), dkv.view(B, Sk, 2, heads, dh)
         ops.attn_bwd(q.view(B, L, heads, dh), kv5[:, :, 0], kv5[:, :, 1], o, lse, do, dq.view(B, L, heads, dh),
                      dkv5[:, :, 0], dkv5[:, :, 1], dh ** -0.5, ops.MASK_SEGMENT, None, seg, n_lat)
-        dwq = _dw(ctx, 5, wq, dq, h)
-        dh_ = ops.gemm(dq, wq, b_ks=True)
-        dwkv = _dw(ctx, 6, wkv, dkv, m2)
-        dmedia = ops.gemm(dkv, wkv, b_ks=True).view(B, Sk, -1) if _need(ctx, 1) else None
+        dwq = _dw(ctx, 5, wq, dq, h, gate=gate)
+        dh_ = ops.gemm(dq, wq, b_ks=True, gate=gate)
+        dwkv = _dw(ctx, 6, wkv, dkv, m2, gate=gate)
+        dmedia = ops.gemm(dkv, wkv, b_ks=True, gate=gate).view(B, Sk, -1) if _need(ctx, 1) else None
         dx, dg, db = _ln_bwd(dh_, x2, ln_w, ctx.ln_b_ref, mean, rstd, _need(ctx, 3), _need(ctx, 4), dres=dy2)
         return dx.view(B, L, D), dmedia, None, dg, db, dwq, dwkv, dwo, dgate, None, None, None
 
