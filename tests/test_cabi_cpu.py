@@ -90,11 +90,13 @@ def test_kernel_register_budgets():
     vg_a = vg + ("-fno-slp-vectorize",)             # the Makefile's flags for the attention kernels
     at = remarks("attention.hip", vg_a)
     plain = {k: r for k, r in at.items() if "Li96ELi80ELb0" in k}
-    assert len(plain) == 3
+    assert len(plain) == 4                                      # forward, dQ, dK/dV with 16 and with 32 keys per wave
     for k, r in plain.items():
         assert r["ScratchSize"] == 0, (k, r)
         if "attn_dq" not in k:                                  # dQ holds two 32-row blocks of q, dO, dq: one wave per SIMD by design
             assert r["Occupancy"] >= 2, (k, r)
+        if "attn_dkv" in k and k.endswith("Li1EEv5AttnPi"):     # the default dK/dV form lives on its third wave per SIMD
+            assert r["Occupancy"] >= 3 and r["VGPRs"] + r.get("AGPRs", 0) <= 168, (k, r)
     # second-generation attention (the default forward and dQ): three waves per SIMD at head dim 80 / 64 is what the design buys
     a2 = remarks("attention2.hip", vg_a)
     hot = {k: r for k, r in a2.items() if ("fwd2_kernelILi80ELi4ELb0" in k or "fwd2_kernelILi64ELi5ELb0" in k or "dq2_kernelILi80ELb0" in k)}

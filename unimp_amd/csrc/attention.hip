@@ -440,10 +440,11 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(AttnP p) {
 }
 
 // ------------------------------------------------------------------------------------------- dK, dV
-// block = 128 keys: each wave owns 32 keys (two 16-key blocks whose K / V fragments live in registers) and sweeps the
+// block = 64 * KU keys: each wave owns 16 * KU keys (KU 16-key blocks whose K / V fragments live in registers) and sweeps the
 // query tiles (32 rows, double-buffered Q / dO images + per-row lse / delta / key range); P and dS stay in registers.
-template <int DQK, int DV, bool ALIBI>
+template <int DQK, int DV, bool ALIBI, int KU = 2>
 __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p, int nx) {
+  constexpr int KPW = 16 * KU, KPB = 4 * KPW;               // keys per wave (KU blocks of 16) and per workgroup
   constexpr int STR = DQK * 2 + 16, NKS = DQK / 32, ND = DV / 16;
   constexpr int STAGE = 2 * 32 * STR + 32 * 16 + 16;
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
@@ -453,15 +454,15 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p, int nx) {
   int kblk = id_ % nx, t_ = id_ / nx;
   int h = t_ % p.H, b = t_ / p.H;
   int wave = threadIdx.x >> 6, l = lane_id(), g = l >> 4;
-  int key0 = kblk * 128 + wave * 32;
+  int key0 = kblk * KPB + wave * KPW;
   const bf16* qb = p.q + b * p.q_bs + h * p.q_hs;
   const bf16* kb = p.k + b * p.k_bs + h * p.k_hs;
   const bf16* vb = p.v + b * p.v_bs + h * p.v_hs;
   const bf16* dob = p.d_o + b * p.do_bs + h * p.do_hs;
-  bf16x8 kf[2][NKS], vf[2][NKS];
-  f32x4 dk[2][ND], dv[2][ND];
+  bf16x8 kf[KU][NKS], vf[KU][NKS];
+  f32x4 dk[KU][ND], dv[KU][ND];
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
+  for (int u = 0; u < KU; ++u) {
     int key = key0 + u * 16 + (l & 15);
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) { kf[u][ks] = gfrag(kb, p.k_ss, key, p.Sk, ks, p.D); vf[u][ks] = gfrag(vb, p.v_ss, key, p.Sk, ks, p.D); }
@@ -471,7 +472,7 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p, int nx) {
   float sc2 = p.scale * LOG2E;
   const float ab = ALIBI ? p.alibi[h] / p.scale : 0.f;
   int nqt = (p.Sq + 31) >> 5;
-  int kfirst = kblk * 128, klast = kblk * 128 + 127;
+  int kfirst = kblk * KPB, klast = kblk * KPB + KPB - 1;
   // block-uniform list of query tiles that can see this key block: [qt_a, qt_b)
   int qt_a = 0, qt_b = nqt;
   if (p.mask_mode == UNIMP_MASK_CAUSAL) qt_a = kfirst >> 5;
@@ -519,19 +520,19 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p, int nx) {
       rdo.g2r(dob + (long)(qt + 1) * 32 * p.do_ss, p.Sq - (qt + 1) * 32);
     }
     if (key0 < p.Sk) {
-    f32x4 s[2][2], dp[2][2];              // [key block u][query block qb2]: lane holds S[q = 16*qb2 + 4g + r][key = l&15]
+    f32x4 s[KU][2], dp[KU][2];              // [key block u][query block qb2]: lane holds S[q = 16*qb2 + 4g + r][key = l&15]
 #pragma unroll
     for (int qb2 = 0; qb2 < 2; ++qb2) {
 #pragma unroll
-      for (int u = 0; u < 2; ++u) { s[u][qb2] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[u][qb2] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      for (int u = 0; u < KU; ++u) { s[u][qb2] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[u][qb2] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
         bf16x8 qf_ = lfrag_kc<STR>(qs_t, qb2 * 16, ks), dof_ = lfrag_kc<STR>(dos_t, qb2 * 16, ks);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) { s[u][qb2] = MFMA16(qf_, kf[u][ks], s[u][qb2]); dp[u][qb2] = MFMA16(dof_, vf[u][ks], dp[u][qb2]); }
+        for (int u = 0; u < KU; ++u) { s[u][qb2] = MFMA16(qf_, kf[u][ks], s[u][qb2]); dp[u][qb2] = MFMA16(dof_, vf[u][ks], dp[u][qb2]); }
       }
     }
-    bf16x8 pf[2], dsf[2];
+    bf16x8 pf[KU], dsf[KU];
     float lse_r[2][4], dl_r[2][4];
 #pragma unroll
     for (int qb2 = 0; qb2 < 2; ++qb2) {
@@ -541,7 +542,7 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p, int nx) {
     }
     bool all_visible = st_lo[64] != 0;        // word 128 of the aux block
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < KU; ++u) {
       int key = key0 + u * 16 + (l & 15);
       if (ALIBI) {
         float kb = ab * (float)key;
@@ -576,7 +577,7 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p, int nx) {
     for (int nd = 0; nd < ND; ++nd) {
       bf16x8 dot_f = lfrag_tr_perm<STR>(dos_t, 0, nd * 16), qt_f = lfrag_tr_perm<STR>(qs_t, 0, nd * 16);
 #pragma unroll
-      for (int u = 0; u < 2; ++u) { dv[u][nd] = MFMA16(dot_f, pf[u], dv[u][nd]); dk[u][nd] = MFMA16(qt_f, dsf[u], dk[u][nd]); }
+      for (int u = 0; u < KU; ++u) { dv[u][nd] = MFMA16(dot_f, pf[u], dv[u][nd]); dk[u][nd] = MFMA16(qt_f, dsf[u], dk[u][nd]); }
     }
     }
     if (more) {
@@ -590,8 +591,8 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p, int nx) {
   // block u, 4 consecutive d) -> whole 16-byte chunks of consecutive key rows; 8-byte stores straight from the accumulators
   // touched 16 different rows per instruction (store-issue bound: ~80 us of this kernel at the LM shape)
   constexpr int EP = DV * 2 + 16, ECPR = DV / 8;
-  static_assert(4 * 32 * EP <= 2 * STAGE, "epilogue staging fits");
-  char* ew = smem + wave * (32 * EP);
+  static_assert(4 * KPW * EP <= 2 * STAGE, "epilogue staging fits");
+  char* ew = smem + wave * (KPW * EP);
   const bool wide = !((p.dk_bs | p.dk_ss | p.dk_hs | p.dv_bs | p.dv_ss | p.dv_hs) & 7) && !(((uintptr_t)p.dk | (uintptr_t)p.dv) & 15);
 #pragma unroll
   for (int which = 0; which < 2; ++which) {
@@ -599,7 +600,7 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p, int nx) {
     long gs = which ? p.dv_ss : p.dk_ss;
     if (wide) {
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+      for (int u = 0; u < KU; ++u)
 #pragma unroll
         for (int nd = 0; nd < ND; ++nd) {
           const f32x4& a = which ? dv[u][nd] : dk[u][nd];
@@ -608,20 +609,20 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p, int nx) {
         }
       __builtin_amdgcn_s_waitcnt(0xc07f);
       __builtin_amdgcn_wave_barrier();
-      constexpr int NCH = (32 * ECPR + 63) / 64;
+      constexpr int NCH = (KPW * ECPR + 63) / 64;
       if (which == 0 && p.rope_step != 0.f) {                // adjacent-pair layout: no tables, no partner chunk
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
           int id = l + 64 * i;
           int r = id / ECPR, c = id - r * ECPR;
-          if (id < 32 * ECPR && key0 + r < p.Sk)
+          if (id < KPW * ECPR && key0 + r < p.Sk)
             *(u32x4*)(gb + (long)(key0 + r) * gs + c * 8) = attn_rope_inv_adjacent(ew + r * EP, c, p.rope_half, (float)(key0 + r), p.rope_step);
         }
       } else if (which == 0 && p.rope_cos) {                  // dk leaves rotated back (attention_params.h): all table loads first
         AttnRopeChunk ch[NCH];
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-          int id = min(l + 64 * i, 32 * ECPR - 1);
+          int id = min(l + 64 * i, KPW * ECPR - 1);
           int r = id / ECPR, c = id - r * ECPR;
           long pos = min(key0 + r, p.Sk - 1);
           attn_rope_inv_load(ch[i], ew + r * EP, c, p.rope_half, p.rope_cos + pos * p.rope_half, p.rope_sin + pos * p.rope_half);
@@ -631,21 +632,21 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p, int nx) {
           int id = l + 64 * i;
           int r = id / ECPR, c = id - r * ECPR;
           u32x4 v = attn_rope_inv_apply(ch[i]);
-          if (id < 32 * ECPR && key0 + r < p.Sk) *(u32x4*)(gb + (long)(key0 + r) * gs + c * 8) = v;
+          if (id < KPW * ECPR && key0 + r < p.Sk) *(u32x4*)(gb + (long)(key0 + r) * gs + c * 8) = v;
         }
       } else {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
           int id = l + 64 * i;
           int r = id / ECPR, c = id - r * ECPR;
-          if (id < 32 * ECPR && key0 + r < p.Sk) *(u32x4*)(gb + (long)(key0 + r) * gs + c * 8) = *(const u32x4*)(ew + r * EP + c * 16);
+          if (id < KPW * ECPR && key0 + r < p.Sk) *(u32x4*)(gb + (long)(key0 + r) * gs + c * 8) = *(const u32x4*)(ew + r * EP + c * 16);
         }
       }
       __builtin_amdgcn_s_waitcnt(0xc07f);
       __builtin_amdgcn_wave_barrier();
     } else {
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+      for (int u = 0; u < KU; ++u) {
         int key = key0 + u * 16 + (l & 15);
         if (key < p.Sk)
 #pragma unroll
@@ -743,13 +744,22 @@ extern "C" int unimp_attn_bwd(const unimp_attn_desc* d, void* stream) {
   // delta = rowsum(dO * O): the second-generation dQ kernel computes and publishes it itself
   if (!(which2 & 1)) hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((n * 16 + 255) / 256)), dim3(256), 0, s, p);
   if (which2) { int e2 = unimp_attn_bwd2_dispatch(p, which2, stream); if (e2) return e2; }
-  const int nkb = (p.Sk + 127) / 128;
+  // dK/dV: 16 keys per wave (KU = 1, 64-key workgroups; default) or 32 (KU = 2, 128-key workgroups; UNIMP_DKV_KU=2).  With 32 the
+  // kernel held 248 registers at head dim 80 (dK^T, dV^T accumulators and the K / V fragments of two 16-key blocks): two waves
+  // per SIMD, 55 % of wave time in waits.  With 16 it holds 166: a third wave per SIMD (hd 64: four; hd 128: two instead of one
+  // and no spill into the AGPRs) for twice the Q / dO fragment reads per product, on an LDS pipe that was 14 % busy: LM shape
+  // backward 0.767 -> 0.704 ms per layer, gated cross-attention -27 %, MPT hd 128 -21 %.
+  static const int ku = [] { const char* e = getenv("UNIMP_DKV_KU"); int v = e ? atoi(e) : 1; return v == 2 ? 2 : 1; }();
+  const int nkb = (p.Sk + 64 * ku - 1) / (64 * ku);
   dim3 gq((p.Sq + 127) / 128, p.H, p.B), gk(nkb * p.H * p.B), block(256);
+#define DKV(DQ_, DV_, A_) do { if (ku == 1) hipLaunchKernelGGL((attn_dkv_kernel<DQ_, DV_, A_, 1>), gk, block, 0, s, p, nkb);          \
+                               else hipLaunchKernelGGL((attn_dkv_kernel<DQ_, DV_, A_, 2>), gk, block, 0, s, p, nkb); } while (0)
 #define BWD(A_) do {                                                                                                   \
-    if (p.D == 64) { if (!(which2 & 1)) hipLaunchKernelGGL((attn_dq_kernel<64, 64, A_>), gq, block, 0, s, p); if (!(which2 & 2)) hipLaunchKernelGGL((attn_dkv_kernel<64, 64, A_>), gk, block, 0, s, p, nkb); }            \
-    else if (p.D == 80) { if (!(which2 & 1)) hipLaunchKernelGGL((attn_dq_kernel<96, 80, A_>), gq, block, 0, s, p); if (!(which2 & 2)) hipLaunchKernelGGL((attn_dkv_kernel<96, 80, A_>), gk, block, 0, s, p, nkb); }       \
-    else { if (!(which2 & 1)) hipLaunchKernelGGL((attn_dq_kernel<128, 128, A_>), gq, block, 0, s, p); if (!(which2 & 2)) hipLaunchKernelGGL((attn_dkv_kernel<128, 128, A_>), gk, block, 0, s, p, nkb); } } while (0)
+    if (p.D == 64) { if (!(which2 & 1)) hipLaunchKernelGGL((attn_dq_kernel<64, 64, A_>), gq, block, 0, s, p); if (!(which2 & 2)) DKV(64, 64, A_); }            \
+    else if (p.D == 80) { if (!(which2 & 1)) hipLaunchKernelGGL((attn_dq_kernel<96, 80, A_>), gq, block, 0, s, p); if (!(which2 & 2)) DKV(96, 80, A_); }       \
+    else { if (!(which2 & 1)) hipLaunchKernelGGL((attn_dq_kernel<128, 128, A_>), gq, block, 0, s, p); if (!(which2 & 2)) DKV(128, 128, A_); } } while (0)
   if (p.alibi) BWD(true); else BWD(false);
 #undef BWD
+#undef DKV
   return unimp_check_launch("attn_bwd");
 }
