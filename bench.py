@@ -2,7 +2,7 @@
 """Throughput of UniMP's Flamingo train step (cfg2: 4b-instruct = ViT-L/14 + GPT-NeoX-3B, xattn every 2 layers,
 T=8 history images 224x224, L=512, V=74 053, bf16) on N MI355X, one process per GPU.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without WORLD_SIZE: starts its own N rank processes)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A step = one full optimizer step over one synthetic batch already resident in HBM: label mask -> ViT (no grad) ->
@@ -144,6 +144,23 @@ def cpu_baseline(T, L, layout, fps, full_steps=2):
     return out
 
 
+def _launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher's environment: this process makes NO GPU call (importing torch and
+    counting devices does not initialise HIP), starts N fresh rank processes under torch.distributed.run on 127.0.0.1, lets
+    rank 0's JSON line through on the inherited stdout and exits with the launcher's code (non-zero if any rank failed)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "4"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -168,8 +185,13 @@ def main():
                     "with E8M0 block scales quantised once, activations quantised on the fly (BASELINE config 5; NOT the headline bf16 configuration)")
     ap.add_argument("--sparse-head", action="store_true", help="Trainer(sparse_head=True): head + loss on the labeled rows only "
                     "(same loss / gradients; NOT the default and not the headline configuration)")
+    ap.add_argument("--dp-hooks", action="store_true", help="N = 1 only: a 1-rank RCCL process group with the data-parallel hooks forced on -- "
+                    "the N > 1 code path (bucketed async all-reduce from the autograd hooks, stream hand-off, finish()) on one GPU")
+    ap.add_argument("--bucket-mb", type=int, default=256, help="gradient bucket size of the data-parallel exchange (MiB)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(_launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", 1))
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -186,6 +208,13 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    dp_on = world > 1 or args.dp_hooks
+    if args.dp_hooks and world == 1:
+        import socket
+        s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port_ = s_.getsockname()[1]; s_.close()
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend, init_method=f"tcp://127.0.0.1:{port_}", rank=0, world_size=1,
+                                **({"device_id": dev} if backend == "nccl" else {}))
 
     from unimp_amd import ops
     from unimp_amd import functional as F_
@@ -201,8 +230,9 @@ def main():
     trainer = Trainer(model, layout.special(), lr=2e-4, weight_decay=0.1, gamma=2.0, use_reweight=True,
                       lr_scheduler="cosine", warmup_steps=10, total_steps=10000, sparse_head=args.sparse_head,
                       grad_accum=args.grad_accum, dense_head_backward=args.dense_head_backward,
-                      shard_optimizer=args.shard_optimizer and world > 1)
-    trainer.dp.record_exposed = world > 1
+                      shard_optimizer=args.shard_optimizer and dp_on, bucket_bytes=args.bucket_mb << 20,
+                      force_dp_hooks=args.dp_hooks)
+    trainer.dp.record_exposed = dp_on
     n_train = sum(p.numel() for p in model.parameters() if p.requires_grad)
     T, L, B, GA = args.images, args.seq, args.batch, args.grad_accum
     # a pool of DIFFERENT seeded batches, staged in HBM before the timed region: every micro-step consumes a fresh one (the
@@ -250,13 +280,16 @@ def main():
         dt = t.item()
     ms = dt / args.steps * 1e3
     value = GA * B * world * args.steps / dt          # mmrec.py:267-272: GA x batch x world / step time
-    exposed = trainer.dp.exposed_ms() if world > 1 else []
+    exposed = trainer.dp.exposed_ms() if dp_on else []
     rccl = None
-    if world > 1:
+    if dp_on:
         rccl = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "buckets": len(trainer.dp.buckets),
                 "optimizer_state": "sharded (reduce-scatter + all-gather)" if trainer.opt.shard else "replicated (all-reduce)",
-                "bucket_bytes": [int((b[1] - b[0]) * 2) for b in trainer.dp.buckets][:4],
+                "bucket_bytes": [int((b[1] - b[0]) * 2) for b in trainer.dp.buckets],
+                "issue_order": list(trainer.dp.last_launch_log),
+                "wire_bytes_per_step": int(sum((b[1] - b[0]) * 2 for b in trainer.dp.buckets)),
                 "exposed_allreduce_ms_per_step": round(sum(exposed) / max(1, len(exposed)), 3),
+                "samples_per_s_per_gpu": round(value / world, 3),
                 "note": "exposed = time the compute stream waits in GradBucketer.finish() for collectives that backward did not hide (HIP events)"}
 
     if rank == 0:
@@ -330,7 +363,7 @@ def main():
                               if args.sparse_head else {})},
                 "roofline": roofline, "cpu_baseline": cpu, **({"rccl": rccl} if rccl else {})}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -121,6 +121,56 @@ def _worker_late(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _worker_order(rank, world, port, q):
+    """issue order = expected completion in backward, not flat index: the flat layout is [decay | no-decay], each half
+    in reverse registration order, so the no-decay half's first bucket (the LM head: registered last, finished first) must lead and
+    a ready bucket must not wait for a bucket that completes later."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from unimp_amd.dp import GradBucketer
+    torch.manual_seed(0)
+    # registration order r0..r5 (forward order); decay group = r1, r3 ; no-decay = r0 (embedding), r2, r4, r5 (head)
+    reg = [torch.nn.Parameter(torch.randn(2048).to(torch.bfloat16)) for _ in range(6)]
+    flat = [("r3", reg[3]), ("r1", reg[1]), ("r5", reg[5]), ("r4", reg[4]), ("r2", reg[2]), ("r0", reg[0])]
+    opt = _FakeOpt(flat)
+    opt.reg_index = {id(p): i for i, p in enumerate(reg)}
+    dp = GradBucketer(opt, bucket_bytes=4096)
+    assert len(dp.buckets) == 6
+    assert dp._order == [2, 3, 0, 4, 1, 5]                       # r5, r4, r3, r2, r1, r0
+    x = torch.full((), float(rank + 1))
+    seen = {}
+    hooks = [p.register_post_accumulate_grad_hook(lambda p_, i=i: (seen.setdefault(i, list(dp.launch_log)), None)[1]) for i, p in enumerate(reg)]
+    h = x
+    loss = 0
+    for i, p in enumerate(reg):                                   # a chain: backward reaches r5 first, r0 last
+        h = (p.float() * h).sum() * 1e-3
+        loss = loss + h
+    loss.backward()
+    dp.finish()
+    for hk in hooks:
+        hk.remove()
+    assert dp.last_launch_log == dp._order
+    assert seen[3][:2] == [2, 3], seen                            # when r3's hook (registered after the bucketer's) runs, r5 and r4 are out
+    logs = [None] * world
+    dist.all_gather_object(logs, dp.last_launch_log)
+    assert logs[0] == logs[1]
+    q.put((rank, "ok"))
+    dist.destroy_process_group()
+
+
+def test_issue_order_follows_backward_completion_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_order, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert sorted(q.get(timeout=5) for _ in range(world)) == [(0, "ok"), (1, "ok")]
+
+
 def test_late_bucket_goes_last_world2():
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")

@@ -112,7 +112,7 @@ def _worker_rccl(q, port):
         assert tr.dp.active and tr.dp.world == 1 and len(tr.dp.buckets) > 3
         tr.dp.record_exposed = True
         losses = [tr.step(b)[0].item() for b in batches]
-        assert tr.dp.last_launch_log == sorted(tr.dp.last_launch_log) and len(tr.dp.last_launch_log) == len(tr.dp.buckets)
+        assert tr.dp.last_launch_log == tr.dp._order + tr.dp._late_buckets and len(tr.dp.last_launch_log) == len(tr.dp.buckets)
         exposed = tr.dp.exposed_ms()
         assert len(exposed) == 3 and all(e >= 0 for e in exposed)
         # a sum over one rank is the identity: the same steps without any collective give the same bits

@@ -75,6 +75,8 @@ _SIGS = {
     "unimp_image_resize_normalize": [c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_p],
 }
 
+ABI_VERSION = 3          # must equal UNIMP_ABI_VERSION of include/unimp_hip.h the library was built from
+
 _lib = None
 
 
@@ -99,8 +101,15 @@ def lib():
         for name, args in _SIGS.items():
             fn = getattr(L, name)
             fn.argtypes, fn.restype = args, c_i
-        if L.unimp_abi_version() != 1:
-            raise ImportError("libunimp_hip.so ABI version mismatch")
+        if L.unimp_abi_version() != ABI_VERSION:
+            raise ImportError(f"{LIB_PATH}: ABI version {L.unimp_abi_version()}, this package binds version {ABI_VERSION} -- a stale build; "
+                              "rebuild with `make -C unimp_amd/csrc`")
+        # the descriptors are passed by pointer: a layout the library and these ctypes mirrors disagree on would bind silently
+        L.unimp_struct_size.restype, L.unimp_struct_size.argtypes = c_i, [c_i]
+        for which, st in ((0, GemmDesc), (1, AttnDesc), (3, MxGemmDesc)):
+            if L.unimp_struct_size(which) != C.sizeof(st):
+                raise ImportError(f"{LIB_PATH}: sizeof descriptor {which} is {L.unimp_struct_size(which)} in the library, "
+                                  f"{C.sizeof(st)} in {st.__name__} -- stale build")
         _lib = L
     return _lib
 

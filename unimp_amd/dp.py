@@ -2,9 +2,12 @@
 while backward is still running (replaces accelerate/DeepSpeed ZeRO-2 reduce-scatter, UniMP/mmrec.py:175,215,706-721).
 
 One process per GPU; gradients live in FlatAdamW's contiguous bf16 buffer, so a bucket is a slice of it.
-Buckets are cut in flat order (= reverse execution order, see optim.py); a bucket becomes READY when the last of its
-parameters has accumulated its gradient, and ready buckets are issued (async, on the communication stream RCCL owns)
-**strictly in bucket-index order**: bucket i goes out only after buckets 0..i-1 have.  Every rank therefore issues the
+Buckets are cut in flat order ([decay group | no-decay group], each in reverse execution order, see optim.py); a bucket
+becomes READY when the last of its parameters has accumulated its gradient, and ready buckets are issued (async, on the
+communication stream RCCL owns) **strictly in one static order**: by expected completion in backward, i.e. by the
+registration index of the bucket's EARLIEST-registered parameter, latest first (the LM head's bucket, which backward
+finishes first, leads although it sits in the no-decay half of the flat buffer; the Perceiver / input-embedding buckets
+close).  A bucket goes out only after all its predecessors in that order have.  Every rank therefore issues the
 same sequence of collectives whatever its autograd order or a parameter without a gradient on one rank does (RCCL, like
 NCCL, pairs collectives by issue order; a bucket that never completes on some rank simply holds the later ones back until
 finish(), on that rank only).  Buckets holding a ``late_params`` entry (a tied embedding / head: its first accumulation is
@@ -58,7 +61,15 @@ class GradBucketer:
                 self.param_bucket[id(p)] = len(self.buckets) - 1
                 self._slot[id(p)] = (o, k)
         self._late_buckets = sorted({self.param_bucket[i] for i in self._late if i in self.param_bucket})
-        self._order = [bi for bi in range(len(self.buckets)) if bi not in self._late_buckets]     # issue order during backward
+        # static issue order during backward: expected completion = the bucket's earliest-registered parameter, latest first
+        reg = getattr(optimizer, "reg_index", None) or {}
+        first = [None] * len(self.buckets)
+        for n, p, o, k in optimizer.layout:
+            bi, r = self.param_bucket[id(p)], reg.get(id(p), 0)
+            first[bi] = r if first[bi] is None else min(first[bi], r)
+        self._order = sorted((bi for bi in range(len(self.buckets)) if bi not in self._late_buckets),
+                             key=lambda bi: (-(first[bi] or 0), bi))
+        self.last_launch_log = []
         self._reset()
         self._hooks = []
         self.sync = True          # False: gradient-accumulation micro-step, gradients only add up locally (accelerate's no_sync)

@@ -206,14 +206,21 @@ TAIL_SPLIT = os.environ.get("UNIMP_GEMM_TAIL_SPLIT", "1") != "0"
 ROPE_VARIANTS = (4, 9)          # pp256 / pp256p: the kernels with a rotary-epilogue instantiation (gemm3.hip, gemm6.hip)
 
 
+ROPE_MIN_M = 1024               # rows from which the QKV projection takes the rotary epilogue
+
+
 def gemm_rope_variant(M, N, K, b_ks, device):
-    """the tuned variant for a plain-epilogue [M, N, K] GEMM if it is one that serves the rotary epilogue, else None"""
-    if M < 256 or N < 128 or N % 8 or M >= 1 << 24:
+    """variant that serves the rotary epilogue for an [M, N, K] QKV projection, or None.  Whether the rotation is FUSED is decided
+    on static criteria only (shape and layout) -- never on the autotune table or on timing: the fused epilogue computes cos / sin
+    on the fly (v_exp / v_sin / v_cos) where the separate pass reads the fp32 tables, so a table- or timing-dependent choice would
+    make a sample's bits depend on the box.  The table only picks WHICH of the two kernels with the same rotary
+    arithmetic runs (ping-pong or persistent ping-pong)."""
+    if M < ROPE_MIN_M or N < 128 or N % 8 or M >= 1 << 24:
         return None
     if b_ks:
         return None
     v = _tune_gemm(M, N, K, False, False, device, False)
-    return v if v in ROPE_VARIANTS else None
+    return v if v in ROPE_VARIANTS else 4
 
 
 def _splitk_count(M, N, K, tiles256):

@@ -53,6 +53,7 @@ class FlatAdamW:
             if id(p) not in seen:
                 seen.add(id(p))
                 uniq.append((n, p))
+        self.reg_index = {id(p): i for i, (n, p) in enumerate(uniq)}      # registration (~ forward execution) order, for dp.GradBucketer
         decay = [(n, p) for n, p in uniq if apply_decay(n)][::-1]
         nodecay = [(n, p) for n, p in uniq if not apply_decay(n)][::-1]
         self.lr, self.betas, self.eps, self.weight_decay, self.max_grad_norm = lr, betas, eps, weight_decay, max_grad_norm
@@ -202,16 +203,18 @@ class FlatAdamW:
                 full[s_:e_].copy_(torch.cat(parts))
         return full
 
-    def state_dict(self):
+    def state_dict(self, to_host=True):
         """{"step", "lr", "names", "master" / "m" / "v": {parameter name: fp32 tensor}} -- per parameter, so a state saved by a
         replicated optimizer loads into a sharded one and back, whatever the bucket padding.  With a sharded state this is a
-        COLLECTIVE (every rank gathers every slice, one state buffer at a time: a transient fp32 copy of the flat buffer)."""
+        COLLECTIVE (every rank gathers every slice, one state buffer at a time: a transient fp32 copy of the flat buffer);
+        ``to_host=False`` takes part in the gathers but builds no host copies (the ranks that do not write the file)."""
         out = {"step": self.step_count, "lr": self.lr, "names": [n for n, _, _, _ in self.layout]}
         for key, buf in (("master", self.master), ("m", self.m), ("v", self.v)):
             full = buf if self.shard is None else self._gather_state(buf)
-            out[key] = {n: full[o:o + k].detach().to("cpu", copy=True) for n, _, o, k in self.layout}
+            if to_host:
+                out[key] = {n: full[o:o + k].detach().to("cpu", copy=True) for n, _, o, k in self.layout}
             del full
-        return out
+        return out if to_host else None
 
     def load_state_dict(self, sd):
         assert sd["names"] == [n for n, _, _, _ in self.layout], "parameter layout changed"

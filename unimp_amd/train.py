@@ -47,17 +47,30 @@ def save_checkpoint(path, model, trainer=None, epoch=0):
     """UniMP writes only the trainable tensors (mmrec.py:873-892: ``get_checkpoint``) and never the optimizer, so its
     resume path is broken.  Same file format for the weights -- a flat ``{name: tensor}`` dict that
     ``model.load_state_dict(sd, strict=False)`` consumes -- plus, optionally, a side file with the fp32 optimizer state
-    and the scheduler position so a run can actually resume."""
+    and the scheduler position so a run can actually resume.
+
+    Calling convention under data parallelism:
+      * replicated optimizer state (default): NOT a collective.  Rank 0 writes, every other rank returns at once without
+        building any host copy -- the reference's pattern (mmrec.py:772-873: ``wait_for_everyone()`` then ``if args.rank == 0:``
+        save) ports as is, and a caller that wants the file to exist on return on every rank adds its own barrier.
+      * sharded optimizer state (``Trainer(shard_optimizer=True)``) with a trainer given: a COLLECTIVE -- **every rank must
+        call it**: the owned slices are gathered bucket by bucket, rank 0 keeps the host copy and writes, and a barrier
+        closes the call so no rank runs ahead into the next step's collectives."""
     import torch.distributed as dist
     rank0 = not dist.is_initialized() or dist.get_rank() == 0
-    sd = {k: v.detach().to("cpu") for k, v in get_checkpoint(model).items()}
-    o = trainer.opt.state_dict() if trainer is not None else None      # a collective when the optimizer state is sharded: every rank calls
-    if rank0:                                                          # replicas hold identical weights: one writer
+    sharded = trainer is not None and trainer.opt.shard is not None
+    if not rank0 and not sharded:
+        return
+    o = None
+    if trainer is not None:
+        o = trainer.opt.state_dict(to_host=rank0)      # sharded: a collective; only rank 0 keeps the per-parameter host copies
+    if rank0:                                          # replicas hold identical weights: one writer
+        sd = {k: v.detach().to("cpu") for k, v in get_checkpoint(model).items()}
         torch.save(sd, path)
         if o is not None:
             torch.save({"epoch": epoch, "sched_step": trainer.sched_step, "optimizer": o}, path + ".resume")
-    if dist.is_initialized():
-        dist.barrier()
+    if sharded:
+        dist.barrier(group=trainer.opt.shard[3])
 
 
 def load_checkpoint(path, model, trainer=None):
@@ -203,6 +216,9 @@ class Trainer:
         return loss, stats, out, labels
 
     def _mask_lm_head_grads(self):
+        if not self._masked:
+            return
+        self.opt._reattach()          # a stray .grad (foreign code) is folded into the flat view FIRST: the mask must see the whole gradient
         a = self.ids["answer_id"]
         for w in self._masked:
             g = w.grad
@@ -220,7 +236,9 @@ class Trainer:
             F_.WGRAD_SINK = None
 
     def step(self, batch):
-        """returns (loss, stats) device tensors; no host synchronisation."""
+        """returns (loss, stats) device tensors.  The default loss path (and sparse_head) takes the number of labeled positions on
+        the host right after the label-mask kernel -- ONE host synchronisation per micro-step, before the model forward;
+        ``dense_head_backward=True`` has none."""
         self.model.train()
         loss, stats, out, _ = self.forward_loss(batch)
         if self.grad_accum > 1:
