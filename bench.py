@@ -192,6 +192,11 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(_launch_ranks(args.gpus))
+    # stdout carries exactly ONE line, the JSON: RCCL prints a version banner to fd 1 when its first communicator comes up (and
+    # any library may chat there), so fd 1 is pointed at stderr for the run and the line goes to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", 1))
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -362,7 +367,8 @@ def main():
                            **({"note": "--sparse-head: the utilisation fields above still count the dense head's FLOPs"}
                               if args.sparse_head else {})},
                 "roofline": roofline, "cpu_baseline": cpu, **({"rccl": rccl} if rccl else {})}
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if dist.is_initialized():
         dist.destroy_process_group()
 

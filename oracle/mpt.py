@@ -6,6 +6,13 @@ under /root/reference: restated from its published modelling file (models/mpt/mo
 ``build_mpt_alibi_tensor``, MptMLP) -- bias-free LayerNorm and Linear layers, fused ``Wqkv`` chunked q | k | v, scores
 ``q k^T / sqrt(hd) + slope_h * (j - (L - 1))`` under a causal + key-padding mask, GELU(erf) MLP with expansion 4, tied head.
 Pinned against the installed transformers' ``MptForCausalLM`` (tests/golden/mpt_tiny.npz, oracle/make_golden.py).
+
+``MosaicGPT`` (the "3b" / "3b-instruct" towers, mmrec.py:475-494: ``anas-awadalla/mpt-1b-redpajama-200b[-dolly]``) is the same
+block with LayerNorm over the full d_model vectors of q and of k before the head split (mosaic_gpt ``attn_qk_ln``; the later
+llm-foundry MPT's ``qk_ln``) under mosaic_gpt's module names.  PARITY UNPINNED for that one option: the model's custom
+``mosaic_gpt.py`` lives in its Hugging Face repo (absent here, no version pinned by the reference) and the installed
+transformers' MPT carries ``qk_ln`` in its config but does not implement it.  Anchors: with q_ln = k_ln = identity-free path
+switched off (``attn_qk_ln=False``) the tower IS the pinned MPT under renamed modules (tests/test_oracle_kat.py).
 """
 import math
 import torch
@@ -42,15 +49,19 @@ class _LN(nn.Module):
 
 
 class _Attn(nn.Module):
-    def __init__(self, c):
+    def __init__(self, c, qk_ln=False):
         super().__init__()
         self.nh, self.hd = c.n_heads, c.d_model // c.n_heads
         self.Wqkv = nn.Linear(c.d_model, 3 * c.d_model, bias=False)
+        if qk_ln:
+            self.q_ln, self.k_ln = _LN(c.d_model, c.layer_norm_epsilon), _LN(c.d_model, c.layer_norm_epsilon)
         self.out_proj = nn.Linear(c.d_model, c.d_model, bias=False)
 
     def forward(self, x, bias):
         B, L, D = x.shape
         q, k, v = self.Wqkv(x).chunk(3, dim=2)
+        if hasattr(self, "q_ln"):              # over the whole d_model vector, before the heads are split
+            q, k = self.q_ln(q), self.k_ln(k)
         q, k, v = (t.reshape(B, L, self.nh, self.hd).transpose(1, 2) for t in (q, k, v))
         s = q @ k.transpose(-1, -2) / math.sqrt(self.hd) + bias
         return self.out_proj((torch.softmax(s.float(), -1).to(v.dtype) @ v).transpose(1, 2).reshape(B, L, D))
@@ -112,3 +123,53 @@ class MptForCausalLM(nn.Module, _ResizeMixin):
         logits = self.lm_head(self.transformer.norm_f(x))
         loss = hf_causal_lm_loss(logits, labels) if labels is not None else None
         return LMOutput(loss, logits)
+
+
+# --------------------------------------------------------------------------- MPT-1B (mosaic_gpt): QK-LayerNorm, other module names
+class MosaicGPTConfig(MPTConfig):
+    def __init__(self, vocab_size=50432, d_model=2048, n_layers=24, n_heads=16, mlp_ratio=4, max_seq_len=2048,
+                 layer_norm_epsilon=1e-5, alibi_bias_max=8, attn_qk_ln=True):
+        super().__init__(vocab_size, d_model, n_layers, n_heads, mlp_ratio, max_seq_len, layer_norm_epsilon, alibi_bias_max)
+        self.model_type, self.mlp_ratio, self.attn_qk_ln = "mosaic_gpt", mlp_ratio, attn_qk_ln
+
+
+class _MosaicMLP(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.mlp_up = nn.Linear(c.d_model, c.mlp_ratio * c.d_model, bias=False)
+        self.mlp_down = nn.Linear(c.mlp_ratio * c.d_model, c.d_model, bias=False)
+
+    def forward(self, x):
+        return self.mlp_down(F.gelu(self.mlp_up(x)))
+
+
+class MosaicGPTBlock(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.ln_1, self.attn = _LN(c.d_model, c.layer_norm_epsilon), _Attn(c, c.attn_qk_ln)
+        self.ln_2, self.mlp = _LN(c.d_model, c.layer_norm_epsilon), _MosaicMLP(c)
+
+    def forward(self, x, attention_mask=None, **kw):
+        x = x + self.attn(self.ln_1(x), attention_mask)
+        return x + self.mlp(self.ln_2(x))
+
+
+class _MosaicBody(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.wte = nn.Embedding(c.vocab_size, c.d_model)
+        self.blocks = nn.ModuleList([MosaicGPTBlock(c) for _ in range(c.n_layers)])
+        self.ln_f = _LN(c.d_model, c.layer_norm_epsilon)
+
+    @property
+    def norm_f(self):
+        return self.ln_f
+
+
+class MosaicGPT(MptForCausalLM):
+    def __init__(self, config):
+        nn.Module.__init__(self)
+        self.config = config
+        self.transformer = _MosaicBody(config)
+        self.lm_head = nn.Linear(config.d_model, config.vocab_size, bias=False)
+        self.lm_head.weight = self.transformer.wte.weight

@@ -19,6 +19,10 @@ TINY_PAR = dict(vit=dict(image_size=32, patch_size=8, width=128, layers=1, heads
 TINY_MPT = dict(vit=dict(image_size=32, patch_size=8, width=128, layers=1, heads=2, mlp_dim=256, output_dim=64),
                 lm=dict(kind="mpt", vocab_size=512, d_model=192, n_layers=2, n_heads=3), every=1, T=2, L=40, B=2,
                 n_items=40, base_vocab=300)          # 3 heads of 64: non-power-of-two ALiBi slopes, tied head
+# the "3b" towers (mmrec.py:475-494): MPT-1B = mosaic_gpt with LayerNorm over q and over k (4 heads of 64, tied head)
+TINY_MOSAIC = dict(vit=dict(image_size=32, patch_size=8, width=128, layers=1, heads=2, mlp_dim=256, output_dim=64),
+                   lm=dict(kind="mosaic", vocab_size=512, d_model=256, n_layers=2, n_heads=4), every=1, T=2, L=40, B=2,
+                   n_items=40, base_vocab=300)
 # every frozen Linear has both dimensions % 128 == 0 (the MX-fp8 path's tile contract): 2 heads of 128, ALiBi, tied head
 TINY_MX = dict(vit=dict(image_size=32, patch_size=8, width=128, layers=2, heads=2, mlp_dim=256, output_dim=64),
                lm=dict(kind="mpt", vocab_size=512, d_model=256, n_layers=2, n_heads=2), every=1, T=2, L=48, B=2,
@@ -49,6 +53,8 @@ def build_oracle(cfg, gate=0.5, seed=0):
         lm = olm.GPTNeoXForCausalLM(olm.NeoXConfig(**lmc))
     elif kind == "mpt":
         lm = ompt.MptForCausalLM(ompt.MPTConfig(**lmc))
+    elif kind == "mosaic":
+        lm = ompt.MosaicGPT(ompt.MosaicGPTConfig(**lmc))
     else:
         lm = olm.OPTForCausalLM(olm.OPTConfig(**lmc))
     m = ofl.Flamingo(v, lm, layout.eoc, layout.media, vis_dim=cfg["vit"]["width"], cross_attn_every_n_layers=cfg["every"])
@@ -72,14 +78,14 @@ def build_oracle(cfg, gate=0.5, seed=0):
 
 def build_hip(cfg, oracle_model, layout, device="cuda"):
     from unimp_amd.flamingo import Flamingo, PerceiverResampler, freeze_like_factory
-    from unimp_amd.lm import build_lm, NeoXConfig, OPTConfig, MPTConfig
+    from unimp_amd.lm import build_lm, NeoXConfig, OPTConfig, MPTConfig, MosaicGPTConfig
     from unimp_amd.vit import VisionTransformer, CLIPStub
     lmc = dict(cfg["lm"])
     kind = lmc.pop("kind")
     lmc["vocab_size"] = layout.vocab
     with torch.device(device):
         v = VisionTransformer(**cfg["vit"])
-        lm = build_lm({"neox": NeoXConfig, "opt": OPTConfig, "mpt": MPTConfig}[kind](**lmc))
+        lm = build_lm({"neox": NeoXConfig, "opt": OPTConfig, "mpt": MPTConfig, "mosaic": MosaicGPTConfig}[kind](**lmc))
         m = Flamingo(CLIPStub(v), lm, layout.eoc, layout.media, vis_dim=cfg["vit"]["width"], cross_attn_every_n_layers=cfg["every"])
         if "perceiver_depth" in cfg:
             m.perceiver = PerceiverResampler(dim=cfg["vit"]["width"], depth=cfg["perceiver_depth"])

@@ -254,3 +254,33 @@ def test_one_rank_rccl_process_group():
     res = q.get(timeout=300)
     p.join(60)
     assert res[0] == "ok", res[1]
+
+
+def test_bench_gpus2_starts_its_own_ranks():
+    """a bare ``python bench.py --gpus 2 ...`` (no WORLD_SIZE / RANK in the environment) must start its two ranks
+    itself -- a GPU-free parent, fresh rank processes under torch.distributed.run on 127.0.0.1 -- and relay rank 0's ONE JSON line.
+    Both ranks share the box's one GPU and exchange over gloo (UNIMP_DIST_BACKEND: RCCL wants one device per rank)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(UNIMP_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2",
+                        "--no-cpu-baseline", "--bucket-mb", "64"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["warmup"] == 1 and j["scaling"] == "weak" and j["value"] > 0
+    assert j["config"]["parallelism"] == "dp2" and j["config"]["global_batch"] == 4
+    rc = j["rccl"]
+    assert rc["world_size"] == 2 and rc["backend"] == "gloo" and rc["buckets"] == len(rc["bucket_bytes"]) > 8
+    assert sorted(rc["issue_order"]) == list(range(rc["buckets"])) and rc["exposed_allreduce_ms_per_step"] >= 0
+    assert rc["wire_bytes_per_step"] >= 2 * j["config"]["trainable_params"]
+    # a rank that fails makes the launcher exit non-zero
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "2",
+                        "--no-cpu-baseline", "--model", "nonexistent"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0

@@ -239,7 +239,7 @@ def test_beam_search_tokens_match_oracle_beam_search(K):
     assert steps_ok >= (20 if K == 4 else 10) and full_ok >= (3 if K == 4 else 0)
 
 
-@pytest.mark.parametrize("cfg_name", ["TINY", "TINY_OPT", "TINY_PAR"])
+@pytest.mark.parametrize("cfg_name", ["TINY", "TINY_OPT", "TINY_PAR", "TINY_MOSAIC"])
 def test_kv_cache_decode_matches_full_rescoring(cfg_name):
     """F1 KV-cache decode: prefill + one-token steps give the logits of a full forward over the grown sequence (same
     kernels, different tiling of the same sums -> bf16-level agreement), and generate(use_cache=True) returns the tokens of

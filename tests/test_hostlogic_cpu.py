@@ -1,6 +1,7 @@
 """Host-side decisions of the GEMM / RoPE routing (pure functions, no GPU): the plans the bench's shapes get, and the
 pair-adjacent row permutation of the rotary epilogue against the half-split rotation it replaces (oracle/lm.py)."""
 import math
+import os
 import torch
 
 
@@ -62,3 +63,33 @@ def test_rope_adjacent_permutation_is_the_half_split_rotation():
             got[:, :, part, :rot] = torch.stack([x1 * c - x2 * s_, x2 * c + x1 * s_], -2).reshape(L, nh, rot)
         got = got.reshape(L, 3 * H) if inter else got.permute(0, 2, 1, 3).reshape(L, 3 * H)
         assert torch.allclose(got, want[:, idx], atol=1e-5), (nh, hd, rot, inter)
+
+
+def test_bench_launcher_command(monkeypatch):
+    """bench.py --gpus N without a launcher environment: the parent builds a torch.distributed.run command on 127.0.0.1 for N
+    ranks with its own arguments and returns the launcher's exit code; it never touches the GPU (none exists here)."""
+    import importlib.util
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    try:
+        bench.main()
+        raise AssertionError("main() must exit with the launcher's code")
+    except SystemExit as e:
+        assert e.code == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

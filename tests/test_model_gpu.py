@@ -25,7 +25,7 @@ def P():
     return _parity
 
 
-@pytest.mark.parametrize("cfgname", ["TINY", "TINY_OPT", "TINY_PAR", "TINY_MPT"])
+@pytest.mark.parametrize("cfgname", ["TINY", "TINY_OPT", "TINY_PAR", "TINY_MPT", "TINY_MOSAIC"])
 def test_forward_backward_parity(P, cfgname):
     from unimp_amd.train import Trainer
     cfg = getattr(P, cfgname)

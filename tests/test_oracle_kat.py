@@ -121,3 +121,50 @@ def test_perceiver_matches_independent_idefics_implementation():
         a0 = mine.layers[0][0](x.reshape(2, 3, 7, D), mine.latents[None, None].expand(2, 3, -1, -1))
         r0 = ref.blocks[0][0](x.reshape(6, 7, D), mine.latents[None].expand(6, -1, -1)).reshape(2, 3, n_lat, D)
         assert (a0 - r0).abs().max() <= 1e-5 * r0.abs().max()
+
+
+def test_mosaic_gpt_without_qk_ln_is_the_pinned_mpt():
+    """the "3b" towers' oracle (oracle/mpt.py MosaicGPT): with attn_qk_ln off it must BE the transformers-pinned MPT oracle under
+    mosaic_gpt's module names; with it on, q and k are LayerNorm'ed over the whole d_model vector before the head split (checked
+    against a direct restatement here), and the factory's tower carries the same parameter names."""
+    import torch.nn.functional as F
+    from oracle import mpt as ompt
+    torch.manual_seed(0)
+    kw = dict(vocab_size=97, d_model=64, n_layers=2, n_heads=4)
+    a = ompt.MptForCausalLM(ompt.MPTConfig(**kw))
+    b = ompt.MosaicGPT(ompt.MosaicGPTConfig(attn_qk_ln=False, **kw))
+    ren = lambda k: (k.replace("norm_1", "ln_1").replace("norm_2", "ln_2").replace("norm_f", "ln_f")
+                     .replace("ffn.up_proj", "mlp.mlp_up").replace("ffn.down_proj", "mlp.mlp_down"))
+    missing, unexpected = b.load_state_dict({ren(k): v for k, v in a.state_dict().items()}, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    ids = torch.randint(0, 97, (2, 11))
+    mask = torch.ones(2, 11, dtype=torch.long); mask[1, 8:] = 0
+    assert torch.equal(a(ids, mask).logits, b(ids, mask).logits)
+    # qk_ln on: one block by hand
+    c = ompt.MosaicGPT(ompt.MosaicGPTConfig(**kw))
+    for p in c.parameters():
+        p.data.normal_(0, 0.3)
+    blk, x = c.transformer.blocks[0], torch.randn(1, 5, 64)
+    at = blk.attn
+    h = F.layer_norm(x, (64,), blk.ln_1.weight, None, 1e-5)
+    q, k, v = (h @ at.Wqkv.weight.t()).chunk(3, -1)
+    q = F.layer_norm(q, (64,), at.q_ln.weight, None, 1e-5)
+    k = F.layer_norm(k, (64,), at.k_ln.weight, None, 1e-5)
+    sp = lambda t: t.view(1, 5, 4, 16).transpose(1, 2)
+    bias = ompt.alibi_slopes(4)[None, :, None, None] * torch.arange(-4, 1, dtype=torch.float32)[None, None, None, :] + \
+        torch.full((5, 5), float("-inf")).triu(1)
+    o = (torch.softmax(sp(q) @ sp(k).transpose(-1, -2) / 4.0 + bias, -1) @ sp(v)).transpose(1, 2).reshape(1, 5, 64) @ at.out_proj.weight.t()
+    want = x + o
+    want = want + F.gelu(F.layer_norm(want, (64,), blk.ln_2.weight, None, 1e-5) @ blk.mlp.mlp_up.weight.t()) @ blk.mlp.mlp_down.weight.t()
+    from oracle.lm import _mask_bias
+    al = ompt.alibi_slopes(4)[None, :, None, None] * torch.arange(-4, 1, dtype=torch.float32)[None, None, None, :]
+    got = blk(x, attention_mask=_mask_bias(None, 5, x.dtype) + al)
+    assert torch.allclose(got, want, atol=1e-4, rtol=1e-4), float((got - want).abs().max())
+    # the product tower carries the same names (no kernels run here)
+    from unimp_amd.lm import build_lm, MosaicGPTConfig
+    hm = build_lm(MosaicGPTConfig(**kw))
+    assert set(hm.state_dict()) == set(c.state_dict())
+    from unimp_amd.lm import LM_CONFIGS
+    for name in ("anas-awadalla/mpt-1b-redpajama-200b", "anas-awadalla/mpt-1b-redpajama-200b-dolly"):       # mmrec.py:475-494
+        c1 = LM_CONFIGS[[k for k in LM_CONFIGS if k.lower() in name.lower()][0]]()
+        assert (c1.model_type, c1.d_model, c1.n_layers, c1.n_heads, c1.attn_qk_ln) == ("mosaic_gpt", 2048, 24, 16, True)

@@ -359,7 +359,10 @@ class SelfAttnBlockFn(Function):
     or [B, L, 3, nh, hd] (blocked q|k|v: OPT / Llama / ViT)."""
 
     @staticmethod
-    def forward(ctx, x, res, ln_w, ln_b, wqkv, bqkv, wd, bd, rope, kv_len, nh, interleaved, causal, eps, rms, q_scale, alibi=None):
+    def forward(ctx, x, res, ln_w, ln_b, wqkv, bqkv, wd, bd, rope, kv_len, nh, interleaved, causal, eps, rms, q_scale, alibi=None,
+                qk_ln=None):
+        """qk_ln = (q_ln weight, k_ln weight, eps): LayerNorm over the full d_model vectors of q and of k before the heads are split
+        (the QK-LayerNorm MPT of mmrec.py:475-494's "3b" towers, mosaic_gpt ``attn_qk_ln``); frozen gains only, blocked q|k|v layout."""
         B, L, H = x.shape
         hd = H // nh
         x2 = x.reshape(B * L, H)
@@ -384,6 +387,14 @@ class SelfAttnBlockFn(Function):
             qkv = ops.gemm_mx(ops.mx_quantize(h), _frozen_mx(wqkv), bias=bqkv) if mx else \
                 ops.gemm(h, _frozen_t(wqkv) if tq else wqkv, b_ks=tq, bias=bqkv, b_pk=None if tq else _frozen_pk(wqkv))
         q, k, v, hs, offs = _split_qkv(qkv, B, L, nh, hd, interleaved)
+        qk_raw = qk_stats = None
+        if qk_ln is not None:
+            if interleaved or rope is not None or qk_ln[0].requires_grad or qk_ln[1].requires_grad:
+                raise NotImplementedError("qk_ln: blocked q|k|v layout, no rotary, frozen gains (the MPT-1B towers)")
+            qk_raw = qkv[:, :2 * H].clone()                 # the backward of the two LayerNorms needs their inputs
+            _, qm, qr = ops.layernorm_fwd(qk_raw[:, :H], qk_ln[0], None, qk_ln[2], out=qkv[:, :H])
+            _, km, kr = ops.layernorm_fwd(qk_raw[:, H:], qk_ln[1], None, qk_ln[2], out=qkv[:, H:2 * H])
+            qk_stats = (qm, qr, km, kr)
         if rope is not None and fused is None:
             cos, sin, rot = rope[:3]
             ops.rope_(qkv, L, nh, hs, rot, offs, cos, sin)
@@ -397,6 +408,7 @@ class SelfAttnBlockFn(Function):
                    ln_b is not None)
         ctx.mx = mx
         ctx.rope_fused = fused
+        ctx.qk_ln = None if qk_ln is None else (qk_ln[0], qk_ln[1], qk_raw) + qk_stats
         return out.view(B, L, H)
 
     @staticmethod
@@ -414,6 +426,9 @@ class SelfAttnBlockFn(Function):
         q, k, v, hs, offs = _split_qkv(qkv, B, L, nh, hd, interleaved)
         dqkv = torch.empty_like(qkv)
         dq, dk, dv, _, _ = _split_qkv(dqkv, B, L, nh, hd, interleaved)
+        if ctx.qk_ln is not None:        # dq / dk of the NORMALISED q, k go to a side buffer; q_ln / k_ln's backward writes the fused one
+            dqk_n = torch.empty((B * L, 2 * H), dtype=qkv.dtype, device=qkv.device)
+            dq, dk = dqk_n[:, :H].view(B, L, nh, hd), dqk_n[:, H:].view(B, L, nh, hd)
         # the backward kernels rotate dq / dk back on their way out (same arithmetic as the separate pass, no trip through HBM)
         if ctx.rope_fused is not None:
             # q, k were rotated by the QKV GEMM in the adjacent-pair order of the permuted projection: dq / dk come back in that
@@ -430,13 +445,17 @@ class SelfAttnBlockFn(Function):
                          rope=(cos, sin) if fuse else None)
             if cos is not None and not fuse:
                 ops.rope_(dqkv, L, nh, hs, rot, offs, cos, sin, inverse=True)
+            if ctx.qk_ln is not None:                        # back through q_ln / k_ln, in place in the fused gradient buffer
+                qw, kw, qk_raw, qm, qr, km, kr = ctx.qk_ln
+                ops.layernorm_bwd(dqk_n[:, :H], qk_raw[:, :H], qw, qm, qr, has_beta=False, dx_out=dqkv[:, :H])
+                ops.layernorm_bwd(dqk_n[:, H:], qk_raw[:, H:], kw, km, kr, has_beta=False, dx_out=dqkv[:, H:2 * H])
             dwqkv = ops.gemm(dqkv, h, a_ks=True, b_ks=True) if _need(ctx, 4) else None
             dh = ops.gemm_mx(ops.mx_quantize(dqkv), _frozen_mx(wqkv, True)) if ctx.mx else ops.gemm(dqkv, wqkv, b_ks=True, b_pk=_frozen_pk(wqkv, True))
         wg = _need(ctx, 2) or (has_lnb and _need(ctx, 3))
         dx, dg, db = ops.layernorm_bwd(dh, x2, ln_w, mean, rstd, dres=dy2 if res_is_x else None, want_wgrad=wg,
                                        has_beta=has_lnb, rms=rms)
         dres = None if res_is_x else dy
-        return (dx.view(B, L, H), dres, dg, db, dwqkv, None, dwd, None) + (None,) * 9
+        return (dx.view(B, L, H), dres, dg, db, dwqkv, None, dwd, None) + (None,) * 10
 
 
 def _split_qkv(qkv, B, L, nh, hd, interleaved):
@@ -450,10 +469,10 @@ def _split_qkv(qkv, B, L, nh, hd, interleaved):
 
 
 def self_attn_block(x, ln_w, ln_b, wqkv, bqkv, wd, bd, nh, *, rope=None, kv_len=None, interleaved=True, causal=True,
-                    eps=1e-5, rms=False, res=None, q_scale=None, alibi=None):
+                    eps=1e-5, rms=False, res=None, q_scale=None, alibi=None, qk_ln=None):
     hd = x.shape[-1] // nh
     return SelfAttnBlockFn.apply(x, res, ln_w, ln_b, wqkv, bqkv, wd, bd, rope, kv_len, nh, interleaved, causal, eps, rms,
-                                 q_scale if q_scale is not None else hd ** -0.5, alibi)
+                                 q_scale if q_scale is not None else hd ** -0.5, alibi, qk_ln)
 
 
 # ----------------------------------------------------------------------------------------------- KV-cache decode (F1)
@@ -538,7 +557,7 @@ def _kv_append(lc, k, v, pos0):
 
 @torch.no_grad()
 def self_attn_block_cached(x, ln_w, ln_b, wqkv, bqkv, wd, bd, nh, lc, pos0, *, rope=None, interleaved=True, eps=1e-5,
-                           rms=False, res=None, q_scale=None, alibi=None):
+                           rms=False, res=None, q_scale=None, alibi=None, qk_ln=None):
     """SelfAttnBlockFn.forward for decoding: the new rows' keys/values are appended to ``lc``; a prefill (pos0 == 0) runs
     the causal kernel on the prompt, a decode step (one new token per row) attends to every cached key.  With
     ``lc.owner.step`` set the position lives on the device (StepState): ``rope`` then holds the one table row of the
@@ -551,6 +570,11 @@ def self_attn_block_cached(x, ln_w, ln_b, wqkv, bqkv, wd, bd, nh, lc, pos0, *, r
     h, _, _ = ops.layernorm_fwd(x2, ln_w, ln_b, eps, rms=rms)
     qkv = ops.gemm(h, wqkv, bias=bqkv)
     q, k, v, hs, offs = _split_qkv(qkv, R, Ln, nh, hd, interleaved)
+    if qk_ln is not None:                      # LayerNorm over the whole d_model vector of q and of k, in place (one wave holds a row)
+        qn, _, _ = ops.layernorm_fwd(qkv[:, :H], qk_ln[0], None, qk_ln[2])
+        kn, _, _ = ops.layernorm_fwd(qkv[:, H:2 * H], qk_ln[1], None, qk_ln[2])
+        qkv[:, :H].copy_(qn)
+        qkv[:, H:2 * H].copy_(kn)
     scale = q_scale if q_scale is not None else hd ** -0.5
     if step is not None:
         if Ln != 1:

@@ -55,7 +55,9 @@ LM_CONFIGS = {
     "opt-125m": lambda: OPTConfig(),
     "opt-1.3b": lambda: OPTConfig(hidden_size=2048, num_hidden_layers=24, num_attention_heads=32, ffn_dim=8192),
     "mpt-7b": lambda: MPTConfig(),                                                      # OpenFlamingo-9B (mmrec.py:515-524)
-    # the "3b" options of mmrec.py:475-494 (mpt-1b-redpajama-200b[-dolly]) use the QK-LayerNorm MPT variant: not built
+    # the "3b" / "3b-instruct" options of mmrec.py:475-494: MosaicML's MPT-1B (mosaic_gpt), the QK-LayerNorm variant
+    "mpt-1b-redpajama-200b-dolly": lambda: MosaicGPTConfig(),
+    "mpt-1b-redpajama-200b": lambda: MosaicGPTConfig(),
 }
 
 
@@ -574,6 +576,83 @@ class MptForCausalLM(_TowerBase):
         return out
 
 
+# --------------------------------------------------------------------------- MPT-1B / mosaic_gpt (OpenFlamingo-3B towers, mmrec.py:475-494)
+def MosaicGPTConfig(vocab_size=50432, d_model=2048, n_layers=24, n_heads=16, mlp_ratio=4, max_seq_len=2048,
+                    layer_norm_epsilon=1e-5, alibi_bias_max=8, attn_qk_ln=True):
+    """``anas-awadalla/mpt-1b-redpajama-200b[-dolly]`` (the repo's own ``mosaic_gpt.py``, third-party: requirements.txt pins nothing
+    for it; mmrec.py:475-494 names it).  Published architecture: ALiBi, no biases, LayerNorm over the FULL d_model vectors of q
+    and of k before the head split (``attn_qk_ln``), GELU MLP with ratio 4, tied head.  16 heads: a power of two, where
+    mosaic_gpt's ALiBi slopes 2^-(i * bias_max / n_heads) equal transformers' (``mpt_alibi_slopes``)."""
+    c = _Cfg(model_type="mosaic_gpt", **{k: v for k, v in locals().items()})
+    c.hidden_size = d_model
+    return c
+
+
+class _MosaicAttnParams(nn.Module):
+    def __init__(self, d, eps, qk_ln):
+        super().__init__()
+        self.Wqkv = nn.Linear(d, 3 * d, bias=False)
+        if qk_ln:
+            self.q_ln = _LNNoBias(d, eps)
+            self.k_ln = _LNNoBias(d, eps)
+        self.out_proj = nn.Linear(d, d, bias=False)
+
+
+class _MosaicMLPParams(nn.Module):
+    def __init__(self, d, r):
+        super().__init__()
+        self.mlp_up = nn.Linear(d, r * d, bias=False)
+        self.mlp_down = nn.Linear(r * d, d, bias=False)
+
+
+class MosaicGPTBlock(nn.Module):
+    """mosaic_gpt GPTBlock: x += out_proj(attn(k_ln / q_ln(Wqkv(ln_1(x)))));  x += mlp_down(gelu(mlp_up(ln_2(x))))"""
+
+    def __init__(self, c):
+        super().__init__()
+        self.c = c
+        self.ln_1 = _LNNoBias(c.d_model, c.layer_norm_epsilon)
+        self.attn = _MosaicAttnParams(c.d_model, c.layer_norm_epsilon, c.attn_qk_ln)
+        self.ln_2 = _LNNoBias(c.d_model, c.layer_norm_epsilon)
+        self.mlp = _MosaicMLPParams(c.d_model, c.mlp_ratio)
+
+    def forward(self, x, attention_mask=None, alibi=None, cache=None, pos0=0, **kw):
+        c, a, f = self.c, self.attn, self.mlp
+        qk = (a.q_ln.weight, a.k_ln.weight, a.q_ln.eps) if c.attn_qk_ln else None
+        if cache is not None:
+            x = F_.self_attn_block_cached(x, self.ln_1.weight, None, a.Wqkv.weight, None, a.out_proj.weight, None, c.n_heads,
+                                          cache, pos0, interleaved=False, eps=self.ln_1.eps, alibi=alibi, qk_ln=qk)
+        else:
+            x = F_.self_attn_block(x, self.ln_1.weight, None, a.Wqkv.weight, None, a.out_proj.weight, None, c.n_heads,
+                                   kv_len=attention_mask, interleaved=False, causal=True, eps=self.ln_1.eps, alibi=alibi, qk_ln=qk)
+        return F_.mlp_block(x, self.ln_2.weight, None, f.mlp_up.weight, None, f.mlp_down.weight, None, "gelu", eps=self.ln_2.eps)
+
+
+class _MosaicBody(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.wte = nn.Embedding(c.vocab_size, c.d_model)
+        self.blocks = nn.ModuleList([MosaicGPTBlock(c) for _ in range(c.n_layers)])
+        self.ln_f = _LNNoBias(c.d_model, c.layer_norm_epsilon)
+
+    @property
+    def norm_f(self):          # MptForCausalLM.forward's name for the final norm
+        return self.ln_f
+
+
+class MosaicGPT(MptForCausalLM):
+    """the MPT-1B tower: MptForCausalLM's forward over mosaic_gpt's module names (``ln_1 / attn.{Wqkv,q_ln,k_ln,out_proj} / ln_2 /
+    mlp.{mlp_up,mlp_down} / ln_f``; logits = h wte^T, no separate head parameter in the checkpoint)."""
+
+    def __init__(self, config):
+        _TowerBase.__init__(self)
+        self.config = config
+        self.transformer = _MosaicBody(config)
+        self.lm_head = nn.Linear(config.d_model, config.vocab_size, bias=False)
+        self.lm_head.weight = self.transformer.wte.weight
+        self._slopes = None
+
+
 def build_lm(name_or_config):
     if isinstance(name_or_config, _Cfg):
         c = name_or_config
@@ -582,4 +661,5 @@ def build_lm(name_or_config):
         if not key:
             raise ValueError(f"unknown lang_encoder_path {name_or_config!r}; known: {sorted(LM_CONFIGS)} (or pass a config object)")
         c = LM_CONFIGS[key[0]]()
-    return {"gpt_neox": GPTNeoXForCausalLM, "opt": OPTForCausalLM, "llama": LlamaForCausalLM, "mpt": MptForCausalLM}[c.model_type](c)
+    return {"gpt_neox": GPTNeoXForCausalLM, "opt": OPTForCausalLM, "llama": LlamaForCausalLM, "mpt": MptForCausalLM,
+            "mosaic_gpt": MosaicGPT}[c.model_type](c)

@@ -206,7 +206,8 @@ TAIL_SPLIT = os.environ.get("UNIMP_GEMM_TAIL_SPLIT", "1") != "0"
 ROPE_VARIANTS = (4, 9)          # pp256 / pp256p: the kernels with a rotary-epilogue instantiation (gemm3.hip, gemm6.hip)
 
 
-ROPE_MIN_M = 1024               # rows from which the QKV projection takes the rotary epilogue
+ROPE_MIN_M = 256                # rows (one tile row) from which the QKV projection takes the rotary epilogue: low enough that a training
+                                # sample's bits do not depend on its batch size (b = 1, L = 512 and b = 64 both take it)
 
 
 def gemm_rope_variant(M, N, K, b_ks, device):
@@ -392,14 +393,15 @@ _PARTIAL_BLOCKS = 512       # 2 blocks per CU: the wgrad variant holds 244 VGPRs
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, *, dres=None, dy2=None, want_wgrad=False, has_beta=True, rms=False, grp=0,
-                  grp_stride=0, grp_off=0, dg_out=None, db_out=None):
+                  grp_stride=0, grp_off=0, dg_out=None, db_out=None, dx_out=None):
     """returns dx, dgamma, dbeta (bf16; None when not wanted).  dy may be the grouped (concat) buffer.
     dg_out / db_out (bf16 [D] views of a gradient buffer, both or -- without beta -- dg_out alone): the weight gradients are
     ADDED there and None is returned for them."""
     x, ldx = _mat(x)
     rows, D = x.shape
     assert dy.stride(-1) == 1
-    dx = torch.empty((rows, D), dtype=bf16, device=x.device)
+    dx = torch.empty((rows, D), dtype=bf16, device=x.device) if dx_out is None else dx_out      # dx_out may alias dy (a wave holds its row)
+    assert dx.stride(-1) == 1 and dx.shape == (rows, D)
     dg = db = part = None
     acc = 0
     if want_wgrad:
@@ -411,7 +413,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, *, dres=None, dy2=None, want_wgrad=F
         part = torch.empty(_PARTIAL_BLOCKS * 2 * D, dtype=torch.float32, device=x.device)
     check(_lib.lib().unimp_layernorm_bwd(dy.data_ptr(), dy.stride(-2), _p(dy2), dy2.stride(0) if dy2 is not None else 0,
                                           x.data_ptr(), ldx, _p(gamma), _p(mean), _p(rstd),
-                                          _p(dres), dres.stride(0) if dres is not None else 0, dx.data_ptr(), D,
+                                          _p(dres), dres.stride(0) if dres is not None else 0, dx.data_ptr(), dx.stride(0),
                                           _p(dg), _p(db), _p(part), _PARTIAL_BLOCKS, rows, D, int(rms), grp, grp_stride,
                                           grp_off, acc, _stream()), "layernorm_bwd")
     if acc:
