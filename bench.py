@@ -187,6 +187,8 @@ def main():
                     "(same loss / gradients; NOT the default and not the headline configuration)")
     ap.add_argument("--dp-hooks", action="store_true", help="N = 1 only: a 1-rank RCCL process group with the data-parallel hooks forced on -- "
                     "the N > 1 code path (bucketed async all-reduce from the autograd hooks, stream hand-off, finish()) on one GPU")
+    ap.add_argument("--graph", action="store_true", help="Trainer(graph=True): forward + loss + backward of a micro-batch replayed as one HIP graph "
+                    "(small per-GPU batches are launch-bound: the reference's shipped shape --batch 3 --grad-accum 2); implies --dense-head-backward")
     ap.add_argument("--bucket-mb", type=int, default=256, help="gradient bucket size of the data-parallel exchange (MiB)")
     args = ap.parse_args()
 
@@ -236,7 +238,9 @@ def main():
                       lr_scheduler="cosine", warmup_steps=10, total_steps=10000, sparse_head=args.sparse_head,
                       grad_accum=args.grad_accum, dense_head_backward=args.dense_head_backward,
                       shard_optimizer=args.shard_optimizer and dp_on, bucket_bytes=args.bucket_mb << 20,
-                      force_dp_hooks=args.dp_hooks)
+                      force_dp_hooks=args.dp_hooks, graph=args.graph)
+    if args.graph:
+        args.dense_head_backward = True
     trainer.dp.record_exposed = dp_on
     n_train = sum(p.numel() for p in model.parameters() if p.requires_grad)
     T, L, B, GA = args.images, args.seq, args.batch, args.grad_accum
@@ -267,11 +271,13 @@ def main():
     if prof_steps:
         ops.GEMM_PROFILE = []
     prof = None
+    ops.marker(101)           # kernel-trace cut points around the timed region (tools/trace_window.py)
     t0 = time.perf_counter()
     for i in range(args.steps):
         if prof_steps and i == prof_steps:
             prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
         loss, stats = one_step()
+    ops.marker(102)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -361,6 +367,7 @@ def main():
                            "tflop_per_sample": round(fps["total"] / 1e12, 3),
                            "tflop_per_sample_note": "executed FLOPs (SURVEY 8d formulae); the LM head's backward runs on the labeled positions only"
                                                     if hb else "SURVEY 8d formulae, dense head backward",
+                           "hip_graph": bool(args.graph),
                            "head_backward": "dense" if args.dense_head_backward else "labeled rows only (zero rows of dlogits skipped; same gradients)",
                            "model_tflops_per_gpu": round(value / world * fps["total"] / 1e12, 1),
                            "mfma_frac_whole_step": round(value / world * fps["total"] / 1e12 / PEAK_BF16_TFLOPS, 4),

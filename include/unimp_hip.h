@@ -159,6 +159,16 @@ typedef struct {
 } unimp_attn_desc;
 int unimp_attn_fwd(const unimp_attn_desc* d, void* stream);
 int unimp_attn_bwd(const unimp_attn_desc* d, void* stream);
+/* Decode step of Flamingo.generate with a KV cache (eval_rec.py:100-110; eval_exp.py:103-113 and eval_img_gen.py:102-111 at
+ * 256 / 600 new tokens): ONE query row per (batch row, head) -- d->Sq == 1, mask_mode NONE, kv_len[b] keys visible (NULL: Sk),
+ * optional ALiBi slopes -- against the cached K / V [B][Sk = capacity][H][D].  The keys are split over `splits` workgroups per
+ * (row, head); partial (max, sum, o[D]) go to `workspace` (fp32 [B*H*splits*(D+2)], caller-provided, may be NULL when splits
+ * == 1) and are merged in a fixed order (no atomics: reproducible, graph-capturable; the grid depends on Sk only, never on
+ * kv_len).  `splits` must be unimp_attn_decode_splits(B, H, Sk) (a fixed number of keys per workgroup: a row's bits do not depend
+ * on the batch it is decoded in or on the cache capacity).  d->lse is not written.  HBM-bound: algorithmic bytes =
+ * 2 * sum_b kv_len[b] * H * D * 2. */
+int unimp_attn_decode(const unimp_attn_desc* d, float* workspace, int splits, void* stream);
+int unimp_attn_decode_splits(int B, int H, int Sk);
 /* tuning / test knob: which generation of attention kernels serves the calls above.  2 (default; env UNIMP_ATTN_GEN):
  * the 32x32x16-MFMA / LDS-DMA kernels of attention2.hip; 1: the first-generation kernels (kept for A/B measurements and
  * run by the tests as a second implementation of the same contract).  Returns the previous value. */
@@ -183,6 +193,9 @@ int unimp_vit_assemble(const void* patch, int64_t ldp, const void* cls, const vo
                        int D, void* stream);
 
 /* ---- elementwise helpers ----------------------------------------------------------------------------------*/
+/* trace marker (measurement aid for mmrec.py:259-296's step timing): an empty kernel launched with `id` workgroups of 64 threads,
+ * so a kernel trace can be cut to the region between two markers (tools/trace_window.py). */
+int unimp_marker(int id, void* stream);
 int unimp_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream);            /* out = a + b */
 int unimp_cast_f32_to_bf16(const float* src, void* dst, int64_t n, float scale, void* stream);
 int unimp_swiglu_fwd(const void* gate_up, int64_t ld, void* out, int64_t ldo, int rows, int F, void* stream);

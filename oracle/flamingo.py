@@ -14,11 +14,20 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .numerics import st
+
+
+class _FF(nn.Sequential):
+    """LayerNorm -> Linear -> GELU -> Linear with the storage points of oracle/numerics.py (identity by default)."""
+
+    def forward(self, x):
+        return self[3](st("act", self[2](self[1](st("ln", self[0](x))))))
+
 
 def FeedForward(dim, mult=4):
     # indices 0,1,2,3 matter for parameter names (A.2)
-    return nn.Sequential(nn.LayerNorm(dim), nn.Linear(dim, dim * mult, bias=False), nn.GELU(),
-                         nn.Linear(dim * mult, dim, bias=False))
+    return _FF(nn.LayerNorm(dim), nn.Linear(dim, dim * mult, bias=False), nn.GELU(),
+               nn.Linear(dim * mult, dim, bias=False))
 
 
 class PerceiverAttention(nn.Module):
@@ -33,17 +42,17 @@ class PerceiverAttention(nn.Module):
 
     def forward(self, x, latents):
         # x (b,T,n1,D)  latents (b,T,n2,D)
-        x, latents = self.norm_media(x), self.norm_latents(latents)
+        x, latents = st("ln", self.norm_media(x)), st("ln", self.norm_latents(latents))
         h = self.heads
-        q = self.to_q(latents)
+        q = st("gemm", self.to_q(latents))
         kv_in = torch.cat((x, latents), -2)
-        k, v = self.to_kv(kv_in).chunk(2, -1)
+        k, v = st("gemm", self.to_kv(kv_in)).chunk(2, -1)
         sp = lambda t: t.view(*t.shape[:3], h, -1).permute(0, 3, 1, 2, 4)   # b h T n d
         q, k, v = sp(q) * self.scale, sp(k), sp(v)
         sim = q @ k.transpose(-1, -2)
         sim = sim - sim.amax(-1, keepdim=True).detach()
-        out = sim.softmax(-1) @ v
-        out = out.permute(0, 2, 3, 1, 4).flatten(-2)                         # b T n (h d)
+        out = st("attn_p", sim.softmax(-1)) @ v
+        out = st("attn_o", out.permute(0, 2, 3, 1, 4).flatten(-2))           # b T n (h d)
         return self.to_out(out)
 
 
@@ -61,9 +70,9 @@ class PerceiverResampler(nn.Module):
         x = x.reshape(b, T, Fr * v, D)
         lat = self.latents[None, None].expand(b, T, -1, -1)
         for attn, ff in self.layers:
-            lat = attn(x, lat) + lat
-            lat = ff(lat) + lat
-        return self.norm(lat)
+            lat = st("res", attn(x, lat) + lat)
+            lat = st("res", ff(lat) + lat)
+        return st("vis", self.norm(lat))
 
 
 class MaskedCrossAttention(nn.Module):
@@ -81,10 +90,10 @@ class MaskedCrossAttention(nn.Module):
         # x (B,L,D)  media (B,T,n,Dv)  media_locations (B,L) bool
         B, T, n = media.shape[:3]
         h = self.heads
-        x = self.norm(x)
-        q = self.to_q(x)
+        x = st("ln", self.norm(x))
+        q = st("gemm", self.to_q(x))
         media = media.reshape(B, T * n, -1)
-        k, v = self.to_kv(media).chunk(2, -1)
+        k, v = st("gemm", self.to_kv(media)).chunk(2, -1)
         sp = lambda t: t.view(B, t.shape[1], h, -1).transpose(1, 2)
         q, k, v = sp(q) * self.scale, sp(k), sp(v)
         sim = q @ k.transpose(-1, -2)                                        # B h L (T n)
@@ -98,10 +107,10 @@ class MaskedCrossAttention(nn.Module):
             mask = op(text_time[:, None, :, None], media_time.repeat_interleave(n)[None, None, None, :])
             sim = sim.masked_fill(~mask, -torch.finfo(sim.dtype).max)
         sim = sim - sim.amax(-1, keepdim=True).detach()
-        attn = sim.softmax(-1)
+        attn = st("attn_p", sim.softmax(-1))
         if media_locations is not None and self.only_attend_immediate_media:
             attn = attn.masked_fill((text_time == 0)[:, None, :, None], 0.0)   # rows with no image yet
-        out = (attn @ v).transpose(1, 2).reshape(B, -1, h * v.shape[-1])
+        out = st("attn_o", (attn @ v).transpose(1, 2).reshape(B, -1, h * v.shape[-1]))
         return self.to_out(out)
 
 
@@ -114,8 +123,8 @@ class GatedCrossAttentionBlock(nn.Module):
         self.ff_gate = nn.Parameter(torch.tensor([0.0]))
 
     def forward(self, x, media, media_locations=None, use_cached_media=False):
-        x = self.attn(x, media, media_locations, use_cached_media) * self.attn_gate.tanh() + x
-        return self.ff(x) * self.ff_gate.tanh() + x
+        x = st("res", self.attn(x, media, media_locations, use_cached_media) * self.attn_gate.tanh() + x)
+        return st("res", self.ff(x) * self.ff_gate.tanh() + x)
 
 
 class FlamingoLayer(nn.Module):
@@ -188,7 +197,7 @@ class Flamingo(nn.Module):
         b, T, Fr = vision_x.shape[:3]
         assert Fr == 1, "Only single frame supported"
         with torch.no_grad():
-            tok = self.vision_encoder(vision_x.flatten(0, 2))[1]
+            tok = st("vis", self.vision_encoder(vision_x.flatten(0, 2))[1])
         vis = self.perceiver(tok.view(b, T, Fr, *tok.shape[1:]))
         media_locations = lang_x == self.media_token_id
         for layer in self._layers():

@@ -16,6 +16,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .numerics import st
+
 
 class LMOutput:
     """Minimal stand-in for HF ``CausalLMOutputWithPast``: ``out[0]`` is the loss when
@@ -87,11 +89,12 @@ class NeoXAttention(nn.Module):
         cos, sin = neox_rope_tables(L, self.rot, self.base)
         qr, qp = q[..., :self.rot], q[..., self.rot:]
         kr, kp = k[..., :self.rot], k[..., self.rot:]
-        q = torch.cat((qr * cos + rotate_half(qr) * sin, qp), -1)
-        k = torch.cat((kr * cos + rotate_half(kr) * sin, kp), -1)
+        q = st("gemm", torch.cat((qr * cos + rotate_half(qr) * sin, qp), -1))
+        k = st("gemm", torch.cat((kr * cos + rotate_half(kr) * sin, kp), -1))
+        v = st("gemm", v)
         att = (q @ k.transpose(-1, -2)) * self.hd ** -0.5 + bias
-        att = att.softmax(-1)
-        o = (att @ v).transpose(1, 2).reshape(B, L, H)
+        att = st("attn_p", att.softmax(-1))
+        o = st("attn_o", (att @ v).transpose(1, 2).reshape(B, L, H))
         return self.dense(o)
 
 
@@ -102,7 +105,7 @@ class NeoXMLP(nn.Module):
         self.dense_4h_to_h = nn.Linear(c.intermediate_size, c.hidden_size)
 
     def forward(self, x):
-        return self.dense_4h_to_h(F.gelu(self.dense_h_to_4h(x)))
+        return self.dense_4h_to_h(st("act", F.gelu(self.dense_h_to_4h(x))))
 
 
 class NeoXLayer(nn.Module):
@@ -115,11 +118,11 @@ class NeoXLayer(nn.Module):
         self.mlp = NeoXMLP(c)
 
     def forward(self, x, attention_mask=None, **kw):
-        a = self.attention(self.input_layernorm(x), attention_mask)
+        a = self.attention(st("ln", self.input_layernorm(x)), attention_mask)
         if self.par:
-            return self.mlp(self.post_attention_layernorm(x)) + a + x
-        a = a + x
-        return self.mlp(self.post_attention_layernorm(a)) + a
+            return st("res", self.mlp(st("ln", self.post_attention_layernorm(x))) + st("res", a + x))
+        a = st("res", a + x)
+        return st("res", self.mlp(st("ln", self.post_attention_layernorm(a))) + a)
 
 
 class _NeoXBody(nn.Module):
@@ -174,7 +177,7 @@ class GPTNeoXForCausalLM(nn.Module, _ResizeMixin):
         bias = _mask_bias(attention_mask, input_ids.shape[1], x.dtype)
         for layer in self.gpt_neox.layers:
             x = layer(x, attention_mask=bias)
-        logits = self.embed_out(self.gpt_neox.final_layer_norm(x))
+        logits = st("logits", self.embed_out(st("ln", self.gpt_neox.final_layer_norm(x))))
         loss = hf_causal_lm_loss(logits, labels) if labels is not None else None
         return LMOutput(loss, logits)
 

@@ -20,6 +20,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .lm import LMOutput, _ResizeMixin, _mask_bias, hf_causal_lm_loss
+from .numerics import st
 
 
 class MPTConfig:
@@ -61,10 +62,11 @@ class _Attn(nn.Module):
         B, L, D = x.shape
         q, k, v = self.Wqkv(x).chunk(3, dim=2)
         if hasattr(self, "q_ln"):              # over the whole d_model vector, before the heads are split
-            q, k = self.q_ln(q), self.k_ln(k)
-        q, k, v = (t.reshape(B, L, self.nh, self.hd).transpose(1, 2) for t in (q, k, v))
+            q, k = self.q_ln(st("gemm", q)), self.k_ln(st("gemm", k))
+        q, k, v = (st("gemm", t).reshape(B, L, self.nh, self.hd).transpose(1, 2) for t in (q, k, v))
         s = q @ k.transpose(-1, -2) / math.sqrt(self.hd) + bias
-        return self.out_proj((torch.softmax(s.float(), -1).to(v.dtype) @ v).transpose(1, 2).reshape(B, L, D))
+        p = st("attn_p", torch.softmax(s.float(), -1).to(v.dtype))
+        return self.out_proj(st("attn_o", (p @ v).transpose(1, 2).reshape(B, L, D)))
 
 
 class _FFN(nn.Module):
@@ -74,7 +76,7 @@ class _FFN(nn.Module):
         self.down_proj = nn.Linear(c.expansion_ratio * c.d_model, c.d_model, bias=False)
 
     def forward(self, x):
-        return self.down_proj(F.gelu(self.up_proj(x)))
+        return self.down_proj(st("act", F.gelu(self.up_proj(x))))
 
 
 class MptBlock(nn.Module):
@@ -84,8 +86,8 @@ class MptBlock(nn.Module):
         self.norm_2, self.ffn = _LN(c.d_model, c.layer_norm_epsilon), _FFN(c)
 
     def forward(self, x, attention_mask=None, **kw):
-        x = x + self.attn(self.norm_1(x), attention_mask)
-        return x + self.ffn(self.norm_2(x))
+        x = st("res", x + self.attn(st("ln", self.norm_1(x)), attention_mask))
+        return st("res", x + self.ffn(st("ln", self.norm_2(x))))
 
 
 class _Body(nn.Module):
@@ -120,7 +122,7 @@ class MptForCausalLM(nn.Module, _ResizeMixin):
         bias = _mask_bias(attention_mask, L, x.dtype) + alibi
         for blk in self.transformer.blocks:
             x = blk(x, attention_mask=bias)
-        logits = self.lm_head(self.transformer.norm_f(x))
+        logits = st("logits", self.lm_head(st("ln", self.transformer.norm_f(x))))
         loss = hf_causal_lm_loss(logits, labels) if labels is not None else None
         return LMOutput(loss, logits)
 
@@ -140,7 +142,7 @@ class _MosaicMLP(nn.Module):
         self.mlp_down = nn.Linear(c.mlp_ratio * c.d_model, c.d_model, bias=False)
 
     def forward(self, x):
-        return self.mlp_down(F.gelu(self.mlp_up(x)))
+        return self.mlp_down(st("act", F.gelu(self.mlp_up(x))))
 
 
 class MosaicGPTBlock(nn.Module):
@@ -150,8 +152,8 @@ class MosaicGPTBlock(nn.Module):
         self.ln_2, self.mlp = _LN(c.d_model, c.layer_norm_epsilon), _MosaicMLP(c)
 
     def forward(self, x, attention_mask=None, **kw):
-        x = x + self.attn(self.ln_1(x), attention_mask)
-        return x + self.mlp(self.ln_2(x))
+        x = st("res", x + self.attn(st("ln", self.ln_1(x)), attention_mask))
+        return st("res", x + self.mlp(st("ln", self.ln_2(x))))
 
 
 class _MosaicBody(nn.Module):

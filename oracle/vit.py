@@ -14,6 +14,9 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+from .numerics import st
+
+
 def quick_gelu(x):
     return x * torch.sigmoid(1.702 * x)
 
@@ -31,11 +34,11 @@ class _MHA(nn.Module):
     def forward(self, x):
         B, S, D = x.shape
         H = self.heads
-        qkv = F.linear(x, self.in_proj_weight, self.in_proj_bias)
+        qkv = st("gemm", F.linear(x, self.in_proj_weight, self.in_proj_bias))
         q, k, v = qkv.view(B, S, 3, H, D // H).permute(2, 0, 3, 1, 4)
         att = (q @ k.transpose(-1, -2)) * (D // H) ** -0.5
-        att = att.softmax(-1)
-        o = (att @ v).transpose(1, 2).reshape(B, S, D)
+        att = st("attn_p", att.softmax(-1))
+        o = st("attn_o", (att @ v).transpose(1, 2).reshape(B, S, D))
         return self.out_proj(o)
 
 
@@ -47,7 +50,7 @@ class _MLP(nn.Module):
         self.act = act
 
     def forward(self, x):
-        return self.c_proj(self.act(self.c_fc(x)))
+        return self.c_proj(st("act", self.act(self.c_fc(x))))
 
 
 class ResidualAttentionBlock(nn.Module):
@@ -59,8 +62,8 @@ class ResidualAttentionBlock(nn.Module):
         self.mlp = _MLP(d, mlp, act)
 
     def forward(self, x):
-        x = x + self.attn(self.ln_1(x))
-        return x + self.mlp(self.ln_2(x))
+        x = st("res", x + self.attn(st("ln", self.ln_1(x))))
+        return st("res", x + self.mlp(st("ln", self.ln_2(x))))
 
 
 class _Transformer(nn.Module):
@@ -91,11 +94,11 @@ class VisionTransformer(nn.Module):
         self.proj = nn.Parameter(torch.randn(width, output_dim) * width ** -0.5)
 
     def forward(self, x):
-        x = self.conv1(x)                                   # (B, D, g, g)          clip.py:77-80
+        x = st("gemm", self.conv1(x))                       # (B, D, g, g)          clip.py:77-80
         x = x.flatten(2).transpose(1, 2)                    # (B, n, D)
         cls = self.class_embedding.expand(x.shape[0], 1, -1)
-        x = torch.cat([cls, x], 1) + self.positional_embedding   # clip.py:82-84
-        x = self.ln_pre(x)                                  # clip.py:460
+        x = st("res", torch.cat([cls, x], 1) + self.positional_embedding)   # clip.py:82-84
+        x = st("res", self.ln_pre(x))                       # clip.py:460
         x = self.transformer(x)
         pooled, tokens = x[:, 0], x[:, 1:]
         pooled = self.ln_post(pooled) @ self.proj           # ln_post on pooled ONLY (SURVEY a-5)

@@ -34,6 +34,12 @@ CFG2_SLIM = dict(vit=dict(image_size=224, patch_size=14, width=1024, layers=3, h
                  lm=dict(kind="neox", vocab_size=0, hidden_size=2560, num_hidden_layers=4, num_attention_heads=32,
                          intermediate_size=10240), every=2, T=8, L=512, B=2, n_items=22738, base_vocab=50277,
                  n_img_tokens=1024, perceiver_depth=1, std=0.02, min_fill=0.75)
+# BASELINE cfg4 (the H&M path, unimp_hm.sh shapes) at full width, reduced depth: 16 history images per user (1024 media latents
+# = the longest segment-masked key range), 14 901 items -> V = 66 216, gamma-2 focal loss
+CFG4_SLIM = dict(vit=dict(image_size=224, patch_size=14, width=1024, layers=2, heads=16, mlp_dim=4096, output_dim=768),
+                 lm=dict(kind="neox", vocab_size=0, hidden_size=2560, num_hidden_layers=4, num_attention_heads=32,
+                         intermediate_size=10240), every=2, T=16, L=512, B=2, n_items=14901, base_vocab=50277,
+                 n_img_tokens=1024, perceiver_depth=1, std=0.02, min_fill=0.8)
 # BASELINE cfg5's model family at full width, reduced depth, on an image-token-generation shaped batch: MPT-7B widths
 # (d_model 4096, 32 heads of 128, ALiBi, tied head) with 2 of 32 blocks and one gated cross-attention block, L = 1024, T = 2
 CFG5_SLIM = dict(vit=dict(image_size=224, patch_size=14, width=1024, layers=2, heads=16, mlp_dim=4096, output_dim=768),

@@ -93,3 +93,29 @@ def test_bench_launcher_command(monkeypatch):
     assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_eval_text_metrics_hand_computed():
+    """the host half of eval_exp / eval_img_sel (UniMP/pipeline/eval/eval_exp.py:116-142, eval_img_sel.py:96-113): parsing of the
+    generated text and the metric definitions, on cases worked out by hand."""
+    from unimp_amd import eval as E
+    # eval_exp.py:116-125
+    assert E.parse_rating_explanation("Describe? What is the rating? rate_4 solid and cheap") == (4.0, "solid and cheap")
+    assert E.parse_rating_explanation("q? nonsense words") == (3.0, "words")           # first word is no rating: 3.0, still dropped
+    assert E.parse_rating_explanation("q?") == (3.0, "Empty")
+    assert E.parse_rating_explanation("q? rate_2") == (2.0, "Empty")
+    # BLEU unigram modified precision, corpus level: clipped matches / predicted unigrams
+    #   "the the the cat" vs "the cat sat": the clipped to 1, cat 1 -> 2 / 4;  "a dog." vs "a dog ." : 3 / 3 (13a splits the period)
+    assert E.bleu1_precision(["the the the cat"], ["the cat sat"]) == 0.5
+    assert abs(E.bleu1_precision(["the the the cat", "a dog."], ["the cat sat", "a dog ."]) - 5 / 7) < 1e-12
+    assert E.bleu1_precision([""], ["x"]) == 0.0
+    # ROUGE: pred "the cat sat on the mat" (6), ref "the cat is on the mat" (6): unigram overlap 5 -> P = R = 5/6; bigrams
+    # (the cat) (on the) (the mat) of 5 -> 3/5; LCS = the cat on the mat = 5
+    r = E.rouge_f(["the cat sat on the mat"], ["The cat is on the mat!"])
+    assert abs(r["rouge1"] - 5 / 6) < 1e-12 and abs(r["rouge2"] - 0.6) < 1e-12 and abs(r["rougeL"] - 5 / 6) < 1e-12
+    r = E.rouge_f(["a b c d"], ["d c b a"])                   # same words, reversed: unigrams 1.0, bigrams 0, LCS 1 -> 0.25
+    assert r["rouge1"] == 1.0 and r["rouge2"] == 0.0 and r["rougeL"] == 0.25
+    # eval_img_sel.py:96-113: the SET of generated words
+    assert E.selection_scores("Select? s_0 s_2 s_2", [0, 1]) == {"recall": 0.5, "precision": 0.5, "f1": 0.5}
+    assert E.selection_scores("Select?", [1]) == {"recall": 0.0, "precision": 0, "f1": 0.0}
+    assert E.selection_scores("x? s_1", [1]) == {"recall": 1.0, "precision": 1.0, "f1": 1.0}

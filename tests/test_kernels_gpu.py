@@ -801,6 +801,47 @@ def test_attention_alibi_causal(ops, attn_gen, B, H, S, D, kvpad):
     close(o1[:, 0], torch.einsum("bhk,bkhd->bhd", rows, v[:, :n].float()), rel=2 ** -6, name="alibi decode row")
 
 
+@pytest.mark.parametrize("B,H,cap,D,lens,alibi", [
+    (10, 32, 583, 80, "ragged", False),        # eval_rec at cfg2: 10 beams, 469-token prompt + 50 new tokens (+64 capacity slack)
+    (1, 32, 1100, 128, "full", True),          # eval_img_gen on the 9b tower: greedy, ALiBi, ~1000 keys
+    (3, 4, 200, 64, "ragged", True), (2, 2, 33, 64, "one", False), (4, 6, 700, 128, "ragged", False), (2, 3, 64, 8, "full", False)])
+def test_split_key_decode_attention(ops, B, H, cap, D, lens, alibi):
+    """csrc/decode_attn.hip: one query row per (cache row, head) against the K/V cache [B, capacity, H, D] with per-row visible
+    lengths -- against fp32 softmax attention over the visible keys, and against the training kernel on the same row (the path it
+    replaces); slots beyond kv_len hold NaN (never read as values), the cache is a strided view (one K/V tensor for all layers),
+    a second call gives the same bits (ordered merges, no atomics), and so does ONE row decoded alone out of a cache with twice the
+    capacity (the key partition is fixed: a row's bits depend neither on its batch nor on the capacity)."""
+    g = torch.Generator().manual_seed(cap + D + B)
+    kv = torch.randn(2, B, cap, H, D, generator=g).to(bf16).cuda()
+    q = torch.randn(B, 1, H, 3 * D, generator=g).to(bf16).cuda()[..., :D]              # a q slice of a fused qkv row
+    n = {"full": [cap] * B, "one": [1] * B, "ragged": [max(1, cap - 37 * i * i - 5 * i) for i in range(B)]}[lens]
+    kv_len = torch.tensor(n, dtype=torch.int32, device="cuda")
+    k, v = kv[0], kv[1]
+    for b in range(B):
+        k[b, n[b]:] = float("nan")
+        v[b, n[b]:] = float("nan")
+    slopes = mpt_alibi_slopes(H).cuda() if alibi else None
+    scale = D ** -0.5
+    got = ops.attn_decode(q, k, v, scale, kv_len if lens != "full" else None, slopes)
+    again = ops.attn_decode(q, k, v, scale, kv_len if lens != "full" else None, slopes)
+    assert torch.equal(got, again)
+    big = torch.full((2, 1, 2 * cap + 5, H, D), float("nan"), dtype=bf16, device="cuda")
+    r = B - 1
+    big[:, 0, :n[r]] = kv[:, r, :n[r]]
+    alone = ops.attn_decode(q[r:r + 1], big[0], big[1], scale, kv_len[r:r + 1], slopes)
+    assert torch.equal(alone[0], got[r]), "a row's bits depend on its batch / the cache capacity"
+    want = torch.empty(B, 1, H, D)
+    for b in range(B):
+        s_ = torch.einsum("hd,khd->hk", q[b, 0].float().cpu(), k[b, :n[b]].float().cpu()) * scale
+        if alibi:
+            s_ = s_ + slopes.cpu()[:, None] * torch.arange(n[b])[None, :]
+        want[b, 0] = torch.einsum("hk,khd->hd", torch.softmax(s_, -1), v[b, :n[b]].float().cpu())
+    close(got, want, rel=2 ** -7, name="decode attention")
+    if D in (64, 80, 128):
+        ref, _ = ops.attn_fwd(q, k.nan_to_num(0.0), v.nan_to_num(0.0), scale, ops.MASK_NONE, kv_len, alibi=slopes)
+        close(got, ref, rel=2 ** -6, name="decode attention vs training kernel")
+
+
 # ------------------------------------------------------------------------------------------------- MX-fp8 (frozen towers, F4)
 def _mx_reference(x):
     """the MX quantisation rule on the host: per 32 consecutive k, shared exponent floor(log2 amax) - 8 (E8M0 byte = exponent

@@ -581,3 +581,35 @@ def test_precision_choice_is_bf16_not_the_reference_default(P):
     loss, stats, out, _ = tr.forward_loss({k: v.cuda() for k, v in P.make_batch(cfg, layout).items()})
     assert out["logits"].dtype == torch.bfloat16 and loss.dtype == torch.float32 and tr.opt.master.dtype == torch.float32
     tr.dp.remove()
+
+
+@pytest.mark.parametrize("ga", [1, 2])
+def test_graphed_micro_step_equals_eager(P, ga):
+    """Trainer(graph=True): the forward + loss + backward of a micro-batch replayed as one HIP graph (first micro-step eager, second
+    captured, then replays; mmrec.py's --gradient_accumulation_steps on top) must give the bits of the same steps launched kernel
+    by kernel: same losses, same fp32 master weights after every optimizer step, fresh data each micro-step."""
+    from unimp_amd.train import Trainer
+    cfg = P.TINY
+    om, layout = P.build_oracle(cfg)
+    batches = [{k: v.cuda() for k, v in P.make_batch(cfg, layout, seed=700 + i).items()} for i in range(6 * ga)]
+    res = {}
+    for mode in ("eager", "graph"):
+        hm = P.build_hip(cfg, om, layout)
+        tr = Trainer(hm, layout.special(), lr=1e-3, lr_scheduler="constant", grad_accum=ga, dense_head_backward=True, graph=mode == "graph")
+        losses, masters = [], []
+        for i, b in enumerate(batches):
+            loss, stats = tr.step(b)
+            losses.append(loss.item())
+            if (i + 1) % ga == 0:
+                masters.append(tr.opt.master.clone())
+        res[mode] = (losses, masters)
+        if mode == "graph":
+            assert tr._graph is not None and tr._graph["key"] is not None, "no graph was captured"
+            # a batch of another shape falls back to an eager warm-up, then gets its own graph
+            other = {k: v[:1].contiguous() for k, v in batches[0].items()}
+            for _ in range(3 * ga):
+                tr.step(other)
+            assert tr._graph["static"]["lang_x"].shape[0] == 1
+    assert res["eager"][0] == res["graph"][0], (res["eager"][0], res["graph"][0])
+    assert all(torch.equal(a, b) for a, b in zip(res["eager"][1], res["graph"][1]))
+    assert len(set(res["eager"][0])) == len(batches)                  # the replays really consumed fresh data

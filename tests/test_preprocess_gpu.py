@@ -102,6 +102,43 @@ def test_eval_loop_generate_to_metrics(tmp_path):
     assert set(m2) == set(m) and all(0.0 <= v <= 1.0 for v in m2.values())
 
 
+def test_the_other_four_eval_loops(tmp_path):
+    """eval_search / eval_exp / eval_img_sel / eval_img_gen (UniMP/pipeline/eval/*.py) end to end on a tiny random model: the
+    dataset's eval samples of each task -> GPU preprocessing -> generate with that loop's settings -> its metrics."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    pytest.importorskip("PIL.Image")
+    from test_preprocess_cpu import _materialise_rec_dataset
+    from unimp_amd import create_model_and_transforms
+    from unimp_amd import eval as E
+    from unimp_amd.data import ImagePreprocessor, RecDataset
+    from unimp_amd.factory import SyntheticTokenizer
+    from unimp_amd.lm import NeoXConfig
+    _materialise_rec_dataset(tmp_path)
+    tok = SyntheticTokenizer(base_vocab=400)
+    tok.add_special_tokens({"additional_special_tokens": ["<answer>"]})
+    torch.manual_seed(0)
+    model, _, tok = create_model_and_transforms(
+        dict(image_size=32, patch_size=8, width=128, layers=1, heads=2, mlp_dim=256, output_dim=64), None,
+        NeoXConfig(vocab_size=512, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256),
+        None, cross_attn_every_n_layers=1, tokenizer=tok, device="cuda")
+    pre_ = ImagePreprocessor(32)
+    get = lambda task, n=2: [RecDataset(str(tmp_path), "all", tok, split="test", defer_images=True, task=task, n_items=14)[i] for i in range(n)]
+    m = E.eval_model_search(model, get("search"), tok, K=4, max_new_tokens=4, image_preprocessor=pre_)
+    assert set(m) == {f"{n}@{k}" for n in ("hr", "ndcg", "mrr") for k in (3, 5, 4)} and all(0.0 <= v <= 1.0 for v in m.values())
+    m = E.eval_model_exp(model, get("exp"), tok, max_new_tokens=12, num_beams=5, image_preprocessor=pre_)
+    assert set(m) == {"mae", "rmse", "bleu", "rouge1", "rouge2", "rougeL"}
+    assert 0.0 <= m["mae"] <= 4.0 and m["rmse"] >= m["mae"] - 1e-9 and all(0.0 <= m[k] <= 1.0 for k in ("bleu", "rouge1", "rouge2", "rougeL"))
+    m = E.eval_model_img_sel(model, get("img_sel"), tok, max_new_tokens=6, image_preprocessor=pre_)
+    assert set(m) == {"recall", "precision", "f1"} and all(0.0 <= v <= 1.0 for v in m.values())
+    # image-token generation: greedy; a long decode (beyond the K/V capacity growth step) must keep working
+    g = E.eval_model_img_gen(model, get("img_gen"), tok, max_new_tokens=100, image_preprocessor=pre_)
+    assert len(g["texts"]) == 2 and all(len(v) == 1 and isinstance(v[0], str) for v in g["texts"].values()) and 0.0 <= g["exact"] <= 1.0
+    # two users per generate() call give the same texts as one by one (greedy: no beam near-ties involved)
+    g2 = E.eval_model_img_gen(model, get("img_gen"), tok, max_new_tokens=100, image_preprocessor=pre_, users_per_batch=2)
+    assert g2["texts"] == g["texts"]
+
+
 def test_train_loop_from_dataset(tmp_path):
     """INTEGRATION.md's end-to-end flow on the tiny dataset: RecDataset -> collate -> GPU preprocessing -> Trainer.step."""
     if not torch.cuda.is_available():

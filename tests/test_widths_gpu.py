@@ -13,12 +13,21 @@ Tolerances (north_star: loss 1e-3 rel, argmax bit-exact; the HIP path stores bf1
   argmax   agreement rate over ALL valid positions is printed; identical wherever the HIP path's own top-2 margin
            exceeds 8 sigma of its measured logit error
   grads    per trainable tensor rel-L2 <= max(3e-2, 5 x that tensor's bf16-autocast noise floor)
+Round 3 adds the SAME-STORAGE reference: the fp32 oracle with every point where the product writes a tensor to HBM rounded to
+bf16 (oracle/numerics.py; the per-class budget is profiles/r03_error_budget_cfg2_slim.txt).  Against it only the arithmetic
+INSIDE the kernels differs (fp32 summation order, exp2 / erf forms, the on-the-fly rotary angles), so the bound is tighter:
+  logits   rel-L2 vs the same-storage oracle <= SAME_STORAGE_BOUND, and strictly below the error vs the pure-fp32 oracle
+and ``test_argmax_exact_where_the_model_is_confident``: with a head in which every position has a clear winner (planted
+rank-one terms, as a trained model has) the argmax must agree on 100 % of the valid positions.
 """
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
 bf16 = torch.bfloat16
+
+
+SAME_STORAGE_BOUND = 8e-3        # calibrated on MI355X (see DESIGN.md section 3); the pure-fp32 bound stays 1e-2
 
 
 @pytest.fixture(scope="module")
@@ -57,6 +66,14 @@ def _check_step(P, om, hm, layout, batch, name, gamma=2.0, reweight=True):
               f"{ag['n_sure']} with margin > 8 sigma ({ag['sigma']:.3e}): identical = {ag['sure_equal']}")
         assert e <= max(1e-2, 1.5 * floor), f"logits rel L2 {e} (floor {floor})"
         assert lerr <= 1e-3, (loss.item(), want_loss.item())
+        from oracle import numerics as N_
+        with torch.no_grad(), N_.storage(*N_.ALL):
+            same = om(batch["vision_x"], batch["lang_x"], batch["attention_mask"])["logits"]
+        e_same, e_model = P.rel_l2(got, same), P.rel_l2(same, want_logits)
+        ag2 = P.argmax_agreement(got, same, valid)
+        print(f"[{name}] vs the oracle at the product's storage precision: logits rel-L2 {e_same:.3e} (that oracle vs pure fp32: "
+              f"{e_model:.3e}); argmax agreement {ag2['rate']:.4f}")
+        assert e_same <= SAME_STORAGE_BOUND and e_same < e, (e_same, e)
         assert ag["n_sure"] > 0 and ag["sure_equal"], ag
         assert ag["rate"] >= 0.9, ag
         loss.backward()
@@ -90,6 +107,59 @@ def test_cfg2_full_width_reduced_depth_vs_oracle(P, slim2):
     _check_step(P, om, hm, layout, batch, "cfg2 slim")
 
 
+def test_argmax_exact_where_the_model_is_confident(P, slim2):
+    """north_star: "token-id argmax bit-exact".  A random-init head over 74 053 tokens has near-ties at a few per cent of the
+    positions whatever the arithmetic (that is what the 96 % of the test above measures).  A trained model is confident: here
+    every valid position (with a hidden state of its own) gets a planted winner -- the head rows t_i gain dW with
+    dW_i . h_j = alpha * delta_ij for the oracle's final hidden states h (least squares; distinct tokens, bf16-representable
+    weights, the SAME head in both models) -- so its top-2 margin is many sigma of the logit error, and the HIP argmax must equal
+    the oracle's at 100 % of those positions."""
+    om, hm, layout = slim2
+    cfg = P.CFG2_SLIM
+    batch = P.make_batch(cfg, layout, seed=4321)
+    grab = {}
+    hk = om.lang_encoder.gpt_neox.final_layer_norm.register_forward_hook(lambda m, i, o: grab.__setitem__("h", o.detach()))
+    head_o = om.lang_encoder.get_output_embeddings().weight
+    head_h = hm.lang_encoder.get_output_embeddings().weight
+    keep_o, keep_h = head_o.data.clone(), head_h.data.clone()
+    try:
+        with torch.no_grad():
+            base = om(batch["vision_x"], batch["lang_x"], batch["attention_mask"])["logits"]
+            hk.remove()
+            hfin = grab["h"].reshape(-1, grab["h"].shape[-1])                     # [B*L, H]
+            valid = batch["attention_mask"].bool().reshape(-1)
+            pos = valid.nonzero()[:, 0]
+            hv = hfin[pos].double()
+            # positions whose hidden state repeats an earlier one (the BOS row of every sample ...) cannot have their own winner
+            d2 = torch.cdist(hv, hv)
+            dup = ((d2 < 1e-3 * hv.norm(dim=1, keepdim=True)) & torch.ones_like(d2, dtype=torch.bool).tril(-1)).any(1)
+            pos, hv = pos[~dup], hv[~dup]
+            g = torch.Generator().manual_seed(0)
+            tok = torch.randperm(layout.base_vocab - 1, generator=g)[:pos.numel()] + 1         # distinct winners
+            alpha = 12.0 * float(base.std())
+            # rows dW with dW_i . h_j = alpha * delta_ij (least squares: n positions < H dims)
+            head_o.data[tok] += (alpha * torch.linalg.pinv(hv).T).float()
+            head_o.data.copy_(head_o.data.to(bf16).float())
+            head_h.data.copy_(head_o.data.to(bf16))
+            want = om(batch["vision_x"], batch["lang_x"], batch["attention_mask"])["logits"]
+            hm.eval()
+            got = hm(batch["vision_x"].cuda(), batch["lang_x"].cuda(), batch["attention_mask"].cuda())["logits"].float().cpu()
+        wv, gv = want.reshape(-1, want.shape[-1])[pos], got.reshape(-1, got.shape[-1])[pos]
+        assert (wv.argmax(-1) == tok).float().mean() > 0.9                         # the plant took
+        top2 = wv.topk(2, -1).values
+        margin = top2[:, 0] - top2[:, 1]
+        sigma = float((gv - wv).std())
+        agree = (gv.argmax(-1) == wv.argmax(-1))
+        print(f"\n[confident head] {pos.numel()} valid positions; top-2 margin min {float(margin.min()):.3f} / median {float(margin.median()):.3f}; "
+              f"logit error sigma {sigma:.3e} (min margin = {float(margin.min()) / sigma:.1f} sigma); argmax identical at {int(agree.sum())} / {agree.numel()}")
+        assert float(margin.min()) > 8 * sigma, "the planted head is not confident enough for the claim"
+        assert bool(agree.all()), f"argmax differs at {int((~agree).sum())} of {agree.numel()} confident positions"
+    finally:
+        hk.remove()
+        head_o.data.copy_(keep_o)
+        head_h.data.copy_(keep_h)
+
+
 def test_cfg3_task_mixed_batch_vs_oracle(P, slim2):
     """cfg3 (unimp_all_tasks.sh): samples of different tasks share a batch, loss weight 2.0 for rec and 1.0 for the other
     tasks (rec_dataset.py:452); plus the unweighted, non-focal loss (mmrec.py:203 without --use_reweight)."""
@@ -98,6 +168,19 @@ def test_cfg3_task_mixed_batch_vs_oracle(P, slim2):
     batch["weights"] = torch.tensor([2.0, 1.0])
     _check_step(P, om, hm, layout, batch, "cfg3 mixed weights")
     _check_step(P, om, hm, layout, batch, "cfg3 mixed weights, no reweight", gamma=0.0, reweight=False)
+
+
+def test_cfg4_hm_shapes_vs_oracle(P):
+    """cfg4 (BASELINE: "H&M dataset path, 16 history images per user, gamma-focal loss"; unimp_hm.sh): T = 16 images -> 1024
+    segment-masked media keys per text row, V = 66 216 (14 901 items), one optimizer-step's forward + loss + backward against the
+    fp32 oracle at full width (round 2 only property-checked this configuration)."""
+    cfg = P.CFG4_SLIM
+    om, layout = P.build_oracle(cfg)
+    assert layout.vocab == 66216
+    hm = P.build_hip(cfg, om, layout)
+    batch = P.make_batch(cfg, layout, seed=404)
+    assert batch["vision_x"].shape[1] == 16 and int((batch["lang_x"] == layout.media).sum(1).min()) == 16
+    _check_step(P, om, hm, layout, batch, "cfg4 slim (T = 16, V = 66 216)", gamma=2.0, reweight=True)
 
 
 def _imggen_batch(layout, L, T, seed=5):

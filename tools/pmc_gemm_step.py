@@ -1,14 +1,65 @@
-"""PMC workload: the step's dominant GEMM shapes at the bench batch (default 64 x 512 tokens), dispatched as the step dispatches them
-(committed autotune table), three launches each, for separate rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | MFMA busy + GRBM)."""
-import sys, os, torch
+"""PMC workload: the step's dominant GEMM kernel INSTANCES at the bench batch (64 x 512 text tokens; 512 x 257 ViT tokens), each with
+its kernel variant PINNED (the committed autotune table's choice, passed explicitly: nothing is tuned inside a PMC pass), one
+warm-up + three launches per case, for separate rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | MFMA busy + GRBM).
+Writes the case manifest (label, expected kernel instance, grid size, shape, algorithmic bytes) to $PMC_MANIFEST or stdout;
+tools/pmc_to_json.py joins the counter CSVs to it by (kernel instance, grid size) -- never by dispatch order."""
+import json
+import os
+import sys
+import torch
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from unimp_amd import ops
+from unimp_amd import ops            # noqa: E402
+
 torch.manual_seed(0)
+bf = torch.bfloat16
 M = int(os.environ.get("PMC_M", 64 * 512))
-for (n, k, bks) in [(10240, 2560, 0), (2560, 10240, 0), (10240, 2560, 1), (2560, 10240, 1)]:
-    a = torch.randn(M, k, device="cuda").to(torch.bfloat16)
-    b = torch.randn((k, n) if bks else (n, k), device="cuda").to(torch.bfloat16)
-    out = torch.empty((M, n), dtype=torch.bfloat16, device="cuda")
-    for _ in range(3):
-        ops.gemm(a, b, b_ks=bool(bks), out=out)
+MV = int(os.environ.get("PMC_MV", 64 * 8 * 257))
+dev = "cuda"
+# label, M, N, K, a_ks, b_ks, epilogue, variant, kernel-instance substring (template args as rocprofv3 prints them)
+CASES = [
+    ("LM dX through the down-projection x GELU' (KC,KS)", M, 10240, 2560, 0, 1, "aux", "pp256", "gemm3_bf16_kernel<false, true, 256, false, false>"),
+    ("LM dX through the up-projection (KC,KS)", M, 2560, 10240, 0, 1, "plain", "pp256", "gemm3_bf16_kernel<false, true, 256, false, false>"),
+    ("gated FF up-projection + GELU (KC,KC)", M, 10240, 2560, 0, 0, "act", "pp256", "gemm3_bf16_kernel<false, false, 256, false, false>"),
+    ("LM down-projection + bias + residual (KC,KC)", M, 2560, 10240, 0, 0, "res", "pp256", "gemm3_bf16_kernel<false, false, 256, false, false>"),
+    ("LM up-projection + GELU + stored GELU' (KC,KC, persistent)", M, 10240, 2560, 0, 0, "out2", "pp256p", "gemm6_bf16_kernel<false, false, false>"),
+    ("LM QKV projection + rotary epilogue (KC,KC, persistent)", M, 7680, 2560, 0, 0, "rope", "pp256p", "gemm6_bf16_kernel<false, false, true>"),
+    ("LM attention-out + bias + residual (KC,KC, 8-wave)", M, 2560, 2560, 0, 0, "res", "w8", "gemm5_bf16_kernel<false, false"),
+    ("gated FF dW up (KS,KS)", 10240, 2560, M, 1, 1, "plain", "pp256", "gemm3_bf16_kernel<true, true, 256, false, false>"),
+    ("ViT MLP up + QuickGELU (KC,KC)", MV, 4096, 1024, 0, 0, "act_q", "pp256", "gemm3_bf16_kernel<false, false, 256, false, false>"),
+    ("ViT attention-out + residual (KC,KC)", MV, 1024, 1024, 0, 0, "res", "pp256", "gemm3_bf16_kernel<false, false, 256, false, false>"),
+]
+manifest = []
+for label, m, n, k, aks, bks, epi, variant, inst in CASES:
+    a = torch.randn((k, m) if aks else (m, k), device=dev).to(bf)
+    b = torch.randn((k, n) if bks else (n, k), device=dev).to(bf)
+    out = torch.empty((m, n), dtype=bf, device=dev)
+    kw, extra = {}, 0
+    if epi == "aux":
+        kw = dict(aux=torch.rand((m, n), device=dev).to(bf), dact="deriv"); extra = m * n * 2
+    elif epi == "res":
+        kw = dict(bias=torch.zeros(n, device=dev, dtype=bf), res=torch.randn((m, n), device=dev).to(bf)); extra = m * n * 2
+    elif epi == "act":
+        kw = dict(act="gelu")
+    elif epi == "act_q":
+        kw = dict(bias=torch.zeros(n, device=dev, dtype=bf), act="quick_gelu")
+    elif epi == "out2":
+        kw = dict(bias=torch.zeros(n, device=dev, dtype=bf), act="gelu", pre=torch.empty((m, n), dtype=bf, device=dev), pre_deriv=True); extra = m * n * 2
+    elif epi == "rope":
+        kw = dict(bias=torch.zeros(n, device=dev, dtype=bf), rope=dict(rot=80, hd=80, period=240, span=160, L=512, log2_base=13.287712379549449))
+    for _ in range(4):                                  # 1 warm-up + 3
+        ops.gemm(a, b, a_ks=bool(aks), b_ks=bool(bks), out=out, variant=variant, **kw)
     torch.cuda.synchronize()
+    tiles = ((m + 255) // 256) * ((n + 255) // 256)
+    wgs = min(tiles, 256) if variant == "pp256p" else tiles
+    manifest.append(dict(label=label, kernel=inst, grid_size=wgs * 512, shape=[m, n, k], a_kstrided=aks, b_kstrided=bks, epilogue=epi,
+                         variant=variant, flop=2 * m * n * k, algorithmic_bytes=(m * k + n * k + m * n) * 2 + extra))
+    del a, b, out, kw
+keys = [(c["kernel"], c["grid_size"]) for c in manifest]
+assert len(set(keys)) == len(keys), "two cases share (kernel instance, grid size): the counter rows could not be told apart"
+path = os.environ.get("PMC_MANIFEST")
+if path:
+    with open(path, "w") as f:
+        json.dump(manifest, f, indent=1)
+else:
+    print(json.dumps(manifest))

@@ -50,10 +50,13 @@ _SIGS = {
     "unimp_rope_halfsplit": [c_p, c_l, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p],
     "unimp_attn_fwd": [C.POINTER(AttnDesc), c_p],
     "unimp_attn_bwd": [C.POINTER(AttnDesc), c_p],
+    "unimp_attn_decode": [C.POINTER(AttnDesc), c_p, c_i, c_p],
+    "unimp_attn_decode_splits": [c_i, c_i, c_i],
     "unimp_embedding_fwd": [c_p, c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p],
     "unimp_embedding_bwd": [c_p, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p],
     "unimp_vit_patchify": [c_p, c_i, c_p, c_l, c_i, c_i, c_i, c_i, c_p],
     "unimp_vit_assemble": [c_p, c_l, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
+    "unimp_marker": [c_i, c_p],
     "unimp_add_bf16": [c_p, c_p, c_p, c_l, c_p],
     "unimp_cast_f32_to_bf16": [c_p, c_p, c_l, c_f, c_p],
     "unimp_swiglu_fwd": [c_p, c_l, c_p, c_l, c_i, c_i, c_p],

@@ -308,6 +308,16 @@ __global__ void cast_kernel(const float* __restrict__ s, bf16* __restrict__ d, l
   if (blockIdx.x == 0 && threadIdx.x < (n & 7)) { long i = (n & ~7L) + threadIdx.x; d[i] = f2bf(s[i] * scale); }
 }
 
+// Trace marker: an empty kernel whose GRID SIZE carries an id (id workgroups of 64 threads), so that a rocprofv3 --kernel-trace of
+// a long process can be cut to a region of interest afterwards (tools/trace_window.py: the timed steps of bench.py without model
+// construction, autotuning and warm-up).  No memory traffic, ~1.5 us.
+__global__ void unimp_marker_kernel(int id) { (void)id; }
+extern "C" int unimp_marker(int id, void* stream) {
+  if (id < 1 || id > 65535) return unimp_set_error(UNIMP_ERR_ARG, "marker: id must be in 1..65535");
+  hipLaunchKernelGGL(unimp_marker_kernel, dim3(id), dim3(64), 0, (hipStream_t)stream, id);
+  return unimp_check_launch("marker");
+}
+
 extern "C" int unimp_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream) {
   if (!a || !b || !out) return unimp_set_error(UNIMP_ERR_ARG, "add: null pointer");
   if (n <= 0) return UNIMP_OK;

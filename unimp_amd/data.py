@@ -57,17 +57,67 @@ class _ImageDesc(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("src_off", "H", "W", "kx_off", "ky_off", "ksx", "ksy", "tmp_off")]
 
 
+class _Slot:
+    """one stage of the H2D ring: pinned host bytes, their device image, and the two events that order its reuse."""
+
+    def __init__(self):
+        self.host = self.dev = None
+        self.h2d_done = torch.cuda.Event()
+        self.kernel_done = torch.cuda.Event()
+
+    def reserve(self, nbytes, device):
+        if self.host is None or self.host.numel() < nbytes:
+            cap = max(nbytes, 2 * (self.host.numel() if self.host is not None else 0), 1 << 20)
+            self.host = torch.empty(cap, dtype=torch.uint8, pin_memory=True)
+            self.dev = torch.empty(cap, dtype=torch.uint8, device=device)
+
+
+class PendingImages:
+    """a batch whose bytes are on their way to the device (ImagePreprocessor.submit); ``get()`` enqueues the kernels."""
+
+    def __init__(self, owner, slot, n, max_h, offs, want_u8):
+        self.owner, self.slot, self.n, self.max_h, self.offs, self.want_u8 = owner, slot, n, max_h, offs, want_u8
+        self._out = None
+
+    def get(self):
+        if self._out is not None:
+            return self._out
+        o, S = self.owner, self.owner.size
+        out = torch.empty((self.n, 3, S, S), dtype=o.dtype, device=o.device)
+        u8 = torch.empty((self.n, S, S, 3), dtype=torch.uint8, device=o.device) if self.want_u8 else None
+        if self.n:
+            sl = self.slot
+            cur = torch.cuda.current_stream(o.device)
+            cur.wait_event(sl.h2d_done)                     # the compute stream waits for this batch's copy only
+            src_off, tab_off, dd_off, tmp_bytes = self.offs
+            base = sl.dev.data_ptr()
+            tmp = torch.empty(max(tmp_bytes, 1), dtype=torch.uint8, device=o.device)
+            _lib.check(_lib.lib().unimp_image_resize_normalize(
+                base + src_off, base + dd_off, self.n, self.max_h, base + tab_off, tmp.data_ptr(), S, S,
+                C.cast(o._mean, C.c_void_p), C.cast(o._std, C.c_void_p), out.data_ptr(), int(o.dtype == torch.float32),
+                u8.data_ptr() if u8 is not None else None, ops._stream()), "image_resize_normalize")
+            sl.kernel_done.record(cur)                      # the slot's device bytes may be overwritten after this
+        self._out = (out, u8) if self.want_u8 else out
+        return self._out
+
+
 class ImagePreprocessor:
     """callable: list of decoded RGB images (uint8 [H, W, 3] numpy arrays / torch tensors / PIL images, any sizes) ->
-    [n, 3, size, size] tensor on `device` (bf16 by default, like ``images.to(device, dtype=cast_dtype)`` at mmrec.py:135)."""
+    [n, 3, size, size] tensor on `device` (bf16 by default, like ``images.to(device, dtype=cast_dtype)`` at mmrec.py:135).
 
-    def __init__(self, size=224, mean=FLAMINGO_MEAN, std=FLAMINGO_STD, device="cuda", dtype=torch.bfloat16):
+    Host -> device: the decoded bytes, the tap tables and the per-image descriptors are packed straight into ONE pinned host
+    buffer and cross PCIe as one asynchronous copy on a dedicated copy stream; a ring of ``depth`` (2) such stages lets
+    ``submit(next_batch)`` pack and copy batch i + 1 while the GPU still computes on batch i (the reference hides the same work
+    behind 4 DataLoader workers per rank, mmrec.py:403).  ``__call__`` = ``submit(...).get()``."""
+
+    def __init__(self, size=224, mean=FLAMINGO_MEAN, std=FLAMINGO_STD, device="cuda", dtype=torch.bfloat16, depth=2):
         if dtype not in (torch.bfloat16, torch.float32):
             raise ValueError("ImagePreprocessor: dtype must be bfloat16 or float32")
         self.size, self.device, self.dtype = size, torch.device(device), dtype
         self._mean = (C.c_float * 3)(*mean)
         self._std = (C.c_float * 3)(*std)
         self._taps = {}                      # in_size -> int32 table (host), shared by both axes
+        self._ring, self._next, self._depth, self._copy_stream = None, 0, depth, None
 
     def _table(self, n):
         t = self._taps.get(n)
@@ -82,16 +132,20 @@ class ImagePreprocessor:
         a = np.asarray(img if isinstance(img, np.ndarray) else img.convert("RGB"))
         if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3:
             raise ValueError(f"ImagePreprocessor: expected a decoded RGB uint8 [H, W, 3] image, got {a.dtype} {a.shape}")
-        return np.ascontiguousarray(a)
+        return a
 
-    def __call__(self, images, return_u8=False):
+    def submit(self, images, return_u8=False):
+        """pack + start the asynchronous H2D copy of a batch; returns a PendingImages (``.get()`` -> tensor)."""
         S = self.size
         imgs = [self._as_u8(i) for i in images]
         n = len(imgs)
-        out = torch.empty((n, 3, S, S), dtype=self.dtype, device=self.device)
-        u8 = torch.empty((n, S, S, 3), dtype=torch.uint8, device=self.device) if return_u8 else None
         if n == 0:
-            return (out, u8) if return_u8 else out
+            return PendingImages(self, None, 0, 0, None, return_u8)
+        if self.device.type != "cuda":
+            raise _lib.UnimpHipError("ImagePreprocessor needs a HIP device (no CPU fallback exists)")
+        if self._ring is None:
+            self._ring = [_Slot() for _ in range(self._depth)]
+            self._copy_stream = torch.cuda.Stream(self.device)
         descs = (_ImageDesc * n)()
         tabs, tab_off, src_off, tmp_off, tpos = [], {}, 0, 0, 0
         for i, a in enumerate(imgs):
@@ -114,15 +168,34 @@ class ImagePreprocessor:
                     d.ky_off, d.ksy = off, ks
             src_off += H * W * 3
             tmp_off += H * S * 3
-        src = torch.from_numpy(np.concatenate([a.reshape(-1) for a in imgs])).to(self.device, non_blocking=True)
-        tables = torch.from_numpy(np.concatenate(tabs) if tabs else np.zeros(1, np.int32)).to(self.device, non_blocking=True)
-        dd = torch.from_numpy(np.frombuffer(descs, dtype=np.int64).copy()).to(self.device, non_blocking=True)
-        tmp = torch.empty(max(tmp_off, 1), dtype=torch.uint8, device=self.device)
-        _lib.check(_lib.lib().unimp_image_resize_normalize(
-            src.data_ptr(), dd.data_ptr(), n, max(a.shape[0] for a in imgs), tables.data_ptr(), tmp.data_ptr(), S, S,
-            C.cast(self._mean, C.c_void_p), C.cast(self._std, C.c_void_p), out.data_ptr(), int(self.dtype == torch.float32),
-            u8.data_ptr() if u8 is not None else None, ops._stream()), "image_resize_normalize")
-        return (out, u8) if return_u8 else out
+        # one pinned image: [ pixels | pad to 16 | tap tables (int32) | pad to 16 | descriptors (int64) ]
+        r16 = lambda x: (x + 15) // 16 * 16
+        t_off = r16(src_off)
+        t_bytes = max(tpos, 1) * 4
+        d_off = r16(t_off + t_bytes)
+        total = d_off + C.sizeof(descs)
+        sl = self._ring[self._next]
+        self._next = (self._next + 1) % self._depth
+        sl.h2d_done.synchronize()                            # the previous copy OUT of this pinned buffer has finished (normally long ago)
+        sl.reserve(total, self.device)
+        hb = sl.host.numpy()
+        pos = 0
+        for a in imgs:                                       # packed straight into pinned memory: no concatenate, no pageable staging
+            k = a.size
+            hb[pos:pos + k] = a.reshape(-1)
+            pos += k
+        if tabs:
+            hb[t_off:t_off + tpos * 4] = np.concatenate(tabs).view(np.uint8)
+        hb[d_off:d_off + C.sizeof(descs)] = np.frombuffer(descs, dtype=np.uint8)
+        cs = self._copy_stream
+        cs.wait_event(sl.kernel_done)                        # the kernels that read this slot's previous device bytes are done
+        with torch.cuda.stream(cs):
+            sl.dev[:total].copy_(sl.host[:total], non_blocking=True)
+            sl.h2d_done.record(cs)
+        return PendingImages(self, sl, n, max(a.shape[0] for a in imgs), (0, t_off, d_off, tmp_off), return_u8)
+
+    def __call__(self, images, return_u8=False):
+        return self.submit(images, return_u8).get()
 
 
 # ------------------------------------------------------------------------------------------------ collate (host logic)

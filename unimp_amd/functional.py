@@ -556,6 +556,14 @@ def _kv_append(lc, k, v, pos0):
 
 
 @torch.no_grad()
+def _decode_attn(q, k, v, scale, kv_len, alibi):
+    """one new token per row against the cache: the split-key kernel (HBM-bound, every CU busy), or -- UNIMP_DECODE_ATTN=0, odd
+    layouts -- the training kernel on one query row."""
+    if ops.DECODE_ATTN and q.shape[-1] % 8 == 0 and q.shape[-1] <= 128:
+        return ops.attn_decode(q, k, v, scale, kv_len, alibi)
+    return ops.attn_fwd(q, k, v, scale, ops.MASK_NONE, kv_len, alibi=alibi)[0]
+
+
 def self_attn_block_cached(x, ln_w, ln_b, wqkv, bqkv, wd, bd, nh, lc, pos0, *, rope=None, interleaved=True, eps=1e-5,
                            rms=False, res=None, q_scale=None, alibi=None, qk_ln=None):
     """SelfAttnBlockFn.forward for decoding: the new rows' keys/values are appended to ``lc``; a prefill (pos0 == 0) runs
@@ -583,7 +591,7 @@ def self_attn_block_cached(x, ln_w, ln_b, wqkv, bqkv, wd, bd, nh, lc, pos0, *, r
             ops.rope_(qkv, R, nh, hs, rope[2], offs, rope[0], rope[1])
         lc.k.index_put_((step.rows, step.pos_idx), k[:, 0])
         lc.v.index_put_((step.rows, step.pos_idx), v[:, 0])
-        o, _ = ops.attn_fwd(q, lc.k, lc.v, scale, ops.MASK_NONE, step.kv_len, alibi=alibi)
+        o = _decode_attn(q, lc.k, lc.v, scale, step.kv_len, alibi)
         return ops.gemm(o.view(R, H), wd, bias=bd, res=r2).view(R, 1, H)
     if rope is not None:
         cos, sin, rot = rope[:3]
@@ -594,7 +602,7 @@ def self_attn_block_cached(x, ln_w, ln_b, wqkv, bqkv, wd, bd, nh, lc, pos0, *, r
     else:
         if Ln != 1:
             raise NotImplementedError("cached decode feeds one new token per row (chunked prefill is not built)")
-        o, _ = ops.attn_fwd(q, kc, vc, scale, ops.MASK_NONE, None, alibi=alibi)
+        o = _decode_attn(q, kc, vc, scale, None, alibi)
     return ops.gemm(o.view(R * Ln, H), wd, bias=bd, res=r2).view(R, Ln, H)
 
 

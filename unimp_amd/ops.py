@@ -10,6 +10,8 @@ import torch
 from . import _lib
 from ._lib import GemmDesc, AttnDesc, MxGemmDesc, check
 
+_os_env = os.environ.get
+
 ACT = {None: 0, "none": 0, "gelu": 1, "quick_gelu": 2, "relu": 3, "silu": 4, "deriv": 5}
 MASK_NONE, MASK_CAUSAL, MASK_SEGMENT = 0, 1, 2
 bf16 = torch.bfloat16
@@ -465,6 +467,27 @@ def attn_fwd(q, k, v, scale, mask_mode=MASK_NONE, kv_len=None, seg=None, seg_len
     return out, lse
 
 
+DECODE_ATTN = _os_env("UNIMP_DECODE_ATTN", "1") != "0"       # split-key decode kernel for one-query-row calls (0: the training kernel)
+
+
+def attn_decode(q, k, v, scale, kv_len=None, alibi=None, out=None):
+    """one query row per (row, head): q [B,1,H,D] against the cached k / v [B,Sk,H,D] (strided views), kv_len int32 [B] keys
+    visible per row (None: all Sk).  Split-key kernel (csrc/decode_attn.hip); returns o [B,1,H,D]."""
+    B, Sq, H, D = q.shape
+    assert Sq == 1
+    Sk = k.shape[1]
+    if out is None:
+        out = torch.empty((B, 1, H, D), dtype=bf16, device=q.device)
+    d = AttnDesc()
+    (qp, qs), (kp, ks), (vp, vs), (op, os_) = _view4(q), _view4(k), _view4(v), _view4(out)
+    _fill_attn(d, qp, kp, vp, op, 0, B, H, 1, Sk, D, scale, MASK_NONE, kv_len, None, 0, qs, ks, vs, os_, alibi)
+    L = _lib.lib()
+    splits = L.unimp_attn_decode_splits(B, H, Sk)
+    ws = torch.empty(B * H * splits * (D + 2), dtype=torch.float32, device=q.device) if splits > 1 else None
+    check(L.unimp_attn_decode(C.byref(d), _p(ws), splits, _stream()), "attn_decode")
+    return out
+
+
 def attn_rope_fusable(dq, dk, dv, rope_half, D, adjacent=False):
     """can unimp_attn_bwd apply the transpose rotation to dq / dk itself?  (second-generation kernels, 16-byte aligned views;
     adjacent: the pair-adjacent layout of the GEMM's rotary epilogue instead of the half-split one)"""
@@ -536,6 +559,11 @@ def add(a, b, out=None):
         out = torch.empty_like(a)
     check(_lib.lib().unimp_add_bf16(_dev(a).data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream()), "add")
     return out
+
+
+def marker(i):
+    """empty kernel with grid = i workgroups on the current stream: a cut point for tools/trace_window.py"""
+    check(_lib.lib().unimp_marker(int(i), _stream()), "marker")
 
 
 def dot(a, b):

@@ -146,15 +146,25 @@ class Trainer:
     def __init__(self, model, special_ids, lr=2e-4, weight_decay=0.1, gamma=2.0, use_reweight=True, max_grad_norm=1.0,
                  lr_scheduler="cosine", warmup_steps=0, total_steps=1000, bucket_bytes=256 << 20, process_group=None,
                  sparse_head=False, grad_accum=1, mask_lm_head=False, force_dp_hooks=False, dense_head_backward=False,
-                 shard_optimizer=False, direct_wgrad=True):
-        """sparse_head (off by default): apply the LM head and the loss only to the positions whose next token carries a
+                 shard_optimizer=False, direct_wgrad=True, graph=False):
+        """graph (off by default): replay the forward + loss + backward of a micro-batch as ONE HIP graph.  At the reference's
+        shipped shape (--batch 3 --grad-accum 2, unimp_task.sh:2-30) a micro-step is ~3 000 launches of kernels that run for
+        10-40 us each: the host, not the GPU, sets the pace.  The first micro-step with a given set of batch shapes runs eagerly
+        (it warms the autotuner, the frozen-weight caches and the allocator), the second is captured (inputs copied to static
+        buffers), every later one is a copy + replay.  Needs the sync-free loss path, so it implies ``dense_head_backward``; the
+        returned loss / stats are static tensors that the next replay overwrites; under data parallelism the gradient exchange
+        of a graphed step is issued from ``finish()`` (nothing Python-side runs during a replay), i.e. not overlapped.
+        sparse_head (off by default): apply the LM head and the loss only to the positions whose next token carries a
         label -- identical loss / gradients / update (unlabeled rows contribute nothing), ~5 % fewer FLOPs at cfg2; the
         returned model output then has no logits.  Costs one host sync per step (the row count).
         dense_head_backward (off by default): form the dense [B*L, V] logit gradient and run the head's dX / dW GEMMs over all
         B*L rows as the reference does.  The default computes the SAME dense forward logits and loss but restricts the head's
         backward to the positions that carry a label -- the gradient is exactly zero on the others (functional.DenseHeadLossFn);
         it needs the number of labeled positions on the host: one sync per step, right after the label-mask kernel."""
-        self.model, self.sparse_head, self.dense_head_backward = model, sparse_head, dense_head_backward
+        self.model, self.sparse_head, self.dense_head_backward = model, sparse_head, dense_head_backward or graph
+        if graph and sparse_head:
+            raise ValueError("Trainer(graph=True) needs the sync-free dense loss path (sparse_head takes a row count on the host)")
+        self.use_graph, self._graph = graph, None
         self.grad_accum, self._micro = grad_accum, 0       # mmrec.py's --gradient_accumulation_steps (accelerator.accumulate)
         self.ids = special_ids                   # dict(answer_id, eoc_id, pad_id, media_id)
         self.gamma, self.use_reweight = gamma, use_reweight
@@ -235,29 +245,56 @@ class Trainer:
         finally:
             F_.WGRAD_SINK = None
 
+    def _micro_step(self, batch):
+        """forward + loss + backward of one micro-batch; gradients ADD into the flat buffer (zeroed by the optimizer kernel only)."""
+        loss, stats, out, _ = self.forward_loss(batch)
+        self._backward(loss)
+        return loss.detach(), stats
+
+    _GRAPH_KEYS = ("vision_x", "lang_x", "attention_mask", "weights")
+
+    def _graphed_micro_step(self, batch):
+        key = tuple((k, tuple(batch[k].shape), batch[k].dtype) for k in self._GRAPH_KEYS)
+        g = self._graph
+        if g is None or g["key"] != key:
+            if g is None or g.get("warm_key") != key:          # first micro-step of this shape: eager
+                self._graph = {"key": None, "warm_key": key}
+                return self._micro_step(batch)
+            static = {k: batch[k].clone() for k in self._GRAPH_KEYS}
+            graph = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(graph):                      # recorded, not executed: the replay below runs this micro-batch
+                loss, stats = self._micro_step(static)
+            g = self._graph = {"key": key, "graph": graph, "static": static, "loss": loss, "stats": stats}
+        else:
+            for k in self._GRAPH_KEYS:
+                g["static"][k].copy_(batch[k])
+        g["graph"].replay()
+        return g["loss"], g["stats"]
+
     def step(self, batch):
         """returns (loss, stats) device tensors.  The default loss path (and sparse_head) takes the number of labeled positions on
         the host right after the label-mask kernel -- ONE host synchronisation per micro-step, before the model forward;
-        ``dense_head_backward=True`` has none."""
+        ``dense_head_backward=True`` (and ``graph=True``, which implies it) has none."""
         self.model.train()
-        loss, stats, out, _ = self.forward_loss(batch)
-        if self.grad_accum > 1:
+        micro = self._graphed_micro_step if self.use_graph else self._micro_step
+        if self.grad_accum > 1 or self.use_graph:
             # micro-batches add their gradients into the flat buffer (zeroed by the optimizer kernel only); ranks exchange
             # once, after the last one; 1/GA is folded into the optimizer's gradient scale like 1/W.  The LR schedule
             # advances once per optimizer step (mmrec.py:691-692 sizes its schedule in optimizer steps).
             self._micro += 1
-            self.dp.sync = False
-            self._backward(loss)
+            self.dp.sync = False          # hooks only fold gradients; finish() issues the exchange (a replayed graph runs no hook)
+            loss, stats = micro(batch)
             if self._micro % self.grad_accum == 0:
                 self._mask_lm_head_grads()
                 gscale = self.dp.finish() / self.grad_accum
                 self.dp.sync = True
                 self.opt.step(lr=self.current_lr(), grad_scale=gscale)
                 self.sched_step += 1
-            return loss.detach(), stats
-        self._backward(loss)
+            return loss, stats
+        loss, stats = micro(batch)
         self._mask_lm_head_grads()
         gscale = self.dp.finish()
         self.opt.step(lr=self.current_lr(), grad_scale=gscale)
         self.sched_step += 1
-        return loss.detach(), stats
+        return loss, stats
