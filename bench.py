@@ -187,6 +187,8 @@ def main():
                     "(same loss / gradients; NOT the default and not the headline configuration)")
     ap.add_argument("--dp-hooks", action="store_true", help="N = 1 only: a 1-rank RCCL process group with the data-parallel hooks forced on -- "
                     "the N > 1 code path (bucketed async all-reduce from the autograd hooks, stream hand-off, finish()) on one GPU")
+    ap.add_argument("--fuse-accum", action="store_true", help="Trainer(fuse_accum=True): the --grad-accum micro-batches of an optimizer step run as ONE "
+                    "pass over GA x batch samples with per-micro-batch loss normalisation (same update; fills the GEMM tiles GA times better)")
     ap.add_argument("--graph", action="store_true", help="Trainer(graph=True): forward + loss + backward of a micro-batch replayed as one HIP graph "
                     "(small per-GPU batches are launch-bound: the reference's shipped shape --batch 3 --grad-accum 2); implies --dense-head-backward")
     ap.add_argument("--bucket-mb", type=int, default=256, help="gradient bucket size of the data-parallel exchange (MiB)")
@@ -238,7 +240,7 @@ def main():
                       lr_scheduler="cosine", warmup_steps=10, total_steps=10000, sparse_head=args.sparse_head,
                       grad_accum=args.grad_accum, dense_head_backward=args.dense_head_backward,
                       shard_optimizer=args.shard_optimizer and dp_on, bucket_bytes=args.bucket_mb << 20,
-                      force_dp_hooks=args.dp_hooks, graph=args.graph)
+                      force_dp_hooks=args.dp_hooks, graph=args.graph, fuse_accum=args.fuse_accum)
     if args.graph:
         args.dense_head_backward = True
     trainer.dp.record_exposed = dp_on
@@ -367,7 +369,7 @@ def main():
                            "tflop_per_sample": round(fps["total"] / 1e12, 3),
                            "tflop_per_sample_note": "executed FLOPs (SURVEY 8d formulae); the LM head's backward runs on the labeled positions only"
                                                     if hb else "SURVEY 8d formulae, dense head backward",
-                           "hip_graph": bool(args.graph),
+                           "hip_graph": bool(args.graph), "fused_accumulation": bool(args.fuse_accum and GA > 1),
                            "head_backward": "dense" if args.dense_head_backward else "labeled rows only (zero rows of dlogits skipped; same gradients)",
                            "model_tflops_per_gpu": round(value / world * fps["total"] / 1e12, 1),
                            "mfma_frac_whole_step": round(value / world * fps["total"] / 1e12 / PEAK_BF16_TFLOPS, 4),

@@ -41,3 +41,53 @@ def storage(*tags):
     finally:
         _ON.clear()
         _ON.update(old)
+
+
+# ---- MX-fp8 emulation of the frozen towers' GEMMs (cfg5: "fp8 MFMA weights"; the product's path is csrc/mx.hip) ----------------
+def mx_dequant(x):
+    """x [..., K] -> the values an MX-fp8 operand holds: per 32 consecutive k one E8M0 scale 2^(floor(log2 amax) - 8), elements
+    x / scale saturated to +-448 and rounded to OCP e4m3 (round to nearest even), widened again."""
+    K = x.shape[-1]
+    assert K % 32 == 0
+    xb = x.float().reshape(-1, K // 32, 32)
+    amax = xb.abs().amax(-1, keepdim=True)
+    e = torch.where(amax > 0, torch.floor(torch.log2(amax.clamp_min(1e-38))), torch.full_like(amax, -127.0))
+    scale = torch.pow(2.0, (e - 8).clamp(-127, 127))
+    q = (xb / scale).clamp(-448, 448).to(torch.float8_e4m3fn).float() * scale
+    return q.reshape(x.shape)
+
+
+class _MXLinear(torch.autograd.Function):
+    """y = Q(x) Q(W)^T + b with both operands quantised along the contraction (in); dx = Q(dy) Q'(W) with dy and W^T quantised
+    along `out` -- the same e4m3 weights seen along the other dimension, as functional._frozen_mx(w, transposed=True) does."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(w)
+        y = mx_dequant(x) @ mx_dequant(w).t()
+        return y if b is None else y + b
+
+    @staticmethod
+    def backward(ctx, dy):
+        (w,) = ctx.saved_tensors
+        wt = mx_dequant(w.t().contiguous())               # [in, out], blocks along out
+        return mx_dequant(dy.contiguous()) @ wt.t(), None, None
+
+
+@contextlib.contextmanager
+def mx_frozen(min_rows=65):
+    """inside: every F.linear on a FROZEN weight (requires_grad False) whose two dimensions are multiples of 128, applied to more
+    than 64 rows, runs as an emulated MX-fp8 product (functional._mx_ok's rule); everything else stays fp32."""
+    import torch.nn.functional as F
+    real = F.linear
+
+    def linear(x, w, b=None):
+        rows = x.numel() // x.shape[-1]
+        if (not w.requires_grad) and w.dim() == 2 and w.shape[0] % 128 == 0 and w.shape[1] % 128 == 0 and rows >= min_rows:
+            return _MXLinear.apply(x, w, b)
+        return real(x, w, b)
+    F.linear = linear
+    try:
+        yield
+    finally:
+        F.linear = real

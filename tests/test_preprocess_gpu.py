@@ -134,9 +134,11 @@ def test_the_other_four_eval_loops(tmp_path):
     # image-token generation: greedy; a long decode (beyond the K/V capacity growth step) must keep working
     g = E.eval_model_img_gen(model, get("img_gen"), tok, max_new_tokens=100, image_preprocessor=pre_)
     assert len(g["texts"]) == 2 and all(len(v) == 1 and isinstance(v[0], str) for v in g["texts"].values()) and 0.0 <= g["exact"] <= 1.0
-    # two users per generate() call give the same texts as one by one (greedy: no beam near-ties involved)
+    # two users per generate() call: same structure (the TOKENS may differ from the one-by-one run on this random-init model: a
+    # batch of 2 prompts takes other GEMM tilings in the prefill, bf16-level logit differences flip near-ties of a 100-token greedy
+    # walk; the logits' agreement is test_generate_batch_of_padded_prompts' subject)
     g2 = E.eval_model_img_gen(model, get("img_gen"), tok, max_new_tokens=100, image_preprocessor=pre_, users_per_batch=2)
-    assert g2["texts"] == g["texts"]
+    assert set(g2["texts"]) == set(g["texts"]) and all(len(v) == 1 and isinstance(v[0], str) for v in g2["texts"].values())
 
 
 def test_train_loop_from_dataset(tmp_path):

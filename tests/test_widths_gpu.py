@@ -13,10 +13,13 @@ Tolerances (north_star: loss 1e-3 rel, argmax bit-exact; the HIP path stores bf1
   argmax   agreement rate over ALL valid positions is printed; identical wherever the HIP path's own top-2 margin
            exceeds 8 sigma of its measured logit error
   grads    per trainable tensor rel-L2 <= max(3e-2, 5 x that tensor's bf16-autocast noise floor)
-Round 3 adds the SAME-STORAGE reference: the fp32 oracle with every point where the product writes a tensor to HBM rounded to
-bf16 (oracle/numerics.py; the per-class budget is profiles/r03_error_budget_cfg2_slim.txt).  Against it only the arithmetic
-INSIDE the kernels differs (fp32 summation order, exp2 / erf forms, the on-the-fly rotary angles), so the bound is tighter:
-  logits   rel-L2 vs the same-storage oracle <= SAME_STORAGE_BOUND, and strictly below the error vs the pure-fp32 oracle
+Round 3 adds the STORAGE-PRECISION MODEL: the fp32 oracle with every point where the product writes a tensor to HBM rounded to
+bf16 (oracle/numerics.py; the per-class budget is profiles/r03_error_budget_cfg2_slim.txt).  Its own deviation from pure fp32
+(7.9e-3 at cfg2 width) is what ANY pipeline with these storage points shows; the two realisations of the rounding noise
+decorrelate (a one-ulp difference upstream flips later roundings), so the product is not closer to the model than to fp32 -- but
+its error MAGNITUDE must be the model's:
+  logits   rel-L2 vs pure fp32 <= STORAGE_MODEL_SLACK x (the model's rel-L2 vs pure fp32): the kernels add nothing measurable on
+           top of the storage rounding (measured ratios 0.98-1.00); the absolute 1e-2 bound stays as a second line
 and ``test_argmax_exact_where_the_model_is_confident``: with a head in which every position has a clear winner (planted
 rank-one terms, as a trained model has) the argmax must agree on 100 % of the valid positions.
 """
@@ -27,7 +30,7 @@ pytestmark = pytest.mark.gpu
 bf16 = torch.bfloat16
 
 
-SAME_STORAGE_BOUND = 8e-3        # calibrated on MI355X; the pure-fp32 bound stays 1e-2
+STORAGE_MODEL_SLACK = 1.10       # product's logits error vs fp32 <= 1.10 x the storage-precision model's own (measured 0.98-1.00)
 
 
 @pytest.fixture(scope="module")
@@ -71,9 +74,10 @@ def _check_step(P, om, hm, layout, batch, name, gamma=2.0, reweight=True):
             same = om(batch["vision_x"], batch["lang_x"], batch["attention_mask"])["logits"]
         e_same, e_model = P.rel_l2(got, same), P.rel_l2(same, want_logits)
         ag2 = P.argmax_agreement(got, same, valid)
-        print(f"[{name}] vs the oracle at the product's storage precision: logits rel-L2 {e_same:.3e} (that oracle vs pure fp32: "
-              f"{e_model:.3e}); argmax agreement {ag2['rate']:.4f}")
-        assert e_same <= SAME_STORAGE_BOUND and e_same < e, (e_same, e)
+        print(f"[{name}] storage-precision model (fp32 oracle, bf16 at the product's storage points): model vs fp32 {e_model:.3e} -> product / "
+              f"model error ratio {e / e_model:.3f}; product vs model {e_same:.3e}, argmax agreement with the model {ag2['rate']:.4f}")
+        assert e <= STORAGE_MODEL_SLACK * e_model, (e, e_model)
+        assert e_same <= 1.5 * e_model, (e_same, e_model)       # two decorrelated realisations of the same noise: ~sqrt(2) x at most
         assert ag["n_sure"] > 0 and ag["sure_equal"], ag
         assert ag["rate"] >= 0.9, ag
         loss.backward()
@@ -136,7 +140,7 @@ def test_argmax_exact_where_the_model_is_confident(P, slim2):
             pos, hv = pos[~dup], hv[~dup]
             g = torch.Generator().manual_seed(0)
             tok = torch.randperm(layout.base_vocab - 1, generator=g)[:pos.numel()] + 1         # distinct winners
-            alpha = 12.0 * float(base.std())
+            alpha = 8.0 * float(base.std())        # the largest of a row's 74 053 random logits sits ~4.3 sigma up: the winner clears it by a few sigma
             # rows dW with dW_i . h_j = alpha * delta_ij (least squares: n positions < H dims)
             head_o.data[tok] += (alpha * torch.linalg.pinv(hv).T).float()
             head_o.data.copy_(head_o.data.to(bf16).float())
@@ -217,3 +221,56 @@ def test_cfg5_mpt_width_image_generation_batch_vs_oracle(P):
     sp = layout.special()
     labels = ots.label_mask_loop(batch["lang_x"].numpy(), sp["answer_id"], sp["eoc_id"], sp["pad_id"], sp["media_id"])
     assert int((labels != -100).sum()) == n_lab
+
+
+def test_cfg5_fp8_frozen_towers_vs_error_model(P, monkeypatch):
+    """cfg5 ("fp8 MFMA weights") at MPT-7B WIDTH (K = 4096 / 16384 contractions; round 2 checked tiny dims only, with bounds of 0.25):
+    the frozen Linear layers on the MX-fp8 GEMMs (e4m3 + E8M0 per 32 k, weights quantised once, activations and dy on the fly).
+    e4m3 carries 3 mantissa bits, so against fp32 this path is an order of magnitude coarser than bf16 BY CONSTRUCTION; what a kernel
+    can be held to is the format's own error model: the fp32 oracle with the same products quantised the same way
+    (oracle/numerics.py: mx_frozen) and the bf16 storage points on top.  Measured values are printed; asserted:
+      * HIP fp8 vs the emulated-fp8 oracle: logits rel-L2 <= FP8_VS_MODEL (the residue: fp32 summation order + elements that sit
+        on an e4m3 rounding boundary and fall the other way after a bf16-level difference upstream);
+      * HIP fp8 vs fp32 oracle no worse than 1.25 x what the error model itself deviates from fp32 (logits and every gradient);
+      * loss within 2e-2 of the fp32 oracle."""
+    from unimp_amd import functional as F_
+    from unimp_amd.train import Trainer
+    from oracle import numerics as N_
+    cfg = P.CFG5_SLIM
+    om, layout = P.build_oracle(cfg)
+    batch = _imggen_batch(layout, cfg["L"], cfg["T"])
+    want_logits, want_loss, want_labels, want_grads = P.oracle_step(om, layout, batch)
+    with N_.mx_frozen(), N_.storage(*N_.ALL):
+        mod_logits, mod_loss, _, mod_grads = P.oracle_step(om, layout, batch)
+    monkeypatch.setattr(F_, "FP8_FROZEN", True)
+    hm = P.build_hip(cfg, om, layout)
+    tr = Trainer(hm, layout.special(), lr=1e-4, gamma=2.0)
+    try:
+        hm.train()
+        loss, stats, out, labels = tr.forward_loss({k: v.cuda() for k, v in batch.items()})
+        got = out["logits"].float().cpu()
+        loss.backward()
+        e_fp32, e_model, m_fp32 = P.rel_l2(got, want_logits), P.rel_l2(got, mod_logits), P.rel_l2(mod_logits, want_logits)
+        l_fp32 = abs(loss.item() - want_loss.item()) / abs(want_loss.item())
+        valid = batch["attention_mask"].bool()
+        ag = P.argmax_agreement(got, mod_logits, valid)
+        print(f"\\n[cfg5 fp8] logits rel-L2: HIP vs fp32 oracle {e_fp32:.3e}; HIP vs emulated-fp8 oracle {e_model:.3e}; emulated vs fp32 {m_fp32:.3e}; "
+              f"loss {loss.item():.5f} vs fp32 {want_loss.item():.5f} ({l_fp32:.2e}) vs model {mod_loss.item():.5f}; argmax vs model {ag['rate']:.4f}")
+        assert e_model <= FP8_VS_MODEL and e_model < e_fp32, (e_model, e_fp32)
+        assert e_fp32 <= 1.25 * m_fp32 + 1e-3, (e_fp32, m_fp32)
+        assert l_fp32 <= 2e-2
+        named = dict(hm.named_parameters())
+        worst = (0.0, None)
+        for n, g in want_grads.items():
+            if g.abs().max() == 0 or g.numel() == 1:
+                continue
+            ge, gm, gx = P.rel_l2(named[n].grad, g), P.rel_l2(mod_grads[n], g), P.rel_l2(named[n].grad, mod_grads[n])
+            if ge / max(gm, 1e-3) > worst[0]:
+                worst = (ge / max(gm, 1e-3), f"{n}: HIP vs fp32 {ge:.3e}, model vs fp32 {gm:.3e}, HIP vs model {gx:.3e}")
+            assert ge <= 1.25 * gm + 3e-2, (n, ge, gm)
+        print(f"[cfg5 fp8] gradient tensor closest to its bound (1.25 x the error model's own deviation + 3e-2): {worst[1]}")
+    finally:
+        tr.dp.remove()
+
+
+FP8_VS_MODEL = 3e-2              # calibrated on MI355X (DESIGN.md section 5.4)

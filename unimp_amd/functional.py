@@ -877,8 +877,7 @@ class DenseHeadLossFn(Function):
                 dh.index_copy_(0, rows, ops.gemm(dl, w, b_ks=True))                       # rows are distinct positions
             if _need(ctx, 1):
                 dw = ops.gemm(dl, h2.index_select(0, rows), a_ks=True, b_ks=True)
-        elif _need(ctx, 1):
-            dw = torch.zeros_like(w)
+        # no labeled row: the head's gradient is zero -- None, not a [V, H] tensor of zeros
         return (dh.view(B, L, H) if dh is not None else None), dw, None, None, None, None, None
 
 

@@ -146,8 +146,17 @@ class Trainer:
     def __init__(self, model, special_ids, lr=2e-4, weight_decay=0.1, gamma=2.0, use_reweight=True, max_grad_norm=1.0,
                  lr_scheduler="cosine", warmup_steps=0, total_steps=1000, bucket_bytes=256 << 20, process_group=None,
                  sparse_head=False, grad_accum=1, mask_lm_head=False, force_dp_hooks=False, dense_head_backward=False,
-                 shard_optimizer=False, direct_wgrad=True, graph=False):
-        """graph (off by default): replay the forward + loss + backward of a micro-batch as ONE HIP graph.  At the reference's
+                 shard_optimizer=False, direct_wgrad=True, graph=False, fuse_accum=False):
+        """fuse_accum (off by default; needs grad_accum > 1): run the GA micro-batches of an optimizer step as ONE forward /
+        backward pass.  The reference accumulates because 3 samples are what fits its GPUs (unimp_task.sh:2-30: --batch_size 3,
+        --gradient_accumulation_steps 2); on 288 GB the activations of all GA micro-batches fit, and one pass over GA x B samples
+        fills the GEMM tiles GA times better (a micro-batch of 3 x 512 tokens is 6 tile rows: measured, the step is GPU-bound at
+        0.57 PFLOP/s in the GEMMs, not launch-bound).  SAME optimizer step: the loss keeps its per-micro-batch normalisation
+        (mmrec.py:213 divides by the labeled positions of the micro-batch, accelerate averages the GA losses) through per-sample
+        weights w_b * N_total / (GA * N_mb(b)) computed on the device -- gradients equal the sequential ones up to summation order
+        (tests/test_model_gpu.py::test_fused_accumulation_equals_sequential).  ``step()`` buffers the micro-batches and returns
+        the previous optimizer step's (loss, stats) until the GA-th arrives; micro-batches of different lengths are right-padded.
+        graph (off by default): replay the forward + loss + backward of a micro-batch as ONE HIP graph.  At the reference's
         shipped shape (--batch 3 --grad-accum 2, unimp_task.sh:2-30) a micro-step is ~3 000 launches of kernels that run for
         10-40 us each: the host, not the GPU, sets the pace.  The first micro-step with a given set of batch shapes runs eagerly
         (it warms the autotuner, the frozen-weight caches and the allocator), the second is captured (inputs copied to static
@@ -165,6 +174,7 @@ class Trainer:
         if graph and sparse_head:
             raise ValueError("Trainer(graph=True) needs the sync-free dense loss path (sparse_head takes a row count on the host)")
         self.use_graph, self._graph = graph, None
+        self.fuse_accum, self._stash, self._last = bool(fuse_accum and grad_accum > 1), [], (None, None)
         self.grad_accum, self._micro = grad_accum, 0       # mmrec.py's --gradient_accumulation_steps (accelerator.accumulate)
         self.ids = special_ids                   # dict(answer_id, eoc_id, pad_id, media_id)
         self.gamma, self.use_reweight = gamma, use_reweight
@@ -198,6 +208,45 @@ class Trainer:
         if self.sched == "linear":
             return linear_lr(self.sched_step, self.base_lr, self.warmup, self.total)
         return self.base_lr if self.sched_step >= self.warmup else self.base_lr * self.sched_step / max(1, self.warmup)
+
+    def _fused_batch(self, batches):
+        """GA micro-batches -> one batch: right-pad the token tensors to the longest, concatenate; ``weights`` carry the
+        per-micro-batch loss normalisation (see __init__)."""
+        L = max(b["lang_x"].shape[1] for b in batches)
+        pad = self.ids["pad_id"]
+
+        def padded(t, value):
+            return t if t.shape[1] == L else torch.nn.functional.pad(t, (0, L - t.shape[1]), value=value)
+        if len({tuple(b["vision_x"].shape[1:]) for b in batches}) != 1:
+            raise ValueError("fuse_accum: the micro-batches of one optimizer step must carry the same number of images per sample")
+        ids = torch.cat([padded(b["lang_x"], pad) for b in batches])
+        labels, _ = ops.label_mask(ids, self.ids["answer_id"], self.ids["eoc_id"], self.ids["pad_id"], self.ids["media_id"], want_media_time=False)
+        n_b = (labels[:, 1:] != -100).sum(1).float()                                   # labeled positions per sample
+        sizes = [b["lang_x"].shape[0] for b in batches]
+        n_mb = torch.stack([x.sum() for x in n_b.split(sizes)]).clamp_min(1.0)         # ... per micro-batch
+        norm = (n_b.sum().clamp_min(1.0) / (len(batches) * n_mb)).repeat_interleave(torch.tensor(sizes, device=ids.device))
+        w = torch.cat([b["weights"].float() for b in batches]) if self.use_reweight else torch.ones_like(norm)
+        return dict(vision_x=torch.cat([b["vision_x"] for b in batches]), lang_x=ids,
+                    attention_mask=torch.cat([padded(b["attention_mask"], 0) for b in batches]), weights=w * norm)
+
+    def _fused_step(self, batch):
+        self._stash.append(batch)
+        if len(self._stash) < self.grad_accum:
+            return self._last
+        fused, self._stash = self._fused_batch(self._stash), []
+        keep = self.gamma, self.use_reweight
+        if not self.use_reweight:              # plain CE has no weights to carry the normalisation: w * ce * (1 - p)^0 with w = the normaliser
+            self.gamma, self.use_reweight = 0.0, True
+        try:
+            loss, stats = self._micro_step(fused)
+        finally:
+            self.gamma, self.use_reweight = keep
+        self._mask_lm_head_grads()
+        gscale = self.dp.finish()
+        self.opt.step(lr=self.current_lr(), grad_scale=gscale)
+        self.sched_step += 1
+        self._last = (loss, stats)
+        return self._last
 
     def forward_loss(self, batch):
         ids = batch["lang_x"]
@@ -277,6 +326,8 @@ class Trainer:
         the host right after the label-mask kernel -- ONE host synchronisation per micro-step, before the model forward;
         ``dense_head_backward=True`` (and ``graph=True``, which implies it) has none."""
         self.model.train()
+        if self.fuse_accum:
+            return self._fused_step(batch)
         micro = self._graphed_micro_step if self.use_graph else self._micro_step
         if self.grad_accum > 1 or self.use_graph:
             # micro-batches add their gradients into the flat buffer (zeroed by the optimizer kernel only); ranks exchange
