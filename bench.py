@@ -334,16 +334,15 @@ def main():
             lm_ms, lm_fl = sum(r[0].elapsed_time(r[1]) for r in lm), sum(r[2] for r in lm)
             lm_ach = lm_fl / (lm_ms * 1e-3) / 1e12 if lm_ms else 0.0
             traffic, note = None, None
-            pmc = os.path.join(ROOT, "profiles", "r02_pmc_gemm.json")
-            if not os.path.exists(pmc):
-                pmc = os.path.join(ROOT, "profiles", "r01_pmc_gemm.json")
+            pmc = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_gemm.json") for r in (3, 2, 1)) if os.path.exists(q)), "")
             if os.path.exists(pmc):                      # PMC passes cannot run inside the timed bench: committed measurement
                 with open(pmc) as f:
                     j = json.load(f)
                 traffic = j["traffic_bytes_per_launch"]
-                note = (f"rocprofv3 --pmc FETCH_SIZE(x2, gfx950 correction)+WRITE_SIZE per launch of {j['kernel']} at M,N,K={j['shape']} "
-                        f"(algorithmic {(j['shape'][0] * j['shape'][2] + j['shape'][1] * j['shape'][2] + j['shape'][0] * j['shape'][1]) * 2} B; "
-                        f"L2-to-fabric requests incl. Infinity-Cache hits); MFMA pipe busy {j['mfma_util']:.3f} of SIMD cycles; {j['source']}")
+                alg = j.get("algorithmic_bytes") or (j['shape'][0] * j['shape'][2] + j['shape'][1] * j['shape'][2] + j['shape'][0] * j['shape'][1]) * 2
+                note = (f"rocprofv3 --pmc FETCH_SIZE(x2, gfx950 correction)+WRITE_SIZE per launch of {j['kernel']} ({j.get('label', 'dominant GEMM instance of the step')}) "
+                        f"at M,N,K={j['shape']} (algorithmic {alg} B; L2-to-fabric requests incl. Infinity-Cache hits); MFMA pipe busy "
+                        f"{j['mfma_util']:.3f} of SIMD cycles at the clock the chip held under that kernel; {j['source']}")
             roofline = {"bound": "mfma", "kernel": "256x256-tile bf16 MFMA GEMMs (gemm3 ping-pong, gemm6 persistent ping-pong, gemm5 8-wave; autotuned per shape), all GEMM launches of the step",
                         "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_note": note,

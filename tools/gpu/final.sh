@@ -1,42 +1,42 @@
-# end-of-round measurement on the final tree: autotune table, bench lines, rocprofv3 kernel stats, PMC passes.  Writes gpurun_out/final/
+# end-of-round measurement on the final tree: autotune table, bench lines, rocprofv3 kernel stats (whole process + timed steps only),
+# PMC passes with pinned kernel instances.  Writes gpurun_out/final/; the summaries to keep are copied to profiles/ by hand.
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
+R=${ROUND:-r03}
 O=gpurun_out/final; mkdir -p $O
 T=$PWD/$O/gemm_autotune_gfx950.json
 cp profiles/gemm_autotune_gfx950.json $T        # keep the committed choices; only shapes / epilogue classes that are missing get tuned
-# 1. autotune table for the shapes of the default bench (b = 64), the reference's shipped shape (b = 3, GA 2) and the 9b model
-UNIMP_GEMM_TUNE_FILE=$T UNIMP_GEMM_TUNE_WRITE=1 timeout 900 python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline > $O/tune1.json 2> $O/tune1.err
-UNIMP_GEMM_TUNE_FILE=$T UNIMP_GEMM_TUNE_WRITE=1 timeout 900 python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --batch 3 --grad-accum 2 > $O/tune2.json 2> $O/tune2.err
-UNIMP_GEMM_TUNE_FILE=$T UNIMP_GEMM_TUNE_WRITE=1 timeout 900 python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --model 9b > $O/tune3.json 2> $O/tune3.err
-UNIMP_GEMM_TUNE_FILE=$T UNIMP_GEMM_TUNE_WRITE=1 timeout 900 python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --batch 48 > $O/tune4.json 2> $O/tune4.err
+# 1. autotune table for the shapes of the default bench (b = 64), the reference's shipped shape (b = 3, GA 2; fused: b = 6), b = 16 / 32 / 48, the 9b model
+for extra in "" "--batch 3 --grad-accum 2" "--batch 3 --grad-accum 2 --fuse-accum" "--batch 16" "--batch 32" "--batch 48" "--model 9b"; do
+  UNIMP_GEMM_TUNE_FILE=$T UNIMP_GEMM_TUNE_WRITE=1 timeout 900 python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline $extra > $O/tune.json 2> $O/tune.err
+done
 cp $T profiles/gemm_autotune_gfx950.json
 # 2. bench lines with the table (no live tuning)
 UNIMP_BENCH_SHAPES=1 timeout 1500 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench default rc=$?" >> $O/rc.txt
+timeout 900 python bench.py --no-cpu-baseline --dp-hooks > $O/bench_dphooks.json 2> $O/bench_dphooks.err
 timeout 900 python bench.py --no-cpu-baseline --batch 3 --grad-accum 2 > $O/bench_b3ga2.json 2> $O/bench_b3ga2.err
+timeout 900 python bench.py --no-cpu-baseline --batch 3 --grad-accum 2 --fuse-accum > $O/bench_b3ga2_fused.json 2> $O/bench_b3ga2_fused.err
+timeout 900 python bench.py --no-cpu-baseline --batch 16 > $O/bench_b16.json 2> $O/bench_b16.err
+timeout 900 python bench.py --no-cpu-baseline --batch 32 > $O/bench_b32.json 2> $O/bench_b32.err
+timeout 900 python bench.py --no-cpu-baseline --batch 48 > $O/bench_b48.json 2> $O/bench_b48.err
 timeout 900 python bench.py --no-cpu-baseline --model 9b > $O/bench_9b.json 2> $O/bench_9b.err
 timeout 900 python bench.py --no-cpu-baseline --model 9b --fp8 > $O/bench_9b_fp8.json 2> $O/bench_9b_fp8.err
-timeout 900 python bench.py --no-cpu-baseline --batch 48 > $O/bench_b48.json 2> $O/bench_b48.err
-# 3. kernel stats of the default bench command
-timeout 900 rocprofv3 --kernel-trace --stats -d $O/stats -o st --output-format csv -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-roofline > $O/prof.log 2>&1
-timeout 900 rocprofv3 --kernel-trace --stats -d $O/stats48 -o st --output-format csv -- python3 bench.py --batch 48 --steps 6 --warmup 2 --no-cpu-baseline --no-roofline > $O/prof48.log 2>&1
-# 3b. micro-benchmarks of the HBM-bound kernels, streaming from HBM
+for f in $O/bench_*.json; do python -c "import json,sys; j=json.load(open('$f')); print('$f', j['value'], j['ms_per_step'], j['roofline']['frac'] if j.get('roofline') else None)"; done > $O/summary.txt 2>&1
+# 3. kernel stats of the default bench command: whole process (--stats) and the timed steps only (markers)
+timeout 900 rocprofv3 --kernel-trace --stats -d $O/stats -o st --output-format csv -- python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-roofline > $O/prof.log 2>&1
+python tools/trace_window.py $(find $O/stats -name "*kernel_trace.csv" | head -1) 6 $O/${R}_bench_b64_timed_steps.csv > $O/window.txt 2>&1
+# 3b. micro-benchmarks of the HBM-bound kernels, streaming from HBM; decode
 timeout 300 python tools/bench_ln.py --rotate 3 > $O/bench_ln.log 2>&1
-timeout 300 python tools/bench_rope.py > $O/bench_rope.log 2>&1
 timeout 300 python tools/bench_adamw.py > $O/bench_adamw.log 2>&1
-# 4. PMC passes: dominant GEMM shapes, attention kernels (both generations)
+timeout 600 python tools/bench_decode.py > $O/bench_decode.log 2>&1
+timeout 300 python tools/bench_gemm_power.py > $O/gemm_power.log 2>&1
+# 4. PMC passes: the step's dominant GEMM kernel instances, variants pinned
+export PMC_MANIFEST=$PWD/$O/pmc_manifest.json
 for pm in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   tag=$(echo $pm | cut -d' ' -f1)
   timeout 600 rocprofv3 --kernel-trace --pmc $pm -d $O/pmcg_$tag -o pmc --output-format csv -- python3 tools/pmc_gemm_step.py > $O/pmcg_$tag.log 2>&1
 done
-export REP=2
-for gen in 1 2; do
-  for pm in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_ACTIVE_INST_ANY" "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE"; do
-    tag=$(echo $pm | cut -d' ' -f1)
-    UNIMP_ATTN_GEN=$gen timeout 600 rocprofv3 --kernel-trace --pmc $pm -d $O/pmca${gen}_$tag -o pmc --output-format csv -- python3 tools/pmc_attn.py > $O/pmca${gen}_$tag.log 2>&1
-  done
-done
+python tools/pmc_to_json.py $O/pmc_manifest.json $O/pmcg_FETCH_SIZE $O/pmcg_WRITE_SIZE $O/pmcg_SQ_VALU_MFMA_BUSY_CYCLES $O/${R}_pmc_gemm > $O/pmc_rows.json 2> $O/pmc_to_json.err
 find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -delete
-python tools/pmc_to_json.py $O/pmcg_* $O/r02_pmc_gemm 32768 > $O/pmc_gemm_rows.json 2> $O/pmc_to_json.err
-python tools/pmc_summary.py $O/pmca1_* --match attn > $O/r02_pmc_attention_gen1.csv 2>> $O/pmc_to_json.err
-python tools/pmc_summary.py $O/pmca2_* --match attn > $O/r02_pmc_attention_gen2.csv 2>> $O/pmc_to_json.err
 echo done >> $O/rc.txt
+cat $O/summary.txt $O/window.txt

@@ -10,4 +10,5 @@ timeout 600 python bench.py --no-cpu-baseline --batch 32 > $O/bench_b32.json 2> 
 for f in $O/bench_b*.json; do python -c "import json,sys; j=json.load(open('$f')); print('$f', j['value'], j['ms_per_step'], j['roofline']['frac'] if j['roofline'] else None)"; done
 UNIMP_BENCH_SHAPES=1 timeout 600 python bench.py --no-cpu-baseline --batch 3 --grad-accum 2 --steps 8 > $O/shapes_b3.json 2> $O/shapes_b3.err
 grep "gemm M=" $O/shapes_b3.err | head -40
+timeout 300 python tools/bench_gemm_power.py > $O/gemm_power.log 2>&1; cat $O/gemm_power.log
 cat $O/rc.txt

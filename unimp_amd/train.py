@@ -225,7 +225,7 @@ class Trainer:
         sizes = [b["lang_x"].shape[0] for b in batches]
         n_mb = torch.stack([x.sum() for x in n_b.split(sizes)]).clamp_min(1.0)         # ... per micro-batch
         norm = (n_b.sum().clamp_min(1.0) / (len(batches) * n_mb)).repeat_interleave(torch.tensor(sizes, device=ids.device))
-        w = torch.cat([b["weights"].float() for b in batches]) if self.use_reweight else torch.ones_like(norm)
+        w = torch.cat([b["weights"].float() for b in batches])        # the task weights apply with and without --use_reweight (mmrec.py:203)
         return dict(vision_x=torch.cat([b["vision_x"] for b in batches]), lang_x=ids,
                     attention_mask=torch.cat([padded(b["attention_mask"], 0) for b in batches]), weights=w * norm)
 
@@ -234,13 +234,7 @@ class Trainer:
         if len(self._stash) < self.grad_accum:
             return self._last
         fused, self._stash = self._fused_batch(self._stash), []
-        keep = self.gamma, self.use_reweight
-        if not self.use_reweight:              # plain CE has no weights to carry the normalisation: w * ce * (1 - p)^0 with w = the normaliser
-            self.gamma, self.use_reweight = 0.0, True
-        try:
-            loss, stats = self._micro_step(fused)
-        finally:
-            self.gamma, self.use_reweight = keep
+        loss, stats = self._micro_step(fused)
         self._mask_lm_head_grads()
         gscale = self.dp.finish()
         self.opt.step(lr=self.current_lr(), grad_scale=gscale)
