@@ -168,6 +168,11 @@ int unimp_attn_bwd(const unimp_attn_desc* d, void* stream);
  * on the batch it is decoded in or on the cache capacity).  d->lse is not written.  HBM-bound: algorithmic bytes =
  * 2 * sum_b kv_len[b] * H * D * 2. */
 int unimp_attn_decode(const unimp_attn_desc* d, float* workspace, int splits, void* stream);
+/* Beam search form: rows [g * group, (g + 1) * group) are the beams of prompt g and hold IDENTICAL K / V for key positions below
+ * shared_len[g] (int32 [B / group], device; the prompt: generate() repeats vision_x / the prompt per beam, eval_rec.py:100-110 with
+ * num_beams = 10).  Those keys are read once per prompt (from the group's first row) for all its queries; each row's own keys from
+ * shared_len[g] to kv_len[b] as above.  group <= 16; workspace B*H*2*splits*(D+2) floats.  group = 1 is unimp_attn_decode. */
+int unimp_attn_decode_grouped(const unimp_attn_desc* d, float* workspace, int splits, int group, const int* shared_len, void* stream);
 int unimp_attn_decode_splits(int B, int H, int Sk);
 /* tuning / test knob: which generation of attention kernels serves the calls above.  2 (default; env UNIMP_ATTN_GEN):
  * the 32x32x16-MFMA / LDS-DMA kernels of attention2.hip; 1: the first-generation kernels (kept for A/B measurements and

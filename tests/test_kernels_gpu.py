@@ -842,6 +842,45 @@ def test_split_key_decode_attention(ops, B, H, cap, D, lens, alibi):
         close(got, ref, rel=2 ** -6, name="decode attention vs training kernel")
 
 
+@pytest.mark.parametrize("n_prompts,group,cap,H,D,alibi", [(1, 10, 583, 32, 80, False), (4, 10, 560, 8, 80, False), (2, 5, 800, 4, 128, True),
+                                                          (3, 3, 200, 2, 64, False), (1, 16, 300, 2, 64, True), (2, 2, 130, 3, 8, False)])
+def test_decode_attention_shared_prefix(ops, n_prompts, group, cap, H, D, alibi):
+    """beam-search form of the decode kernel: the `group` rows of a prompt hold identical K / V below shared_len[prompt] (and their
+    own keys above it); the grouped launch reads the prefix once per prompt.  Against fp32 attention per row and against the
+    ungrouped kernel on the same cache; prompts of different lengths, tails of different lengths, NaN in every dead slot AND in the
+    prefix slots of the rows the grouped kernel must not read (rows 1.. of a group: only row 0's prefix is touched)."""
+    B = n_prompts * group
+    g = torch.Generator().manual_seed(cap + D + group)
+    kv = torch.randn(2, B, cap, H, D, generator=g).to(bf16)
+    q = torch.randn(B, 1, H, D, generator=g).to(bf16).cuda()
+    shared = [max(1, cap - 60 - 41 * p_) for p_ in range(n_prompts)]
+    n = [min(cap, shared[b // group] + (7 * b) % 50) for b in range(B)]
+    for p_ in range(n_prompts):                       # the beams of a prompt share the prompt's K / V
+        kv[:, p_ * group:(p_ + 1) * group, :shared[p_]] = kv[:, p_ * group:p_ * group + 1, :shared[p_]]
+    for b in range(B):
+        kv[:, b, n[b]:] = float("nan")
+    kv = kv.cuda()
+    kv_len = torch.tensor(n, dtype=torch.int32, device="cuda")
+    sl = torch.tensor(shared, dtype=torch.int32, device="cuda")
+    slopes = mpt_alibi_slopes(H).cuda() if alibi else None
+    scale = D ** -0.5
+    plain = ops.attn_decode(q, kv[0], kv[1], scale, kv_len, slopes)
+    poisoned = kv.clone()
+    for b in range(B):
+        if b % group:
+            poisoned[:, b, :shared[b // group]] = float("nan")
+    got = ops.attn_decode(q, poisoned[0], poisoned[1], scale, kv_len, slopes, group=group, shared_len=sl)
+    assert torch.equal(got, ops.attn_decode(q, poisoned[0], poisoned[1], scale, kv_len, slopes, group=group, shared_len=sl))
+    want = torch.empty(B, 1, H, D)
+    for b in range(B):
+        s_ = torch.einsum("hd,khd->hk", q[b, 0].float().cpu(), kv[0, b, :n[b]].float().cpu()) * scale
+        if alibi:
+            s_ = s_ + slopes.cpu()[:, None] * torch.arange(n[b])[None, :]
+        want[b, 0] = torch.einsum("hk,khd->hd", torch.softmax(s_, -1), kv[1, b, :n[b]].float().cpu())
+    close(got, want, rel=2 ** -7, name="grouped decode attention")
+    close(got, plain, rel=2 ** -7, name="grouped vs plain decode attention")
+
+
 # ------------------------------------------------------------------------------------------------- MX-fp8 (frozen towers, F4)
 def _mx_reference(x):
     """the MX quantisation rule on the host: per 32 consecutive k, shared exponent floor(log2 amax) - 8 (E8M0 byte = exponent

@@ -18,19 +18,25 @@ model, layout = bench.build_cfg2(dev, gate=0.5)
 bt = make_batch(layout, 1, 8, 512, seed=7, device="cuda", vision_dtype=torch.bfloat16)
 n = int(bt["attention_mask"][0].sum())
 ids, vx = bt["lang_x"][:1, :n - 2], bt["vision_x"][:1]
-cases = [("eval_rec   K=10,  50 new", 10, 50), ("eval_exp   K=5,  256 new", 5, 256), ("eval_img_gen greedy, 600 new", 1, 600)]
+cases = [("eval_rec   K=10,  50 new", 10, 50, 1), ("eval_rec   K=10,  50 new, 4 users per call", 10, 50, 4), ("eval_exp   K=5,  256 new", 5, 256, 1),
+         ("eval_img_gen greedy, 600 new", 1, 600, 1)]
 if quick:
-    cases = cases[:1]
-for name, K, new in cases:
-    for dec in (True, False):
-        ops.DECODE_ATTN = dec
+    cases = cases[:2]
+modes = [("split-key kernel, prompt keys read once per prompt", True, True), ("split-key kernel, every beam reads its own copy", True, False),
+         ("training kernel on one query row", False, False)]
+for name, K, new, users in cases:
+    for label, dec, shared in modes:
+        if K == 1 and dec and not shared:
+            continue                       # no beams: the two split-key modes are the same launch
+        ops.DECODE_ATTN, ops.DECODE_SHARED_PREFIX = dec, shared
         kw = dict(num_beams=K, num_return_sequences=K, early_stopping=False, max_new_tokens=new, eos_token_id=-1, pad_token_id=layout.eos)
-        model.generate(vx, ids, **{**kw, "max_new_tokens": 3})
+        ii, vv = ids.repeat(users, 1), vx.repeat(users, 1, 1, 1, 1, 1)
+        model.generate(vv, ii, **{**kw, "max_new_tokens": 3})
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        out = model.generate(vx, ids, **kw)
+        out = model.generate(vv, ii, **kw)
         torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        print(f"{name:30s} decode attention = {'split-key kernel' if dec else 'training kernel, 1 query row'}: prompt {ids.shape[1]} tokens, "
-              f"{out.shape[1] - ids.shape[1]} new tokens: {dt:.3f} s per user ({dt / new * 1e3:.2f} ms per token-step incl. vision + prefill)", flush=True)
-ops.DECODE_ATTN = True
+        dt = (time.perf_counter() - t0) / users
+        print(f"{name:44s} {label:52s}: prompt {ids.shape[1]} tokens, {out.shape[1] - ids.shape[1]} new tokens: {dt:.3f} s per user "
+              f"({dt * users / new * 1e3:.2f} ms per token-step incl. vision + prefill)", flush=True)
+ops.DECODE_ATTN = ops.DECODE_SHARED_PREFIX = True

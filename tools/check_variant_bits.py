@@ -1,0 +1,30 @@
+"""Do all GEMM kernel variants give the same BITS on a forward (k-contiguous) problem?  The per-sample-independence tests rely on it:
+the variant is chosen per (M, N, K), so a sample decoded alone (M = L) and inside a batch (M = B L) may run different variants."""
+import os
+import sys
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from unimp_amd import ops       # noqa: E402
+
+bf = torch.bfloat16
+torch.manual_seed(0)
+shapes = [(512, 4096, 4096), (1024, 4096, 4096), (512, 12288, 4096), (1024, 16384, 4096), (1024, 4096, 16384), (512, 74053, 4096), (1024, 2560, 2560),
+          (1024, 1024, 1024), (2056, 1024, 1024)]
+for M, N, K in shapes:
+    a = torch.randn(M, K, device="cuda").to(bf)
+    b = (torch.randn(N, K, device="cuda") * 0.02).to(bf)
+    res = torch.randn(M, N, device="cuda").to(bf)
+    for epi in ("plain", "res", "gelu"):
+        kw = {"plain": {}, "res": dict(res=res), "gelu": dict(act="gelu")}[epi]
+        outs = {}
+        for v in ("v1", "dma256", "dma128", "pp256", "pp128", "w8", "pp256p"):
+            try:
+                ldc = (N + 7) // 8 * 8
+                o = ops.gemm(a, b, variant=v, ldc=ldc, **kw)
+                outs[v] = o.clone()
+            except Exception as e:       # noqa: BLE001
+                outs[v] = None
+        ref = outs["v1"]
+        diff = {v: (None if o is None else int((o.view(torch.int16) != ref.view(torch.int16)).sum())) for v, o in outs.items()}
+        print(f"M={M:5d} N={N:6d} K={K:6d} {epi:6s} elements differing from v1: {diff}", flush=True)

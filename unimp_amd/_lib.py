@@ -51,6 +51,7 @@ _SIGS = {
     "unimp_attn_fwd": [C.POINTER(AttnDesc), c_p],
     "unimp_attn_bwd": [C.POINTER(AttnDesc), c_p],
     "unimp_attn_decode": [C.POINTER(AttnDesc), c_p, c_i, c_p],
+    "unimp_attn_decode_grouped": [C.POINTER(AttnDesc), c_p, c_i, c_i, c_p, c_p],
     "unimp_attn_decode_splits": [c_i, c_i, c_i],
     "unimp_embedding_fwd": [c_p, c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p],
     "unimp_embedding_bwd": [c_p, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p],

@@ -420,20 +420,6 @@ static void launch_v1(const unimp_gemm_desc* d, void* stream, int splits = 1, fl
   }
   dim3 grid(p.nbm * p.nbn, splits > 1 ? (d->K + p.ksplit - 1) / p.ksplit : 1), block(256);
   size_t lds = 2 * STAGE_BYTES;
-  // A grid of at most one workgroup per CU: two of these 256-thread workgroups fit on a CU, and where the dispatcher co-locates them
-  // half of the chip idles (3 x 512-token micro-batches: 240 tiles).  Asking for more than half of the CU's LDS makes the second
-  // workgroup of a CU impossible, so the grid spreads over the CUs (UNIMP_V1_SPREAD=0 restores the plain launch; A/B in DESIGN 6).
-  static const int spread = [] { const char* e = getenv("UNIMP_V1_SPREAD"); return e ? atoi(e) : 0; }();
-  static int ncu = 0;
-  if (spread) {
-    if (!ncu) { int dev = 0; hipDeviceProp_t pr; (void)hipGetDevice(&dev); (void)hipGetDeviceProperties(&pr, dev); ncu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
-      const size_t big = 82 * 1024;
-      (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big);
-      (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big);
-      (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big);
-      (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big); }
-    if ((long)grid.x * grid.y <= ncu && lds < 82 * 1024) lds = 82 * 1024;
-  }
   hipStream_t s = (hipStream_t)stream;
   if (!d->a_kstrided && !d->b_kstrided) hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, lds, s, p);
   else if (!d->a_kstrided && d->b_kstrided) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, lds, s, p);

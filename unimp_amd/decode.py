@@ -63,6 +63,8 @@ class DecodeSession:
         c.media_count = ((prompts == m.media_token_id) & (torch.arange(Lmax, device=dev)[None, :] < row_len[::K, None])) \
             .sum(1, keepdim=True).to(torch.int32).repeat_interleave(K, 0)
         c.step = F_.StepState(R, row_len, dev)
+        if K > 1:              # the K rows of a prompt share its prefix: the decode attention reads those keys once per prompt
+            c.group, c.shared_len = K, row_len[::K].to(torch.int32).contiguous()
         self.tok = torch.zeros((R, 1), dtype=torch.long, device=dev)
         self.src = torch.arange(R, dtype=torch.long, device=dev)
         self.base = (torch.arange(R, device=dev) // K) * K               # first row of each row's beam group

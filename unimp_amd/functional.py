@@ -521,6 +521,7 @@ class DecodeCache:
         self.media_count = None
         self.row_len = None                # prefill of right-padded prompts: valid tokens per row (device tensor)
         self.shared_prefix = 0
+        self.group, self.shared_len = 1, None     # beam search: rows per prompt and int32 [prompts] prefix length whose K / V the rows of a group share
         self.step = None                   # StepState while decoding with device-side positions
 
     def _reserve(self, like, need):
@@ -556,11 +557,13 @@ def _kv_append(lc, k, v, pos0):
 
 
 @torch.no_grad()
-def _decode_attn(q, k, v, scale, kv_len, alibi):
-    """one new token per row against the cache: the split-key kernel (HBM-bound, every CU busy), or -- UNIMP_DECODE_ATTN=0, odd
-    layouts -- the training kernel on one query row."""
+def _decode_attn(q, k, v, scale, kv_len, alibi, group=1, shared_len=None):
+    """one new token per row against the cache: the split-key kernel (HBM-bound, every CU busy; with ``group`` beams per prompt
+    the prompt's keys are read once per prompt), or -- UNIMP_DECODE_ATTN=0, odd layouts -- the training kernel on one query row."""
     if ops.DECODE_ATTN and q.shape[-1] % 8 == 0 and q.shape[-1] <= 128:
-        return ops.attn_decode(q, k, v, scale, kv_len, alibi)
+        if not ops.DECODE_SHARED_PREFIX:
+            group, shared_len = 1, None
+        return ops.attn_decode(q, k, v, scale, kv_len, alibi, group=group, shared_len=shared_len)
     return ops.attn_fwd(q, k, v, scale, ops.MASK_NONE, kv_len, alibi=alibi)[0]
 
 
@@ -591,7 +594,7 @@ def self_attn_block_cached(x, ln_w, ln_b, wqkv, bqkv, wd, bd, nh, lc, pos0, *, r
             ops.rope_(qkv, R, nh, hs, rope[2], offs, rope[0], rope[1])
         lc.k.index_put_((step.rows, step.pos_idx), k[:, 0])
         lc.v.index_put_((step.rows, step.pos_idx), v[:, 0])
-        o = _decode_attn(q, lc.k, lc.v, scale, step.kv_len, alibi)
+        o = _decode_attn(q, lc.k, lc.v, scale, step.kv_len, alibi, lc.owner.group, lc.owner.shared_len)
         return ops.gemm(o.view(R, H), wd, bias=bd, res=r2).view(R, 1, H)
     if rope is not None:
         cos, sin, rot = rope[:3]

@@ -473,11 +473,14 @@ def attn_fwd(q, k, v, scale, mask_mode=MASK_NONE, kv_len=None, seg=None, seg_len
 
 
 DECODE_ATTN = _os_env("UNIMP_DECODE_ATTN", "1") != "0"       # split-key decode kernel for one-query-row calls (0: the training kernel)
+DECODE_SHARED_PREFIX = _os_env("UNIMP_DECODE_SHARED_PREFIX", "1") != "0"   # beam search: read a prompt's K / V once per prompt, not once per beam
 
 
-def attn_decode(q, k, v, scale, kv_len=None, alibi=None, out=None):
+def attn_decode(q, k, v, scale, kv_len=None, alibi=None, out=None, group=1, shared_len=None):
     """one query row per (row, head): q [B,1,H,D] against the cached k / v [B,Sk,H,D] (strided views), kv_len int32 [B] keys
-    visible per row (None: all Sk).  Split-key kernel (csrc/decode_attn.hip); returns o [B,1,H,D]."""
+    visible per row (None: all Sk).  Split-key kernel (csrc/decode_attn.hip); returns o [B,1,H,D].
+    group > 1 with shared_len (int32 [B // group]): the rows of a group (the beams of a prompt) hold identical K / V below
+    shared_len[g]; those keys are read once per group."""
     B, Sq, H, D = q.shape
     assert Sq == 1
     Sk = k.shape[1]
@@ -488,8 +491,14 @@ def attn_decode(q, k, v, scale, kv_len=None, alibi=None, out=None):
     _fill_attn(d, qp, kp, vp, op, 0, B, H, 1, Sk, D, scale, MASK_NONE, kv_len, None, 0, qs, ks, vs, os_, alibi)
     L = _lib.lib()
     splits = L.unimp_attn_decode_splits(B, H, Sk)
-    ws = torch.empty(B * H * splits * (D + 2), dtype=torch.float32, device=q.device) if splits > 1 else None
-    check(L.unimp_attn_decode(C.byref(d), _p(ws), splits, _stream()), "attn_decode")
+    grouped = group > 1 and shared_len is not None and B % group == 0 and group <= 16
+    nslots = 2 * splits if grouped else splits
+    ws = torch.empty(B * H * nslots * (D + 2), dtype=torch.float32, device=q.device) if nslots > 1 else None
+    if grouped:
+        assert shared_len.dtype == torch.int32 and shared_len.numel() == B // group
+        check(L.unimp_attn_decode_grouped(C.byref(d), _p(ws), splits, group, shared_len.data_ptr(), _stream()), "attn_decode")
+    else:
+        check(L.unimp_attn_decode(C.byref(d), _p(ws), splits, _stream()), "attn_decode")
     return out
 
 
