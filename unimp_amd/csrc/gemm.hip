@@ -326,8 +326,14 @@ static void launch_skinny(const unimp_gemm_desc* d, void* stream) {
   // few row groups (N small) or a long K: 8 waves per block split K eight ways so enough loads are in flight chip-wide
   static int force_nw = -1;
   if (force_nw < 0) { const char* e = getenv("UNIMP_SKINNY_NW"); force_nw = e ? atoi(e) : 0; }
-  bool wide = force_nw ? force_nw == 8 : (p.nbn < 512 && d->K >= 1024);
-#define SK_LAUNCH(MB_) do { if (wide) hipLaunchKernelGGL((gemm_skinny_kernel<MB_, 8>), grid, dim3(512), 0, s, p);   \
+  bool wide = force_nw ? force_nw >= 8 : (p.nbn < 512 && d->K >= 1024);
+  // fewer row groups than CUs and a deep K (the down-projections: N = 2560, K = 10240 -> 160 blocks): 16 waves per block split K
+  // sixteen ways, twice the bytes in flight per block (UNIMP_SKINNY_NW=16 forces it, =8 / =4 the others; A/B in DESIGN 8 F1)
+  static int auto16 = -1;
+  if (auto16 < 0) { const char* e = getenv("UNIMP_SKINNY_AUTO16"); auto16 = e ? atoi(e) : 0; }
+  bool wide16 = force_nw ? force_nw == 16 : (auto16 && p.nbn <= 256 && d->K >= 4096);
+#define SK_LAUNCH(MB_) do { if (wide16) hipLaunchKernelGGL((gemm_skinny_kernel<MB_, 16>), grid, dim3(1024), 0, s, p);  \
+                            else if (wide) hipLaunchKernelGGL((gemm_skinny_kernel<MB_, 8>), grid, dim3(512), 0, s, p);   \
                             else hipLaunchKernelGGL((gemm_skinny_kernel<MB_, 4>), grid, dim3(256), 0, s, p); } while (0)
   switch ((d->M + 15) / 16) {
     case 1: SK_LAUNCH(1); break;

@@ -473,7 +473,11 @@ def attn_fwd(q, k, v, scale, mask_mode=MASK_NONE, kv_len=None, seg=None, seg_len
 
 
 DECODE_ATTN = _os_env("UNIMP_DECODE_ATTN", "1") != "0"       # split-key decode kernel for one-query-row calls (0: the training kernel)
-DECODE_SHARED_PREFIX = _os_env("UNIMP_DECODE_SHARED_PREFIX", "1") != "0"   # beam search: read a prompt's K / V once per prompt, not once per beam
+# beam search: read a prompt's K / V once per prompt instead of once per beam (10x less K / V traffic at K = 10).  Opt-in: at the
+# reference's eval sizes (469-token prompt, 10 beams) the decode step is bound by ~600 small launches, not by K / V bytes, and the
+# grouped pass has 10x fewer workgroups in flight -- measured 6.84 vs 6.46 ms per token-step (profiles/r03_decode_timings.txt);
+# it pays with long prompts / many users per call
+DECODE_SHARED_PREFIX = _os_env("UNIMP_DECODE_SHARED_PREFIX", "0") != "0"
 
 
 def attn_decode(q, k, v, scale, kv_len=None, alibi=None, out=None, group=1, shared_len=None):
