@@ -233,7 +233,8 @@ def test_gemm_epilogue_gate_res_dact_accum(ops, M):
 
 
 @pytest.mark.parametrize("M", [1, 10, 16, 17, 40, 64])
-@pytest.mark.parametrize("N,K", [(256, 64), (1005, 192), (2560, 2560), (24, 1344)])
+@pytest.mark.parametrize("N,K", [(256, 64), (1005, 192), (2560, 2560), (24, 1344),
+                                 (7680, 1024), (5133, 1088), (17000, 1024)])      # two / four weight tiles per block (ragged last block), 16 waves at M <= 16
 def test_gemm_skinny_decode_rows(ops, M, N, K):
     """the weight-streaming kernel used for decode rows (M <= 64): against fp32, against the 128x128 kernel, every
     epilogue flavour the decode GEMMs use (bias, act, gate, residual), ragged N with a padded ldc."""

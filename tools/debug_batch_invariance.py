@@ -45,13 +45,12 @@ def run(bt):
     return out
 
 
-def sample1(t, B):
-    if t.shape[0] == B:
-        return t[B - 1:]
-    if t.shape[0] % B == 0:                    # [B*T, ...] vision rows
-        k = t.shape[0] // B
-        return t[(B - 1) * k:]
-    return t
+def sample1(t, B, like):
+    if t.shape[0] == like.shape[0]:            # not batch-shaped
+        return t
+    if t.shape[0] == B * like.shape[0]:        # [B, ...] or [B*T, ...] rows: the last sample's share
+        return t[(B - 1) * like.shape[0]:]
+    raise ValueError((t.shape, like.shape))
 
 
 for trial in range(trials):
@@ -62,7 +61,7 @@ for trial in range(trials):
     c = run(one)
     keys = [k for k in a if k in c]
     first_rr = next((k for k in sorted(keys, key=lambda s: (s == "logits", s)) if not torch.equal(a[k], a2[k])), None)
-    first_bi = next((k for k in sorted(keys, key=lambda s: (s == "logits", s)) if not torch.equal(sample1(a[k], 2), c[k])), None)
-    worst = max((float((sample1(a[k], 2).float() - c[k].float()).abs().max()), k) for k in keys)
+    first_bi = next((k for k in sorted(keys, key=lambda s: (s == "logits", s)) if not torch.equal(sample1(a[k], 2, c[k]), c[k])), None)
+    worst = max((float((sample1(a[k], 2, c[k]).float() - c[k].float()).abs().max()), k) for k in keys)
     print(f"trial {trial}: run-to-run first difference: {first_rr}; batch-of-2 vs alone first difference: {first_bi}; largest |diff| {worst[0]:.4g} at {worst[1]}; "
           f"live-tuned shapes so far {len(ops.TUNE_MISSES)}", flush=True)

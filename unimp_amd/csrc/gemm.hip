@@ -243,68 +243,86 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
 
 // ---- skinny GEMM for decoding (M <= 64 rows: K beams x one new token).  Weight-bandwidth bound: every element of W is
 // used once, so W streams global -> registers directly in MFMA operand layout (no LDS); the few X rows come out of L2.
-// One block = 16 rows of W; its 4 waves take interleaved 64-k chunks (4 adjacent 128-B lines per W row and iteration) and
-// meet in LDS.  Inside a chunk lane (r, g) owns k = 16g .. 16g+15 of row r -- 32 contiguous bytes -- and feeds them to two
+// One block = NR tiles of 16 rows of W; its NW waves take interleaved 64-k chunks (4 adjacent 128-B lines per W row and iteration)
+// and meet in LDS.  Inside a chunk lane (r, g) owns k = 16g .. 16g+15 of row r -- 32 contiguous bytes -- and feeds them to two
 // MFMAs; X uses the same k assignment, and a contraction does not care in which order k is visited.
-#ifndef SK_U
-#define SK_U 4                      // chunks in flight per wave (8 x 16 B of W per lane)
-#endif
-template <int MB, int NW>
+// Round 3: NR > 1 -- an X fragment fetched from L2 serves NR weight tiles.  With one tile per block every block re-read all of X
+// (as many L2 -> CU bytes as W itself at 10 rows, 2.5x as many at 40: the 4-users-per-call decode ran its GEMMs at 1.5 TB/s) --
+// and 16 waves per block at <= 16 rows (+10-23 % weight bandwidth: tools/bench_skinny.py, profiles/r03_decode_timings.txt).
+template <int MB, int NW, int NR, int U>
 __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(GemmParams p) {
-  __shared__ f32x4 red[NW][MB][64];
+  extern __shared__ __attribute__((aligned(16))) char sk_smem[];
+  f32x4* red = (f32x4*)sk_smem;                       // [NW][MB][NR][64]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int g = lane >> 4, r = lane & 15;
-  const int n0 = blockIdx.x * 16;
-  const bf16* wp = p.B + (long)min(n0 + r, p.N - 1) * p.ldb + g * 16;
+  const int n0 = blockIdx.x * (16 * NR);
+  const bf16* wp[NR];
+#pragma unroll
+  for (int t = 0; t < NR; ++t) wp[t] = p.B + (long)min(n0 + 16 * t + r, p.N - 1) * p.ldb + g * 16;
   const bf16* xp[MB];
 #pragma unroll
   for (int i = 0; i < MB; ++i) xp[i] = p.A + (long)min(i * 16 + r, p.M - 1) * p.lda + g * 16;
-  f32x4 acc[MB];
+  f32x4 acc[MB][NR];
 #pragma unroll
-  for (int i = 0; i < MB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int t = 0; t < NR; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int nchunk = p.K >> 6;
   int c = w;
-  for (; c + NW * (SK_U - 1) < nchunk; c += NW * SK_U) {
-    u32x4 wv[SK_U][2];
+  for (; c + NW * (U - 1) < nchunk; c += NW * U) {
+    u32x4 wv[U][NR][2];
 #pragma unroll
-    for (int u = 0; u < SK_U; ++u) {
-      const bf16* q = wp + (long)(c + NW * u) * 64;
-      wv[u][0] = __builtin_nontemporal_load((const u32x4*)q);
-      wv[u][1] = __builtin_nontemporal_load((const u32x4*)(q + 8));
-    }
+    for (int u = 0; u < U; ++u)
 #pragma unroll
-    for (int u = 0; u < SK_U; ++u) {
+      for (int t = 0; t < NR; ++t) {
+        const bf16* q = wp[t] + (long)(c + NW * u) * 64;
+        wv[u][t][0] = __builtin_nontemporal_load((const u32x4*)q);
+        wv[u][t][1] = __builtin_nontemporal_load((const u32x4*)(q + 8));
+      }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
 #pragma unroll
       for (int i = 0; i < MB; ++i) {
         const bf16* q = xp[i] + (long)(c + NW * u) * 64;
         u32x4 x0 = *(const u32x4*)q, x1 = *(const u32x4*)(q + 8);
-        acc[i] = MFMA16(wv[u][0], x0, acc[i]);
-        acc[i] = MFMA16(wv[u][1], x1, acc[i]);
+#pragma unroll
+        for (int t = 0; t < NR; ++t) {
+          acc[i][t] = MFMA16(wv[u][t][0], x0, acc[i][t]);
+          acc[i][t] = MFMA16(wv[u][t][1], x1, acc[i][t]);
+        }
       }
     }
   }
   for (; c < nchunk; c += NW) {
-    const bf16* q = wp + (long)c * 64;
-    u32x4 w0 = *(const u32x4*)q, w1 = *(const u32x4*)(q + 8);
 #pragma unroll
     for (int i = 0; i < MB; ++i) {
       const bf16* qx = xp[i] + (long)c * 64;
-      acc[i] = MFMA16(w0, *(const u32x4*)qx, acc[i]);
-      acc[i] = MFMA16(w1, *(const u32x4*)(qx + 8), acc[i]);
+      u32x4 x0 = *(const u32x4*)qx, x1 = *(const u32x4*)(qx + 8);
+#pragma unroll
+      for (int t = 0; t < NR; ++t) {
+        const bf16* q = wp[t] + (long)c * 64;
+        acc[i][t] = MFMA16(*(const u32x4*)q, x0, acc[i][t]);
+        acc[i][t] = MFMA16(*(const u32x4*)(q + 8), x1, acc[i][t]);
+      }
     }
   }
 #pragma unroll
-  for (int i = 0; i < MB; ++i) red[w][i][lane] = acc[i];
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int t = 0; t < NR; ++t) red[((w * MB + i) * NR + t) * 64 + lane] = acc[i][t];
   __syncthreads();
   float gate = 1.f;
   if (p.gate) gate = tanhf(bf2f(*p.gate));
   bool fast = ((p.N & 3) == 0) && (((p.ldc | p.ldres | p.ldaux | p.ldpre) & 3) == 0);
-  for (int i = w; i < MB; i += NW) {
-    f32x4 a = red[0][i][lane];
+  for (int it = w; it < MB * NR; it += NW) {           // waves share the (row group, weight tile) pairs; fixed summation order over the waves
+    const int i = it / NR, t = it % NR;
+    f32x4 a = red[((0 * MB + i) * NR + t) * 64 + lane];
 #pragma unroll
-    for (int ww = 1; ww < NW; ++ww) a += red[ww][i][lane];
-    if (fast) epi_tile<true>(p, a, i * 16 + r, n0 + g * 4, gate);
-    else epi_tile<false>(p, a, i * 16 + r, n0 + g * 4, gate);
+    for (int ww = 1; ww < NW; ++ww) a += red[((ww * MB + i) * NR + t) * 64 + lane];
+    const int nn = n0 + 16 * t + g * 4;
+    if (n0 + 16 * t >= p.N) continue;
+    if (fast) epi_tile<true>(p, a, i * 16 + r, nn, gate);
+    else epi_tile<false>(p, a, i * 16 + r, nn, gate);
   }
 }
 
@@ -321,27 +339,39 @@ static void launch_skinny(const unimp_gemm_desc* d, void* stream) {
   p.gate = (const bf16*)d->gate; p.alpha = d->alpha; p.act = d->act; p.dact = d->dact;
   p.out_f32 = d->out_f32; p.accumulate = d->accumulate; p.pre_deriv = d->pre_deriv;
   p.nbm = 1; p.nbn = (d->N + 15) / 16; p.ksplit = 0;
-  dim3 grid(p.nbn);
   hipStream_t s = (hipStream_t)stream;
-  // few row groups (N small) or a long K: 8 waves per block split K eight ways so enough loads are in flight chip-wide
-  static int force_nw = -1;
-  if (force_nw < 0) { const char* e = getenv("UNIMP_SKINNY_NW"); force_nw = e ? atoi(e) : 0; }
-  bool wide = force_nw ? force_nw >= 8 : (p.nbn < 512 && d->K >= 1024);
-  // fewer row groups than CUs and a deep K (the down-projections: N = 2560, K = 10240 -> 160 blocks): 16 waves per block split K
-  // sixteen ways, twice the bytes in flight per block (UNIMP_SKINNY_NW=16 forces it, =8 / =4 the others; A/B in DESIGN 8 F1)
-  static int auto16 = -1;
-  if (auto16 < 0) { const char* e = getenv("UNIMP_SKINNY_AUTO16"); auto16 = e ? atoi(e) : 0; }
-  bool wide16 = force_nw ? force_nw == 16 : (auto16 && p.nbn <= 256 && d->K >= 4096);
-#define SK_LAUNCH(MB_) do { if (wide16) hipLaunchKernelGGL((gemm_skinny_kernel<MB_, 16>), grid, dim3(1024), 0, s, p);  \
-                            else if (wide) hipLaunchKernelGGL((gemm_skinny_kernel<MB_, 8>), grid, dim3(512), 0, s, p);   \
-                            else hipLaunchKernelGGL((gemm_skinny_kernel<MB_, 4>), grid, dim3(256), 0, s, p); } while (0)
-  switch ((d->M + 15) / 16) {
-    case 1: SK_LAUNCH(1); break;
-    case 2: SK_LAUNCH(2); break;
-    case 3: SK_LAUNCH(3); break;
-    default: SK_LAUNCH(4); break;
+  // Configuration by shape (UNIMP_SKINNY_CFG = "nw,nr" overrides for A/B):
+  //   rows <= 16: 16 waves split K sixteen ways; two weight tiles per block when that still leaves >= 240 blocks
+  //   more rows:  8 waves; four weight tiles per block when >= 256 blocks remain, else two, else one -- X fragments are re-read per
+  //               block, so with 40 rows (4 users x 10 beams) one tile per block moved 2.5x as many X bytes as W bytes
+  static int f_nw = -1, f_nr = 0;
+  if (f_nw < 0) { const char* e = getenv("UNIMP_SKINNY_CFG"); f_nw = 0; if (e) sscanf(e, "%d,%d", &f_nw, &f_nr); }
+  const int mb = (d->M + 15) / 16;
+  int nw = mb == 1 ? 16 : 8;
+  if (d->K < 1024) nw = mb == 1 ? 8 : 4;                                             // short K: fewer waves have a chunk each
+  int nr = 1;
+  if (mb == 1) nr = p.nbn >= 480 ? 2 : 1;
+  else nr = p.nbn >= 1024 ? 4 : (p.nbn >= 320 ? 2 : 1);
+  if (f_nw) { nw = f_nw; nr = f_nr ? f_nr : nr; }
+  dim3 grid((p.nbn + nr - 1) / nr);
+#define SK_GO(MB_, NW_, NR_, U_) do {                                                                                              \
+    auto kern = gemm_skinny_kernel<MB_, NW_, NR_, U_>;                                                                            \
+    size_t lds = (size_t)NW_ * MB_ * NR_ * 64 * sizeof(f32x4);                                                                    \
+    static bool attr = false;                                                                                                     \
+    if (!attr) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; } \
+    hipLaunchKernelGGL(kern, grid, dim3(64 * NW_), lds, s, p); } while (0)
+#define SK_NR(MB_, NW_) do { if (nr >= 4) SK_GO(MB_, NW_, 4, 2); else if (nr == 2) SK_GO(MB_, NW_, 2, 2); else SK_GO(MB_, NW_, 1, 4); } while (0)
+#define SK_NW(MB_) do { if (nw >= 16) { if (nr >= 2) SK_GO(MB_, 16, 2, 2); else SK_GO(MB_, 16, 1, 4); }                             \
+                        else if (nw >= 8) SK_NR(MB_, 8); else SK_NR(MB_, 4); } while (0)
+  switch (mb) {
+    case 1: SK_NW(1); break;
+    case 2: if (nw > 8) nw = 8; SK_NW(2); break;
+    case 3: if (nw > 8) nw = 8; SK_NW(3); break;
+    default: if (nw > 8) nw = 8; SK_NW(4); break;
   }
-#undef SK_LAUNCH
+#undef SK_NW
+#undef SK_NR
+#undef SK_GO
 }
 
 extern "C" int unimp_gemm2_launch(const unimp_gemm_desc* d, int bn, void* stream);   // gemm2.hip: 256-row tiles, LDS-DMA, 2-stage
