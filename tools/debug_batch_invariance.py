@@ -22,7 +22,8 @@ names, store = [], {}
 def hook(name):
     def f(m, i, o):
         t = o[0] if isinstance(o, (tuple, list)) else o
-        t = t[1] if (name == "vision_encoder" and isinstance(o, (tuple, list))) else t
+        if name == "vision_encoder" and isinstance(o, (tuple, list)):
+            t = o[1]                               # (pooled, tokens): the tokens feed the Perceiver
         if torch.is_tensor(t):
             store[name] = t.detach().clone()
     return f

@@ -340,18 +340,18 @@ static void launch_skinny(const unimp_gemm_desc* d, void* stream) {
   p.out_f32 = d->out_f32; p.accumulate = d->accumulate; p.pre_deriv = d->pre_deriv;
   p.nbm = 1; p.nbn = (d->N + 15) / 16; p.ksplit = 0;
   hipStream_t s = (hipStream_t)stream;
-  // Configuration by shape (UNIMP_SKINNY_CFG = "nw,nr" overrides for A/B):
-  //   rows <= 16: 16 waves split K sixteen ways; two weight tiles per block when that still leaves >= 240 blocks
-  //   more rows:  8 waves; four weight tiles per block when >= 256 blocks remain, else two, else one -- X fragments are re-read per
-  //               block, so with 40 rows (4 users x 10 beams) one tile per block moved 2.5x as many X bytes as W bytes
+  // Configuration by shape, from tools/bench_skinny.py on MI355X (profiles/r03_skinny_gemm_configs.txt; UNIMP_SKINNY_CFG = "nw,nr"
+  // overrides for A/B):
+  //   rows <= 16: 16 waves split K sixteen ways, ONE weight tile per block (two tiles halve the blocks in flight and lose 10-60 %)
+  //   more rows:  8 waves; two weight tiles per block once that still leaves >= 160 blocks (N >= 5120) -- X fragments are re-read per
+  //               block: with 40 rows (4 users x 10 beams) one tile per block moved 2.5x as many X bytes as W bytes; 7680 x 2560:
+  //               24.8 -> 17.7 us, the 74 053-row head 208 -> 146 us; four tiles lose again (too few blocks)
   static int f_nw = -1, f_nr = 0;
   if (f_nw < 0) { const char* e = getenv("UNIMP_SKINNY_CFG"); f_nw = 0; if (e) sscanf(e, "%d,%d", &f_nw, &f_nr); }
   const int mb = (d->M + 15) / 16;
   int nw = mb == 1 ? 16 : 8;
   if (d->K < 1024) nw = mb == 1 ? 8 : 4;                                             // short K: fewer waves have a chunk each
-  int nr = 1;
-  if (mb == 1) nr = p.nbn >= 480 ? 2 : 1;
-  else nr = p.nbn >= 1024 ? 4 : (p.nbn >= 320 ? 2 : 1);
+  int nr = (mb >= 2 && p.nbn >= 320) ? 2 : 1;
   if (f_nw) { nw = f_nw; nr = f_nr ? f_nr : nr; }
   dim3 grid((p.nbn + nr - 1) / nr);
 #define SK_GO(MB_, NW_, NR_, U_) do {                                                                                              \
