@@ -30,6 +30,8 @@ timeout 300 python tools/bench_ln.py --rotate 3 > $O/bench_ln.log 2>&1
 timeout 300 python tools/bench_adamw.py > $O/bench_adamw.log 2>&1
 timeout 600 python tools/bench_decode.py > $O/bench_decode.log 2>&1
 timeout 300 python tools/bench_gemm_power.py > $O/gemm_power.log 2>&1
+timeout 600 python tools/check_variant_bits.py > $O/variant_bits.log 2>&1
+timeout 300 python tools/bench_skinny.py 10 > $O/skinny_m10.log 2>&1; timeout 300 python tools/bench_skinny.py 40 > $O/skinny_m40.log 2>&1
 # 4. PMC passes: the step's dominant GEMM kernel instances, variants pinned
 export PMC_MANIFEST=$PWD/$O/pmc_manifest.json
 for pm in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
@@ -40,3 +42,6 @@ python tools/pmc_to_json.py $O/pmc_manifest.json $O/pmcg_FETCH_SIZE $O/pmcg_WRIT
 find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -delete
 echo done >> $O/rc.txt
 cat $O/summary.txt $O/window.txt
+# 5. the whole GPU suite on the final tree
+timeout 2400 python -m pytest tests -m gpu -q -rf > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/rc.txt
+grep -E "^(FAILED|ERROR)|passed|failed" $O/pytest.log | tail -10
