@@ -487,6 +487,37 @@ def test_cfg1_opt125m_vitb32_vs_oracle():
     assert abs(float(loss) - float(wloss)) <= 2e-3 * abs(float(wloss)), (float(loss), float(wloss))
 
 
+def _first_divergence(model, bt):
+    """re-run both forwards with hooks on the vision encoder, the Perceiver and every decoder layer; name the first module whose
+    output for sample 1 differs between the batch of 2 and the sample alone, and whether the batch run itself repeats bitwise."""
+    store = {}
+
+    def hook(name):
+        def f(m, i, o):
+            t = o[1] if (name == "vision_encoder" and isinstance(o, (tuple, list))) else (o[0] if isinstance(o, (tuple, list)) else o)
+            if torch.is_tensor(t):
+                store[name] = t.detach().clone()
+        return f
+    hs = [model.vision_encoder.register_forward_hook(hook("00 vision_encoder")), model.perceiver.register_forward_hook(hook("01 perceiver"))]
+    for i, layer in enumerate(model.lang_encoder._get_decoder_layers()):
+        hs.append(layer.register_forward_hook(hook(f"02 layer{i:02d}")))
+
+    def run(b):
+        store.clear()
+        with torch.no_grad():
+            lg = model(b["vision_x"], b["lang_x"], b["attention_mask"])["logits"]
+        return dict(store, **{"99 logits": lg.clone()})
+    try:
+        a, a2, c = run(bt), run(bt), run({k: v[1:] for k, v in bt.items()})
+    finally:
+        for h in hs:
+            h.remove()
+    tail = lambda t, like: t if t.shape[0] == like.shape[0] else t[t.shape[0] - like.shape[0]:]
+    rr = next((k for k in sorted(a) if not torch.equal(a[k], a2[k])), None)
+    bi = next((k for k in sorted(a) if not torch.equal(tail(a[k], c[k]), c[k])), None)
+    return f"on a re-run: first module differing batch-vs-alone = {bi}, first module differing between two identical batch runs = {rr}"
+
+
 def test_cfg5_9b_mpt_tower_train_step():
     """BASELINE config 5's model in bf16 (ViT-L/14 + MPT-7B, gated cross-attention every 4th block; the fp8 weights and the
     VQGAN task of that config are not built): forward properties and one optimizer step at full width."""
@@ -506,7 +537,12 @@ def test_cfg5_9b_mpt_tower_train_step():
     with torch.no_grad():
         a = model(bt["vision_x"], bt["lang_x"], bt["attention_mask"])["logits"]
         c = model(bt["vision_x"][1:], bt["lang_x"][1:], bt["attention_mask"][1:])["logits"]
-    assert a.shape == (2, 512, layout.vocab) and torch.isfinite(a.float()).all() and torch.equal(a[1:], c)
+    assert a.shape == (2, 512, layout.vocab) and torch.isfinite(a.float()).all()
+    if not torch.equal(a[1:], c):
+        # this bitwise check failed ONCE in ~8 full-suite runs of round 3 and never alone (tools/debug_batch_invariance.py: 18 trials
+        # equal in every module; every GEMM variant is bit-identical on these shapes, profiles/r03_gemm_variant_bit_identity.txt):
+        # if it happens again, say WHERE the two forwards part
+        raise AssertionError("sample 1 alone != sample 1 in a batch of 2; " + _first_divergence(model, bt))
     tr = Trainer(model, layout.special(), lr=1e-4, gamma=2.0, total_steps=10)
     loss, stats = tr.step(bt)
     assert torch.isfinite(loss) and float(stats[1]) > 0 and torch.isfinite(tr.opt.grad_norm())
