@@ -187,6 +187,8 @@ def main():
                     "(same loss / gradients; NOT the default and not the headline configuration)")
     ap.add_argument("--dp-hooks", action="store_true", help="N = 1 only: a 1-rank RCCL process group with the data-parallel hooks forced on -- "
                     "the N > 1 code path (bucketed async all-reduce from the autograd hooks, stream hand-off, finish()) on one GPU")
+    ap.add_argument("--task", choices=["rec", "img_gen"], default="rec", help="img_gen: BASELINE config 5's workload -- image-token generation "
+                    "samples (2 history images, ~860 tokens padded to L = 1024, 257 labeled positions; rec_dataset.py:613-664) -- NOT the headline")
     ap.add_argument("--fuse-accum", action="store_true", help="Trainer(fuse_accum=True): the --grad-accum micro-batches of an optimizer step run as ONE "
                     "pass over GA x batch samples with per-micro-batch loss normalisation (same update; fills the GEMM tiles GA times better)")
     ap.add_argument("--graph", action="store_true", help="Trainer(graph=True): forward + loss + backward of a micro-batch replayed as one HIP graph "
@@ -245,11 +247,17 @@ def main():
         args.dense_head_backward = True
     trainer.dp.record_exposed = dp_on
     n_train = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    if args.task == "img_gen":
+        args.images, args.seq = 2, 1024
     T, L, B, GA = args.images, args.seq, args.batch, args.grad_accum
     # a pool of DIFFERENT seeded batches, staged in HBM before the timed region: every micro-step consumes a fresh one (the
     # reported loss is then a loss on unseen data, not a memorised batch); longer runs cycle through the pool
     n_pool = max(2, min(args.pool, (args.steps + args.warmup) * GA))
-    pool = [make_batch(layout, B, T, L, seed=1234 + rank + 1000 * i, device=dev, vision_dtype=torch.bfloat16) for i in range(n_pool)]
+    if args.task == "img_gen":
+        from unimp_amd.synthetic import make_imggen_batch
+        pool = [make_imggen_batch(layout, B, T, L, seed=1234 + rank + 1000 * i, device=dev, vision_dtype=torch.bfloat16) for i in range(n_pool)]
+    else:
+        pool = [make_batch(layout, B, T, L, seed=1234 + rank + 1000 * i, device=dev, vision_dtype=torch.bfloat16) for i in range(n_pool)]
     it = [0]
 
     def one_step():
@@ -257,7 +265,7 @@ def main():
             out = trainer.step(pool[it[0] % n_pool])
             it[0] += 1
         return out
-    hb = None if args.dense_head_backward else 10          # synthetic template: 9 item answers + EOS carry a label per sample
+    hb = None if args.dense_head_backward else (257 if args.task == "img_gen" else 10)   # labeled positions per sample of the synthetic templates
     fps = flops_per_sample(T, L, layout.vocab, H=4096, F=16384, lm_layers=32, n_xattn=8, head_bwd_rows=hb) if nine else \
         flops_per_sample(T, L, layout.vocab, head_bwd_rows=hb)
 
@@ -359,7 +367,7 @@ def main():
                 "dtype": "bf16 (trainable blocks, activations, attention) + MX-fp8 e4m3 frozen-tower GEMMs" if args.fp8 else "bf16", "data": "synthetic",
                 "config": {"workload": ("cfg5 model in bf16: 9b Flamingo (ViT-L/14 + MPT-7B dims, xattn every 4), " if nine else
                                         "cfg2: 4b-instruct Flamingo (ViT-L/14 + GPT-NeoX-3B RedPajama dims, xattn every 2), ") +
-                                       "single-task rec, full optimizer step" + (", LM head on labeled rows only" if args.sparse_head else ""), "per_gpu_batch": B, "grad_accum": GA, "global_batch": GA * B * world,
+                                       ("image-token generation task (2 history images, 257 labeled code tokens), " if args.task == "img_gen" else "single-task rec, ") + "full optimizer step" + (", LM head on labeled rows only" if args.sparse_head else ""), "per_gpu_batch": B, "grad_accum": GA, "global_batch": GA * B * world,
                            "history_images": T, "seq_len": L, "vocab": layout.vocab, "trainable_params": n_train,
                            "parallelism": f"dp{world}", "weights": "random-init", "loss": float(loss),
                            "batches": f"{n_pool} distinct pre-staged synthetic batches, a fresh one per micro-step" + ("" if (args.steps + args.warmup) * GA <= n_pool else " (pool cycled)"),

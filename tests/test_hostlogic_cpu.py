@@ -119,3 +119,20 @@ def test_eval_text_metrics_hand_computed():
     assert E.selection_scores("Select? s_0 s_2 s_2", [0, 1]) == {"recall": 0.5, "precision": 0.5, "f1": 0.5}
     assert E.selection_scores("Select?", [1]) == {"recall": 0.0, "precision": 0, "f1": 0.0}
     assert E.selection_scores("x? s_1", [1]) == {"recall": 1.0, "precision": 1.0, "f1": 1.0}
+
+
+def test_imggen_synthetic_batch_layout():
+    """BASELINE config 5's workload generator (bench.py --task img_gen; rec_dataset.py:613-664): every sample has T <image> chunks, 855
+    real tokens at T = 2, exactly the 256 code tokens + EOS of the target labeled, loss weight 1.0."""
+    from unimp_amd.synthetic import TokenLayout, make_imggen_batch
+    from oracle import train_step as ots
+    lay = TokenLayout()
+    b = make_imggen_batch(lay, 3, 2, 1024, image_size=8)
+    sp = lay.special()
+    lab = ots.label_mask(b["lang_x"].numpy(), sp["answer_id"], sp["eoc_id"], sp["pad_id"], sp["media_id"])
+    assert b["vision_x"].shape == (3, 2, 1, 3, 8, 8) and b["weights"].tolist() == [1.0] * 3
+    assert b["attention_mask"].sum(1).tolist() == [855] * 3 and ((lab != -100).sum(1) == 257).all()
+    assert ((b["lang_x"] == lay.media).sum(1) == 2).all()
+    img0 = lay.item0 + lay.n_items
+    labeled = b["lang_x"].numpy()[lab != -100].reshape(3, 257)
+    assert ((labeled[:, :256] >= img0) & (labeled[:, :256] < img0 + 1024)).all() and (labeled[:, 256] == lay.eos).all()

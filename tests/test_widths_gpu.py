@@ -204,24 +204,11 @@ def test_cfg4_hm_shapes_vs_oracle(P):
 
 
 def _imggen_batch(layout, L, T, seed=5):
-    """image-token generation sample (rec_dataset.py:613-664): history chunks "<image> Title ... ID img_a,img_b,...(256 codes)
-    <|endofchunk|>", then the query and "<answer>" + the target item's 256 VQGAN code tokens; only the final span is
-    labeled; loss weight 1.0."""
-    g = torch.Generator().manual_seed(seed)
-    img0 = layout.item0 + layout.n_items
-    codes = lambda: (img0 + torch.randint(0, 1024, (256,), generator=g)).tolist()
-    text = lambda n: torch.randint(1, layout.base_vocab, (n,), generator=g).tolist()
-    s = [layout.bos]
-    for _ in range(T):
-        s += [layout.media] + text(20) + codes() + [layout.eoc]
-    s += text(40) + [layout.answer] + codes() + [layout.eos]
-    assert len(s) <= L
-    ids = torch.full((1, L), layout.pad, dtype=torch.int64)
-    mask = torch.zeros((1, L), dtype=torch.int64)
-    ids[0, :len(s)] = torch.tensor(s)
-    mask[0, :len(s)] = 1
-    vis = torch.randn((1, T, 1, 3, 224, 224), generator=g).to(bf16).float()
-    return dict(vision_x=vis, lang_x=ids, attention_mask=mask, weights=torch.ones(1))
+    """image-token generation sample (rec_dataset.py:613-664): unimp_amd.synthetic.make_imggen_batch with bf16-representable pixels."""
+    from unimp_amd.synthetic import make_imggen_batch
+    b = make_imggen_batch(layout, 1, T, L, seed=seed)
+    b["vision_x"] = b["vision_x"].to(bf16).float()
+    return b
 
 
 def test_cfg5_mpt_width_image_generation_batch_vs_oracle(P):

@@ -7,7 +7,7 @@ O=gpurun_out/final; mkdir -p $O
 T=$PWD/$O/gemm_autotune_gfx950.json
 cp profiles/gemm_autotune_gfx950.json $T        # keep the committed choices; only shapes / epilogue classes that are missing get tuned
 # 1. autotune table for the shapes of the default bench (b = 64), the reference's shipped shape (b = 3, GA 2; fused: b = 6), b = 16 / 32 / 48, the 9b model
-for extra in "" "--batch 3 --grad-accum 2" "--batch 3 --grad-accum 2 --fuse-accum" "--batch 16" "--batch 32" "--batch 48" "--model 9b"; do
+for extra in "" "--batch 3 --grad-accum 2" "--batch 3 --grad-accum 2 --fuse-accum" "--batch 16" "--batch 32" "--batch 48" "--model 9b" "--model 9b --task img_gen --batch 12"; do
   UNIMP_GEMM_TUNE_FILE=$T UNIMP_GEMM_TUNE_WRITE=1 timeout 900 python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline $extra > $O/tune.json 2> $O/tune.err
 done
 cp $T profiles/gemm_autotune_gfx950.json
@@ -21,6 +21,9 @@ timeout 900 python bench.py --no-cpu-baseline --batch 32 > $O/bench_b32.json 2> 
 timeout 900 python bench.py --no-cpu-baseline --batch 48 > $O/bench_b48.json 2> $O/bench_b48.err
 timeout 900 python bench.py --no-cpu-baseline --model 9b > $O/bench_9b.json 2> $O/bench_9b.err
 timeout 900 python bench.py --no-cpu-baseline --model 9b --fp8 > $O/bench_9b_fp8.json 2> $O/bench_9b_fp8.err
+# BASELINE config 5's own workload: the 9b model on image-token generation samples (L = 1024, 2 history images, 257 labeled positions), bf16 and fp8
+timeout 900 python bench.py --no-cpu-baseline --model 9b --task img_gen --batch 12 > $O/bench_9b_imggen.json 2> $O/bench_9b_imggen.err
+timeout 900 python bench.py --no-cpu-baseline --model 9b --task img_gen --batch 12 --fp8 > $O/bench_9b_imggen_fp8.json 2> $O/bench_9b_imggen_fp8.err
 for f in $O/bench_*.json; do python -c "import json,sys; j=json.load(open('$f')); print('$f', j['value'], j['ms_per_step'], j['roofline']['frac'] if j.get('roofline') else None)"; done > $O/summary.txt 2>&1
 # 3. kernel stats of the default bench command: whole process (--stats) and the timed steps only (markers)
 timeout 900 rocprofv3 --kernel-trace --stats -d $O/stats -o st --output-format csv -- python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-roofline > $O/prof.log 2>&1

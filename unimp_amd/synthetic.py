@@ -53,3 +53,29 @@ def make_batch(layout, batch, T, L, image_size=224, seed=1234, weight=2.0, min_f
     if device is not None:
         out = {k: v.to(device) for k, v in out.items()}
     return out
+
+
+def make_imggen_batch(layout, batch, T=2, L=1024, image_size=224, seed=5, device=None, vision_dtype=torch.float32):
+    """image-token generation samples (BASELINE config 5's task; rec_dataset.py:613-664, eval_img_gen.py:102-111): T history chunks
+    ``<image> title... ID img_a,img_b,...(256 VQGAN code tokens) <|endofchunk|>``, then the query and ``<answer>`` + the target item's
+    256 code tokens + EOS; only that final span is labeled (257 positions); loss weight 1.0; ~860 real tokens padded to L."""
+    g = torch.Generator().manual_seed(seed)
+    img0 = layout.item0 + layout.n_items
+    ids = torch.full((batch, L), layout.pad, dtype=torch.int64)
+    mask = torch.zeros((batch, L), dtype=torch.int64)
+    for b in range(batch):
+        codes = lambda: (img0 + torch.randint(0, 1024, (256,), generator=g)).tolist()
+        text = lambda n: torch.randint(1, layout.base_vocab, (n,), generator=g).tolist()
+        s = [layout.bos]
+        for _ in range(T):
+            s += [layout.media] + text(20) + codes() + [layout.eoc]
+        s += text(40) + [layout.answer] + codes() + [layout.eos]
+        if len(s) > L:
+            raise ValueError(f"img-gen sample of {len(s)} tokens does not fit L = {L}")
+        ids[b, :len(s)] = torch.tensor(s)
+        mask[b, :len(s)] = 1
+    vis = torch.randn((batch, T, 1, 3, image_size, image_size), generator=g).to(vision_dtype)
+    out = dict(vision_x=vis, lang_x=ids, attention_mask=mask, weights=torch.ones(batch))
+    if device is not None:
+        out = {k: v.to(device) for k, v in out.items()}
+    return out
