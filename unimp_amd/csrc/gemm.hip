@@ -353,10 +353,7 @@ static void launch_skinny(const unimp_gemm_desc* d, void* stream) {
   if (d->K < 1024) nw = mb == 1 ? 8 : 4;                                             // short K: fewer waves have a chunk each
   int nr = (mb >= 2 && p.nbn >= 320) ? 2 : 1;
   if (f_nw) { nw = f_nw; nr = f_nr ? f_nr : nr; }
-  // fewer blocks than CUs and a deep K (the down-projections, 160 blocks x K = 10240): 8 chunks in flight per wave instead of 4
-  static int deep_on = -1;
-  if (deep_on < 0) { const char* e = getenv("UNIMP_SKINNY_DEEP"); deep_on = e ? atoi(e) : 1; }
-  const bool deep = deep_on && mb == 1 && d->K >= 8192 && p.nbn <= 256;
+  // (measured and dropped: 8 chunks in flight per wave on the 160-block K = 10240 down-projection -- 25.0 vs 22.9 us)
   dim3 grid((p.nbn + nr - 1) / nr);
 #define SK_GO(MB_, NW_, NR_, U_) do {                                                                                              \
     auto kern = gemm_skinny_kernel<MB_, NW_, NR_, U_>;                                                                            \
@@ -365,7 +362,7 @@ static void launch_skinny(const unimp_gemm_desc* d, void* stream) {
     if (!attr) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; } \
     hipLaunchKernelGGL(kern, grid, dim3(64 * NW_), lds, s, p); } while (0)
 #define SK_NR(MB_, NW_) do { if (nr >= 4) SK_GO(MB_, NW_, 4, 2); else if (nr == 2) SK_GO(MB_, NW_, 2, 2); else SK_GO(MB_, NW_, 1, 4); } while (0)
-#define SK_NW(MB_) do { if (nw >= 16) { if (nr >= 2) SK_GO(MB_, 16, 2, 2); else if (deep) SK_GO(MB_, 16, 1, 8); else SK_GO(MB_, 16, 1, 4); } \
+#define SK_NW(MB_) do { if (nw >= 16) { if (nr >= 2) SK_GO(MB_, 16, 2, 2); else SK_GO(MB_, 16, 1, 4); }                             \
                         else if (nw >= 8) SK_NR(MB_, 8); else SK_NR(MB_, 4); } while (0)
   switch (mb) {
     case 1: SK_NW(1); break;
