@@ -189,6 +189,8 @@ def main():
                     "the N > 1 code path (bucketed async all-reduce from the autograd hooks, stream hand-off, finish()) on one GPU")
     ap.add_argument("--task", choices=["rec", "img_gen"], default="rec", help="img_gen: BASELINE config 5's workload -- image-token generation "
                     "samples (2 history images, ~860 tokens padded to L = 1024, 257 labeled positions; rec_dataset.py:613-664) -- NOT the headline")
+    ap.add_argument("--packed", action="store_true", help="Trainer(packed=True): the language tower's row-wise kernels run on the valid tokens only "
+                    "(the synthetic batches are filled 75-100 %%: 12.5 %% of the B x L rows are <PAD>); same loss / gradients; NOT the headline")
     ap.add_argument("--fuse-accum", action="store_true", help="Trainer(fuse_accum=True): the --grad-accum micro-batches of an optimizer step run as ONE "
                     "pass over GA x batch samples with per-micro-batch loss normalisation (same update; fills the GEMM tiles GA times better)")
     ap.add_argument("--graph", action="store_true", help="Trainer(graph=True): forward + loss + backward of a micro-batch replayed as one HIP graph "
@@ -242,7 +244,7 @@ def main():
                       lr_scheduler="cosine", warmup_steps=10, total_steps=10000, sparse_head=args.sparse_head,
                       grad_accum=args.grad_accum, dense_head_backward=args.dense_head_backward,
                       shard_optimizer=args.shard_optimizer and dp_on, bucket_bytes=args.bucket_mb << 20,
-                      force_dp_hooks=args.dp_hooks, graph=args.graph, fuse_accum=args.fuse_accum)
+                      force_dp_hooks=args.dp_hooks, graph=args.graph, fuse_accum=args.fuse_accum, packed=args.packed or None)
     if args.graph:
         args.dense_head_backward = True
     trainer.dp.record_exposed = dp_on
@@ -376,7 +378,7 @@ def main():
                            "tflop_per_sample": round(fps["total"] / 1e12, 3),
                            "tflop_per_sample_note": "executed FLOPs (SURVEY 8d formulae); the LM head's backward runs on the labeled positions only"
                                                     if hb else "SURVEY 8d formulae, dense head backward",
-                           "hip_graph": bool(args.graph), "fused_accumulation": bool(args.fuse_accum and GA > 1),
+                           "hip_graph": bool(args.graph), "packed_token_order": bool(F_.PACKED), "fused_accumulation": bool(args.fuse_accum and GA > 1),
                            "head_backward": "dense" if args.dense_head_backward else "labeled rows only (zero rows of dlogits skipped; same gradients)",
                            "model_tflops_per_gpu": round(value / world * fps["total"] / 1e12, 1),
                            "mfma_frac_whole_step": round(value / world * fps["total"] / 1e12 / PEAK_BF16_TFLOPS, 4),

@@ -198,6 +198,10 @@ int unimp_vit_assemble(const void* patch, int64_t ldp, const void* cls, const vo
                        int D, void* stream);
 
 /* ---- elementwise helpers ----------------------------------------------------------------------------------*/
+/* dst[r][0..D) = idx[r] >= 0 ? src[idx[r]][0..D) : 0 (bf16 rows, D % 8 == 0): packs the valid tokens of right-padded sequences into a
+ * dense row range and unpacks them again (idx = the inverse map, -1 at the <PAD> positions of collate_rec.py:38-74's batches), so that
+ * the row-wise kernels of the step skip the padding rows (Trainer(packed=True)). */
+int unimp_gather_rows(const void* src, int64_t ld_src, const int32_t* idx, void* dst, int64_t ld_dst, int rows, int D, void* stream);
 /* trace marker (measurement aid for mmrec.py:259-296's step timing): an empty kernel launched with `id` workgroups of 64 threads,
  * so a kernel trace can be cut to the region between two markers (tools/trace_window.py). */
 int unimp_marker(int id, void* stream);

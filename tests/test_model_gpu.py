@@ -678,3 +678,53 @@ def test_fused_accumulation_equals_sequential(P, reweight):
         assert e <= 2e-2, (k, e)
     assert lf[0] is None and lf[2] == lf[1]                       # buffered micro-steps return the previous optimizer step's loss
     assert P.rel_l2(mf, ms) <= 5e-3                               # fp32 masters after two AdamW steps (Adam amplifies tiny gradients' noise)
+
+
+@pytest.mark.parametrize("cfgname,round_to", [("TINY", 8), ("TINY_PAR", 8), ("CFG2_SLIM", 256)])
+def test_packed_token_order_equals_padded(P, monkeypatch, cfgname, round_to):
+    """Trainer(packed=True): the language tower's row-wise kernels (LayerNorm, QKV / out / MLP / gated feed-forward projections) run on
+    the valid tokens only; the attention kernels keep the padded addressing behind an unpack / pack pair.  Against the padded run on
+    the same weights and batch: the same labels, logits equal at every VALID position (every valid row goes through the same
+    arithmetic; bitwise where both runs rotate q / k from the tables, bf16-close where the padded run uses the rotary epilogue), zero
+    hidden state behind the <PAD> logits, the same loss, every gradient equal up to the summation order of the weight-gradient
+    GEMMs (their contraction runs over another row order)."""
+    from unimp_amd import functional as F_
+    from unimp_amd.train import Trainer
+    cfg = getattr(P, cfgname)
+    om, layout = P.build_oracle(cfg)
+    batch = {k: v.cuda() for k, v in P.make_batch(cfg, layout, seed=31).items()}
+    monkeypatch.setattr(F_, "PACK_ROUND", round_to)
+    res = {}
+    for packed in (False, True):
+        hm = P.build_hip(cfg, om, layout)
+        tr = Trainer(hm, layout.special(), lr=1e-3, gamma=2.0, packed=packed)
+        hm.train()
+        loss, stats, out, labels = tr.forward_loss(batch)
+        tr._backward(loss)
+        res[packed] = (out["logits"].float(), loss.item(), labels.clone(), {n: p.grad.float().clone() for n, p in hm.named_parameters() if p.grad is not None})
+        tr.dp.remove()
+    monkeypatch.setattr(F_, "PACKED", False)
+    valid = batch["attention_mask"].bool()
+    assert int(valid.sum()) < valid.numel(), "the batch has no padding: nothing is tested"
+    (la, lossa, laba, ga), (lb, lossb, labb, gb) = res[False], res[True]
+    assert torch.equal(laba, labb)
+    same_rope = valid.numel() < 256                         # below ops.ROPE_MIN_M rows both runs rotate from the tables
+    if same_rope:
+        assert torch.equal(la[valid], lb[valid]), float((la[valid] - lb[valid]).abs().max())
+        assert lossa == lossb
+    else:
+        assert P.rel_l2(lb[valid], la[valid]) <= 4e-3, P.rel_l2(lb[valid], la[valid])
+        assert abs(lossa - lossb) <= 2e-4 * abs(lossa)
+    # <PAD> rows of the packed run: final LayerNorm of a zero row -> beta -> the same logits at every <PAD> position
+    pad_logits = lb[~valid]
+    assert torch.equal(pad_logits, pad_logits[:1].expand_as(pad_logits))
+    worst = (0.0, None)
+    for n, g in ga.items():
+        assert n in gb, n
+        if g.abs().max() == 0:
+            assert gb[n].abs().max() == 0, n
+            continue
+        e = P.rel_l2(gb[n], g)
+        worst = max(worst, (e, n))
+        assert e <= (1e-2 if same_rope else 3e-2), (n, e)
+    print(f"\\n[packed {cfgname}] valid rows {int(valid.sum())} of {valid.numel()}; loss {lossb:.6f} vs padded {lossa:.6f}; worst gradient rel-L2 {worst[0]:.2e} ({worst[1]})")

@@ -58,6 +58,7 @@ _SIGS = {
     "unimp_vit_patchify": [c_p, c_i, c_p, c_l, c_i, c_i, c_i, c_i, c_p],
     "unimp_vit_assemble": [c_p, c_l, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "unimp_marker": [c_i, c_p],
+    "unimp_gather_rows": [c_p, c_l, c_p, c_p, c_l, c_i, c_i, c_p],
     "unimp_add_bf16": [c_p, c_p, c_p, c_l, c_p],
     "unimp_cast_f32_to_bf16": [c_p, c_p, c_l, c_f, c_p],
     "unimp_swiglu_fwd": [c_p, c_l, c_p, c_l, c_i, c_i, c_p],

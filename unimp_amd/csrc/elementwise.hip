@@ -308,6 +308,27 @@ __global__ void cast_kernel(const float* __restrict__ s, bf16* __restrict__ d, l
   if (blockIdx.x == 0 && threadIdx.x < (n & 7)) { long i = (n & ~7L) + threadIdx.x; d[i] = f2bf(s[i] * scale); }
 }
 
+// Row gather (packed token order, round 3): dst[r] = idx[r] >= 0 ? src[idx[r]] : 0 for rows of D bf16 (D % 8 == 0), one wave per row,
+// 16-byte chunks.  Packs the valid tokens of right-padded sequences ([B*L] -> [M] rows, idx = flat positions) and unpacks them again
+// ([M] -> [B*L], idx = the inverse map with -1 at <PAD> positions, which come out as zeros: no separate memset).
+__global__ __launch_bounds__(256) void gather_rows_kernel(const bf16* __restrict__ src, long lds_, const int* __restrict__ idx,
+                                                          bf16* __restrict__ dst, long ldd, int rows, int D) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= rows) return;
+  const int s = idx[r];
+  const u32x4* sp = (const u32x4*)(src + (long)max(s, 0) * lds_);
+  u32x4* dp = (u32x4*)(dst + (long)r * ldd);
+  const int nc = D >> 3;
+  for (int c = lane; c < nc; c += 64) dp[c] = s >= 0 ? sp[c] : u32x4{0u, 0u, 0u, 0u};
+}
+extern "C" int unimp_gather_rows(const void* src, int64_t lds_, const int32_t* idx, void* dst, int64_t ldd, int rows, int D, void* stream) {
+  if (rows <= 0) return UNIMP_OK;
+  if (!src || !idx || !dst) return unimp_set_error(UNIMP_ERR_ARG, "gather_rows: null pointer");
+  if ((D & 7) || (lds_ & 7) || (ldd & 7) || (((uintptr_t)src | (uintptr_t)dst) & 15)) return unimp_set_error(UNIMP_ERR_ALIGN, "gather_rows: D and leading dimensions % 8, 16-byte aligned bases");
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)src, (long)lds_, idx, (bf16*)dst, (long)ldd, rows, D);
+  return unimp_check_launch("gather_rows");
+}
+
 // Trace marker: an empty kernel whose GRID SIZE carries an id (id workgroups of 64 threads), so that a rocprofv3 --kernel-trace of
 // a long process can be cut to a region of interest afterwards (tools/trace_window.py: the timed steps of bench.py without model
 // construction, autotuning and warm-up).  No memory traffic, ~1.5 us.

@@ -80,6 +80,68 @@ def _no_bias_grad(ctx, idx, name):
                                   "(no trainable Linear bias exists in the UniMP configuration)")
 
 
+# ----------------------------------------------------------------------------------------------- packed token order (opt-in)
+# collate_rec.py:38-74 right-pads every sequence of a batch to the longest; the reference then runs every row-wise operation of the
+# language tower (LayerNorm, the QKV / out / MLP / gated feed-forward projections) over the <PAD> rows too.  In packed mode
+# (Trainer(packed=True), bench.py --packed, UNIMP_PACKED=1) the tower's residual stream holds the VALID tokens only, as [1, M, H] with
+# M = the valid count rounded up to PACK_ROUND rows; the attention kernels keep their padded [B, L] addressing: the projected q / k / v
+# are unpacked (gather with the inverse map, zeros at <PAD>) in front of them and the attention output is packed again behind them.
+# Every valid row goes through the same arithmetic as in the padded run; nothing reads the rows that are skipped.
+PACKED = _os.environ.get("UNIMP_PACKED", "0") == "1"
+PACK_ROUND = 2048           # M granularity: keeps the number of distinct GEMM shapes (autotune keys) per batch size at two or three
+PACK = None                 # the Pack of the forward in progress (set by the tower's forward)
+
+
+class Pack:
+    """idx int32 [M]: flat position b * L + j of packed row r (rows beyond the valid count point at one <PAD> position: they are
+    computed, never read back); inv int32 [B * L]: packed row of a position, -1 at <PAD>."""
+
+    def __init__(self, attention_mask):
+        B, L = attention_mask.shape
+        flat = attention_mask.reshape(-1) != 0
+        pos = flat.nonzero().view(-1)                      # host sync: the valid count
+        nv = pos.numel()
+        M = min(B * L, (nv + PACK_ROUND - 1) // PACK_ROUND * PACK_ROUND)
+        self.B, self.L, self.nv, self.M = B, L, nv, M
+        self.useful = nv > 0 and M < B * L
+        if not self.useful:
+            return
+        dev = attention_mask.device
+        dummy = (~flat).nonzero()[0]                        # exists: M < B * L
+        idx = torch.cat([pos, dummy.expand(M - nv)]) if M > nv else pos
+        self.idx_long = idx
+        self.idx = idx.to(torch.int32).contiguous()
+        inv = torch.full((B * L,), -1, dtype=torch.int32, device=dev)
+        inv[pos] = torch.arange(nv, dtype=torch.int32, device=dev)
+        self.inv = inv
+
+
+class PackRowsFn(Function):
+    """padded [B * L, D] -> packed [M, D]"""
+
+    @staticmethod
+    def forward(ctx, x, pack):
+        ctx.pack = pack
+        return ops.gather_rows(x, pack.idx)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.gather_rows(dy.contiguous(), ctx.pack.inv), None
+
+
+class UnpackRowsFn(Function):
+    """packed [M, D] -> padded [B * L, D], zeros at <PAD>"""
+
+    @staticmethod
+    def forward(ctx, x, pack):
+        ctx.pack = pack
+        return ops.gather_rows(x, pack.inv)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.gather_rows(dy.contiguous(), ctx.pack.idx), None
+
+
 # ----------------------------------------------------------------------------------------------- LayerNorm
 class LayerNormFn(Function):
     @staticmethod
@@ -363,6 +425,11 @@ class SelfAttnBlockFn(Function):
                 qk_ln=None):
         """qk_ln = (q_ln weight, k_ln weight, eps): LayerNorm over the full d_model vectors of q and of k before the heads are split
         (the QK-LayerNorm MPT of mmrec.py:475-494's "3b" towers, mosaic_gpt ``attn_qk_ln``); frozen gains only, blocked q|k|v layout."""
+        pack = PACK
+        if pack is not None:
+            return SelfAttnBlockFn._forward_packed(ctx, pack, x, res, ln_w, ln_b, wqkv, bqkv, wd, bd, rope, kv_len, nh, interleaved, causal, eps,
+                                                   rms, q_scale, alibi, qk_ln)
+        ctx.pack = None
         B, L, H = x.shape
         hd = H // nh
         x2 = x.reshape(B * L, H)
@@ -412,7 +479,63 @@ class SelfAttnBlockFn(Function):
         return out.view(B, L, H)
 
     @staticmethod
+    def _forward_packed(ctx, pack, x, res, ln_w, ln_b, wqkv, bqkv, wd, bd, rope, kv_len, nh, interleaved, causal, eps, rms, q_scale, alibi, qk_ln):
+        """x [1, M, H] packed rows.  LayerNorm and both projections on the M packed rows; q / k / v unpacked to [B, L] (zeros at <PAD>)
+        for the rotation and the attention kernels, the attention output packed again."""
+        if qk_ln is not None:
+            raise NotImplementedError("packed token order: qk_ln towers are not wired")
+        B, L, M = pack.B, pack.L, pack.M
+        H = x.shape[-1]
+        hd = H // nh
+        x2 = x.reshape(M, H)
+        r2 = x2 if res is None else res.reshape(M, H)
+        h, mean, rstd = ops.layernorm_fwd(x2, ln_w, ln_b, eps, rms=rms)
+        qkv = ops.gather_rows(ops.gemm(h, wqkv, bias=bqkv), pack.inv)                      # [B * L, 3H]
+        q, k, v, hs, offs = _split_qkv(qkv, B, L, nh, hd, interleaved)
+        if rope is not None:
+            ops.rope_(qkv, L, nh, hs, rope[2], offs, rope[0], rope[1])
+        o, lse = ops.attn_fwd(q, k, v, q_scale, ops.MASK_CAUSAL if causal else ops.MASK_NONE, kv_len, alibi=alibi)
+        o_p = ops.gather_rows(o.view(B * L, H), pack.idx)
+        out = ops.gemm(o_p, wd, bias=bd, res=r2)
+        ctx.save_for_backward(x2, ln_w, mean, rstd, wqkv, wd, qkv, o, lse, kv_len, h if wqkv.requires_grad else None,
+                              rope[0] if rope is not None else None, rope[1] if rope is not None else None, alibi)
+        ctx.cfg = (B, L, H, nh, hd, interleaved, causal, rms, q_scale, rope[2] if rope is not None else 0, res is None, ln_b is not None)
+        ctx.mx, ctx.rope_fused, ctx.qk_ln, ctx.pack = False, None, None, pack
+        return out.view(1, M, H)
+
+    @staticmethod
+    def _backward_packed(ctx, dy):
+        x2, ln_w, mean, rstd, wqkv, wd, qkv, o, lse, kv_len, h, cos, sin, alibi = ctx.saved_tensors
+        B, L, H, nh, hd, interleaved, causal, rms, q_scale, rot, res_is_x, has_lnb = ctx.cfg
+        pack = ctx.pack
+        M = pack.M
+        _no_bias_grad(ctx, 5, "qkv bias")
+        _no_bias_grad(ctx, 7, "dense bias")
+        dy2 = dy.reshape(M, H)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        do = ops.gather_rows(ops.gemm(dy2, wd, b_ks=True), pack.inv).view(B, L, nh, hd)   # zeros at <PAD>: their dq / dk / dv contributions vanish
+        dwd = ops.gemm(dy2, ops.gather_rows(o.view(B * L, H), pack.idx), a_ks=True, b_ks=True) if _need(ctx, 6) else None
+        q, k, v, hs, offs = _split_qkv(qkv, B, L, nh, hd, interleaved)
+        dqkv = torch.empty_like(qkv)
+        dq, dk, dv, _, _ = _split_qkv(dqkv, B, L, nh, hd, interleaved)
+        fuse = ROPE_FUSE and cos is not None and cos.shape[0] >= L and cos.shape[1] * 2 == rot and ops.attn_rope_fusable(dq, dk, dv, rot // 2, hd)
+        ops.attn_bwd(q, k, v, o, lse, do, dq, dk, dv, q_scale, ops.MASK_CAUSAL if causal else ops.MASK_NONE, kv_len, alibi=alibi,
+                     rope=(cos, sin) if fuse else None)
+        if cos is not None and not fuse:
+            ops.rope_(dqkv, L, nh, hs, rot, offs, cos, sin, inverse=True)
+        dqkv_p = ops.gather_rows(dqkv, pack.idx)
+        dwqkv = ops.gemm(dqkv_p, h, a_ks=True, b_ks=True) if _need(ctx, 4) else None
+        dh = ops.gemm(dqkv_p, wqkv, b_ks=True)
+        wg = _need(ctx, 2) or (has_lnb and _need(ctx, 3))
+        dx, dg, db = ops.layernorm_bwd(dh, x2, ln_w, mean, rstd, dres=dy2 if res_is_x else None, want_wgrad=wg, has_beta=has_lnb, rms=rms)
+        dres = None if res_is_x else dy
+        return (dx.view(1, M, H), dres, dg, db, dwqkv, None, dwd, None) + (None,) * 10
+
+    @staticmethod
     def backward(ctx, dy):
+        if ctx.pack is not None:
+            return SelfAttnBlockFn._backward_packed(ctx, dy)
         x2, ln_w, mean, rstd, wqkv, wd, qkv, o, lse, kv_len, h, cos, sin, alibi = ctx.saved_tensors
         B, L, H, nh, hd, interleaved, causal, rms, q_scale, rot, res_is_x, has_lnb = ctx.cfg
         _no_bias_grad(ctx, 5, "qkv bias")
@@ -632,51 +755,62 @@ class GatedXAttnFn(Function):
 
     @staticmethod
     def forward(ctx, x, media, seg, ln_w, ln_b, wq, wkv, wo, gate, heads, n_lat, eps):
-        B, L, D = x.shape
+        pack = PACK                               # packed token order: x is [1, M, D]; q is unpacked for the attention, o packed behind it
+        ctx.pack = pack
         Sk = media.shape[1]                       # media [B, T*n, Dv]
+        B = media.shape[0]
+        D = x.shape[-1]
+        L = pack.L if pack is not None else x.shape[1]
+        rows = pack.M if pack is not None else B * L
         inner = wq.shape[0]
         dh = inner // heads
-        x2 = x.reshape(B * L, D)
+        x2 = x.reshape(rows, D)
         m2 = media.reshape(B * Sk, -1)
         h, mean, rstd = ops.layernorm_fwd(x2, ln_w, ln_b, eps)
         q = ops.gemm(h, wq)
+        if pack is not None:
+            q = ops.gather_rows(q, pack.inv)
         kv = ops.gemm(m2, wkv)
         kv5 = kv.view(B, Sk, 2, heads, dh)
         o, lse = ops.attn_fwd(q.view(B, L, heads, dh), kv5[:, :, 0], kv5[:, :, 1], dh ** -0.5, ops.MASK_SEGMENT, None, seg, n_lat)
-        out = ops.gemm(o.view(B * L, inner), wo, gate=gate, res=x2)
-        ctx.save_for_backward(x2, m2, seg, ln_w, mean, rstd, wq, wkv, wo, gate, h, q, kv, o, lse)
+        o2 = o.view(B * L, inner) if pack is None else ops.gather_rows(o.view(B * L, inner), pack.idx)
+        out = ops.gemm(o2, wo, gate=gate, res=x2)
+        ctx.save_for_backward(x2, m2, seg, ln_w, mean, rstd, wq, wkv, wo, gate, h, q, kv, o, lse, o2 if pack is not None else None)
         ctx.cfg = (B, L, D, Sk, heads, dh, n_lat)
         ctx.ln_b_ref = ln_b
-        return out.view(B, L, D)
+        return out.view(x.shape)
 
     @staticmethod
     def backward(ctx, dy):
-        x2, m2, seg, ln_w, mean, rstd, wq, wkv, wo, gate, h, q, kv, o, lse = ctx.saved_tensors
+        x2, m2, seg, ln_w, mean, rstd, wq, wkv, wo, gate, h, q, kv, o, lse, o_p = ctx.saved_tensors
         B, L, D, Sk, heads, dh, n_lat = ctx.cfg
+        pack = ctx.pack
         inner = heads * dh
-        dy2 = dy.reshape(B * L, D)
+        dy2 = dy.reshape(-1, D)
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
-        o2 = o.view(B * L, inner)
+        o2 = o.view(B * L, inner) if pack is None else o_p
         # do is kept UN-gated: d/d gate of tanh(gate) * (o Wo^T) contracted with dy is <dy Wo, o> -- a dot over [B L, inner] instead
         # of one over dy and a saved copy of the un-gated block output (both [B L, D], D = 5 inner: the copy and its store in the
         # forward's epilogue are gone) -- and everything downstream of do is linear in it, so tanh(gate) moves into the epilogues
         # of the four GEMMs that consume dq / dkv (0 at initialisation there exactly as it was here)
         do2 = ops.gemm(dy2, wo, b_ks=True)
         dgate = _gate_grad(do2, o2, gate) if _need(ctx, 8) else None
-        do = do2.view(B, L, heads, dh)
+        do = (do2 if pack is None else ops.gather_rows(do2, pack.inv)).view(B, L, heads, dh)
         dwo = _dw(ctx, 7, wo, dy2, o2, gate=gate)
         dq = torch.empty_like(q)
         dkv = torch.empty_like(kv)
         kv5, dkv5 = kv.view(B, Sk, 2, heads, dh), dkv.view(B, Sk, 2, heads, dh)
         ops.attn_bwd(q.view(B, L, heads, dh), kv5[:, :, 0], kv5[:, :, 1], o, lse, do, dq.view(B, L, heads, dh),
                      dkv5[:, :, 0], dkv5[:, :, 1], dh ** -0.5, ops.MASK_SEGMENT, None, seg, n_lat)
+        if pack is not None:
+            dq = ops.gather_rows(dq, pack.idx)
         dwq = _dw(ctx, 5, wq, dq, h, gate=gate)
         dh_ = ops.gemm(dq, wq, b_ks=True, gate=gate)
         dwkv = _dw(ctx, 6, wkv, dkv, m2, gate=gate)
         dmedia = ops.gemm(dkv, wkv, b_ks=True, gate=gate).view(B, Sk, -1) if _need(ctx, 1) else None
         dx, dg, db = _ln_bwd(dh_, x2, ln_w, ctx.ln_b_ref, mean, rstd, _need(ctx, 3), _need(ctx, 4), dres=dy2)
-        return dx.view(B, L, D), dmedia, None, dg, db, dwq, dwkv, dwo, dgate, None, None, None
+        return dx.view(dy.shape), dmedia, None, dg, db, dwq, dwkv, dwo, dgate, None, None, None
 
 
 def gated_xattn(x, media, seg, ln_w, ln_b, wq, wkv, wo, gate, heads, n_lat, eps=1e-5):

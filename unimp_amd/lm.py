@@ -241,11 +241,27 @@ class GPTNeoXForCausalLM(_TowerBase):
     def forward(self, input_ids, attention_mask=None, labels=None, past_key_values=None, use_cache=False, **kw):
         B, L = input_ids.shape
         cache, pos0 = self._decode_state(past_key_values, use_cache, labels, attention_mask)
-        x = F_.embedding(input_ids, self.gpt_neox.embed_in.weight)
         kv_len = self._kv_len(attention_mask)
-        rope = self._step_rope(cache, self._rope_tables(max(pos0 + L, cache.kv.shape[3] if cache and cache.kv is not None else 0), x.device))
-        for i, layer in enumerate(self.gpt_neox.layers):
-            x = layer(x, attention_mask=kv_len, rope=rope, cache=cache.layers[i] if cache else None, pos0=pos0)
+        pack = None
+        if F_.PACKED and cache is None and attention_mask is not None and self.training:
+            pack = F_.Pack(attention_mask)                 # packed token order: the tower's row-wise kernels skip the <PAD> rows
+            if not pack.useful:
+                pack = None
+        if pack is not None:
+            x = F_.embedding(input_ids.reshape(-1)[pack.idx_long].view(1, pack.M), self.gpt_neox.embed_in.weight)
+            rope = self._rope_tables(L, x.device)
+            F_.PACK = pack
+            try:
+                for layer in self.gpt_neox.layers:
+                    x = layer(x, attention_mask=kv_len, rope=rope, cache=None, pos0=0)
+            finally:
+                F_.PACK = None
+            x = F_.UnpackRowsFn.apply(x.view(pack.M, -1), pack).view(B, L, -1)
+        else:
+            x = F_.embedding(input_ids, self.gpt_neox.embed_in.weight)
+            rope = self._step_rope(cache, self._rope_tables(max(pos0 + L, cache.kv.shape[3] if cache and cache.kv is not None else 0), x.device))
+            for i, layer in enumerate(self.gpt_neox.layers):
+                x = layer(x, attention_mask=kv_len, rope=rope, cache=cache.layers[i] if cache else None, pos0=pos0)
         f = self.gpt_neox.final_layer_norm
         h = F_.layer_norm(x, f.weight, f.bias, f.eps)
         out = self._head(h, labels, kw.get("logits_last_only", False), kw.get("head_rows"), kw.get("last_index"))

@@ -579,6 +579,17 @@ def add(a, b, out=None):
     return out
 
 
+def gather_rows(src, idx, out=None):
+    """out[r] = src[idx[r]] (zeros where idx[r] < 0); src [rows_src, D] bf16 with unit inner stride, idx int32 [n]."""
+    src, ld = _mat(src)
+    n, D = idx.numel(), src.shape[1]
+    assert idx.dtype == torch.int32 and idx.is_contiguous()
+    if out is None:
+        out = torch.empty((n, D), dtype=bf16, device=src.device)
+    check(_lib.lib().unimp_gather_rows(src.data_ptr(), ld, _dev(idx).data_ptr(), out.data_ptr(), out.stride(0), n, D, _stream()), "gather_rows")
+    return out
+
+
 def marker(i):
     """empty kernel with grid = i workgroups on the current stream: a cut point for tools/trace_window.py"""
     check(_lib.lib().unimp_marker(int(i), _stream()), "marker")

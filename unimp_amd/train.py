@@ -146,8 +146,14 @@ class Trainer:
     def __init__(self, model, special_ids, lr=2e-4, weight_decay=0.1, gamma=2.0, use_reweight=True, max_grad_norm=1.0,
                  lr_scheduler="cosine", warmup_steps=0, total_steps=1000, bucket_bytes=256 << 20, process_group=None,
                  sparse_head=False, grad_accum=1, mask_lm_head=False, force_dp_hooks=False, dense_head_backward=False,
-                 shard_optimizer=False, direct_wgrad=True, graph=False, fuse_accum=False):
-        """fuse_accum (off by default; needs grad_accum > 1): run the GA micro-batches of an optimizer step as ONE forward /
+                 shard_optimizer=False, direct_wgrad=True, graph=False, fuse_accum=False, packed=None):
+        """packed (None: the UNIMP_PACKED environment default, off): packed token order in the language tower -- LayerNorm and the
+        QKV / out / MLP / gated feed-forward projections run on the VALID tokens only ([1, M, H], M = the valid count rounded up to 2048
+        rows), the attention kernels keep the padded [B, L] addressing behind an unpack / pack pair (functional.Pack).  The reference
+        computes the <PAD> rows too (collate_rec.py:38-74 pads to the longest sequence of the batch); nothing reads them: loss and
+        gradients are those of the padded run (tests/test_model_gpu.py::test_packed_token_order_equals_padded), logits at <PAD>
+        positions become those of a zero hidden state.  GPT-NeoX tower only; one extra host sync per step (the valid count).
+        fuse_accum (off by default; needs grad_accum > 1): run the GA micro-batches of an optimizer step as ONE forward /
         backward pass.  The reference accumulates because 3 samples are what fits its GPUs (unimp_task.sh:2-30: --batch_size 3,
         --gradient_accumulation_steps 2); on 288 GB the activations of all GA micro-batches fit, and one pass over GA x B samples
         fills the GEMM tiles GA times better (a micro-batch of 3 x 512 tokens is 6 tile rows: measured, the step is GPU-bound at
@@ -175,6 +181,8 @@ class Trainer:
             raise ValueError("Trainer(graph=True) needs the sync-free dense loss path (sparse_head takes a row count on the host)")
         self.use_graph, self._graph = graph, None
         self.fuse_accum, self._stash, self._last = bool(fuse_accum and grad_accum > 1), [], (None, None)
+        if packed is not None:
+            F_.PACKED = bool(packed)
         self.grad_accum, self._micro = grad_accum, 0       # mmrec.py's --gradient_accumulation_steps (accelerator.accumulate)
         self.ids = special_ids                   # dict(answer_id, eoc_id, pad_id, media_id)
         self.gamma, self.use_reweight = gamma, use_reweight
