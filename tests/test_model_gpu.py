@@ -680,12 +680,13 @@ def test_fused_accumulation_equals_sequential(P, reweight):
     assert P.rel_l2(mf, ms) <= 5e-3                               # fp32 masters after two AdamW steps (Adam amplifies tiny gradients' noise)
 
 
-@pytest.mark.parametrize("cfgname,round_to", [("TINY", 8), ("TINY_PAR", 8), ("CFG2_SLIM", 256)])
+@pytest.mark.parametrize("cfgname,round_to", [("TINY", 8), ("TINY_PAR", 8), ("CFG2_SLIM", 64)])
 def test_packed_token_order_equals_padded(P, monkeypatch, cfgname, round_to):
     """Trainer(packed=True): the language tower's row-wise kernels (LayerNorm, QKV / out / MLP / gated feed-forward projections) run on
     the valid tokens only; the attention kernels keep the padded addressing behind an unpack / pack pair.  Against the padded run on
     the same weights and batch: the same labels, logits equal at every VALID position (every valid row goes through the same
-    arithmetic; bitwise where both runs rotate q / k from the tables, bf16-close where the padded run uses the rotary epilogue), zero
+    arithmetic: BITWISE, with both runs rotating q / k from the tables -- the padded default's rotary epilogue computes cos / sin on the
+    fly and differs from either at the bf16 level, 9e-3 rel-L2 at cfg2 width, like any two bf16 evaluations), zero
     hidden state behind the <PAD> logits, the same loss, every gradient equal up to the summation order of the weight-gradient
     GEMMs (their contraction runs over another row order)."""
     from unimp_amd import functional as F_
@@ -694,6 +695,8 @@ def test_packed_token_order_equals_padded(P, monkeypatch, cfgname, round_to):
     om, layout = P.build_oracle(cfg)
     batch = {k: v.cuda() for k, v in P.make_batch(cfg, layout, seed=31).items()}
     monkeypatch.setattr(F_, "PACK_ROUND", round_to)
+    monkeypatch.setattr(F_, "ROPE_EPILOGUE", False)        # both runs rotate q / k from the fp32 tables (the packed run always does): same bits expected
+    assert F_.Pack(batch["attention_mask"]).useful, "rounding leaves no row to skip: nothing is tested"
     res = {}
     for packed in (False, True):
         hm = P.build_hip(cfg, om, layout)
@@ -708,7 +711,7 @@ def test_packed_token_order_equals_padded(P, monkeypatch, cfgname, round_to):
     assert int(valid.sum()) < valid.numel(), "the batch has no padding: nothing is tested"
     (la, lossa, laba, ga), (lb, lossb, labb, gb) = res[False], res[True]
     assert torch.equal(laba, labb)
-    same_rope = valid.numel() < 256                         # below ops.ROPE_MIN_M rows both runs rotate from the tables
+    same_rope = True
     if same_rope:
         assert torch.equal(la[valid], lb[valid]), float((la[valid] - lb[valid]).abs().max())
         assert lossa == lossb
@@ -718,7 +721,7 @@ def test_packed_token_order_equals_padded(P, monkeypatch, cfgname, round_to):
     # <PAD> rows of the packed run: final LayerNorm of a zero row -> beta -> the same logits at every <PAD> position
     pad_logits = lb[~valid]
     assert torch.equal(pad_logits, pad_logits[:1].expand_as(pad_logits))
-    worst = (0.0, None)
+    worst = (-1.0, "")
     for n, g in ga.items():
         assert n in gb, n
         if g.abs().max() == 0:
