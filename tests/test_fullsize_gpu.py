@@ -238,7 +238,7 @@ def test_beam_search_tokens_match_oracle_beam_search(K):
     # divergence above was checked to be a legitimate near-tie
     # (round 3: the split-key decode kernel sums the same keys in another order, which moved one K = 4 prompt from "identical end
     # to end" to "left at an oracle near-tie" -- the in-loop assertions are the content, these counts only guard against a vacuous walk)
-    assert steps_ok >= (20 if K == 4 else 10) and full_ok >= (2 if K == 4 else 0)
+    assert steps_ok >= (20 if K == 4 else 10) and full_ok >= (1 if K == 4 else 0)
 
 
 @pytest.mark.parametrize("cfg_name", ["TINY", "TINY_OPT", "TINY_PAR", "TINY_MOSAIC"])
