@@ -183,6 +183,8 @@ class Trainer:
         self.fuse_accum, self._stash, self._last = bool(fuse_accum and grad_accum > 1), [], (None, None)
         if packed is not None:
             F_.PACKED = bool(packed)
+        if graph and F_.PACKED:
+            raise ValueError("Trainer(graph=True) cannot be combined with the packed token order (its valid-token count is a host sync per step)")
         self.grad_accum, self._micro = grad_accum, 0       # mmrec.py's --gradient_accumulation_steps (accelerator.accumulate)
         self.ids = special_ids                   # dict(answer_id, eoc_id, pad_id, media_id)
         self.gamma, self.use_reweight = gamma, use_reweight
