@@ -23,6 +23,18 @@
 #define EXP2(x) __builtin_amdgcn_exp2f(x)
 
 #include "attention_params.h"
+// LDS row pitch of the register-staged Q / K / V / dO tiles = row bytes + ATTN_PAD.  The transposed fragment reads (lfrag_tr_perm:
+// ds_read_b64_tr_b16, 32 lanes = 8 rows x 8-byte pieces per LDS cycle) are conflict-free when the pitch in dwords is 8 mod 16 -- the 8 rows
+// then start 8 banks apart: row bytes rounded up to 32 mod 64 gives 40 / 56 / 72 dwords at head dims 64 / 96 / 128.  With +16 (rounds 1-2) the pitches 36 / 52 / 68
+// put rows (0,5), (1,6), (2,7) on overlapping banks: PMC showed 18 % of the dK/dV kernel's CU cycles as LDS bank conflicts.  The row reads
+// (ds_read_b128, 16 rows per group) stay conflict-free at both pitches.
+#ifdef ATTN_PITCH_R2      // A/B: the pitch of rounds 1-2
+__host__ __device__ constexpr int attn_pitch(int row_bytes) { return row_bytes + 16; }
+#else                     // smallest pitch >= row_bytes with pitch % 64 == 32 (dwords: 8 mod 16); rows of 160 bytes (head dim 80 as V) need no pad.
+// Head dim 64 keeps +16: at 160 bytes the dK/dV kernel loses its eighth workgroup per CU (21.5 instead of 19.9 KiB of LDS) and measured
+// 7-14 % SLOWER (ViT / Perceiver / cross-attention shapes); head dims 80 and 128 gain 2.4 / 3.3 % on the backward (tools/gpu/r3q.sh)
+__host__ __device__ constexpr int attn_pitch(int row_bytes) { return row_bytes == 128 ? 144 : row_bytes + (32 - row_bytes % 64 + 64) % 64; }
+#endif
 
 // key range [lo, hi) attended by query row `qr` of batch b
 __device__ __forceinline__ void key_range(const AttnP& p, int b, int qr, int& lo, int& hi) {
@@ -144,7 +156,7 @@ __device__ __forceinline__ void lds_zero(char* smem, int bytes) {
 // two LDS stages, one barrier per tile.
 template <int DQK, int DV, bool ALIBI>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
-  constexpr int KSTR = DQK * 2 + 16, VSTR = DV * 2 + 16, NKS = DQK / 32, ND = DV / 16;
+  constexpr int KSTR = attn_pitch(DQK * 2), VSTR = attn_pitch(DV * 2), NKS = DQK / 32, ND = DV / 16;
   constexpr int STAGE = 64 * KSTR + 64 * VSTR;
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
   int b = blockIdx.z, h = blockIdx.y;
@@ -313,7 +325,7 @@ __global__ void attn_delta_kernel(AttnP p) {
 // layout (row reads for S and dP, transposed K reads for dQ).
 template <int DQK, int DV, bool ALIBI>
 __global__ __launch_bounds__(256) void attn_dq_kernel(AttnP p) {
-  constexpr int STR = DQK * 2 + 16, NKS = DQK / 32, ND = DV / 16;
+  constexpr int STR = attn_pitch(DQK * 2), NKS = DQK / 32, ND = DV / 16;
   constexpr int STAGE = 2 * 64 * STR;
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
   int b = blockIdx.z, h = blockIdx.y;
@@ -445,7 +457,7 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(AttnP p) {
 template <int DQK, int DV, bool ALIBI, int KU = 2>
 __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p, int nx) {
   constexpr int KPW = 16 * KU, KPB = 4 * KPW;               // keys per wave (KU blocks of 16) and per workgroup
-  constexpr int STR = DQK * 2 + 16, NKS = DQK / 32, ND = DV / 16;
+  constexpr int STR = attn_pitch(DQK * 2), NKS = DQK / 32, ND = DV / 16;
   constexpr int STAGE = 2 * 32 * STR + 32 * 16 + 16;
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
   // 1-D launch decoded XCD-aware (attention2.hip a2_decode): the key blocks of one (batch, head) share an XCD's L2, first
