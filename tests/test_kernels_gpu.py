@@ -137,6 +137,29 @@ def test_gemm_persistent_many_tiles_per_workgroup(ops):
         assert torch.equal(got, want), f"pp256p != pp256 for layout {a_ks}{b_ks}"
 
 
+def test_gemm_variants_same_bits_under_every_forward_epilogue(ops):
+    """The kernel variant is chosen per (M, N, K) -- from the autotune table, or by timing on a shape the table lacks -- so a sample
+    run alone (M = L) and inside a batch (M = B L) may go through different kernels: every variant must give the SAME BITS under every
+    epilogue the forward pass uses.  Round 3: `v * tanh(gate) + res` compiled to v_mul + v_add in the 128 x 128 / LDS-DMA kernels and
+    to one v_fmac in the ping-pong kernels (HIP's __fmul_rn is a plain, contractable `x * y`): ~4 elements per million one bf16 ulp
+    apart, a once-per-ten-boxes failure of the per-sample-independence tests.  The gated cross-attention's shapes, and the rotary
+    epilogue's two kernels."""
+    gate = torch.tensor([0.5], dtype=bf16, device="cuda")
+    for M, N, K in ((512, 2560, 512), (1024, 2560, 2048), (640, 1032, 416)):
+        a, b = rnd(M, K, seed=M + K).cuda(), rnd(N, K, seed=N + K, scale=0.05).cuda()
+        bias, res = rnd(N, seed=3).cuda(), rnd(M, N, seed=4).cuda()
+        for kw in (dict(), dict(bias=bias), dict(res=res), dict(res=res, gate=gate), dict(bias=bias, res=res, gate=gate), dict(gate=gate), dict(act="gelu"),
+                   dict(bias=bias, act="gelu"), dict(bias=bias, act="quick_gelu"), dict(alpha=0.125, bias=bias), dict(alpha=0.125, res=res, gate=gate)):
+            outs = {v: ops.gemm(a, b, variant=v, **kw) for v in ("v1", "dma256", "dma128", "pp256", "pp128", "w8", "pp256p")}
+            for v, o in outs.items():
+                assert torch.equal(o, outs["v1"]), f"[{M}, {N}, {K}] {sorted(kw)}: {v} differs from v1 in {int((o != outs['v1']).sum())} elements"
+    M, H, hd, L = 1024, 8, 80, 512
+    a, b, bias = rnd(M, H * hd, seed=7).cuda(), rnd(3 * H * hd, H * hd, seed=8, scale=0.05).cuda(), rnd(3 * H * hd, seed=9).cuda()
+    rope = dict(rot=hd, hd=hd, period=3 * hd, span=2 * hd, L=L, log2_base=float(np.log2(10000.0)))
+    o4, o9 = ops.gemm(a, b, bias=bias, rope=rope, variant=4), ops.gemm(a, b, bias=bias, rope=rope, variant=9)
+    assert torch.equal(o4, o9), f"rotary epilogue: pp256 and pp256p differ in {int((o4 != o9).sum())} elements"
+
+
 def test_gemm_ragged_n_padded_rows(ops):
     """N % 8 != 0 with row strides padded to a multiple of 8 (the 74 053-column LM head): full 8-column groups take the vector
     epilogue, the last partial group is written element by element; nothing beyond column N - 1 is touched."""

@@ -14,15 +14,17 @@ shapes = [(512, 4096, 4096), (1024, 4096, 4096), (512, 12288, 4096), (1024, 1638
           # the vision path at 8 / 16 images: ViT-L (257 tokens per image) and the Perceiver (320 kv rows, 64 latents per image)
           (2056, 3072, 1024), (4112, 3072, 1024), (2056, 4096, 1024), (4112, 4096, 1024), (2056, 1024, 4096), (4112, 1024, 4096), (4112, 1024, 1024),
           (2560, 1024, 1024), (5120, 1024, 1024), (512, 512, 1024), (1024, 512, 1024), (512, 1024, 512), (512, 4096, 1024), (1024, 4096, 1024),
-          (512, 1024, 4096), (1024, 1024, 4096), (2048, 602, 1024)]
+          (512, 1024, 4096), (1024, 1024, 4096), (2048, 602, 1024),
+          (512, 2560, 512), (1024, 2560, 512), (512, 2560, 10240), (1024, 2560, 10240)]      # the gated cross-attention
 for M, N, K in shapes:
     a = torch.randn(M, K, device="cuda").to(bf)
     b = (torch.randn(N, K, device="cuda") * 0.02).to(bf)
     res = torch.randn(M, N, device="cuda").to(bf)
     bias = torch.randn(N, device="cuda").to(bf)
-    for epi in ("plain", "res", "gelu", "bias", "bias+quick_gelu", "bias+res"):
+    gate = torch.tensor([0.5], dtype=bf, device="cuda")
+    for epi in ("plain", "res", "gelu", "bias", "bias+quick_gelu", "bias+res", "gate+res", "bias+gate+res"):
         kw = {"plain": {}, "res": dict(res=res), "gelu": dict(act="gelu"), "bias": dict(bias=bias), "bias+quick_gelu": dict(bias=bias, act="quick_gelu"),
-              "bias+res": dict(bias=bias, res=res)}[epi]
+              "bias+res": dict(bias=bias, res=res), "gate+res": dict(res=res, gate=gate), "bias+gate+res": dict(bias=bias, res=res, gate=gate)}[epi]
         outs = {}
         for v in ("v1", "dma256", "dma128", "pp256", "pp128", "w8", "pp256p"):
             try:

@@ -16,6 +16,19 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 __device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
 __device__ __forceinline__ bf16 f2bf(float x) { return (bf16)x; }   // v_cvt_pk_bf16_f32 (RNE, NaN-safe)
+// A multiply / add that is rounded on its own, NEVER contracted with a neighbour into an fma.  hipcc's default is
+// -ffp-contract=fast-honor-pragmas and HIP's __fmul_rn / __fadd_rn are plain `x * y` / `x + y` (__clang_hip_math.h): the same
+// `v * gate + res` source became v_mul + v_add in one GEMM epilogue and v_fmac in another (round 3: tools/hunt_invariance.py replay,
+// ~4 elements per million one bf16 ulp apart), so a sample's bits depended on which kernel variant its batch size was tuned to.
+// Every GEMM epilogue does its alpha / bias / gate / residual / rotary arithmetic through these two.
+__device__ __forceinline__ float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ float add_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 

@@ -84,12 +84,12 @@ __device__ __forceinline__ void epi_tile(const GemmParams& p, f32x4 a, int m, in
   int nv = FAST ? 4 : min(4, p.N - n);
   float v[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) v[r] = __fmul_rn(a[r], p.alpha);
+  for (int r = 0; r < 4; ++r) v[r] = mul_rn(a[r], p.alpha);
   if (p.bias) {
     if (FAST) { bf16x4 b = *(const bf16x4*)(p.bias + n);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = __fadd_rn(v[r], bf2f(b[r])); }
-    else { for (int r = 0; r < nv; ++r) v[r] = __fadd_rn(v[r], bf2f(p.bias[n + r])); }
+      for (int r = 0; r < 4; ++r) v[r] = add_rn(v[r], bf2f(b[r])); }
+    else { for (int r = 0; r < nv; ++r) v[r] = add_rn(v[r], bf2f(p.bias[n + r])); }
   }
   if (p.pre && p.pre_deriv) {
     float dv[4];
@@ -113,13 +113,13 @@ __device__ __forceinline__ void epi_tile(const GemmParams& p, f32x4 a, int m, in
     else { for (int r = 0; r < nv; ++r) v[r] *= act_bwd(p.dact, bf2f(s[r])); }
   }
 #pragma unroll
-  for (int r = 0; r < 4; ++r) v[r] = __fmul_rn(v[r], gate);
+  for (int r = 0; r < 4; ++r) v[r] = mul_rn(v[r], gate);
   if (p.res) {
     const bf16* s = p.res + (long)m * p.ldres + n;
     if (FAST) { bf16x4 x = *(const bf16x4*)s;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = __fadd_rn(v[r], bf2f(x[r])); }
-    else { for (int r = 0; r < nv; ++r) v[r] = __fadd_rn(v[r], bf2f(s[r])); }
+      for (int r = 0; r < 4; ++r) v[r] = add_rn(v[r], bf2f(x[r])); }
+    else { for (int r = 0; r < nv; ++r) v[r] = add_rn(v[r], bf2f(s[r])); }
   }
   if (p.out_f32) {
     float* d = (float*)p.C + (long)m * p.ldc + n;

@@ -51,19 +51,19 @@ __device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
 }
 
 // 8 consecutive columns of one output row.  PRE: the caller already fetched this row group's aux / res chunks (FAST only).
-// alpha / bias / gate / residual use explicitly rounded multiplies and adds (no fma contraction): every kernel variant and
+// alpha / bias / gate / residual use individually rounded multiplies and adds (common.h mul_rn / add_rn: no fma contraction): every kernel variant and
 // every epilogue form must produce the same bits, or the result of a sample would depend on which variant its batch size tuned to.
 template <bool FAST, bool PRE = false>
 __device__ __forceinline__ void epi8(const Gemm2Params& p, float (&v)[8], int m, int n, float gate,
                                      bf16x8 auxv = bf16x8{}, bf16x8 resv = bf16x8{}, bf16x8 biasv = bf16x8{}) {
   int nv = FAST ? 8 : min(8, p.N - n);
 #pragma unroll
-  for (int r = 0; r < 8; ++r) v[r] = __fmul_rn(v[r], p.alpha);
+  for (int r = 0; r < 8; ++r) v[r] = mul_rn(v[r], p.alpha);
   if (p.bias) {
     if (FAST) { bf16x8 b = PRE ? biasv : *(const bf16x8*)(p.bias + n);
 #pragma unroll
-      for (int r = 0; r < 8; ++r) v[r] = __fadd_rn(v[r], bf2f(b[r])); }
-    else { for (int r = 0; r < nv; ++r) v[r] = __fadd_rn(v[r], bf2f(p.bias[n + r])); }
+      for (int r = 0; r < 8; ++r) v[r] = add_rn(v[r], bf2f(b[r])); }
+    else { for (int r = 0; r < nv; ++r) v[r] = add_rn(v[r], bf2f(p.bias[n + r])); }
   }
   if (p.pre && p.pre_deriv) {                 // y = act(v) and act'(v) from one exponential; store the derivative
     float dv[8];
@@ -95,13 +95,13 @@ __device__ __forceinline__ void epi8(const Gemm2Params& p, float (&v)[8], int m,
     else { for (int r = 0; r < nv; ++r) v[r] *= act_bwd(p.dact, bf2f(s[r])); }
   }
 #pragma unroll
-  for (int r = 0; r < 8; ++r) v[r] = __fmul_rn(v[r], gate);
+  for (int r = 0; r < 8; ++r) v[r] = mul_rn(v[r], gate);
   if (p.res) {
     const bf16* s = p.res + (long)m * p.ldres + n;
     if (FAST) { bf16x8 x = PRE ? resv : *(const bf16x8*)s;
 #pragma unroll
-      for (int r = 0; r < 8; ++r) v[r] = __fadd_rn(v[r], bf2f(x[r])); }
-    else { for (int r = 0; r < nv; ++r) v[r] = __fadd_rn(v[r], bf2f(s[r])); }
+      for (int r = 0; r < 8; ++r) v[r] = add_rn(v[r], bf2f(x[r])); }
+    else { for (int r = 0; r < nv; ++r) v[r] = add_rn(v[r], bf2f(s[r])); }
   }
   if (p.out_f32) {
     float* d = (float*)p.C + (long)m * p.ldc + n;
@@ -196,10 +196,10 @@ __device__ __forceinline__ void epi_inputs_ready() { __builtin_amdgcn_s_waitcnt(
 template <int KIND>
 __device__ __forceinline__ void epi8k(const Gemm2Params& p, float (&v)[8], int m, int n, float gate, bf16x8 x, bf16x8 biasv) {
 #pragma unroll
-  for (int r = 0; r < 8; ++r) v[r] = __fmul_rn(v[r], p.alpha);
+  for (int r = 0; r < 8; ++r) v[r] = mul_rn(v[r], p.alpha);
   if (p.bias) {
 #pragma unroll
-    for (int r = 0; r < 8; ++r) v[r] = __fadd_rn(v[r], bf2f(biasv[r]));
+    for (int r = 0; r < 8; ++r) v[r] = add_rn(v[r], bf2f(biasv[r]));
   }
   if (KIND == EK_ROPE) {                      // rotary epilogue: the 8 columns are 4 adjacent pairs (j, j + 4)
     int pp = n % p.rope_hd;
@@ -209,8 +209,8 @@ __device__ __forceinline__ void epi8k(const Gemm2Params& p, float (&v)[8], int m
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float x1 = v[j], x2 = v[j + 4];
-        v[j] = x1 * co[j] - x2 * si[j];
-        v[j + 4] = x2 * co[j] + x1 * si[j];
+        v[j] = add_rn(mul_rn(x1, co[j]), -mul_rn(x2, si[j]));
+        v[j + 4] = add_rn(mul_rn(x2, co[j]), mul_rn(x1, si[j]));
       }
     }
   }
@@ -235,7 +235,7 @@ __device__ __forceinline__ void epi8k(const Gemm2Params& p, float (&v)[8], int m
   }
   if (KIND != EK_RES) {                       // the gated cross-attention's dX / dW GEMMs: x tanh(gate), after act / aux like the general form
 #pragma unroll
-    for (int r = 0; r < 8; ++r) v[r] = __fmul_rn(v[r], gate);
+    for (int r = 0; r < 8; ++r) v[r] = mul_rn(v[r], gate);
   }
   if (KIND == EK_RES) {
     if (p.pre) {                            // gated blocks keep the un-gated value for the gate's gradient
@@ -245,7 +245,7 @@ __device__ __forceinline__ void epi8k(const Gemm2Params& p, float (&v)[8], int m
       *(bf16x8*)(p.pre + (long)m * p.ldpre + n) = o;
     }
 #pragma unroll
-    for (int r = 0; r < 8; ++r) v[r] = __fadd_rn(__fmul_rn(v[r], gate), bf2f(x[r]));
+    for (int r = 0; r < 8; ++r) v[r] = add_rn(mul_rn(v[r], gate), bf2f(x[r]));
   }
   if (p.out_f32) {
     float* d = (float*)p.C + (long)m * p.ldc + n;
