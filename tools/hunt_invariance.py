@@ -24,7 +24,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench                                  # noqa: E402
 from unimp_amd.synthetic import make_batch    # noqa: E402
 from unimp_amd import ops, _lib               # noqa: E402
-import ctypes as C                            # noqa: E402
 
 dev = torch.device("cuda")
 model, layout = bench.build_cfg2(dev, gate=0.5, lang="anas-awadalla/mpt-7b", every=4) if which == "9b" else bench.build_cfg2(dev, gate=0.5)
@@ -83,7 +82,6 @@ def _splitk(dref, splits, slabs, stream):
 
 
 _L.unimp_gemm_bf16_splitk = _splitk
-_tune0, _tunepk0 = ops._tune_gemm, ops._tune_packed
 if mode == "random":
     rnd = random.Random(1)
 
@@ -146,7 +144,8 @@ for trial in range(trials):
         if first is None:
             continue
         bad += 1
-        nm = first if first != "99 logits" else model.lang_encoder._get_decoder_layers().__len__() and "02 layer%02d (after)" % (len(model.lang_encoder._get_decoder_layers()) - 1)
+        # the head's GEMM runs after the last decoder layer's hook
+        nm = first if first != "99 logits" else "02 layer%02d (after)" % (len(model.lang_encoder._get_decoder_layers()) - 1)
         print(f"  {what}: GEMM launches in {nm!r}  (M, N, K, variant, a_ks, b_ks, bias, res, act, rope_hd)")
         for tag, lg in (("first ", l0), ("second", l1)):
             for e in lg:
