@@ -22,7 +22,7 @@ extern "C" {
 
 /* bumped whenever a signature, a descriptor layout or a buffer-size requirement changes incompatibly (2: round-2 additions --
  * layernorm_bwd(wgrad_accumulate), dot_bf16's fp32[1+1024] scratch, grown gemm / attention descriptors; 3: round 3) */
-#define UNIMP_ABI_VERSION 3
+#define UNIMP_ABI_VERSION 4
 enum { UNIMP_OK = 0, UNIMP_ERR_ARG = 1, UNIMP_ERR_SHAPE = 2, UNIMP_ERR_ALIGN = 3, UNIMP_ERR_LAUNCH = 4,
        UNIMP_ERR_UNSUPPORTED = 5 };
 enum { UNIMP_ACT_NONE = 0, UNIMP_ACT_GELU = 1, UNIMP_ACT_QUICKGELU = 2, UNIMP_ACT_RELU = 3, UNIMP_ACT_SILU = 4,
@@ -68,6 +68,8 @@ typedef struct {
    * ldc % 8 == 0, k-contiguous A and B, variants PP256 / PP256P (UNIMP_ERR_UNSUPPORTED otherwise).  rope_log2_base = log2(base). */
   int rope_rot, rope_hd, rope_period, rope_span, rope_L;
   float rope_log2_base;
+  /* ABI 4: NULL, or int32 [M]: the position of row m (instead of m % rope_L) -- packed rows, where a sequence starts at any row */
+  const int32_t* rope_pos;
 } unimp_gemm_desc;
 /* Pre-packed B operand for FROZEN weights (b_kstrided = 2 in the descriptor; ping-pong variants only): every MFMA B fragment
  * of the 16x16x32 instruction -- (n-tile of 16, 32-k step) -- stored as one contiguous 1-KiB block in lane order, so a wave
@@ -120,6 +122,10 @@ int unimp_layernorm_bwd(const void* dy, int64_t lddy, const void* dy2, int64_t l
 int unimp_rope_halfsplit(void* x, int64_t row_stride, int64_t head_stride, int rows, int L, int heads, int rot,
                          int nvec, int vec_off0, int vec_off1, const float* cos_t, const float* sin_t, int inverse,
                          void* stream);
+/* the same with the position of every row given (int32 [rows], each < the tables' row count) instead of row % L: packed rows (ABI 4) */
+int unimp_rope_halfsplit_pos(void* x, int64_t row_stride, int64_t head_stride, int rows, const int32_t* pos, int heads, int rot,
+                             int nvec, int vec_off0, int vec_off1, const float* cos_t, const float* sin_t, int inverse,
+                             void* stream);
 
 /* ---- attention (flash-style, MFMA) -------------------------------------------------------------------------
  * replaces xformers.ops.memory_efficient_attention (clip.py:130-136; llama.py:287-301), the GPT-NeoX causal
@@ -156,6 +162,15 @@ typedef struct {
    * (unimp_gemm_desc.rope_*): dims 8g + j and 8g + 4 + j of every dq / dk row are rotated back at frequency 4g + j, cos / sin
    * computed in the epilogue -- no tables, no partner chunk. */
   float rope_log2_base;
+  /* packed rows (ABI 4; training entry points only, NULL = the padded layout above): q_row_off int32 [B] -- the query-side
+   * tensors (q, o, d_o, dq) are ONE [rows][H][D] buffer in which sequence b owns rows q_row_off[b] .. q_row_off[b] + q_len[b] - 1
+   * (q_len int32 [B], required with q_row_off); the *_bs strides are ignored for them, Sq is the LONGEST sequence (it sizes the grid
+   * and the per-row statistics lse / delta, which stay [B][H][Sq]), and seg, if set, is packed like q (seg[q_row_off[b] + i]).
+   * k_row_off int32 [B]: the same for k, v, dk, dv with kv_len[b] rows each (kv_len required; a sequence with kv_len 0 must have
+   * q_len 0).  Rows outside a sequence are neither read as data nor written.  collate_rec.py:38-74 right-pads every sequence to the
+   * longest of the batch; this is the layout in which the language tower never computes the <PAD> rows.  Needs kernel
+   * generation >= 2 in the backward (UNIMP_ERR_UNSUPPORTED otherwise); the decode entry points refuse it. */
+  const int32_t* q_row_off; const int32_t* q_len; const int32_t* k_row_off;
 } unimp_attn_desc;
 int unimp_attn_fwd(const unimp_attn_desc* d, void* stream);
 int unimp_attn_bwd(const unimp_attn_desc* d, void* stream);

@@ -549,6 +549,81 @@ def test_attention_bwd_fused_inverse_rope(ops, attn_gen, B, H, S, D, rot, interl
     assert bad.float().mean() < 1e-3 and diff.max() <= 2 ** -6 * two.float().abs().max(), (bad.float().mean(), diff.max())
 
 
+@pytest.mark.parametrize("H,D,L,lens,mode", [(4, 80, 200, (200, 77, 130), 1), (2, 64, 257, (257, 31, 5, 190), 0), (2, 128, 300, (129, 300), 1),
+                                             (4, 64, 150, (150, 64, 97), 2), (3, 80, 512, (512, 300, 511, 1, 64), 1)])
+def test_attention_packed_rows(ops, H, D, L, lens, mode):
+    """include/unimp_hip.h q_row_off / k_row_off: the sequences of a batch as row ranges of one [rows, H, D] buffer.  Same kernels,
+    same per-sequence tiles as the padded [B, L] call with kv_len -- forward output, lse and all three gradients must come back with
+    the SAME BITS on every valid row, and no row outside a sequence may be written (the buffers carry guard rows of NaN).
+    mode 2: the gated cross-attention's form -- packed queries (and packed media_time), padded media keys."""
+    B = len(lens)
+    g = torch.Generator().manual_seed(L + D + B)
+    scale = D ** -0.5
+    lens_t = torch.tensor(lens, dtype=torch.int32)
+    off = torch.cumsum(lens_t, 0) - lens_t
+    n = int(lens_t.sum())
+    M = n + 7                                                           # spare rows behind the last sequence
+    rows_of = torch.cat([b * L + torch.arange(lens[b]) for b in range(B)])          # flat padded position of every packed row
+    pr = ops.PackedRows(B, L, off.to(torch.int32).cuda(), lens_t.cuda(), n)
+    nan = float("nan")
+    if mode == 2:
+        Sk, seg_len = 192, 64
+        q = torch.randn(B, L, H, D, generator=g).to(bf16)
+        kv = torch.randn(B, Sk, 2, H, D, generator=g).to(bf16).cuda()
+        k, v = kv[:, :, 0], kv[:, :, 1]
+        seg = torch.zeros(B, L, dtype=torch.int32)
+        for b in range(B):
+            for c in sorted(torch.randint(1, max(2, lens[b]), (Sk // seg_len,), generator=g).tolist()):
+                seg[b, c:] += 1
+        seg.clamp_(max=Sk // seg_len)
+        do = torch.randn(B, L, H, D, generator=g).to(bf16)
+        do[torch.arange(L)[None] >= lens_t[:, None]] = 0
+        qd, dod, segd = q.cuda(), do.cuda(), seg.cuda()
+        o_pad, lse_pad = ops.attn_fwd(qd, k, v, scale, 2, None, segd, seg_len)
+        dq_pad, dkv_pad = torch.empty_like(qd), torch.empty_like(kv)
+        ops.attn_bwd(qd, k, v, o_pad, lse_pad, dod, dq_pad, dkv_pad[:, :, 0], dkv_pad[:, :, 1], scale, 2, None, segd, seg_len)
+        # packed queries
+        qp = torch.full((1, M, H, D), 0.5, dtype=bf16); qp[0, :n] = q.view(B * L, H, D)[rows_of]
+        dop = torch.zeros((1, M, H, D), dtype=bf16); dop[0, :n] = do.view(B * L, H, D)[rows_of]
+        segp = torch.zeros(M, dtype=torch.int32); segp[:n] = seg.view(-1)[rows_of]
+        qp, dop, segp = qp.cuda(), dop.cuda(), segp.cuda()
+        out = torch.full((1, M, H, D), nan, dtype=bf16, device="cuda")
+        o_p, lse_p = ops.attn_fwd(qp, k, v, scale, 2, None, segp, seg_len, out=out, q_rows=pr)
+        dq_p = torch.full((1, M, H, D), nan, dtype=bf16, device="cuda")
+        dkv_p = torch.empty_like(kv)
+        ops.attn_bwd(qp, k, v, o_p, lse_p, dop, dq_p, dkv_p[:, :, 0], dkv_p[:, :, 1], scale, 2, None, segp, seg_len, q_rows=pr)
+        assert torch.equal(o_p[0, :n], o_pad.view(B * L, H, D)[rows_of.cuda()]) and torch.isnan(o_p[0, n:].float()).all()
+        assert torch.equal(dq_p[0, :n], dq_pad.view(B * L, H, D)[rows_of.cuda()]) and torch.isnan(dq_p[0, n:].float()).all()
+        assert torch.equal(dkv_p, dkv_pad)
+        return
+    qkv = torch.randn(B, L, H, 3 * D, generator=g).to(bf16)
+    do = torch.randn(B, L, H, D, generator=g).to(bf16)
+    do[torch.arange(L)[None] >= lens_t[:, None]] = 0                    # what autograd delivers at <PAD> rows
+    qkv_d, dod, kvl = qkv.cuda(), do.cuda(), lens_t.cuda()
+    q, k, v = qkv_d[..., :D], qkv_d[..., D:2 * D], qkv_d[..., 2 * D:]
+    o_pad, lse_pad = ops.attn_fwd(q, k, v, scale, mode, kvl)
+    dqkv_pad = torch.zeros_like(qkv_d)
+    ops.attn_bwd(q, k, v, o_pad, lse_pad, dod, dqkv_pad[..., :D], dqkv_pad[..., D:2 * D], dqkv_pad[..., 2 * D:], scale, mode, kvl)
+    # the same sequences as row ranges
+    qkv_p = torch.full((1, M, H, 3 * D), 0.25, dtype=bf16); qkv_p[0, :n] = qkv.view(B * L, H, 3 * D)[rows_of]
+    do_p = torch.zeros((1, M, H, D), dtype=bf16); do_p[0, :n] = do.view(B * L, H, D)[rows_of]
+    qkv_p, do_p = qkv_p.cuda(), do_p.cuda()
+    qp, kp, vp = qkv_p[..., :D], qkv_p[..., D:2 * D], qkv_p[..., 2 * D:]
+    out = torch.full((1, M, H, D), nan, dtype=bf16, device="cuda")
+    o_p, lse_p = ops.attn_fwd(qp, kp, vp, scale, mode, out=out, q_rows=pr, k_rows=pr)
+    dqkv_p = torch.full_like(qkv_p, nan)
+    ops.attn_bwd(qp, kp, vp, o_p, lse_p, do_p, dqkv_p[..., :D], dqkv_p[..., D:2 * D], dqkv_p[..., 2 * D:], scale, mode, q_rows=pr, k_rows=pr)
+    rd = rows_of.cuda()
+    assert torch.equal(o_p[0, :n], o_pad.view(B * L, H, D)[rd]), float((o_p[0, :n].float() - o_pad.view(B * L, H, D)[rd].float()).abs().max())
+    assert torch.isnan(o_p[0, n:].float()).all(), "the forward wrote a row outside every sequence"
+    for b in range(B):
+        assert torch.equal(lse_p[b, :, :lens[b]], lse_pad[b, :, :lens[b]])
+    got, want = dqkv_p[0, :n], dqkv_pad.view(B * L, H, 3 * D)[rd]
+    for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
+        assert torch.equal(got[..., sl], want[..., sl]), (name, float((got[..., sl].float() - want[..., sl].float()).abs().max()))
+    assert torch.isnan(dqkv_p[0, n:].float()).all(), "the backward wrote a row outside every sequence"
+
+
 def test_attention_spiked_row_online_softmax(ops, attn_gen):
     """force the running-max rescale branch: one key far above the rest in a late tile (cdna guide rule 26)."""
     B, H, S, D = 1, 1, 256, 64

@@ -680,22 +680,22 @@ def test_fused_accumulation_equals_sequential(P, reweight):
     assert P.rel_l2(mf, ms) <= 5e-3                               # fp32 masters after two AdamW steps (Adam amplifies tiny gradients' noise)
 
 
-@pytest.mark.parametrize("cfgname,round_to", [("TINY", 8), ("TINY_PAR", 8), ("CFG2_SLIM", 64)])
-def test_packed_token_order_equals_padded(P, monkeypatch, cfgname, round_to):
-    """Trainer(packed=True): the language tower's row-wise kernels (LayerNorm, QKV / out / MLP / gated feed-forward projections) run on
-    the valid tokens only; the attention kernels keep the padded addressing behind an unpack / pack pair.  Against the padded run on
-    the same weights and batch: the same labels, logits equal at every VALID position (every valid row goes through the same
-    arithmetic: BITWISE, with both runs rotating q / k from the tables -- the padded default's rotary epilogue computes cos / sin on the
-    fly and differs from either at the bf16 level, 9e-3 rel-L2 at cfg2 width, like any two bf16 evaluations), zero
-    hidden state behind the <PAD> logits, the same loss, every gradient equal up to the summation order of the weight-gradient
-    GEMMs (their contraction runs over another row order)."""
+@pytest.mark.parametrize("cfgname,round_to,rope_epilogue", [("TINY", 8, True), ("TINY_PAR", 8, True), ("CFG2_SLIM", 64, False), ("CFG2_SLIM", 64, True)])
+def test_packed_token_order_equals_padded(P, monkeypatch, cfgname, round_to, rope_epilogue):
+    """Trainer(packed=True): the language tower runs on the valid tokens only -- LayerNorm, the QKV / out / MLP / gated feed-forward
+    projections on the packed rows, the attention kernels on the sequences as row ranges of the packed buffers (q_row_off / k_row_off),
+    the rotation with each row's position from a table (the QKV GEMM's rotary epilogue where the padded path takes it too -- cfg2
+    width, rope_epilogue True -- else the table pass).  Against the padded run on the same weights and batch: the same labels, logits
+    equal at every VALID position BITWISE (every valid row goes through the same arithmetic), zero hidden state behind the <PAD>
+    logits, the same loss, every gradient equal up to the summation order of the weight-gradient GEMMs (their contraction runs over
+    another row order)."""
     from unimp_amd import functional as F_
     from unimp_amd.train import Trainer
     cfg = getattr(P, cfgname)
     om, layout = P.build_oracle(cfg)
     batch = {k: v.cuda() for k, v in P.make_batch(cfg, layout, seed=31).items()}
     monkeypatch.setattr(F_, "PACK_ROUND", round_to)
-    monkeypatch.setattr(F_, "ROPE_EPILOGUE", False)        # both runs rotate q / k from the fp32 tables (the packed run always does): same bits expected
+    monkeypatch.setattr(F_, "ROPE_EPILOGUE", rope_epilogue)   # off: both runs rotate q / k from the fp32 tables; on: both in the QKV GEMM's epilogue where it applies
     assert F_.Pack(batch["attention_mask"]).useful, "rounding leaves no row to skip: nothing is tested"
     res = {}
     for packed in (False, True):

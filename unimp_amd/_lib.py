@@ -18,7 +18,8 @@ class GemmDesc(C.Structure):
                 ("bias", c_p), ("res", c_p), ("ldres", c_l), ("aux", c_p), ("ldaux", c_l),
                 ("pre", c_p), ("ldpre", c_l), ("gate", c_p), ("alpha", c_f), ("act", c_i), ("dact", c_i),
                 ("out_f32", c_i), ("accumulate", c_i), ("pre_deriv", c_i),
-                ("rope_rot", c_i), ("rope_hd", c_i), ("rope_period", c_i), ("rope_span", c_i), ("rope_L", c_i), ("rope_log2_base", c_f)]
+                ("rope_rot", c_i), ("rope_hd", c_i), ("rope_period", c_i), ("rope_span", c_i), ("rope_L", c_i), ("rope_log2_base", c_f),
+                ("rope_pos", c_p)]
 
 
 class AttnDesc(C.Structure):
@@ -29,7 +30,8 @@ class AttnDesc(C.Structure):
                 ("kv_len", c_p), ("seg", c_p), ("seg_len", c_i),
                 ("d_o", c_p), ("dq", c_p), ("dk", c_p), ("dv", c_p), ("delta", c_p)] + \
                [(n, c_l) for n in ("do_bs", "do_ss", "do_hs", "dq_bs", "dq_ss", "dq_hs", "dk_bs", "dk_ss", "dk_hs",
-                                   "dv_bs", "dv_ss", "dv_hs")] + [("alibi_slopes", c_p), ("rope_cos", c_p), ("rope_sin", c_p), ("rope_half", c_i), ("rope_log2_base", c_f)]
+                                   "dv_bs", "dv_ss", "dv_hs")] + [("alibi_slopes", c_p), ("rope_cos", c_p), ("rope_sin", c_p), ("rope_half", c_i), ("rope_log2_base", c_f),
+                                                    ("q_row_off", c_p), ("q_len", c_p), ("k_row_off", c_p)]
 
 
 class MxGemmDesc(C.Structure):
@@ -48,6 +50,7 @@ _SIGS = {
     "unimp_layernorm_bwd": [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_i,
                             c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "unimp_rope_halfsplit": [c_p, c_l, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p],
+    "unimp_rope_halfsplit_pos": [c_p, c_l, c_l, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p],
     "unimp_attn_fwd": [C.POINTER(AttnDesc), c_p],
     "unimp_attn_bwd": [C.POINTER(AttnDesc), c_p],
     "unimp_attn_decode": [C.POINTER(AttnDesc), c_p, c_i, c_p],
@@ -80,7 +83,7 @@ _SIGS = {
     "unimp_image_resize_normalize": [c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_p],
 }
 
-ABI_VERSION = 3          # must equal UNIMP_ABI_VERSION of include/unimp_hip.h the library was built from
+ABI_VERSION = 4          # must equal UNIMP_ABI_VERSION of include/unimp_hip.h the library was built from
 
 _lib = None
 

@@ -43,7 +43,7 @@ __device__ __forceinline__ void key_range(const AttnP& p, int b, int qr, int& lo
   int kvl = p.kv_len ? p.kv_len[b] : p.Sk;
   if (p.mask_mode == UNIMP_MASK_NONE) { hi = kvl; }
   else if (p.mask_mode == UNIMP_MASK_CAUSAL) { hi = min(qr + 1, kvl); }
-  else { int t = p.seg[(long)b * p.Sq + qr]; if (t > 0) { lo = (t - 1) * p.seg_len; hi = min(t * p.seg_len, p.Sk); } }
+  else { int t = p.seg[(long)b * p.SqS + qr]; if (t > 0) { lo = (t - 1) * p.seg_len; hi = min(t * p.seg_len, p.Sk); } }
 }
 
 // cooperative [rows x DPAD] bf16 tile load into LDS with row stride STR bytes; zero fill outside (nrows, D)
@@ -98,7 +98,7 @@ __device__ __forceinline__ void block_key_tiles(const AttnP& p, int b, int q_fir
   if (p.mask_mode == UNIMP_MASK_NONE) { kt_lo = 0; kt_hi = (kvl + 63) >> 6; }
   else if (p.mask_mode == UNIMP_MASK_CAUSAL) { kt_lo = 0; kt_hi = (min(q_last + 1, kvl) + 63) >> 6; }
   else {
-    int t0 = p.seg[(long)b * p.Sq + q_first], t1 = p.seg[(long)b * p.Sq + q_last];
+    int t0 = p.seg[(long)b * p.SqS + q_first], t1 = p.seg[(long)b * p.SqS + q_last];
     if (t1 == 0) { kt_lo = 0; kt_hi = 0; }
     else { kt_lo = (max(t0 - 1, 0) * p.seg_len) >> 6; kt_hi = (min(t1 * p.seg_len, p.Sk) + 63) >> 6; }
   }
@@ -160,6 +160,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
   constexpr int STAGE = 64 * KSTR + 64 * VSTR;
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
   int b = blockIdx.z, h = blockIdx.y;
+  if (!attn_varlen(p, b) || (int)blockIdx.x * 128 >= p.Sq) return;
   int wave = threadIdx.x >> 6, l = lane_id(), g = l >> 4;
   int q0 = blockIdx.x * 128 + wave * 32;
   const bf16* qb = p.q + b * p.q_bs + h * p.q_hs;
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
         bf16x4 w = {f2bf(o[u][nd][0] * inv), f2bf(o[u][nd][1] * inv), f2bf(o[u][nd][2] * inv), f2bf(o[u][nd][3] * inv)};
         *(bf16x4*)(ob + nd * 16 + g * 4) = w;
       }
-      if (g == 0 && p.lse) p.lse[((long)b * p.H + h) * p.Sq + qr] = lsum[u] > 0.f ? (m[u] + log2f(lsum[u])) * LN2 : -INFINITY;
+      if (g == 0 && p.lse) p.lse[((long)b * p.H + h) * p.SqS + qr] = lsum[u] > 0.f ? (m[u] + log2f(lsum[u])) * LN2 : -INFINITY;
     }
   }
 }
@@ -316,7 +317,7 @@ __global__ void attn_delta_kernel(AttnP p) {
   for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
   if (i < n && c == 0) {
     int h = i % p.H; long t = i / p.H; int qr = t % p.Sq; int b = t / p.Sq;
-    p.delta[((long)b * p.H + h) * p.Sq + qr] = acc;
+    p.delta[((long)b * p.H + h) * p.SqS + qr] = acc;
   }
 }
 
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(AttnP p) {
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) { qf[u][ks] = gfrag(qb, p.q_ss, qr, p.Sq, ks, p.D); dof[u][ks] = gfrag(dob, p.do_ss, qr, p.Sq, ks, p.D); }
     key_range(p, b, qr, lo[u], hi[u]);
-    long sidx = ((long)b * p.H + h) * p.Sq + min(qr, p.Sq - 1);
+    long sidx = ((long)b * p.H + h) * p.SqS + min(qr, p.Sq - 1);
     lse2[u] = p.lse[sidx] * LOG2E; dl[u] = p.delta[sidx];
   }
   int kt_lo, kt_hi;
@@ -465,6 +466,7 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p, int nx) {
   int id_ = xcd_remap(blockIdx.x, nx * p.H * p.B);
   int kblk = id_ % nx, t_ = id_ / nx;
   int h = t_ % p.H, b = t_ / p.H;
+  if (!attn_varlen(p, b) || kblk * KPB >= p.Sk) return;       // packed rows: the grid covers the longest sequence
   int wave = threadIdx.x >> 6, l = lane_id(), g = l >> 4;
   int key0 = kblk * KPB + wave * KPW;
   const bf16* qb = p.q + b * p.q_bs + h * p.q_hs;
@@ -490,8 +492,8 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p, int nx) {
   if (p.mask_mode == UNIMP_MASK_CAUSAL) qt_a = kfirst >> 5;
   else if (p.mask_mode == UNIMP_MASK_SEGMENT) {
     // media_time is non-decreasing along the sequence: first / last tile whose rows can attend [kfirst, klast]
-    while (qt_a < nqt) { int tb = p.seg[(long)b * p.Sq + min(qt_a * 32 + 31, p.Sq - 1)]; if (tb * p.seg_len > kfirst) break; ++qt_a; }
-    while (qt_b > qt_a) { int ta = p.seg[(long)b * p.Sq + (qt_b - 1) * 32]; if ((max(ta, 1) - 1) * p.seg_len <= klast) break; --qt_b; }
+    while (qt_a < nqt) { int tb = p.seg[(long)b * p.SqS + min(qt_a * 32 + 31, p.Sq - 1)]; if (tb * p.seg_len > kfirst) break; ++qt_a; }
+    while (qt_b > qt_a) { int ta = p.seg[(long)b * p.SqS + (qt_b - 1) * 32]; if ((max(ta, 1) - 1) * p.seg_len <= klast) break; --qt_b; }
   }
   TileCopy<32, DQK, STR> rq, rdo;
   rq.init(p.q_ss, p.D); rdo.init(p.do_ss, p.D);
@@ -500,7 +502,7 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p, int nx) {
     if (threadIdx.x < 32) {
       float* st_lse = (float*)(st + 2 * 32 * STR);
       int qr = qt * 32 + threadIdx.x;
-      long sidx = ((long)b * p.H + h) * p.Sq + min(qr, p.Sq - 1);
+      long sidx = ((long)b * p.H + h) * p.SqS + min(qr, p.Sq - 1);
       st_lse[threadIdx.x] = p.lse[sidx] * LOG2E;
       st_lse[32 + threadIdx.x] = p.delta[sidx];
       int lo, hi;
@@ -674,6 +676,7 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p, int nx) {
 
 // ------------------------------------------------------------------------------------------- host
 static int fill(AttnP& p, const unimp_attn_desc* d, bool bwd) {
+  p = AttnP{};
   if (!d || !d->q || !d->k || !d->v || !d->o) return unimp_set_error(UNIMP_ERR_ARG, "attn: null pointer");
   if (d->D != 64 && d->D != 80 && d->D != 128) return unimp_set_error(UNIMP_ERR_UNSUPPORTED, "attn: head dim must be 64, 80 or 128");
   if (d->mask_mode == UNIMP_MASK_SEGMENT && (!d->seg || d->seg_len <= 0)) return unimp_set_error(UNIMP_ERR_ARG, "attn: segment mask needs seg/seg_len");
@@ -686,7 +689,11 @@ static int fill(AttnP& p, const unimp_attn_desc* d, bool bwd) {
   p.q_bs = d->q_bs; p.q_ss = d->q_ss; p.q_hs = d->q_hs; p.k_bs = d->k_bs; p.k_ss = d->k_ss; p.k_hs = d->k_hs;
   p.v_bs = d->v_bs; p.v_ss = d->v_ss; p.v_hs = d->v_hs; p.o_bs = d->o_bs; p.o_ss = d->o_ss; p.o_hs = d->o_hs;
   p.B = d->B; p.H = d->H; p.Sq = d->Sq; p.Sk = d->Sk; p.D = d->D; p.scale = d->scale; p.mask_mode = d->mask_mode;
-  p.kv_len = d->kv_len; p.seg = d->seg; p.seg_len = d->seg_len; p.alibi = d->alibi_slopes;
+  p.kv_len = d->kv_len; p.seg = d->seg; p.seg_len = d->seg_len;
+  p.q_off = d->q_row_off; p.q_len = d->q_len; p.k_off = d->k_row_off; p.SqS = d->Sq;
+  if (p.q_off && !p.q_len) return unimp_set_error(UNIMP_ERR_ARG, "attn: q_row_off needs q_len");
+  if (p.k_off && !p.kv_len) return unimp_set_error(UNIMP_ERR_ARG, "attn: k_row_off needs kv_len");
+  p.alibi = d->alibi_slopes;
   p.d_o = nullptr; p.dq = p.dk = p.dv = nullptr; p.delta = nullptr;
   p.rope_cos = p.rope_sin = nullptr; p.rope_half = 0; p.rope_step = 0.f;
   if (bwd && d->rope_log2_base != 0.f) {
@@ -751,6 +758,8 @@ extern "C" int unimp_attn_bwd(const unimp_attn_desc* d, void* stream) {
   bool al16 = !(((p.dq_bs | p.dq_ss | p.dq_hs | p.dk_bs | p.dk_ss | p.dk_hs | p.dv_bs | p.dv_ss | p.dv_hs) & 7) ||
                 (((uintptr_t)p.dq | (uintptr_t)p.dk | (uintptr_t)p.dv) & 15)) && p.Sq >= 4;
   int which2 = (gen >= 2 && al16) ? (gen >= 3 ? 3 : 1) : 0;
+  if ((p.q_off || p.k_off) && !(which2 & 1))
+    return unimp_set_error(UNIMP_ERR_UNSUPPORTED, "attn_bwd: packed rows need kernel generation >= 2 and 16-byte aligned dq / dk / dv views");
   if ((p.rope_cos || p.rope_step != 0.f) && !(which2 & 1))
     return unimp_set_error(UNIMP_ERR_UNSUPPORTED, "attn_bwd: fused rope needs kernel generation >= 2 and 16-byte aligned dq / dk / dv views");
   // delta = rowsum(dO * O): the second-generation dQ kernel computes and publishes it itself

@@ -148,7 +148,7 @@ __device__ __forceinline__ void a2_key_range(const AttnP& p, int b, int qr, int&
   int kvl = p.kv_len ? p.kv_len[b] : p.Sk;
   if (p.mask_mode == UNIMP_MASK_NONE) { hi = kvl; }
   else if (p.mask_mode == UNIMP_MASK_CAUSAL) { hi = min(qr + 1, kvl); }
-  else { int t = p.seg[(long)b * p.Sq + qr]; if (t > 0) { lo = (t - 1) * p.seg_len; hi = min(t * p.seg_len, p.Sk); } }
+  else { int t = p.seg[(long)b * p.SqS + qr]; if (t > 0) { lo = (t - 1) * p.seg_len; hi = min(t * p.seg_len, p.Sk); } }
 }
 
 // the same with the batch row's key count already in a register (no load inside a tile loop)
@@ -157,7 +157,7 @@ __device__ __forceinline__ void a2_key_range_kvl(const AttnP& p, int b, int qr, 
   if (qr >= p.Sq) return;
   if (p.mask_mode == UNIMP_MASK_NONE) { hi = kvl; }
   else if (p.mask_mode == UNIMP_MASK_CAUSAL) { hi = min(qr + 1, kvl); }
-  else { int t = p.seg[(long)b * p.Sq + qr]; if (t > 0) { lo = (t - 1) * p.seg_len; hi = min(t * p.seg_len, p.Sk); } }
+  else { int t = p.seg[(long)b * p.SqS + qr]; if (t > 0) { lo = (t - 1) * p.seg_len; hi = min(t * p.seg_len, p.Sk); } }
 }
 
 template <int D, int NW, bool ALIBI>
@@ -168,8 +168,10 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd2_kernel(AttnP p, int row_bas
   __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
   int bx, h, b;
   a2_decode(nx, p.H, p.B, bx, h, b);
+  if (!attn_varlen(p, b)) return;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = lane_id(), hi5 = l >> 5, ql = l & 31;
   const int qblk0 = row_base + bx * (32 * NW);               // first query row of the block
+  if (qblk0 >= p.Sq) return;                                 // packed rows: the grid covers the longest sequence
   const int q0 = qblk0 + wave * 32;
   const bf16* qb = p.q + b * p.q_bs + h * p.q_hs;
   const char* kb = (const char*)(p.k + b * p.k_bs + h * p.k_hs);
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd2_kernel(AttnP p, int row_bas
     if (p.mask_mode == UNIMP_MASK_NONE) kt_hi = (kvl + 63) >> 6;
     else if (p.mask_mode == UNIMP_MASK_CAUSAL) kt_hi = (min(q_last + 1, kvl) + 63) >> 6;
     else {
-      int t0 = p.seg[(long)b * p.Sq + qblk0], t1 = p.seg[(long)b * p.Sq + q_last];
+      int t0 = p.seg[(long)b * p.SqS + qblk0], t1 = p.seg[(long)b * p.SqS + q_last];
       if (t1 > 0) { kt_lo = (max(t0 - 1, 0) * p.seg_len) >> 6; kt_hi = (min(t1 * p.seg_len, p.Sk) + 63) >> 6; }
     }
   }
@@ -338,7 +340,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd2_kernel(AttnP p, int row_bas
     float ltot = lsum + __shfl_xor(lsum, 32, 64);
     int qr = q0 + ql;
     float inv = ltot > 0.f ? 1.f / ltot : 0.f;
-    if (qr < p.Sq && hi5 == 0 && p.lse) p.lse[((long)b * p.H + h) * p.Sq + qr] = ltot > 0.f ? (m + log2f(ltot)) * LN2 : -INFINITY;
+    if (qr < p.Sq && hi5 == 0 && p.lse) p.lse[((long)b * p.H + h) * p.SqS + qr] = ltot > 0.f ? (m + log2f(ltot)) * LN2 : -INFINITY;
     static_assert(NW * 32 * (D * 2 + 16) <= 2 * STAGE, "epilogue staging fits the tile stages");
     // per-row scale: inv differs per lane row, so scale while writing (mul is per lane = per row here)
     a2_store_rows<D, ND>(smem + wave * (32 * (D * 2 + 16)), o, inv, p.o + b * p.o_bs + h * p.o_hs, p.o_ss, q0, p.Sq);
@@ -372,8 +374,10 @@ __global__ __launch_bounds__(256) void attn_dq2_kernel(AttnP p, int nx) {
   __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
   int bx, h, b;
   a2_decode(nx, p.H, p.B, bx, h, b);
+  if (!attn_varlen(p, b)) return;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = lane_id(), hi5 = l >> 5, ql = l & 31;
   const int qblk0 = bx * 128, q0 = qblk0 + wave * 32;
+  if (qblk0 >= p.Sq) return;                                 // packed rows: the grid covers the longest sequence
   const bf16* qb = p.q + b * p.q_bs + h * p.q_hs;
   const bf16* dob = p.d_o + b * p.do_bs + h * p.do_hs;
   const char* kb = (const char*)(p.k + b * p.k_bs + h * p.k_hs);
@@ -386,7 +390,7 @@ __global__ __launch_bounds__(256) void attn_dq2_kernel(AttnP p, int nx) {
     if (p.mask_mode == UNIMP_MASK_NONE) kt_hi = (kvl + 63) >> 6;
     else if (p.mask_mode == UNIMP_MASK_CAUSAL) kt_hi = (min(q_last + 1, kvl) + 63) >> 6;
     else {
-      int t0 = p.seg[(long)b * p.Sq + qblk0], t1 = p.seg[(long)b * p.Sq + q_last];
+      int t0 = p.seg[(long)b * p.SqS + qblk0], t1 = p.seg[(long)b * p.SqS + q_last];
       if (t1 > 0) { kt_lo = (max(t0 - 1, 0) * p.seg_len) >> 6; kt_hi = (min(t1 * p.seg_len, p.Sk) + 63) >> 6; }
     }
   }
@@ -432,7 +436,7 @@ __global__ __launch_bounds__(256) void attn_dq2_kernel(AttnP p, int nx) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) { qf[ks] = *(const bf16x8*)(qrow + ks * 16 + hi5 * 8); dof[ks] = *(const bf16x8*)(dorow + ks * 16 + hi5 * 8); }
     a2_key_range(p, b, qr, lo, hi);
-    long sidx = ((long)b * p.H + h) * p.Sq + qc;
+    long sidx = ((long)b * p.H + h) * p.SqS + qc;
     lse2 = p.lse[sidx] * LOG2E;
     // delta = rowsum(dO * O), computed here (the wave holds its dO rows anyway) and published for the dK/dV kernel that
     // follows on the stream: the separate delta pass over O and dO is gone
@@ -537,6 +541,7 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void attn_dkv2_kernel(AttnP 
   int kblk, h, b;
   a2_decode(nx, p.H, p.B, kblk, h, b);
   kblk = nx - 1 - kblk;                                      // causal: the FIRST key block sees the most query tiles
+  if (!attn_varlen(p, b) || kblk * 128 >= p.Sk) return;      // packed rows: the grid covers the longest sequence
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = lane_id(), hi5 = l >> 5, kl = l & 31;
   const int key0 = kblk * 128 + wave * 32;
   const char* qb = (const char*)(p.q + b * p.q_bs + h * p.q_hs);
@@ -551,8 +556,8 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void attn_dkv2_kernel(AttnP 
   int qt_a = 0, qt_b = nqt;
   if (mode == UNIMP_MASK_CAUSAL) qt_a = kfirst >> 5;
   else if (mode == UNIMP_MASK_SEGMENT) {
-    while (qt_a < nqt) { int tb = p.seg[(long)b * p.Sq + min(qt_a * 32 + 31, p.Sq - 1)]; if (tb * p.seg_len > kfirst) break; ++qt_a; }
-    while (qt_b > qt_a) { int ta = p.seg[(long)b * p.Sq + (qt_b - 1) * 32]; if ((max(ta, 1) - 1) * p.seg_len <= klast) break; --qt_b; }
+    while (qt_a < nqt) { int tb = p.seg[(long)b * p.SqS + min(qt_a * 32 + 31, p.Sq - 1)]; if (tb * p.seg_len > kfirst) break; ++qt_a; }
+    while (qt_b > qt_a) { int ta = p.seg[(long)b * p.SqS + (qt_b - 1) * 32]; if ((max(ta, 1) - 1) * p.seg_len <= klast) break; --qt_b; }
   }
 
   // DMA plan: instruction i = wave + 4 t.  Images 0..3 = Q-row, Q-tr, dO-row, dO-tr; instruction NI - 1 = the row block;
@@ -570,9 +575,9 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void attn_dkv2_kernel(AttnP 
   }
   const uint32_t smem_lds = (uint32_t)(uintptr_t)LDS_PTR(char, smem);
   const long q_sb = p.q_ss * 2, do_sb = p.do_ss * 2;
-  const char* lse_b = (const char*)(p.lse + ((long)b * p.H + h) * p.Sq);
-  const char* dl_b = (const char*)(p.delta + ((long)b * p.H + h) * p.Sq);
-  const char* seg_b = mode == UNIMP_MASK_SEGMENT ? (const char*)(p.seg + (long)b * p.Sq) : lse_b;
+  const char* lse_b = (const char*)(p.lse + ((long)b * p.H + h) * p.SqS);
+  const char* dl_b = (const char*)(p.delta + ((long)b * p.H + h) * p.SqS);
+  const char* seg_b = mode == UNIMP_MASK_SEGMENT ? (const char*)(p.seg + (long)b * p.SqS) : lse_b;
   auto dma_tile = [&](int qt, int stage) {
     int rows_left = p.Sq - qt * 32;
     const char* q_base = qb + (long)qt * 32 * q_sb;

@@ -15,7 +15,37 @@ struct AttnP {
   const float* alibi;        // per-head slopes or null: raw score += slope / scale * key  (so that score * scale gains slope * key)
   const float* rope_cos; const float* rope_sin; int rope_half;     // backward: transpose half-split rotation of dq / dk rows (null: none)
   float rope_step;           // != 0: adjacent-pair layout, cos / sin computed in the epilogue (2 log2(base) / (2 rope_half)); tables unused
+  // packed rows (unimp_attn_desc.q_row_off / k_row_off): the query-side rows of sequence b (q, o, dO, dq, seg) are rows q_off[b] ..
+  // q_off[b] + q_len[b] - 1 of ONE [rows][H][D] buffer, the key-side rows (k, v, dk, dv) rows k_off[b] .. + kv_len[b] - 1.
+  // attn_varlen() rebases the pointers of the by-value parameter block for the block's batch index and sets Sq / Sk to the
+  // sequence's own counts; every kernel then addresses "its" sequence exactly as in the padded layout.
+  const int* q_off; const int* q_len; const int* k_off;
+  int SqS;                   // rows per (batch, head) of lse / delta [B][H][SqS] and of an unpacked seg [B][SqS]: the descriptor's Sq
 };
+
+// call once per block, right after the batch index is known; false: this sequence has no row for the block to work on
+__device__ __forceinline__ bool attn_varlen(AttnP& p, int b) {
+  if (p.q_off) {
+    const long o = p.q_off[b];
+    p.q += o * p.q_ss - (long)b * p.q_bs;
+    p.o += o * p.o_ss - (long)b * p.o_bs;
+    p.d_o += o * p.do_ss - (long)b * p.do_bs;            // forward: strides 0, pointer null and never used
+    p.dq += o * p.dq_ss - (long)b * p.dq_bs;
+    if (p.seg) p.seg += o - (long)b * p.SqS;             // seg is indexed b * SqS + row: lands on packed row o + row
+    p.Sq = p.q_len[b];
+    if (p.Sq <= 0) return false;
+  }
+  if (p.k_off) {
+    const long o = p.k_off[b];
+    p.k += o * p.k_ss - (long)b * p.k_bs;
+    p.v += o * p.v_ss - (long)b * p.v_bs;
+    p.dk += o * p.dk_ss - (long)b * p.dk_bs;
+    p.dv += o * p.dv_ss - (long)b * p.dv_bs;
+    p.Sk = p.kv_len[b];
+    if (p.Sk <= 0) return false;
+  }
+  return true;
+}
 
 // Adjacent-pair form (the layout the GEMM's rotary epilogue writes, gemm_tile.h): chunk c holds the pairs (j, j + 4), j < 4, at
 // frequencies 4c + j; the transpose rotation needs neither a partner chunk nor a table.

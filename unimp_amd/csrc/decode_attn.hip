@@ -285,6 +285,7 @@ extern "C" int unimp_attn_decode_splits(int B, int H, int Sk) {
 extern "C" int unimp_attn_decode_grouped(const unimp_attn_desc* d, float* workspace, int splits, int group, const int* shared_len, void* stream) {
   if (!d || !d->q || !d->k || !d->v || !d->o) return unimp_set_error(UNIMP_ERR_ARG, "attn_decode: null pointer");
   if (d->Sq != 1) return unimp_set_error(UNIMP_ERR_SHAPE, "attn_decode: one query row per (batch row, head) (Sq == 1)");
+  if (d->q_row_off || d->k_row_off) return unimp_set_error(UNIMP_ERR_UNSUPPORTED, "attn_decode: packed rows are a training-path layout");
   if (d->D % 8 || d->D > 128 || d->D < 8) return unimp_set_error(UNIMP_ERR_SHAPE, "attn_decode: head dim must be a multiple of 8, <= 128");
   if (d->mask_mode != UNIMP_MASK_NONE) return unimp_set_error(UNIMP_ERR_UNSUPPORTED, "attn_decode: kv_len masking only (the new token attends every cached key)");
   if (d->B <= 0 || d->H <= 0) return UNIMP_OK;

@@ -13,7 +13,7 @@
 template <int CH>
 __global__ __launch_bounds__(256) void rope_kernel(bf16* __restrict__ x, long row_stride, long head_stride, int rows, int L, int heads,
                                                    int half, int nvec, int off0, int off1, const float* __restrict__ cs,
-                                                   const float* __restrict__ sn, int inverse) {
+                                                   const float* __restrict__ sn, int inverse, const int* __restrict__ pos_tab) {
   constexpr int MAXI = 4;                                   // items per thread and row (a row has heads * nvec * half / CH items)
   const int cpr = half / CH, per_head = nvec * cpr, items = heads * per_head;
   int eoff[MAXI], toff[MAXI];
@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void rope_kernel(bf16* __restrict__ x, long ro
   }
   const float sgn = inverse ? -1.f : 1.f;
   for (int r = blockIdx.x; r < rows; r += gridDim.x) {
-    int pos = r % L;
+    int pos = pos_tab ? pos_tab[r] : r % L;
     bf16* xr = x + (long)r * row_stride;
     const float* cr = cs + (long)pos * half;
     const float* sr = sn + (long)pos * half;
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void rope_kernel(bf16* __restrict__ x, long ro
 template <int NS>
 __global__ __launch_bounds__(256) void rope_rows_kernel(bf16* __restrict__ x, long row_stride, long head_stride, int rows, int L, int heads,
                                                         int half, int nvec, int off0, int off1, const float* __restrict__ cs,
-                                                        const float* __restrict__ sn, int inverse, int G) {
+                                                        const float* __restrict__ sn, int inverse, int G, const int* __restrict__ pos_tab) {
   const int cpr = half >> 3, per_head = nvec * cpr, items = heads * per_head;
   int eoff[NS], toff[NS], rg[NS];
   bool has[NS];
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void rope_rows_kernel(bf16* __restrict__ x, lo
       int r = r0 + rg[k];
       ok[k] = has[k] && r < rows;
       if (!ok[k]) r = r0;
-      int pos = r % L;
+      int pos = pos_tab ? pos_tab[r] : r % L;
       p[k] = x + (long)r * row_stride + eoff[k];
       const float* cr = cs + (long)pos * half + toff[k];
       const float* sr = sn + (long)pos * half + toff[k];
@@ -124,9 +124,9 @@ __global__ __launch_bounds__(256) void rope_rows_kernel(bf16* __restrict__ x, lo
   }
 }
 
-extern "C" int unimp_rope_halfsplit(void* x, int64_t row_stride, int64_t head_stride, int rows, int L, int heads, int rot,
-                                    int nvec, int vec_off0, int vec_off1, const float* cos_t, const float* sin_t, int inverse,
-                                    void* stream) {
+static int rope_launch(void* x, int64_t row_stride, int64_t head_stride, int rows, int L, int heads, int rot,
+                       int nvec, int vec_off0, int vec_off1, const float* cos_t, const float* sin_t, int inverse, const int* pos_tab,
+                       void* stream) {
   if (!x || !cos_t || !sin_t) return unimp_set_error(UNIMP_ERR_ARG, "rope: null pointer");
   if (rot <= 0 || (rot & 1) || nvec < 1 || nvec > 2) return unimp_set_error(UNIMP_ERR_SHAPE, "rope: bad rot/nvec");
   if (rows <= 0) return UNIMP_OK;
@@ -152,18 +152,30 @@ extern "C" int unimp_rope_halfsplit(void* x, int64_t row_stride, int64_t head_st
     int ns = (G * items + 255) / 256;
     int g2 = (rows + G - 1) / G; if (g2 > 16384) g2 = 16384;
 #define ROPE_NS(N) case N: hipLaunchKernelGGL((rope_rows_kernel<N>), dim3(g2), dim3(256), 0, s, (bf16*)x, (long)row_stride, (long)head_stride, rows, L, \
-                       heads, half, nvec, vec_off0, vec_off1, cos_t, sin_t, inverse, G); break
+                       heads, half, nvec, vec_off0, vec_off1, cos_t, sin_t, inverse, G, pos_tab); break
     switch (ns) { ROPE_NS(1); ROPE_NS(2); ROPE_NS(3); ROPE_NS(4); ROPE_NS(5); ROPE_NS(6); default: break; }
 #undef ROPE_NS
     return unimp_check_launch("rope");
   }
   if (vec16)
     hipLaunchKernelGGL((rope_kernel<8>), dim3(grid), dim3(256), 0, s, (bf16*)x, (long)row_stride, (long)head_stride, rows, L,
-                       heads, half, nvec, vec_off0, vec_off1, cos_t, sin_t, inverse);
+                       heads, half, nvec, vec_off0, vec_off1, cos_t, sin_t, inverse, pos_tab);
   else
     hipLaunchKernelGGL((rope_kernel<1>), dim3(grid), dim3(256), 0, s, (bf16*)x, (long)row_stride, (long)head_stride, rows, L,
-                       heads, half, nvec, vec_off0, vec_off1, cos_t, sin_t, inverse);
+                       heads, half, nvec, vec_off0, vec_off1, cos_t, sin_t, inverse, pos_tab);
   return unimp_check_launch("rope");
+}
+
+extern "C" int unimp_rope_halfsplit(void* x, int64_t row_stride, int64_t head_stride, int rows, int L, int heads, int rot,
+                                    int nvec, int vec_off0, int vec_off1, const float* cos_t, const float* sin_t, int inverse,
+                                    void* stream) {
+  return rope_launch(x, row_stride, head_stride, rows, L, heads, rot, nvec, vec_off0, vec_off1, cos_t, sin_t, inverse, nullptr, stream);
+}
+extern "C" int unimp_rope_halfsplit_pos(void* x, int64_t row_stride, int64_t head_stride, int rows, const int32_t* pos, int heads, int rot,
+                                        int nvec, int vec_off0, int vec_off1, const float* cos_t, const float* sin_t, int inverse,
+                                        void* stream) {
+  if (!pos) return unimp_set_error(UNIMP_ERR_ARG, "rope: null position table");
+  return rope_launch(x, row_stride, head_stride, rows, 1, heads, rot, nvec, vec_off0, vec_off1, cos_t, sin_t, inverse, pos, stream);
 }
 
 // ------------------------------------------------------------------------------------------- embedding

@@ -18,12 +18,13 @@ struct Gemm2Params {
   int ksplit;                       // > 0 (gemm3 only): blockIdx.y reduces k in [y*ksplit, (y+1)*ksplit) into f32 slab y of C
   int rope_rot, rope_hd, rope_period, rope_span, rope_L;      // rotary epilogue (EK_PLAIN only; include/unimp_hip.h), rope_rot == 0: none
   float rope_step, rope_invL;       // 2 log2(base) / rope_rot;  1 / rope_L
+  const int* rope_tab;              // null: position = m % rope_L; else position = rope_tab[m] (packed rows)
 };
 
 #define GEMM2_FILL_ROPE(P_, D_) do { (P_).rope_rot = (D_)->rope_rot; (P_).rope_hd = (D_)->rope_hd; (P_).rope_period = (D_)->rope_period;   \
     (P_).rope_span = (D_)->rope_span; (P_).rope_L = (D_)->rope_L;                                                                      \
     (P_).rope_step = (D_)->rope_rot > 0 ? 2.f * (D_)->rope_log2_base / (float)(D_)->rope_rot : 0.f;                                     \
-    (P_).rope_invL = (D_)->rope_L > 0 ? 1.f / (float)(D_)->rope_L : 0.f; } while (0)
+    (P_).rope_invL = (D_)->rope_L > 0 ? 1.f / (float)(D_)->rope_L : 0.f; (P_).rope_tab = (D_)->rope_pos; } while (0)
 
 // cos / sin of position * base^(-2 i / rot) for the 4 frequencies i0 .. i0 + 3, from the fractional number of turns
 __device__ __forceinline__ void rope_cs4(float pos, int i0, float step, float (&co)[4], float (&si)[4]) {
@@ -205,7 +206,7 @@ __device__ __forceinline__ void epi8k(const Gemm2Params& p, float (&v)[8], int m
     int pp = n % p.rope_hd;
     if (n % p.rope_period < p.rope_span && pp < p.rope_rot) {
       float co[4], si[4];
-      rope_cs4((float)rope_pos(m, p.rope_L, p.rope_invL), (pp >> 3) * 4, p.rope_step, co, si);
+      rope_cs4((float)(p.rope_tab ? p.rope_tab[m] : rope_pos(m, p.rope_L, p.rope_invL)), (pp >> 3) * 4, p.rope_step, co, si);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float x1 = v[j], x2 = v[j + 4];

@@ -84,8 +84,9 @@ def _no_bias_grad(ctx, idx, name):
 # collate_rec.py:38-74 right-pads every sequence of a batch to the longest; the reference then runs every row-wise operation of the
 # language tower (LayerNorm, the QKV / out / MLP / gated feed-forward projections) over the <PAD> rows too.  In packed mode
 # (Trainer(packed=True), bench.py --packed, UNIMP_PACKED=1) the tower's residual stream holds the VALID tokens only, as [1, M, H] with
-# M = the valid count rounded up to PACK_ROUND rows; the attention kernels keep their padded [B, L] addressing: the projected q / k / v
-# are unpacked (gather with the inverse map, zeros at <PAD>) in front of them and the attention output is packed again behind them.
+# M = the valid count rounded up to PACK_ROUND rows, sequence after sequence.  The attention kernels take that layout directly
+# (include/unimp_hip.h q_row_off / k_row_off: sequence b = rows off[b] .. off[b] + len[b] - 1), the QKV projection's rotary epilogue
+# reads each row's position from a table: nothing is gathered or scattered between the embedding and the final hidden state.
 # Every valid row goes through the same arithmetic as in the padded run; nothing reads the rows that are skipped.
 PACKED = _os.environ.get("UNIMP_PACKED", "0") == "1"
 PACK_ROUND = 2048           # M granularity: keeps the number of distinct GEMM shapes (autotune keys) per batch size at two or three
@@ -94,11 +95,14 @@ PACK = None                 # the Pack of the forward in progress (set by the to
 
 class Pack:
     """idx int32 [M]: flat position b * L + j of packed row r (rows beyond the valid count point at one <PAD> position: they are
-    computed, never read back); inv int32 [B * L]: packed row of a position, -1 at <PAD>."""
+    computed by the row-wise kernels, never read back, and hold exact zeros in every gradient); inv int32 [B * L]: packed row of a
+    position, -1 at <PAD>; rows: the sequences as row ranges (ops.PackedRows); pos int32 [M]: position of a row inside its sequence.
+    Needs RIGHT-padded sequences (pipeline/train/data.py:274 ``tokenizer.padding_side = "right"``): a sequence is one row range."""
 
     def __init__(self, attention_mask):
         B, L = attention_mask.shape
-        flat = attention_mask.reshape(-1) != 0
+        m = attention_mask != 0
+        flat = m.reshape(-1)
         pos = flat.nonzero().view(-1)                      # host sync: the valid count
         nv = pos.numel()
         M = min(B * L, (nv + PACK_ROUND - 1) // PACK_ROUND * PACK_ROUND)
@@ -106,6 +110,8 @@ class Pack:
         self.useful = nv > 0 and M < B * L
         if not self.useful:
             return
+        if bool((m[:, 1:] & ~m[:, :-1]).any()):
+            raise ValueError("packed token order needs right-padded sequences (every attention_mask row a prefix of ones)")
         dev = attention_mask.device
         dummy = (~flat).nonzero()[0]                        # exists: M < B * L
         idx = torch.cat([pos, dummy.expand(M - nv)]) if M > nv else pos
@@ -114,6 +120,17 @@ class Pack:
         inv = torch.full((B * L,), -1, dtype=torch.int32, device=dev)
         inv[pos] = torch.arange(nv, dtype=torch.int32, device=dev)
         self.inv = inv
+        lens = m.sum(1).to(torch.int32)
+        off = (torch.cumsum(lens, 0) - lens).to(torch.int32)
+        self.rows = ops.PackedRows(B, L, off, lens, nv)
+        self.pos = (idx % L).to(torch.int32).contiguous()
+        self._seg = None
+
+    def seg(self, seg):
+        """a per-token int32 [B, L] map (media_time of the gated cross-attention) in the packed row order; one gather per forward"""
+        if self._seg is None or self._seg[0] is not seg:
+            self._seg = (seg, seg.reshape(-1)[self.idx_long].contiguous())
+        return self._seg[1]
 
 
 class PackRowsFn(Function):
@@ -480,8 +497,9 @@ class SelfAttnBlockFn(Function):
 
     @staticmethod
     def _forward_packed(ctx, pack, x, res, ln_w, ln_b, wqkv, bqkv, wd, bd, rope, kv_len, nh, interleaved, causal, eps, rms, q_scale, alibi, qk_ln):
-        """x [1, M, H] packed rows.  LayerNorm and both projections on the M packed rows; q / k / v unpacked to [B, L] (zeros at <PAD>)
-        for the rotation and the attention kernels, the attention output packed again."""
+        """x [1, M, H] packed rows (functional.Pack): LayerNorm, both projections and the attention kernels on the packed rows; the
+        rotation takes each row's position from pack.pos (the QKV GEMM's rotary epilogue under the same static criteria as the padded
+        path, else the table pass)."""
         if qk_ln is not None:
             raise NotImplementedError("packed token order: qk_ln towers are not wired")
         B, L, M = pack.B, pack.L, pack.M
@@ -490,17 +508,27 @@ class SelfAttnBlockFn(Function):
         x2 = x.reshape(M, H)
         r2 = x2 if res is None else res.reshape(M, H)
         h, mean, rstd = ops.layernorm_fwd(x2, ln_w, ln_b, eps, rms=rms)
-        qkv = ops.gather_rows(ops.gemm(h, wqkv, bias=bqkv), pack.inv)                      # [B * L, 3H]
-        q, k, v, hs, offs = _split_qkv(qkv, B, L, nh, hd, interleaved)
-        if rope is not None:
-            ops.rope_(qkv, L, nh, hs, rope[2], offs, rope[0], rope[1])
-        o, lse = ops.attn_fwd(q, k, v, q_scale, ops.MASK_CAUSAL if causal else ops.MASK_NONE, kv_len, alibi=alibi)
-        o_p = ops.gather_rows(o.view(B * L, H), pack.idx)
-        out = ops.gemm(o_p, wd, bias=bd, res=r2)
+        fused = None
+        if (ROPE_EPILOGUE and rope is not None and len(rope) > 3 and not wqkv.requires_grad and not FROZEN_PK
+                and (bqkv is None or not bqkv.requires_grad) and rope[2] % 8 == 0 and hd % 8 == 0 and M < (1 << 24)
+                and ops.attn_generation() >= 2 and ops.gemm_rope_variant(M, 3 * H, H, False, x.device) is not None):
+            fused = dict(rot=rope[2], hd=hd, period=3 * hd if interleaved else 3 * H, span=2 * hd if interleaved else 2 * H, L=L,
+                         log2_base=math.log2(rope[3]), pos=pack.pos)
+        if fused is not None:
+            wp = _frozen_rope_perm(wqkv, nh, hd, fused["rot"], interleaved)
+            bp = _frozen_rope_perm(bqkv, nh, hd, fused["rot"], interleaved) if bqkv is not None else None
+            qkv = ops.gemm(h, wp, bias=bp, rope=fused)
+        else:
+            qkv = ops.gemm(h, wqkv, bias=bqkv)
+        q, k, v, hs, offs = _split_qkv(qkv, 1, M, nh, hd, interleaved)
+        if rope is not None and fused is None:
+            ops.rope_(qkv, L, nh, hs, rope[2], offs, rope[0], rope[1], pos=pack.pos)
+        o, lse = ops.attn_fwd(q, k, v, q_scale, ops.MASK_CAUSAL if causal else ops.MASK_NONE, alibi=alibi, q_rows=pack.rows, k_rows=pack.rows)
+        out = ops.gemm(o.view(M, H), wd, bias=bd, res=r2)
         ctx.save_for_backward(x2, ln_w, mean, rstd, wqkv, wd, qkv, o, lse, kv_len, h if wqkv.requires_grad else None,
                               rope[0] if rope is not None else None, rope[1] if rope is not None else None, alibi)
         ctx.cfg = (B, L, H, nh, hd, interleaved, causal, rms, q_scale, rope[2] if rope is not None else 0, res is None, ln_b is not None)
-        ctx.mx, ctx.rope_fused, ctx.qk_ln, ctx.pack = False, None, None, pack
+        ctx.mx, ctx.rope_fused, ctx.qk_ln, ctx.pack = False, fused, None, pack
         return out.view(1, M, H)
 
     @staticmethod
@@ -508,25 +536,33 @@ class SelfAttnBlockFn(Function):
         x2, ln_w, mean, rstd, wqkv, wd, qkv, o, lse, kv_len, h, cos, sin, alibi = ctx.saved_tensors
         B, L, H, nh, hd, interleaved, causal, rms, q_scale, rot, res_is_x, has_lnb = ctx.cfg
         pack = ctx.pack
-        M = pack.M
+        M, mask = pack.M, ops.MASK_CAUSAL if causal else ops.MASK_NONE
         _no_bias_grad(ctx, 5, "qkv bias")
         _no_bias_grad(ctx, 7, "dense bias")
         dy2 = dy.reshape(M, H)
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
-        do = ops.gather_rows(ops.gemm(dy2, wd, b_ks=True), pack.inv).view(B, L, nh, hd)   # zeros at <PAD>: their dq / dk / dv contributions vanish
-        dwd = ops.gemm(dy2, ops.gather_rows(o.view(B * L, H), pack.idx), a_ks=True, b_ks=True) if _need(ctx, 6) else None
-        q, k, v, hs, offs = _split_qkv(qkv, B, L, nh, hd, interleaved)
+        do = ops.gemm(dy2, wd, b_ks=True).view(1, M, nh, hd)
+        dwd = ops.gemm(dy2, o.view(M, H), a_ks=True, b_ks=True) if _need(ctx, 6) else None
+        q, k, v, hs, offs = _split_qkv(qkv, 1, M, nh, hd, interleaved)
         dqkv = torch.empty_like(qkv)
-        dq, dk, dv, _, _ = _split_qkv(dqkv, B, L, nh, hd, interleaved)
-        fuse = ROPE_FUSE and cos is not None and cos.shape[0] >= L and cos.shape[1] * 2 == rot and ops.attn_rope_fusable(dq, dk, dv, rot // 2, hd)
-        ops.attn_bwd(q, k, v, o, lse, do, dq, dk, dv, q_scale, ops.MASK_CAUSAL if causal else ops.MASK_NONE, kv_len, alibi=alibi,
-                     rope=(cos, sin) if fuse else None)
-        if cos is not None and not fuse:
-            ops.rope_(dqkv, L, nh, hs, rot, offs, cos, sin, inverse=True)
-        dqkv_p = ops.gather_rows(dqkv, pack.idx)
-        dwqkv = ops.gemm(dqkv_p, h, a_ks=True, b_ks=True) if _need(ctx, 4) else None
-        dh = ops.gemm(dqkv_p, wqkv, b_ks=True)
+        if pack.nv < M:
+            dqkv[pack.nv:].zero_()                         # the kernels write the sequences' rows only; the dW / dX GEMMs contract over all M
+        dq, dk, dv, _, _ = _split_qkv(dqkv, 1, M, nh, hd, interleaved)
+        kw = dict(alibi=alibi, q_rows=pack.rows, k_rows=pack.rows)
+        if ctx.rope_fused is not None:
+            if not ops.attn_rope_fusable(dq, dk, dv, rot // 2, hd, adjacent=True):
+                raise RuntimeError("rotary epilogue: the attention backward cannot rotate dq / dk (kernel generation changed after the forward?)")
+            ops.attn_bwd(q, k, v, o, lse, do, dq, dk, dv, q_scale, mask, rope=(rot // 2, ctx.rope_fused["log2_base"]), **kw)
+            dh = ops.gemm(dqkv, _frozen_rope_perm(wqkv, nh, hd, rot, interleaved), b_ks=True)
+            dwqkv = None
+        else:
+            fuse = ROPE_FUSE and cos is not None and cos.shape[0] >= L and cos.shape[1] * 2 == rot and ops.attn_rope_fusable(dq, dk, dv, rot // 2, hd)
+            ops.attn_bwd(q, k, v, o, lse, do, dq, dk, dv, q_scale, mask, rope=(cos, sin) if fuse else None, **kw)
+            if cos is not None and not fuse:
+                ops.rope_(dqkv, L, nh, hs, rot, offs, cos, sin, inverse=True, pos=pack.pos)
+            dwqkv = ops.gemm(dqkv, h, a_ks=True, b_ks=True) if _need(ctx, 4) else None
+            dh = ops.gemm(dqkv, wqkv, b_ks=True)
         wg = _need(ctx, 2) or (has_lnb and _need(ctx, 3))
         dx, dg, db = ops.layernorm_bwd(dh, x2, ln_w, mean, rstd, dres=dy2 if res_is_x else None, want_wgrad=wg, has_beta=has_lnb, rms=rms)
         dres = None if res_is_x else dy
@@ -755,7 +791,7 @@ class GatedXAttnFn(Function):
 
     @staticmethod
     def forward(ctx, x, media, seg, ln_w, ln_b, wq, wkv, wo, gate, heads, n_lat, eps):
-        pack = PACK                               # packed token order: x is [1, M, D]; q is unpacked for the attention, o packed behind it
+        pack = PACK                               # packed token order: x is [1, M, D]; q, o (and seg) as row ranges of the packed buffer
         ctx.pack = pack
         Sk = media.shape[1]                       # media [B, T*n, Dv]
         B = media.shape[0]
@@ -768,43 +804,45 @@ class GatedXAttnFn(Function):
         m2 = media.reshape(B * Sk, -1)
         h, mean, rstd = ops.layernorm_fwd(x2, ln_w, ln_b, eps)
         q = ops.gemm(h, wq)
-        if pack is not None:
-            q = ops.gather_rows(q, pack.inv)
         kv = ops.gemm(m2, wkv)
         kv5 = kv.view(B, Sk, 2, heads, dh)
-        o, lse = ops.attn_fwd(q.view(B, L, heads, dh), kv5[:, :, 0], kv5[:, :, 1], dh ** -0.5, ops.MASK_SEGMENT, None, seg, n_lat)
-        o2 = o.view(B * L, inner) if pack is None else ops.gather_rows(o.view(B * L, inner), pack.idx)
-        out = ops.gemm(o2, wo, gate=gate, res=x2)
-        ctx.save_for_backward(x2, m2, seg, ln_w, mean, rstd, wq, wkv, wo, gate, h, q, kv, o, lse, o2 if pack is not None else None)
+        if pack is not None:
+            seg = pack.seg(seg)
+            o, lse = ops.attn_fwd(q.view(1, rows, heads, dh), kv5[:, :, 0], kv5[:, :, 1], dh ** -0.5, ops.MASK_SEGMENT, None, seg, n_lat, q_rows=pack.rows)
+        else:
+            o, lse = ops.attn_fwd(q.view(B, L, heads, dh), kv5[:, :, 0], kv5[:, :, 1], dh ** -0.5, ops.MASK_SEGMENT, None, seg, n_lat)
+        out = ops.gemm(o.view(rows, inner), wo, gate=gate, res=x2)
+        ctx.save_for_backward(x2, m2, seg, ln_w, mean, rstd, wq, wkv, wo, gate, h, q, kv, o, lse)
         ctx.cfg = (B, L, D, Sk, heads, dh, n_lat)
         ctx.ln_b_ref = ln_b
         return out.view(x.shape)
 
     @staticmethod
     def backward(ctx, dy):
-        x2, m2, seg, ln_w, mean, rstd, wq, wkv, wo, gate, h, q, kv, o, lse, o_p = ctx.saved_tensors
+        x2, m2, seg, ln_w, mean, rstd, wq, wkv, wo, gate, h, q, kv, o, lse = ctx.saved_tensors
         B, L, D, Sk, heads, dh, n_lat = ctx.cfg
         pack = ctx.pack
         inner = heads * dh
         dy2 = dy.reshape(-1, D)
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
-        o2 = o.view(B * L, inner) if pack is None else o_p
+        rows = dy2.shape[0]
+        o2 = o.view(rows, inner)
         # do is kept UN-gated: d/d gate of tanh(gate) * (o Wo^T) contracted with dy is <dy Wo, o> -- a dot over [B L, inner] instead
         # of one over dy and a saved copy of the un-gated block output (both [B L, D], D = 5 inner: the copy and its store in the
         # forward's epilogue are gone) -- and everything downstream of do is linear in it, so tanh(gate) moves into the epilogues
         # of the four GEMMs that consume dq / dkv (0 at initialisation there exactly as it was here)
         do2 = ops.gemm(dy2, wo, b_ks=True)
         dgate = _gate_grad(do2, o2, gate) if _need(ctx, 8) else None
-        do = (do2 if pack is None else ops.gather_rows(do2, pack.inv)).view(B, L, heads, dh)
         dwo = _dw(ctx, 7, wo, dy2, o2, gate=gate)
         dq = torch.empty_like(q)
         dkv = torch.empty_like(kv)
         kv5, dkv5 = kv.view(B, Sk, 2, heads, dh), dkv.view(B, Sk, 2, heads, dh)
-        ops.attn_bwd(q.view(B, L, heads, dh), kv5[:, :, 0], kv5[:, :, 1], o, lse, do, dq.view(B, L, heads, dh),
-                     dkv5[:, :, 0], dkv5[:, :, 1], dh ** -0.5, ops.MASK_SEGMENT, None, seg, n_lat)
-        if pack is not None:
-            dq = ops.gather_rows(dq, pack.idx)
+        qshape = (B, L, heads, dh) if pack is None else (1, rows, heads, dh)
+        if pack is not None and pack.nv < rows:
+            dq[pack.nv:].zero_()                         # rows behind the last sequence: not written by the kernels, contracted by dwq / dh_
+        ops.attn_bwd(q.view(qshape), kv5[:, :, 0], kv5[:, :, 1], o, lse, do2.view(qshape), dq.view(qshape),
+                     dkv5[:, :, 0], dkv5[:, :, 1], dh ** -0.5, ops.MASK_SEGMENT, None, seg, n_lat, q_rows=pack.rows if pack is not None else None)
         dwq = _dw(ctx, 5, wq, dq, h, gate=gate)
         dh_ = ops.gemm(dq, wq, b_ks=True, gate=gate)
         dwkv = _dw(ctx, 6, wkv, dkv, m2, gate=gate)

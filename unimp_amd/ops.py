@@ -327,6 +327,9 @@ def gemm(a, b, *, a_ks=False, b_ks=False, bias=None, act=None, res=None, aux=Non
     if rope is not None:             # rotary epilogue (include/unimp_hip.h): dict(rot, hd, period, span, L, log2_base); see gemm_rope_variant()
         d.rope_rot, d.rope_hd, d.rope_period, d.rope_span, d.rope_L = rope["rot"], rope["hd"], rope["period"], rope["span"], rope["L"]
         d.rope_log2_base = rope["log2_base"]
+        if rope.get("pos") is not None:       # packed rows: int32 [M] position of every row (instead of row % L)
+            assert rope["pos"].dtype == torch.int32 and rope["pos"].numel() >= M and rope["pos"].is_contiguous()
+            d.rope_pos = rope["pos"].data_ptr()
         _splits = 0
         if variant is None:
             variant = gemm_rope_variant(M, N, K, b_ks, a.device)
@@ -428,11 +431,17 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, *, dres=None, dy2=None, want_wgrad=F
     return dx, dg, db
 
 
-def rope_(x2d, L, heads, head_stride, rot, offs, cos, sin, inverse=False):
-    """in place on x2d [rows, *]; offs: element offsets of the vectors to rotate inside each head slot."""
+def rope_(x2d, L, heads, head_stride, rot, offs, cos, sin, inverse=False, pos=None):
+    """in place on x2d [rows, *]; offs: element offsets of the vectors to rotate inside each head slot.  Position of row r: r % L, or
+    pos[r] (int32 [rows]: packed rows)."""
     rows = x2d.shape[0]
     o0 = offs[0]
     o1 = offs[1] if len(offs) > 1 else 0
+    if pos is not None:
+        assert pos.dtype == torch.int32 and pos.numel() >= rows and pos.is_contiguous()
+        check(_lib.lib().unimp_rope_halfsplit_pos(_dev(x2d).data_ptr(), x2d.stride(0), head_stride, rows, pos.data_ptr(), heads, rot, len(offs),
+                                                   o0, o1, cos.data_ptr(), sin.data_ptr(), int(inverse), _stream()), "rope")
+        return x2d
     check(_lib.lib().unimp_rope_halfsplit(_dev(x2d).data_ptr(), x2d.stride(0), head_stride, rows, L, heads, rot, len(offs),
                                            o0, o1, cos.data_ptr(), sin.data_ptr(), int(inverse), _stream()), "rope")
     return x2d
@@ -458,14 +467,48 @@ def _view4(t):
     return _dev(t).data_ptr(), (t.stride(0), t.stride(1), t.stride(2))
 
 
-def attn_fwd(q, k, v, scale, mask_mode=MASK_NONE, kv_len=None, seg=None, seg_len=0, out=None, alibi=None):
-    """q [B,Sq,H,D], k/v [B,Sk,H,D] strided views; returns o [B,Sq,H,D] (contiguous unless `out`), lse [B,H,Sq]."""
-    B, Sq, H, D = q.shape
-    Sk = k.shape[1]
-    if out is None:
-        out = torch.empty((B, Sq, H, D), dtype=bf16, device=q.device)
-    lse = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device)
+class PackedRows:
+    """the sequences of a batch as row ranges of ONE [rows, H, D] buffer (include/unimp_hip.h: q_row_off / k_row_off): sequence b owns
+    rows off[b] .. off[b] + len[b] - 1.  off, len: int32 [B] device tensors; S: the longest sequence (or any bound of it: it sizes the
+    launch and the per-row statistics); n: rows in use (the rows behind them are padding of the buffer, never touched by the kernels)."""
+    __slots__ = ("B", "S", "off", "len", "n")
+
+    def __init__(self, B, S, off, len_, n):
+        assert off.dtype == torch.int32 and len_.dtype == torch.int32 and off.numel() == B and len_.numel() == B
+        self.B, self.S, self.off, self.len, self.n = B, S, off.contiguous(), len_.contiguous(), n
+
+
+def _packed_dims(d, q, k, q_rows, k_rows, kv_len):
+    """(B, Sq, Sk) of a call and the descriptor's packed-row fields."""
+    B, Sq = (q_rows.B, q_rows.S) if q_rows is not None else (q.shape[0], q.shape[1])
+    Sk = k_rows.S if k_rows is not None else k.shape[1]
+    if q_rows is not None:
+        assert q.shape[0] == 1, "packed rows: q is [1, rows, H, D]"
+        d.q_row_off, d.q_len = q_rows.off.data_ptr(), q_rows.len.data_ptr()
+    if k_rows is not None:
+        assert k.shape[0] == 1 and (kv_len is None or kv_len is k_rows.len), "packed rows: k / v are [1, rows, H, D] and kv_len is their row count"
+        assert k_rows.B == B
+        d.k_row_off = k_rows.off.data_ptr()
+    else:
+        assert k.shape[0] == B
+    return B, Sq, Sk
+
+
+def attn_fwd(q, k, v, scale, mask_mode=MASK_NONE, kv_len=None, seg=None, seg_len=0, out=None, alibi=None, q_rows=None, k_rows=None):
+    """q [B,Sq,H,D], k/v [B,Sk,H,D] strided views; returns o [B,Sq,H,D] (contiguous unless `out`), lse [B,H,Sq].
+    q_rows / k_rows (PackedRows): the query side / key side is [1, rows, H, D] with the sequences as row ranges; o then comes back in
+    the packed layout too (rows behind the last sequence zero), lse stays [B, H, S] (entries behind a sequence's length unset); a
+    segment mask's ``seg`` is packed like q."""
     d = AttnDesc()
+    B, Sq, Sk = _packed_dims(d, q, k, q_rows, k_rows, kv_len)
+    if k_rows is not None:
+        kv_len = k_rows.len
+    H, D = q.shape[2], q.shape[3]
+    if out is None:
+        out = torch.empty((q.shape[0], q.shape[1], H, D), dtype=bf16, device=q.device)
+        if q_rows is not None and q_rows.n < q.shape[1]:
+            out[:, q_rows.n:].zero_()
+    lse = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device)
     (qp, qs), (kp, ks), (vp, vs), (op, os_) = _view4(q), _view4(k), _view4(v), _view4(out)
     _fill_attn(d, qp, kp, vp, op, lse.data_ptr(), B, H, Sq, Sk, D, scale, mask_mode, kv_len, seg, seg_len, qs, ks, vs, os_, alibi)
     check(_lib.lib().unimp_attn_fwd(C.byref(d), _stream()), "attn_fwd")
@@ -521,14 +564,19 @@ def attn_generation():
     return _lib.lib().unimp_attn_get_generation()
 
 
-def attn_bwd(q, k, v, o, lse, do, dq, dk, dv, scale, mask_mode=MASK_NONE, kv_len=None, seg=None, seg_len=0, alibi=None, rope=None):
+def attn_bwd(q, k, v, o, lse, do, dq, dk, dv, scale, mask_mode=MASK_NONE, kv_len=None, seg=None, seg_len=0, alibi=None, rope=None,
+             q_rows=None, k_rows=None):
     """writes dq/dk/dv (strided [B,S,H,D] views, every element of the views is overwritten).
     rope = (cos, sin) fp32 [positions][half] tables: dq and dk leave the kernels already rotated back (the transpose of the
-    forward's rotation) -- only when attn_rope_fusable(); otherwise the caller runs rope_(inverse=True) itself."""
-    B, Sq, H, D = q.shape
-    Sk = k.shape[1]
-    delta = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device)
+    forward's rotation) -- only when attn_rope_fusable(); otherwise the caller runs rope_(inverse=True) itself.
+    q_rows / k_rows: as in attn_fwd (do, dq packed like q; dk, dv like k); only the rows of the sequences are written -- the caller
+    zeroes the buffer rows behind them if anything contracts over all rows."""
     d = AttnDesc()
+    B, Sq, Sk = _packed_dims(d, q, k, q_rows, k_rows, kv_len)
+    if k_rows is not None:
+        kv_len = k_rows.len
+    H, D = q.shape[2], q.shape[3]
+    delta = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device)
     (qp, qs), (kp, ks), (vp, vs), (op, os_) = _view4(q), _view4(k), _view4(v), _view4(o)
     _fill_attn(d, qp, kp, vp, op, lse.data_ptr(), B, H, Sq, Sk, D, scale, mask_mode, kv_len, seg, seg_len, qs, ks, vs, os_, alibi)
     d.d_o, (d.do_bs, d.do_ss, d.do_hs) = _view4(do)

@@ -149,7 +149,8 @@ class Trainer:
                  shard_optimizer=False, direct_wgrad=True, graph=False, fuse_accum=False, packed=None):
         """packed (None: the UNIMP_PACKED environment default, off): packed token order in the language tower -- LayerNorm and the
         QKV / out / MLP / gated feed-forward projections run on the VALID tokens only ([1, M, H], M = the valid count rounded up to 2048
-        rows), the attention kernels keep the padded [B, L] addressing behind an unpack / pack pair (functional.Pack).  The reference
+        rows), the attention kernels take the sequences as row ranges of the packed buffers (functional.Pack, include/unimp_hip.h
+        q_row_off / k_row_off), the rotation reads each row's position from a table.  Needs right-padded sequences.  The reference
         computes the <PAD> rows too (collate_rec.py:38-74 pads to the longest sequence of the batch); nothing reads them: loss and
         gradients are those of the padded run (tests/test_model_gpu.py::test_packed_token_order_equals_padded), logits at <PAD>
         positions become those of a zero hidden state.  GPT-NeoX tower only; one extra host sync per step (the valid count).
