@@ -84,12 +84,13 @@ def _no_bias_grad(ctx, idx, name):
 # collate_rec.py:38-74 right-pads every sequence of a batch to the longest; the reference then runs every row-wise operation of the
 # language tower (LayerNorm, the QKV / out / MLP / gated feed-forward projections) over the <PAD> rows too.  In packed mode
 # (Trainer(packed=True), bench.py --packed, UNIMP_PACKED=1) the tower's residual stream holds the VALID tokens only, as [1, M, H] with
-# M = the valid count rounded up to PACK_ROUND rows, sequence after sequence.  The attention kernels take that layout directly
+# M = the valid count rounded up to PACK_ROUND rows (default: 1/16 of B * L), sequence after sequence.  The attention kernels take that layout directly
 # (include/unimp_hip.h q_row_off / k_row_off: sequence b = rows off[b] .. off[b] + len[b] - 1), the QKV projection's rotary epilogue
 # reads each row's position from a table: nothing is gathered or scattered between the embedding and the final hidden state.
 # Every valid row goes through the same arithmetic as in the padded run; nothing reads the rows that are skipped.
 PACKED = _os.environ.get("UNIMP_PACKED", "0") == "1"
-PACK_ROUND = 2048           # M granularity: keeps the number of distinct GEMM shapes (autotune keys) per batch size at two or three
+PACK_ROUND = None           # M granularity in rows; None: 1/16 of B * L in multiples of 256 (2 048 at b = 64, L = 512) -- keeps the number of
+                            # distinct GEMM shapes (autotune keys) per batch size at two or three
 PACK = None                 # the Pack of the forward in progress (set by the tower's forward)
 
 
@@ -105,7 +106,8 @@ class Pack:
         flat = m.reshape(-1)
         pos = flat.nonzero().view(-1)                      # host sync: the valid count
         nv = pos.numel()
-        M = min(B * L, (nv + PACK_ROUND - 1) // PACK_ROUND * PACK_ROUND)
+        rnd = PACK_ROUND or max(256, B * L // 16 // 256 * 256)
+        M = min(B * L, (nv + rnd - 1) // rnd * rnd)
         self.B, self.L, self.nv, self.M = B, L, nv, M
         self.useful = nv > 0 and M < B * L
         if not self.useful:

@@ -69,6 +69,25 @@ class _TowerBase(nn.Module):
     """shared: resize_token_embeddings (HF semantics), kv_len from the attention mask, head + loss."""
     tied = False
 
+    def _pack(self, attention_mask, cache):
+        """the functional.Pack of a training forward in packed token order (Trainer(packed=True)), or None"""
+        if not (F_.PACKED and cache is None and attention_mask is not None and self.training):
+            return None
+        pack = F_.Pack(attention_mask)                     # packed token order: the tower never computes the <PAD> rows
+        return pack if pack.useful else None
+
+    def _run_packed(self, pack, input_ids, emb_weight, layers, **layer_kw):
+        """embedding of the valid tokens -> the decoder layers on [1, M, H] packed rows -> padded [B, L, H] (zeros at <PAD>)"""
+        B, L = input_ids.shape
+        x = F_.embedding(input_ids.reshape(-1)[pack.idx_long].view(1, pack.M), emb_weight)
+        F_.PACK = pack
+        try:
+            for layer in layers:
+                x = layer(x, **layer_kw)
+        finally:
+            F_.PACK = None
+        return F_.UnpackRowsFn.apply(x.view(pack.M, -1), pack).view(B, L, -1)
+
     def resize_token_embeddings(self, n, preserve_requires_grad=False):
         """HF ``resize_token_embeddings`` (mmrec.py:595).  With the reference's pinned transformers (4.29,
         requirements.txt:26) the new nn.Embedding -- and, for an untied tower, the new nn.Linear head -- are fresh modules
@@ -242,21 +261,10 @@ class GPTNeoXForCausalLM(_TowerBase):
         B, L = input_ids.shape
         cache, pos0 = self._decode_state(past_key_values, use_cache, labels, attention_mask)
         kv_len = self._kv_len(attention_mask)
-        pack = None
-        if F_.PACKED and cache is None and attention_mask is not None and self.training:
-            pack = F_.Pack(attention_mask)                 # packed token order: the tower's row-wise kernels skip the <PAD> rows
-            if not pack.useful:
-                pack = None
+        pack = self._pack(attention_mask, cache)
         if pack is not None:
-            x = F_.embedding(input_ids.reshape(-1)[pack.idx_long].view(1, pack.M), self.gpt_neox.embed_in.weight)
-            rope = self._rope_tables(L, x.device)
-            F_.PACK = pack
-            try:
-                for layer in self.gpt_neox.layers:
-                    x = layer(x, attention_mask=kv_len, rope=rope, cache=None, pos0=0)
-            finally:
-                F_.PACK = None
-            x = F_.UnpackRowsFn.apply(x.view(pack.M, -1), pack).view(B, L, -1)
+            rope = self._rope_tables(L, input_ids.device)
+            x = self._run_packed(pack, input_ids, self.gpt_neox.embed_in.weight, self.gpt_neox.layers, attention_mask=kv_len, rope=rope, cache=None, pos0=0)
         else:
             x = F_.embedding(input_ids, self.gpt_neox.embed_in.weight)
             rope = self._step_rope(cache, self._rope_tables(max(pos0 + L, cache.kv.shape[3] if cache and cache.kv is not None else 0), x.device))
@@ -576,12 +584,17 @@ class MptForCausalLM(_TowerBase):
     def forward(self, input_ids, attention_mask=None, labels=None, past_key_values=None, use_cache=False, **kw):
         B, L = input_ids.shape
         cache, pos0 = self._decode_state(past_key_values, use_cache, labels, attention_mask)
-        x = F_.embedding(input_ids, self.transformer.wte.weight)
-        if self._slopes is None or self._slopes.device != x.device:
-            self._slopes = mpt_alibi_slopes(self.config.n_heads, self.config.alibi_bias_max).to(x.device)
+        if self._slopes is None or self._slopes.device != input_ids.device:
+            self._slopes = mpt_alibi_slopes(self.config.n_heads, self.config.alibi_bias_max).to(input_ids.device)
         kv_len = self._kv_len(attention_mask)
-        for i, blk in enumerate(self.transformer.blocks):
-            x = blk(x, attention_mask=kv_len, alibi=self._slopes, cache=cache.layers[i] if cache else None, pos0=pos0)
+        pack = self._pack(attention_mask, cache)
+        if pack is not None:
+            x = self._run_packed(pack, input_ids, self.transformer.wte.weight, self.transformer.blocks, attention_mask=kv_len, alibi=self._slopes,
+                                 cache=None, pos0=0)
+        else:
+            x = F_.embedding(input_ids, self.transformer.wte.weight)
+            for i, blk in enumerate(self.transformer.blocks):
+                x = blk(x, attention_mask=kv_len, alibi=self._slopes, cache=cache.layers[i] if cache else None, pos0=pos0)
         f = self.transformer.norm_f
         h = F_.layer_norm(x, f.weight, None, f.eps)
         out = self._head(h, labels, kw.get("logits_last_only", False), kw.get("head_rows"), kw.get("last_index"))
