@@ -191,6 +191,7 @@ def main():
                     "samples (2 history images, ~860 tokens padded to L = 1024, 257 labeled positions; rec_dataset.py:613-664) -- NOT the headline")
     ap.add_argument("--packed", action="store_true", help="Trainer(packed=True): the language tower's row-wise kernels run on the valid tokens only "
                     "(the synthetic batches are filled 75-100 %%: 12.5 %% of the B x L rows are <PAD>); same loss / gradients; NOT the headline")
+    ap.add_argument("--no-packed-leg", action="store_true", help="skip the short opt-in measurement (packed token order) that follows the timed steps")
     ap.add_argument("--fuse-accum", action="store_true", help="Trainer(fuse_accum=True): the --grad-accum micro-batches of an optimizer step run as ONE "
                     "pass over GA x batch samples with per-micro-batch loss normalisation (same update; fills the GEMM tiles GA times better)")
     ap.add_argument("--graph", action="store_true", help="Trainer(graph=True): forward + loss + backward of a micro-batch replayed as one HIP graph "
@@ -303,6 +304,41 @@ def main():
         dt = t.item()
     ms = dt / args.steps * 1e3
     value = GA * B * world * args.steps / dt          # mmrec.py:267-272: GA x batch x world / step time
+    # second, SHORT leg after the headline is in: the same trainer, the same batches, the language tower in packed token order
+    # (Trainer(packed=True): no <PAD> row is computed; same loss and gradients).  Reported beside the headline, never as `value`.
+    packed_leg = None
+    if not (args.packed or args.no_packed_leg or args.graph or args.fuse_accum or args.fp8 or args.sparse_head or GA > 1):
+        try:
+            F_.PACKED = True
+            for _ in range(4):                       # both row counts of the packed batches (28 672 / 30 720 at b = 64) pass the allocator once
+                one_step()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            kp = max(1, min(args.steps, 10))
+            tp0 = time.perf_counter()
+            for _ in range(kp):
+                loss_p, _ = one_step()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            dtp = time.perf_counter() - tp0
+            if world > 1:
+                t = torch.tensor([dtp], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dtp = t.item()
+            packed_leg = {"value": round(B * world * kp / dtp, 3), "unit": "samples/s", "ms_per_step": round(dtp / kp * 1e3, 2), "steps": kp, "warmup": 4,
+                          "loss": float(loss_p), "vs_padded": round(B * world * kp / dtp / value, 4),
+                          "note": "opt-in Trainer(packed=True) / --packed, measured after the headline's timed steps on the same trainer and batch pool: "
+                                  "the language tower runs on the valid tokens only (collate_rec.py:38-74 right-pads; the synthetic fill is 75-100 %), "
+                                  "attention on the sequences as row ranges (q_row_off / k_row_off); same loss and gradients, logits at <PAD> positions "
+                                  "are those of a zero hidden state.  NOT the headline."}
+        except Exception as e:       # noqa: BLE001  (the headline must not depend on the opt-in leg)
+            packed_leg = {"error": f"{type(e).__name__}: {e}"}
+        finally:
+            F_.PACKED = False
     exposed = trainer.dp.exposed_ms() if dp_on else []
     rccl = None
     if dp_on:
@@ -384,7 +420,7 @@ def main():
                            "mfma_frac_whole_step": round(value / world * fps["total"] / 1e12 / PEAK_BF16_TFLOPS, 4),
                            **({"note": "--sparse-head: the utilisation fields above still count the dense head's FLOPs"}
                               if args.sparse_head else {})},
-                "roofline": roofline, "cpu_baseline": cpu, **({"rccl": rccl} if rccl else {})}
+                "roofline": roofline, "cpu_baseline": cpu, **({"rccl": rccl} if rccl else {}), **({"packed_token_order": packed_leg} if packed_leg else {})}
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if dist.is_initialized():

@@ -550,7 +550,7 @@ def test_attention_bwd_fused_inverse_rope(ops, attn_gen, B, H, S, D, rot, interl
 
 
 @pytest.mark.parametrize("H,D,L,lens,mode", [(4, 80, 200, (200, 77, 130), 1), (2, 64, 257, (257, 31, 5, 190), 0), (2, 128, 300, (129, 300), 1),
-                                             (4, 64, 150, (150, 64, 97), 2), (3, 80, 512, (512, 300, 511, 1, 64), 1)])
+                                             (4, 64, 150, (150, 64, 97), 2), (3, 80, 512, (512, 300, 511, 1, 64), 1), (2, 64, 128, (128, 0, 50), 1)])
 def test_attention_packed_rows(ops, H, D, L, lens, mode):
     """include/unimp_hip.h q_row_off / k_row_off: the sequences of a batch as row ranges of one [rows, H, D] buffer.  Same kernels,
     same per-sequence tiles as the padded [B, L] call with kv_len -- forward output, lse and all three gradients must come back with

@@ -7,13 +7,14 @@ O=gpurun_out/final; mkdir -p $O
 T=$PWD/$O/gemm_autotune_gfx950.json
 cp profiles/gemm_autotune_gfx950.json $T        # keep the committed choices; only shapes / epilogue classes that are missing get tuned
 # 1. autotune table for the shapes of the default bench (b = 64), the reference's shipped shape (b = 3, GA 2; fused: b = 6), b = 16 / 32 / 48, the 9b model
-for extra in "" "--batch 3 --grad-accum 2" "--batch 3 --grad-accum 2 --fuse-accum" "--batch 16" "--batch 32" "--batch 48" "--model 9b" "--model 9b --task img_gen --batch 12"; do
+for extra in "" "--packed" "--batch 3 --grad-accum 2" "--batch 3 --grad-accum 2 --fuse-accum" "--batch 16" "--batch 32" "--batch 48" "--model 9b" "--model 9b --packed" "--model 9b --task img_gen --batch 12"; do
   UNIMP_GEMM_TUNE_FILE=$T UNIMP_GEMM_TUNE_WRITE=1 timeout 900 python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline $extra > $O/tune.json 2> $O/tune.err
 done
 cp $T profiles/gemm_autotune_gfx950.json
 # 2. bench lines with the table (no live tuning)
 UNIMP_BENCH_SHAPES=1 timeout 1500 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench default rc=$?" >> $O/rc.txt
 timeout 900 python bench.py --no-cpu-baseline --dp-hooks > $O/bench_dphooks.json 2> $O/bench_dphooks.err
+timeout 900 python bench.py --no-cpu-baseline --packed > $O/bench_packed.json 2> $O/bench_packed.err
 timeout 900 python bench.py --no-cpu-baseline --batch 3 --grad-accum 2 > $O/bench_b3ga2.json 2> $O/bench_b3ga2.err
 timeout 900 python bench.py --no-cpu-baseline --batch 3 --grad-accum 2 --fuse-accum > $O/bench_b3ga2_fused.json 2> $O/bench_b3ga2_fused.err
 timeout 900 python bench.py --no-cpu-baseline --batch 16 > $O/bench_b16.json 2> $O/bench_b16.err
@@ -26,8 +27,10 @@ timeout 900 python bench.py --no-cpu-baseline --model 9b --task img_gen --batch 
 timeout 900 python bench.py --no-cpu-baseline --model 9b --task img_gen --batch 12 --fp8 > $O/bench_9b_imggen_fp8.json 2> $O/bench_9b_imggen_fp8.err
 for f in $O/bench_*.json; do python -c "import json,sys; j=json.load(open('$f')); print('$f', j['value'], j['ms_per_step'], j['roofline']['frac'] if j.get('roofline') else None)"; done > $O/summary.txt 2>&1
 # 3. kernel stats of the default bench command: whole process (--stats) and the timed steps only (markers)
-timeout 900 rocprofv3 --kernel-trace --stats -d $O/stats -o st --output-format csv -- python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-roofline > $O/prof.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats -d $O/stats -o st --output-format csv -- python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-roofline --no-packed-leg > $O/prof.log 2>&1
 python tools/trace_window.py $(find $O/stats -name "*kernel_trace.csv" | head -1) 6 $O/${R}_bench_b64_timed_steps.csv > $O/window.txt 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats -d $O/stats_packed -o st --output-format csv -- python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-roofline --packed > $O/prof_packed.log 2>&1
+python tools/trace_window.py $(find $O/stats_packed -name "*kernel_trace.csv" | head -1) 6 $O/${R}_bench_b64_packed_timed_steps.csv > $O/window_packed.txt 2>&1
 # 3b. micro-benchmarks of the HBM-bound kernels, streaming from HBM; decode
 timeout 300 python tools/bench_ln.py --rotate 3 > $O/bench_ln.log 2>&1
 timeout 300 python tools/bench_adamw.py > $O/bench_adamw.log 2>&1
