@@ -25,7 +25,7 @@ timeout 900 python bench.py --no-cpu-baseline --model 9b --fp8 > $O/bench_9b_fp8
 # BASELINE config 5's own workload: the 9b model on image-token generation samples (L = 1024, 2 history images, 257 labeled positions), bf16 and fp8
 timeout 900 python bench.py --no-cpu-baseline --model 9b --task img_gen --batch 12 > $O/bench_9b_imggen.json 2> $O/bench_9b_imggen.err
 timeout 900 python bench.py --no-cpu-baseline --model 9b --task img_gen --batch 12 --fp8 > $O/bench_9b_imggen_fp8.json 2> $O/bench_9b_imggen_fp8.err
-for f in $O/bench_*.json; do python -c "import json,sys; j=json.load(open('$f')); print('$f', j['value'], j['ms_per_step'], j['roofline']['frac'] if j.get('roofline') else None)"; done > $O/summary.txt 2>&1
+for f in $O/bench_*.json; do python -c "import json,sys; j=json.load(open('$f')); print('$f', j['value'], j['ms_per_step'], j['roofline']['frac'] if j.get('roofline') else None, 'packed leg:', (j.get('packed_token_order') or {}).get('value'))"; done > $O/summary.txt 2>&1
 # 3. kernel stats of the default bench command: whole process (--stats) and the timed steps only (markers)
 timeout 900 rocprofv3 --kernel-trace --stats -d $O/stats -o st --output-format csv -- python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-roofline --no-packed-leg > $O/prof.log 2>&1
 python tools/trace_window.py $(find $O/stats -name "*kernel_trace.csv" | head -1) 6 $O/${R}_bench_b64_timed_steps.csv > $O/window.txt 2>&1
@@ -37,6 +37,7 @@ timeout 300 python tools/bench_adamw.py > $O/bench_adamw.log 2>&1
 timeout 600 python tools/bench_decode.py > $O/bench_decode.log 2>&1
 timeout 300 python tools/bench_gemm_power.py > $O/gemm_power.log 2>&1
 timeout 600 python tools/check_variant_bits.py > $O/variant_bits.log 2>&1
+timeout 600 python tools/hunt_invariance.py random 2 > $O/hunt_random.log 2>&1
 timeout 300 python tools/bench_skinny.py 10 > $O/skinny_m10.log 2>&1; timeout 300 python tools/bench_skinny.py 40 > $O/skinny_m40.log 2>&1
 # 4. PMC passes: the step's dominant GEMM kernel instances, variants pinned
 export PMC_MANIFEST=$PWD/$O/pmc_manifest.json
