@@ -307,7 +307,8 @@ def main():
     # second, SHORT leg after the headline is in: the same trainer, the same batches, the language tower in packed token order
     # (Trainer(packed=True): no <PAD> row is computed; same loss and gradients).  Reported beside the headline, never as `value`.
     packed_leg = None
-    if not (args.packed or args.no_packed_leg or args.graph or args.fuse_accum or args.fp8 or args.sparse_head or GA > 1):
+    # N = 1 only: an exception on one rank of several would leave the others waiting in the leg's barrier -- the headline is not put at risk
+    if world == 1 and not (args.packed or args.no_packed_leg or args.graph or args.fuse_accum or args.fp8 or args.sparse_head or GA > 1):
         try:
             F_.PACKED = True
             for _ in range(4):                       # both row counts of the packed batches (28 672 / 30 720 at b = 64) pass the allocator once

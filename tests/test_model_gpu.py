@@ -680,7 +680,7 @@ def test_fused_accumulation_equals_sequential(P, reweight):
     assert P.rel_l2(mf, ms) <= 5e-3                               # fp32 masters after two AdamW steps (Adam amplifies tiny gradients' noise)
 
 
-@pytest.mark.parametrize("cfgname,round_to,rope_epilogue", [("TINY", 8, True), ("TINY_PAR", 8, True), ("TINY_MPT", 8, True), ("CFG2_SLIM", 64, False), ("CFG2_SLIM", 64, True)])
+@pytest.mark.parametrize("cfgname,round_to,rope_epilogue", [("TINY", 8, True), ("TINY_PAR", 8, True), ("TINY_MPT", 8, True), ("TINY_OPT", 8, True), ("CFG2_SLIM", 64, False), ("CFG2_SLIM", 64, True)])
 def test_packed_token_order_equals_padded(P, monkeypatch, cfgname, round_to, rope_epilogue):
     """Trainer(packed=True): the language tower runs on the valid tokens only -- LayerNorm, the QKV / out / MLP / gated feed-forward
     projections on the packed rows, the attention kernels on the sequences as row ranges of the packed buffers (q_row_off / k_row_off),

@@ -76,10 +76,15 @@ class _TowerBase(nn.Module):
         pack = F_.Pack(attention_mask)                     # packed token order: the tower never computes the <PAD> rows
         return pack if pack.useful else None
 
-    def _run_packed(self, pack, input_ids, emb_weight, layers, **layer_kw):
-        """embedding of the valid tokens -> the decoder layers on [1, M, H] packed rows -> padded [B, L, H] (zeros at <PAD>)"""
+    def _run_packed(self, pack, input_ids, emb_weight, layers, pos_emb=None, **layer_kw):
+        """embedding of the valid tokens -> the decoder layers on [1, M, H] packed rows -> padded [B, L, H] (zeros at <PAD>).
+        pos_emb = (position ids [B, L], table): learned positional embeddings added to the token embeddings (OPT)."""
         B, L = input_ids.shape
-        x = F_.embedding(input_ids.reshape(-1)[pack.idx_long].view(1, pack.M), emb_weight)
+        ids = input_ids.reshape(-1)[pack.idx_long].view(1, pack.M)
+        if pos_emb is not None:
+            x = F_.embedding(ids, emb_weight, pos_emb[0].reshape(-1)[pack.idx_long].view(1, pack.M), pos_emb[1])
+        else:
+            x = F_.embedding(ids, emb_weight)
         F_.PACK = pack
         try:
             for layer in layers:
@@ -359,10 +364,15 @@ class OPTForCausalLM(_TowerBase):
         am = attention_mask if attention_mask is not None else torch.ones_like(input_ids)
         pos = (torch.cumsum(am, 1) * am).long() + 1                      # OPTLearnedPositionalEmbedding (offset 2)
         pos = pos + (cache.step.pos_idx[:, None] if cache is not None and cache.step is not None else pos0)
-        x = F_.embedding(input_ids, d.embed_tokens.weight, pos, d.embed_positions.weight)
         kv_len = self._kv_len(attention_mask)
-        for i, layer in enumerate(d.layers):
-            x = layer(x, attention_mask=kv_len, cache=cache.layers[i] if cache else None, pos0=pos0)
+        pack = self._pack(attention_mask, cache)
+        if pack is not None:
+            x = self._run_packed(pack, input_ids, d.embed_tokens.weight, d.layers, pos_emb=(pos, d.embed_positions.weight), attention_mask=kv_len,
+                                 cache=None, pos0=0)
+        else:
+            x = F_.embedding(input_ids, d.embed_tokens.weight, pos, d.embed_positions.weight)
+            for i, layer in enumerate(d.layers):
+                x = layer(x, attention_mask=kv_len, cache=cache.layers[i] if cache else None, pos0=pos0)
         f = d.final_layer_norm
         h = F_.layer_norm(x, f.weight, f.bias, f.eps)
         out = self._head(h, labels, kw.get("logits_last_only", False), kw.get("head_rows"), kw.get("last_index"))

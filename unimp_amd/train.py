@@ -153,7 +153,7 @@ class Trainer:
         q_row_off / k_row_off), the rotation reads each row's position from a table.  Needs right-padded sequences.  The reference
         computes the <PAD> rows too (collate_rec.py:38-74 pads to the longest sequence of the batch); nothing reads them: loss and
         gradients are those of the padded run (tests/test_model_gpu.py::test_packed_token_order_equals_padded), logits at <PAD>
-        positions become those of a zero hidden state.  GPT-NeoX and MPT towers; one extra host sync per step (the valid count).
+        positions become those of a zero hidden state.  GPT-NeoX, MPT and OPT towers; one extra host sync per step (the valid count).
         fuse_accum (off by default; needs grad_accum > 1): run the GA micro-batches of an optimizer step as ONE forward /
         backward pass.  The reference accumulates because 3 samples are what fits its GPUs (unimp_task.sh:2-30: --batch_size 3,
         --gradient_accumulation_steps 2); on 288 GB the activations of all GA micro-batches fit, and one pass over GA x B samples
