@@ -136,3 +136,34 @@ def test_imggen_synthetic_batch_layout():
     img0 = lay.item0 + lay.n_items
     labeled = b["lang_x"].numpy()[lab != -100].reshape(3, 257)
     assert ((labeled[:, :256] >= img0) & (labeled[:, :256] < img0 + 1024)).all() and (labeled[:, 256] == lay.eos).all()
+
+
+def test_pack_maps_right_padded_batches_to_row_ranges(monkeypatch):
+    """functional.Pack (Trainer(packed=True)): the valid tokens of a right-padded batch (collate_rec.py:38-74, data.py:274) as row ranges of
+    one buffer -- idx / inv are inverse maps, sequence b owns rows off[b] .. off[b] + len[b] - 1, pos is the position inside the
+    sequence, M is the valid count rounded up; a mask that is not a prefix of ones per row is refused."""
+    import pytest
+    from unimp_amd import functional as F_
+    lens = [7, 0, 12, 3]
+    B, L = len(lens), 12
+    mask = torch.zeros(B, L, dtype=torch.int64)
+    for b, n in enumerate(lens):
+        mask[b, :n] = 1
+    monkeypatch.setattr(F_, "PACK_ROUND", 8)
+    pk = F_.Pack(mask)
+    nv = sum(lens)
+    assert pk.useful and pk.nv == nv and pk.M == 24 and pk.M % 8 == 0
+    want = [b * L + j for b, n in enumerate(lens) for j in range(n)]
+    assert pk.idx[:nv].tolist() == want
+    assert all(mask.reshape(-1)[i] == 0 for i in pk.idx[nv:].tolist())          # the spare rows point at a <PAD> slot
+    assert pk.inv[want].tolist() == list(range(nv)) and int((pk.inv >= 0).sum()) == nv
+    assert pk.rows.len.tolist() == lens and pk.rows.off.tolist() == [0, 7, 7, 19] and pk.rows.n == nv and pk.rows.S == L
+    assert pk.pos[:nv].tolist() == [j for n in lens for j in range(n)]
+    seg = torch.arange(B * L, dtype=torch.int32).view(B, L)
+    assert pk.seg(seg)[:nv].tolist() == want
+    monkeypatch.setattr(F_, "PACK_ROUND", None)                                  # default granularity: 1/16 of B * L, at least 256 rows
+    assert not F_.Pack(mask).useful                                              # 22 valid tokens round up to all 48 rows: nothing to skip
+    left = mask.flip(1)
+    monkeypatch.setattr(F_, "PACK_ROUND", 8)
+    with pytest.raises(ValueError):
+        F_.Pack(left)
