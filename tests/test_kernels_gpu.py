@@ -160,6 +160,19 @@ def test_gemm_variants_same_bits_under_every_forward_epilogue(ops):
     assert torch.equal(o4, o9), f"rotary epilogue: pp256 and pp256p differ in {int((o4 != o9).sum())} elements"
 
 
+def test_forward_gemm_rows_do_not_depend_on_the_row_count(ops):
+    """A sample's rows of a FORWARD projection must come out with the same bits whatever the batch around them: no split-K outside a
+    backward pass (its slice count follows the tile count), and every variant the tuner may pick per M sums k in the same order.
+    The gated cross-attention's to_q ([B L, 512] x K = 2560: 16 tiles at b = 1, 96 at b = 6, 384 at b = 24 -- round 3 found it under
+    5 / 3 / 0 slices), a Perceiver-sized and an LM-sized projection."""
+    for N, K in ((512, 2560), (1024, 4096), (2560, 2560)):
+        a, b = rnd(12288, K, seed=N).cuda(), rnd(N, K, seed=K, scale=0.05).cuda()
+        want = ops.gemm(a[:512], b)
+        for M in (1024, 3072, 6144, 12288):
+            got = ops.gemm(a[:M], b)
+            assert torch.equal(got[:512], want), f"[{M}, {N}, {K}]: the first 512 rows differ from the M = 512 call in {int((got[:512] != want).sum())} elements"
+
+
 def test_gemm_ragged_n_padded_rows(ops):
     """N % 8 != 0 with row strides padded to a multiple of 8 (the 74 053-column LM head): full 8-column groups take the vector
     epilogue, the last partial group is written element by element; nothing beyond column N - 1 is touched."""
@@ -322,7 +335,7 @@ def test_gemm_splitk_weight_grad(ops, M, N, K, gate):
     close(ref, want, name="v1 dW")
     assert torch.equal(got, ops.gemm(dy.cuda(), x.cuda(), a_ks=True, b_ks=True, gate=g.cuda() if gate else None))   # reproducible
     if K % 8 == 0:                                   # the same product from k-contiguous operands (kc x kc split-K)
-        got_kc = ops.gemm(dy.t().contiguous().cuda(), x.t().contiguous().cuda(), gate=g.cuda() if gate else None)
+        got_kc = ops.gemm(dy.t().contiguous().cuda(), x.t().contiguous().cuda(), gate=g.cuda() if gate else None, _splits=-1)   # (a forward-form call never splits by itself)
         close(got_kc, want, name="splitk kc")
     # accumulate: the reduction pass adds into C (the weight-gradient sink of train.Trainer), bf16 and fp32 outputs
     c0 = rnd(M, N, seed=3)
@@ -342,9 +355,9 @@ def test_gemm_splitk_head_dx_shape(ops):
     dl = torch.zeros(M, ld, dtype=bf16)
     dl[:, :K] = rnd(M, K, seed=1, scale=0.05)
     w = rnd(K, N, seed=2)
-    got = ops.gemm(dl.cuda()[:, :K], w.cuda(), b_ks=True)
+    got = ops.gemm(dl.cuda()[:, :K], w.cuda(), b_ks=True, _splits=-1)              # inside a backward pass this form splits by itself
     close(got, dl[:, :K].float() @ w.float(), name="head dX split-K")
-    assert torch.equal(got, ops.gemm(dl.cuda()[:, :K], w.cuda(), b_ks=True))
+    assert torch.equal(got, ops.gemm(dl.cuda()[:, :K], w.cuda(), b_ks=True, _splits=-1))
     close(ops.gemm(dl.cuda()[:, :K], w.cuda(), b_ks=True, variant="v1"), dl[:, :K].float() @ w.float(), name="head dX v1")
 
 

@@ -343,16 +343,21 @@ def gemm(a, b, *, a_ks=False, b_ks=False, bias=None, act=None, res=None, aux=Non
     # dX form (dy [M, K] x W [K, N], k-strided weight) INSIDE a backward pass with few 256 x 256 tiles and a deep K: at the
     # reference's shipped shape (3 x 512 tokens) [1536, 2560] x K = 10240 / 7680 is 60 tiles -- the 128 x 128 kernel ran them at
     # 0.44-0.48 PFLOP/s (r3d per-shape table).  Forward GEMMs never split (their summation order must not depend on the batch size).
-    dx_split = ((not a_ks) and b_ks and M >= 256 and N >= 256 and K >= 5120 and tiles256 <= 128 and plain and variant is None
-                and torch._C._current_graph_task_id() >= 0)
+    in_bwd = torch._C._current_graph_task_id() >= 0
+    dx_split = (not a_ks) and b_ks and M >= 256 and N >= 256 and K >= 5120 and tiles256 <= 128 and plain and variant is None and in_bwd
     wide = M >= 256 and N >= 256 and a_ks and b_ks   # weight-gradient form only (a forward GEMM of a small batch must not change
     #                                                  its summation order with the batch size); 256 x 256 ping-pong tiles under split-K
     # (K >= 16384 with up to 160 tiles: the LM head's dX over the labeled rows only, [~640, 74 053] x [74 053, 2560] -- 100 tiles, 170 TFLOP/s unsplit)
-    if (variant is None and plain and _splits != 0 and ((tiles256 <= 128 if wide else (dx_split or tiles <= 96 or (tiles <= 160 and K >= 16384))) or _splits)
+    # Never in a FORWARD pass (outside autograd's backward, k-contiguous or mixed operands): the slice count follows the tile count, i.e. the
+    # batch size, and a sample's bits must not (round 3: the gated cross-attention's to_q, [B L, 512] x K = 2560, ran under 5 slices up to
+    # b = 6, 3 at b = 12, none beyond)
+    may_split = (a_ks and b_ks) or in_bwd or bool(_splits)           # _splits = -1: allowed here, slice count chosen as in a backward pass
+    if (variant is None and plain and _splits != 0 and may_split
+            and ((tiles256 <= 128 if wide else (dx_split or tiles <= 96 or (tiles <= 160 and K >= 16384))) or (_splits or 0) > 0)
             and K >= 2048 and N % 4 == 0 and out.stride(0) % 4 == 0):
         # weight gradient of a narrow projection: far fewer tiles than CUs, very deep K -> split-K over the chip
         big = wide or dx_split or (K >= 16384 and M >= 256 and N >= 256)        # the C side runs 256 x 256 tiles whenever M, N >= 256
-        splits = _splits or (_splitk_count(M, N, K, tiles256) if big else max(2, min(32, 320 // tiles, K // 512)))
+        splits = _splits if (_splits or 0) > 0 else (_splitk_count(M, N, K, tiles256) if big else max(2, min(32, 320 // tiles, K // 512)))
         slabs = torch.empty((splits, M, N), dtype=torch.float32, device=a.device)
         if GEMM_PROFILE is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
