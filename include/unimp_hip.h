@@ -57,7 +57,10 @@ typedef struct {
   float alpha;
   int act, dact;
   int out_f32, accumulate;
-  int pre_deriv;   /* pre receives act'(v) instead of v: the backward multiply then needs no transcendental (dact = DERIV) */
+  int pre_deriv;   /* 1: pre receives act'(v) instead of v: the backward multiply then needs no transcendental (dact = DERIV = 5).
+                    * 2: the same as uint8 [M][ldpre BYTES], q = round(202 act'(v) + 27) -- every derivative served lies in [-0.129, 1.129],
+                    * 0 and 1 are exact, |error| <= 0.0025 (finer than bf16 above 0.63); read back with dact = 6 (aux uint8, ldaux in bytes).
+                    * Half the bytes of the up-projection's second output and of the backward's aux operand. */
   /* optional rotary epilogue (rope_rot > 0; the fused QKV projection of a GPT-NeoX / Llama block): C is [tokens][N] with
    * position = row % rope_L; column n belongs to a rotated vector iff (n % rope_period) < rope_span, its index inside the
    * head vector is n % rope_hd, and the first rope_rot indices are rotated.  The rotation pairs are ADJACENT in memory:

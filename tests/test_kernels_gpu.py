@@ -173,6 +173,51 @@ def test_forward_gemm_rows_do_not_depend_on_the_row_count(ops):
             assert torch.equal(got[:512], want), f"[{M}, {N}, {K}]: the first 512 rows differ from the M = 512 call in {int((got[:512] != want).sum())} elements"
 
 
+@pytest.mark.parametrize("M,N,K,act", [(512, 1024, 256, "gelu"), (300, 520, 192, "gelu"), (1024, 2560, 512, "quick_gelu"), (128, 264, 128, "gelu")])
+def test_gemm_stored_derivative_uint8(ops, M, N, K, act):
+    """act'(z) in 8 bits (pre_deriv = 2 / dact = 6: q = round(202 g + 27)): the up-projection's second output and the backward's aux
+    operand at half the bytes.  Every variant writes the same bytes; they decode to the bf16 form's derivative within half a step
+    (0.0025) plus bf16's own rounding; 0 and 1 are exact (a ReLU'd copy); the backward product through the uint8 operand equals the
+    one through the decoded values, and is as close to fp32 as the bf16 form's."""
+    a, b, bias = rnd(M, K, seed=1).cuda(), rnd(N, K, seed=2, scale=0.2).cuda(), rnd(N, seed=3).cuda()
+    ld = (N + 7) // 8 * 8
+    outs = {}
+    for v in (["v1"] if M < 256 else ["v1", "dma256", "pp256", "pp128", "w8", "pp256p"]):
+        q = torch.full((M, ld), 255, dtype=torch.uint8, device="cuda")
+        y = ops.gemm(a, b, bias=bias, act=act, pre=q[:, :N], pre_deriv=True, variant=v)
+        outs[v] = (y, q)
+    y0, q0 = outs["v1"]
+    for v, (y, q) in outs.items():
+        assert torch.equal(y, y0) and torch.equal(q, q0), f"{v}: {int((q != q0).sum())} bytes differ from v1"
+    assert torch.all(q0[:, N:] == 255), "wrote past column N"
+    g16 = torch.empty((M, ld), dtype=bf16, device="cuda")
+    ops.gemm(a, b, bias=bias, act=act, pre=g16[:, :N], pre_deriv=True, variant="v1")
+    dec = (q0[:, :N].float() - 27.0) / 202.0
+    err = (dec - g16[:, :N].float()).abs()
+    assert float(err.max()) <= 0.5 / 202 + 2 ** -8 + 1e-6, float(err.max())
+    z = (a.float() @ b.float().t() + bias.float())
+    dead, sat = z < -8.0, z > 8.0
+    assert torch.all(dec[dead] == 0.0) and torch.all(dec[sat] == 1.0)
+    # backward: dz = (dy W2) * g through the uint8 operand
+    dy, w2 = rnd(M, 96, seed=5).cuda(), rnd(96, N, seed=6, scale=0.2).cuda()
+    want = (dy.float() @ w2.float()) * dec
+    for v in (["v1"] if M < 256 else ["v1", "dma256", "pp256", "w8", "pp256p"]):
+        got = ops.gemm(dy, w2, b_ks=True, aux=q0[:, :N], dact="deriv", variant=v)
+        close(got, want, name=f"dz through uint8 act' [{v}]")
+    ref16 = ops.gemm(dy, w2, b_ks=True, aux=g16[:, :N], dact="deriv", variant="v1")
+    zc = z.cpu().double()
+    if act == "gelu":
+        gt = 0.5 * (1 + torch.erf(zc / 2 ** 0.5)) + zc * torch.exp(-zc * zc / 2) / (2 * math.pi) ** 0.5
+    else:
+        sg = torch.sigmoid(1.702 * zc)
+        gt = sg * (1 + 1.702 * zc * (1 - sg))
+    truth = ((dy.float() @ w2.float()).cpu().double() * gt).float()
+    got = ops.gemm(dy, w2, b_ks=True, aux=q0[:, :N], dact="deriv", variant="v1").float().cpu()
+    e8 = float((got - truth).norm() / truth.norm())
+    e16 = float((ref16.float().cpu() - truth).norm() / truth.norm())
+    assert e8 <= max(2.0 * e16, 6e-3), (e8, e16)
+
+
 def test_gemm_ragged_n_padded_rows(ops):
     """N % 8 != 0 with row strides padded to a multiple of 8 (the 74 053-column LM head): full 8-column groups take the vector
     epilogue, the last partial group is written element by element; nothing beyond column N - 1 is touched."""

@@ -45,7 +45,24 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // ---- activations (fp32 math) -------------------------------------------------------------
-enum { ACT_NONE = 0, ACT_GELU = 1, ACT_QUICKGELU = 2, ACT_RELU = 3, ACT_SILU = 4, ACT_DERIV = 5 };   // DERIV: aux IS act'(z)
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_QUICKGELU = 2, ACT_RELU = 3, ACT_SILU = 4, ACT_DERIV = 5, ACT_DERIV_U8 = 6 };   // DERIV: aux IS act'(z); _U8: as uint8
+// act'(z) stored in 8 bits (pre_deriv = 2 / dact = ACT_DERIV_U8; VERDICT r2 #2b): every derivative served here lies in [-0.129, 1.129]
+// (GELU' extremes; QuickGELU' / SiLU' / ReLU' inside), so q = round(202 g + 27) in 0 .. 255, g' = (q - 27) / 202: step 0.00495, 0 and 1
+// exact (dead and saturated units keep their exact derivative), |g' - g| <= 0.00248 -- finer than bf16 above 0.63, coarser below 0.3.
+#define DERIV_U8_SCALE 202.f
+#define DERIV_U8_ZERO 27.f
+__device__ __forceinline__ uint32_t deriv_u8_pack4(float a, float b, float c, float d) {
+  uint32_t r = 0;
+  // v_cvt_pk_u8_f32: round-to-nearest, saturating, byte `sel` of the destination dword
+  r = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(a, DERIV_U8_SCALE, DERIV_U8_ZERO), 0, r);
+  r = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(b, DERIV_U8_SCALE, DERIV_U8_ZERO), 1, r);
+  r = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(c, DERIV_U8_SCALE, DERIV_U8_ZERO), 2, r);
+  r = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(d, DERIV_U8_SCALE, DERIV_U8_ZERO), 3, r);
+  return r;
+}
+__device__ __forceinline__ float deriv_u8_get(uint32_t w, int byte) {       // v_cvt_f32_ubyte{0..3} + one fma
+  return fmaf((float)((w >> (8 * byte)) & 0xffu), 1.f / DERIV_U8_SCALE, -DERIV_U8_ZERO / DERIV_U8_SCALE);
+}
 
 // erf-GELU with ONE exponential: Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below bf16 resolution);
 // e = exp(-x^2/2) serves both erf(x/sqrt2) and the Gaussian density of the derivative.

@@ -94,9 +94,16 @@ __device__ __forceinline__ void epi_tile(const GemmParams& p, f32x4 a, int m, in
   if (p.pre && p.pre_deriv) {
     float dv[4];
     act_fwd_deriv_n<4>(p.act, v, dv);
+    if (p.pre_deriv == 2) {                     // derivative as uint8 (common.h DERIV_U8): ldpre counts bytes
+      uint8_t* d8 = (uint8_t*)p.pre + (long)m * p.ldpre + n;
+      uint32_t w = deriv_u8_pack4(dv[0], dv[1], dv[2], dv[3]);
+      if (FAST) *(uint32_t*)d8 = w;
+      else { for (int r = 0; r < nv; ++r) d8[r] = (uint8_t)((w >> (8 * r)) & 0xffu); }
+    } else {
     bf16* d = p.pre + (long)m * p.ldpre + n;
     if (FAST) { bf16x4 o = {f2bf(dv[0]), f2bf(dv[1]), f2bf(dv[2]), f2bf(dv[3])}; *(bf16x4*)d = o; }
     else { for (int r = 0; r < nv; ++r) d[r] = f2bf(dv[r]); }
+    }
   } else {
     if (p.pre) {
       bf16* d = p.pre + (long)m * p.ldpre + n;
@@ -105,7 +112,13 @@ __device__ __forceinline__ void epi_tile(const GemmParams& p, f32x4 a, int m, in
     }
     if (p.act) act_fwd_n<4>(p.act, v);
   }
-  if (p.aux) {
+  if (p.aux && p.dact == ACT_DERIV_U8) {
+    const uint8_t* s8 = (const uint8_t*)p.aux + (long)m * p.ldaux + n;
+    if (FAST) { uint32_t w = *(const uint32_t*)s8;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] *= deriv_u8_get(w, r); }
+    else { for (int r = 0; r < nv; ++r) v[r] *= deriv_u8_get(s8[r], 0); }
+  } else if (p.aux) {
     const bf16* s = p.aux + (long)m * p.ldaux + n;
     if (FAST) { bf16x4 x = *(const bf16x4*)s;
       float xf[4] = {bf2f(x[0]), bf2f(x[1]), bf2f(x[2]), bf2f(x[3])};

@@ -69,12 +69,19 @@ __device__ __forceinline__ void epi8(const Gemm2Params& p, float (&v)[8], int m,
   if (p.pre && p.pre_deriv) {                 // y = act(v) and act'(v) from one exponential; store the derivative
     float dv[8];
     act_fwd_deriv_n<8>(p.act, v, dv);
+    if (p.pre_deriv == 2) {                     // derivative as uint8 (common.h DERIV_U8): ldpre counts bytes
+      uint8_t* d8 = (uint8_t*)p.pre + (long)m * p.ldpre + n;
+      uint32_t w0 = deriv_u8_pack4(dv[0], dv[1], dv[2], dv[3]), w1 = deriv_u8_pack4(dv[4], dv[5], dv[6], dv[7]);
+      if (FAST) *(uint2*)d8 = uint2{w0, w1};
+      else { for (int r = 0; r < nv; ++r) d8[r] = (uint8_t)(((r < 4 ? w0 : w1) >> (8 * (r & 3))) & 0xffu); }
+    } else {
     bf16* d = p.pre + (long)m * p.ldpre + n;
     if (FAST) { bf16x8 o;
 #pragma unroll
       for (int r = 0; r < 8; ++r) o[r] = f2bf(dv[r]);
       *(bf16x8*)d = o; }
     else { for (int r = 0; r < nv; ++r) d[r] = f2bf(dv[r]); }
+    }
   } else {
     if (p.pre) {
       bf16* d = p.pre + (long)m * p.ldpre + n;
@@ -86,7 +93,13 @@ __device__ __forceinline__ void epi8(const Gemm2Params& p, float (&v)[8], int m,
     }
     if (p.act) act_fwd_n<8>(p.act, v);
   }
-  if (p.aux) {
+  if (p.aux && p.dact == ACT_DERIV_U8) {       // stored derivative in 8 bits: ldaux counts bytes
+    const uint8_t* s8 = (const uint8_t*)p.aux + (long)m * p.ldaux + n;
+    if (FAST) { uint2 w = *(const uint2*)s8;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] *= deriv_u8_get(r < 4 ? w.x : w.y, r & 3); }
+    else { for (int r = 0; r < nv; ++r) v[r] *= deriv_u8_get(s8[r], 0); }
+  } else if (p.aux) {
     const bf16* s = p.aux + (long)m * p.ldaux + n;
     if (FAST) { bf16x8 x = PRE ? auxv : *(const bf16x8*)s;
       float xf[8];
@@ -162,7 +175,7 @@ __device__ __forceinline__ void epi_pass(const Gemm2Params& p, const char* er, i
 enum { EK_PLAIN = 0, EK_ACT = 1, EK_AUX = 2, EK_RES = 3, EK_GENERIC = 4, EK_ROPE = 5 /* EK_PLAIN + rotary pairs (QKV projection) */ };
 __device__ __forceinline__ int epi_kind(const Gemm2Params& p, bool fast) {
   if (!fast || p.accumulate || (p.aux && p.res)) return EK_GENERIC;
-  if (p.aux) return (p.dact == ACT_DERIV && !p.act && !p.pre) ? EK_AUX : EK_GENERIC;
+  if (p.aux) return ((p.dact == ACT_DERIV || p.dact == ACT_DERIV_U8) && !p.act && !p.pre) ? EK_AUX : EK_GENERIC;
   if (p.res) return (!p.act && !(p.pre && p.pre_deriv)) ? EK_RES : EK_GENERIC;     // a raw (pre-gate) second output is part of EK_RES
   return (p.act || p.pre) ? EK_ACT : EK_PLAIN;                                        // every kind applies tanh(gate) (1 when absent)
 }
@@ -185,6 +198,16 @@ __device__ __forceinline__ void epi_fetch(const Gemm2Params& p, int lane, int mb
   if ((kind != EK_AUX && kind != EK_RES) || n >= p.N) return;
   const bf16* src = kind == EK_AUX ? p.aux : p.res;
   const long ld = kind == EK_AUX ? p.ldaux : p.ldres;
+  if (kind == EK_AUX && p.dact == ACT_DERIV_U8) {                          // 8 bytes per chunk, kept in the low half of the register
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) {
+      int m = min(mbase + u * RPI + lane / LPR, p.M - 1);
+      uint2 w = *(const uint2*)((const uint8_t*)src + (long)m * ld + n);
+      union { uint2 q[2]; bf16x8 b; } cv; cv.q[0] = w; cv.q[1] = uint2{0, 0};
+      e.xv[u] = cv.b;
+    }
+    return;
+  }
 #pragma unroll
   for (int u = 0; u < NIT; ++u) {
     int m = min(mbase + u * RPI + lane / LPR, p.M - 1);                    // clamped: rows beyond M are loaded, never stored
@@ -224,15 +247,25 @@ __device__ __forceinline__ void epi8k(const Gemm2Params& p, float (&v)[8], int m
         for (int r = 0; r < 8; ++r) dv[r] = v[r];
         act_fwd_n<8>(p.act, v);
       }
-      bf16x8 o;
+      if (p.pre_deriv == 2) {
+        *(uint2*)((uint8_t*)p.pre + (long)m * p.ldpre + n) = uint2{deriv_u8_pack4(dv[0], dv[1], dv[2], dv[3]), deriv_u8_pack4(dv[4], dv[5], dv[6], dv[7])};
+      } else {
+        bf16x8 o;
 #pragma unroll
-      for (int r = 0; r < 8; ++r) o[r] = f2bf(dv[r]);
-      *(bf16x8*)(p.pre + (long)m * p.ldpre + n) = o;
+        for (int r = 0; r < 8; ++r) o[r] = f2bf(dv[r]);
+        *(bf16x8*)(p.pre + (long)m * p.ldpre + n) = o;
+      }
     } else act_fwd_n<8>(p.act, v);
   }
   if (KIND == EK_AUX) {
+    if (p.dact == ACT_DERIV_U8) {
+      union { bf16x8 b; uint2 q[2]; } cv; cv.b = x;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) v[r] *= bf2f(x[r]);
+      for (int r = 0; r < 8; ++r) v[r] *= deriv_u8_get(r < 4 ? cv.q[0].x : cv.q[0].y, r & 3);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] *= bf2f(x[r]);
+    }
   }
   if (KIND != EK_RES) {                       // the gated cross-attention's dX / dW GEMMs: x tanh(gate), after act / aux like the general form
 #pragma unroll

@@ -12,7 +12,7 @@ from ._lib import GemmDesc, AttnDesc, MxGemmDesc, check
 
 _os_env = os.environ.get
 
-ACT = {None: 0, "none": 0, "gelu": 1, "quick_gelu": 2, "relu": 3, "silu": 4, "deriv": 5}
+ACT = {None: 0, "none": 0, "gelu": 1, "quick_gelu": 2, "relu": 3, "silu": 4, "deriv": 5, "deriv_u8": 6}
 MASK_NONE, MASK_CAUSAL, MASK_SEGMENT = 0, 1, 2
 bf16 = torch.bfloat16
 
@@ -324,6 +324,12 @@ def gemm(a, b, *, a_ks=False, b_ks=False, bias=None, act=None, res=None, aux=Non
     d.act, d.dact = ACT[act], ACT[dact]
     d.out_f32, d.accumulate = int(out.dtype == torch.float32), int(accumulate)
     d.pre_deriv = int(pre_deriv)
+    if pre is not None and pre.dtype == torch.uint8:         # act'(z) in 8 bits (include/unimp_hip.h: pre_deriv = 2, ldpre in bytes)
+        assert pre_deriv and act is not None, "a uint8 second output holds the activation's derivative"
+        d.pre_deriv = 2
+    if aux is not None and aux.dtype == torch.uint8:
+        assert dact in ("deriv", "deriv_u8"), "a uint8 aux operand is a stored derivative"
+        d.dact = ACT["deriv_u8"]
     if rope is not None:             # rotary epilogue (include/unimp_hip.h): dict(rot, hd, period, span, L, log2_base); see gemm_rope_variant()
         d.rope_rot, d.rope_hd, d.rope_period, d.rope_span, d.rope_L = rope["rot"], rope["hd"], rope["period"], rope["span"], rope["L"]
         d.rope_log2_base = rope["log2_base"]
