@@ -182,7 +182,7 @@ def test_gemm_stored_derivative_uint8(ops, M, N, K, act):
     a, b, bias = rnd(M, K, seed=1).cuda(), rnd(N, K, seed=2, scale=0.2).cuda(), rnd(N, seed=3).cuda()
     ld = (N + 7) // 8 * 8
     outs = {}
-    for v in (["v1"] if M < 256 else ["v1", "dma256", "pp256", "pp128", "w8", "pp256p"]):
+    for v in (["v1"] if M < 256 else ["v1", "pp256", "pp128", "w8", "pp256p"]):       # the kernels with the specialised epilogue kinds
         q = torch.full((M, ld), 255, dtype=torch.uint8, device="cuda")
         y = ops.gemm(a, b, bias=bias, act=act, pre=q[:, :N], pre_deriv=True, variant=v)
         outs[v] = (y, q)
@@ -201,7 +201,7 @@ def test_gemm_stored_derivative_uint8(ops, M, N, K, act):
     # backward: dz = (dy W2) * g through the uint8 operand
     dy, w2 = rnd(M, 96, seed=5).cuda(), rnd(96, N, seed=6, scale=0.2).cuda()
     want = (dy.float() @ w2.float()) * dec
-    for v in (["v1"] if M < 256 else ["v1", "dma256", "pp256", "w8", "pp256p"]):
+    for v in (["v1"] if M < 256 else ["v1", "pp256", "pp128", "w8", "pp256p"]):
         got = ops.gemm(dy, w2, b_ks=True, aux=q0[:, :N], dact="deriv", variant=v)
         close(got, want, name=f"dz through uint8 act' [{v}]")
     ref16 = ops.gemm(dy, w2, b_ks=True, aux=g16[:, :N], dact="deriv", variant="v1")
@@ -213,6 +213,9 @@ def test_gemm_stored_derivative_uint8(ops, M, N, K, act):
         gt = sg * (1 + 1.702 * zc * (1 - sg))
     truth = ((dy.float() @ w2.float()).cpu().double() * gt).float()
     got = ops.gemm(dy, w2, b_ks=True, aux=q0[:, :N], dact="deriv", variant="v1").float().cpu()
+    from unimp_amd._lib import UnimpHipError
+    with pytest.raises(UnimpHipError):           # a kernel without the uint8 forms refuses instead of reading the bytes as bf16
+        ops.gemm(dy, w2, b_ks=True, aux=q0[:, :N], dact="deriv", variant="dma256")
     e8 = float((got - truth).norm() / truth.norm())
     e16 = float((ref16.float().cpu() - truth).norm() / truth.norm())
     assert e8 <= max(2.0 * e16, 6e-3), (e8, e16)

@@ -414,6 +414,15 @@ static int validate(const unimp_gemm_desc* d) {
     return unimp_set_error(e, "gemm: operand base must be 16-B aligned, ld %% 8 == 0, k-strided ld >= roundup8(rows)");
   if (!d->a_kstrided && d->lda < ((d->K + 7) & ~7)) return unimp_set_error(UNIMP_ERR_SHAPE, "gemm: lda < roundup8(K)");
   if (!d->b_kstrided && d->ldb < ((d->K + 7) & ~7)) return unimp_set_error(UNIMP_ERR_SHAPE, "gemm: ldb < roundup8(K)");
+  // the 8-bit stored derivative is served by the specialised epilogue kinds only (gemm_tile.h epi_kind): the MLP blocks' two forms
+  const bool pre_u8 = d->pre && d->pre_deriv == 2, aux_u8 = d->aux && d->dact == ACT_DERIV_U8;
+  if (pre_u8 || aux_u8) {
+    if ((d->N & 7) || (d->ldc & 7) || d->accumulate || d->res || (pre_u8 && ((d->ldpre & 7) || !d->act || d->aux || d->gate)) ||
+        (aux_u8 && ((d->ldaux & 7) || d->act || d->pre || d->bias)))
+      return unimp_set_error(UNIMP_ERR_UNSUPPORTED, "gemm: the uint8 derivative needs N, ld % 8 == 0 and one of the two forms: "
+                             "[bias +] act with the derivative as second output, or plain [x gate] times the stored derivative");
+  }
+  if (d->dact == ACT_DERIV_U8 && !d->aux) return unimp_set_error(UNIMP_ERR_ARG, "gemm: dact = 6 without an aux operand");
   return 0;
 }
 
@@ -496,6 +505,9 @@ extern "C" int unimp_gemm_bf16_variant(const unimp_gemm_desc* d, int variant, vo
   if (variant == UNIMP_GEMM_AUTO) variant = auto_variant(d);
   if (d->b_kstrided == 2 && variant != UNIMP_GEMM_PP256 && variant != UNIMP_GEMM_PP128)
     return unimp_set_error(UNIMP_ERR_UNSUPPORTED, "gemm: a pre-packed B operand is served by the ping-pong kernels only (variants pp256 / pp128)");
+  if (((d->pre && d->pre_deriv == 2) || d->dact == ACT_DERIV_U8) &&
+      (variant == UNIMP_GEMM_DMA256 || variant == UNIMP_GEMM_DMA128 || variant == UNIMP_GEMM_W4 || variant == UNIMP_GEMM_SKINNY))
+    return unimp_set_error(UNIMP_ERR_UNSUPPORTED, "gemm: the uint8 derivative is served by variants v1 / pp256 / pp128 / w8 / pp256p (kernels with the specialised epilogue kinds)");
   if (d->rope_rot) {
     if (d->rope_rot < 0 || (d->rope_rot & 7) || d->rope_hd <= 0 || (d->rope_hd & 7) || d->rope_rot > d->rope_hd || d->rope_L <= 0 ||
         d->rope_period <= 0 || d->rope_period % d->rope_hd || d->rope_span % d->rope_hd || d->rope_span > d->rope_period || !(d->rope_log2_base > 0.f))

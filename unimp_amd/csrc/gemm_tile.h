@@ -69,19 +69,12 @@ __device__ __forceinline__ void epi8(const Gemm2Params& p, float (&v)[8], int m,
   if (p.pre && p.pre_deriv) {                 // y = act(v) and act'(v) from one exponential; store the derivative
     float dv[8];
     act_fwd_deriv_n<8>(p.act, v, dv);
-    if (p.pre_deriv == 2) {                     // derivative as uint8 (common.h DERIV_U8): ldpre counts bytes
-      uint8_t* d8 = (uint8_t*)p.pre + (long)m * p.ldpre + n;
-      uint32_t w0 = deriv_u8_pack4(dv[0], dv[1], dv[2], dv[3]), w1 = deriv_u8_pack4(dv[4], dv[5], dv[6], dv[7]);
-      if (FAST) *(uint2*)d8 = uint2{w0, w1};
-      else { for (int r = 0; r < nv; ++r) d8[r] = (uint8_t)(((r < 4 ? w0 : w1) >> (8 * (r & 3))) & 0xffu); }
-    } else {
-    bf16* d = p.pre + (long)m * p.ldpre + n;
+    bf16* d = p.pre + (long)m * p.ldpre + n;    // (the uint8 derivative never reaches this form: gemm.hip validate(), epi_kind)
     if (FAST) { bf16x8 o;
 #pragma unroll
       for (int r = 0; r < 8; ++r) o[r] = f2bf(dv[r]);
       *(bf16x8*)d = o; }
     else { for (int r = 0; r < nv; ++r) d[r] = f2bf(dv[r]); }
-    }
   } else {
     if (p.pre) {
       bf16* d = p.pre + (long)m * p.ldpre + n;
@@ -93,13 +86,7 @@ __device__ __forceinline__ void epi8(const Gemm2Params& p, float (&v)[8], int m,
     }
     if (p.act) act_fwd_n<8>(p.act, v);
   }
-  if (p.aux && p.dact == ACT_DERIV_U8) {       // stored derivative in 8 bits: ldaux counts bytes
-    const uint8_t* s8 = (const uint8_t*)p.aux + (long)m * p.ldaux + n;
-    if (FAST) { uint2 w = *(const uint2*)s8;
-#pragma unroll
-      for (int r = 0; r < 8; ++r) v[r] *= deriv_u8_get(r < 4 ? w.x : w.y, r & 3); }
-    else { for (int r = 0; r < nv; ++r) v[r] *= deriv_u8_get(s8[r], 0); }
-  } else if (p.aux) {
+  if (p.aux) {
     const bf16* s = p.aux + (long)m * p.ldaux + n;
     if (FAST) { bf16x8 x = PRE ? auxv : *(const bf16x8*)s;
       float xf[8];
@@ -164,8 +151,8 @@ __device__ __forceinline__ void epi_pass(const Gemm2Params& p, const char* er, i
 // ---- specialised epilogues ---------------------------------------------------------------------------------------------
 // The combinations the step actually uses, chosen once per tile (epi_kind) and compiled without inner option branches:
 //   EK_PLAIN  alpha (+bias)                                   -> C                 (qkv, dX of plain linears, weight gradients)
-//   EK_ACT    alpha (+bias), act, optional second output      -> C, pre            (MLP up-projection: act(z) and z or act'(z))
-//   EK_AUX    alpha (+bias), x stored act'(z)                 -> C                 (dX through the activation)
+//   EK_ACT    alpha (+bias), act, optional second output      -> C, pre            (MLP up-projection: act(z) and act'(z) as uint8)
+//   EK_AUX    alpha (+bias), x stored act'(z) (uint8)         -> C                 (dX through the activation)
 //   EK_RES    alpha (+bias), x tanh(gate), + residual         -> C (, raw pre)     (attention-out / MLP down-projection, gated xattn)
 // Every global load (bias, aux / residual chunks) is issued by epi_fetch() BEFORE the accumulators are staged and waited for
 // once (epi_inputs_ready) before the first store: a load consumed inside the store loop makes hipcc emit `s_waitcnt vmcnt(0)`
@@ -175,9 +162,12 @@ __device__ __forceinline__ void epi_pass(const Gemm2Params& p, const char* er, i
 enum { EK_PLAIN = 0, EK_ACT = 1, EK_AUX = 2, EK_RES = 3, EK_GENERIC = 4, EK_ROPE = 5 /* EK_PLAIN + rotary pairs (QKV projection) */ };
 __device__ __forceinline__ int epi_kind(const Gemm2Params& p, bool fast) {
   if (!fast || p.accumulate || (p.aux && p.res)) return EK_GENERIC;
-  if (p.aux) return ((p.dact == ACT_DERIV || p.dact == ACT_DERIV_U8) && !p.act && !p.pre) ? EK_AUX : EK_GENERIC;
+  // the specialised kinds serve the stored derivative in its 8-bit form only (what the MLP blocks use); a bf16 derivative or a raw
+  // pre-activation output takes the generic form -- one copy of each in the instruction cache instead of two
+  if (p.aux) return (p.dact == ACT_DERIV_U8 && !p.act && !p.pre) ? EK_AUX : EK_GENERIC;
   if (p.res) return (!p.act && !(p.pre && p.pre_deriv)) ? EK_RES : EK_GENERIC;     // a raw (pre-gate) second output is part of EK_RES
-  return (p.act || p.pre) ? EK_ACT : EK_PLAIN;                                        // every kind applies tanh(gate) (1 when absent)
+  if (p.pre) return p.pre_deriv == 2 ? EK_ACT : EK_GENERIC;
+  return p.act ? EK_ACT : EK_PLAIN;                                                   // every kind applies tanh(gate) (1 when absent)
 }
 template <int WN, int ROWS = 64>
 struct EpiPre {
@@ -198,7 +188,7 @@ __device__ __forceinline__ void epi_fetch(const Gemm2Params& p, int lane, int mb
   if ((kind != EK_AUX && kind != EK_RES) || n >= p.N) return;
   const bf16* src = kind == EK_AUX ? p.aux : p.res;
   const long ld = kind == EK_AUX ? p.ldaux : p.ldres;
-  if (kind == EK_AUX && p.dact == ACT_DERIV_U8) {                          // 8 bytes per chunk, kept in the low half of the register
+  if (kind == EK_AUX) {                                                    // uint8 derivative: 8 bytes per chunk, kept in the low half of the register
 #pragma unroll
     for (int u = 0; u < NIT; ++u) {
       int m = min(mbase + u * RPI + lane / LPR, p.M - 1);
@@ -239,33 +229,16 @@ __device__ __forceinline__ void epi8k(const Gemm2Params& p, float (&v)[8], int m
     }
   }
   if (KIND == EK_ACT) {
-    if (p.pre) {
+    if (p.pre) {                                // epi_kind: the second output of this kind is the uint8 derivative
       float dv[8];
-      if (p.pre_deriv) act_fwd_deriv_n<8>(p.act, v, dv);
-      else {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) dv[r] = v[r];
-        act_fwd_n<8>(p.act, v);
-      }
-      if (p.pre_deriv == 2) {
-        *(uint2*)((uint8_t*)p.pre + (long)m * p.ldpre + n) = uint2{deriv_u8_pack4(dv[0], dv[1], dv[2], dv[3]), deriv_u8_pack4(dv[4], dv[5], dv[6], dv[7])};
-      } else {
-        bf16x8 o;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) o[r] = f2bf(dv[r]);
-        *(bf16x8*)(p.pre + (long)m * p.ldpre + n) = o;
-      }
+      act_fwd_deriv_n<8>(p.act, v, dv);
+      *(uint2*)((uint8_t*)p.pre + (long)m * p.ldpre + n) = uint2{deriv_u8_pack4(dv[0], dv[1], dv[2], dv[3]), deriv_u8_pack4(dv[4], dv[5], dv[6], dv[7])};
     } else act_fwd_n<8>(p.act, v);
   }
-  if (KIND == EK_AUX) {
-    if (p.dact == ACT_DERIV_U8) {
-      union { bf16x8 b; uint2 q[2]; } cv; cv.b = x;
+  if (KIND == EK_AUX) {                         // epi_kind: the uint8 derivative
+    union { bf16x8 b; uint2 q[2]; } cv; cv.b = x;
 #pragma unroll
-      for (int r = 0; r < 8; ++r) v[r] *= deriv_u8_get(r < 4 ? cv.q[0].x : cv.q[0].y, r & 3);
-    } else {
-#pragma unroll
-      for (int r = 0; r < 8; ++r) v[r] *= bf2f(x[r]);
-    }
+    for (int r = 0; r < 8; ++r) v[r] *= deriv_u8_get(r < 4 ? cv.q[0].x : cv.q[0].y, r & 3);
   }
   if (KIND != EK_RES) {                       // the gated cross-attention's dX / dW GEMMs: x tanh(gate), after act / aux like the general form
 #pragma unroll

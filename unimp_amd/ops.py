@@ -74,7 +74,7 @@ def _tune_gemm(M, N, K, a_ks, b_ks, device, reads_mn=False):
         return v
     if not GEMM_AUTOTUNE or torch.cuda.is_current_stream_capturing():
         return 0
-    cands = [1] if (M < 512 or N < 128 or K < 128) else [1, 4, 5, 2, 3, 8, 9]
+    cands = [1] if (M < 512 or N < 128 or K < 128) else ([1, 4, 5, 8, 9] if reads_mn == "out2" else [1, 4, 5, 2, 3, 8, 9])   # "out2": the uint8 derivative
     if len(cands) == 1:
         _GEMM_CHOICE[key] = cands[0]
         return cands[0]
@@ -86,10 +86,10 @@ def _tune_gemm(M, N, K, a_ks, b_ks, device, reads_mn=False):
     d = GemmDesc()
     d.A, d.B, d.C, d.M, d.N, d.K = a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K
     d.lda, d.ldb, d.ldc, d.a_kstrided, d.b_kstrided, d.alpha = a.stride(0), b.stride(0), ldc, int(a_ks), int(b_ks), 1.0
-    if reads_mn == "out2":
-        r = torch.empty((M, ldc), dtype=bf16, device=device)
+    if reads_mn == "out2":                     # the form the MLP blocks use: act(z) and act'(z) as uint8
+        r = torch.empty((M, ldc), dtype=torch.uint8, device=device)
         bias = torch.zeros(r8(N), dtype=bf16, device=device)
-        d.pre, d.ldpre, d.pre_deriv, d.act, d.bias = r.data_ptr(), ldc, 1, ACT["gelu"], bias.data_ptr()
+        d.pre, d.ldpre, d.pre_deriv, d.act, d.bias = r.data_ptr(), ldc, 2, ACT["gelu"], bias.data_ptr()
     elif reads_mn:
         r = torch.randn((M, ldc), device=device, dtype=torch.float32).to(bf16)
         d.res, d.ldres = r.data_ptr(), ldc
@@ -381,6 +381,9 @@ def gemm(a, b, *, a_ks=False, b_ks=False, bias=None, act=None, res=None, aux=Non
                                                                       _tune_gemm(M, N, K, bool(a_ks), bool(b_ks), a.device,
                                                                                  True if (res is not None or aux is not None) else
                                                                                  ("out2" if pre is not None else False)))
+    if (d.pre_deriv == 2 or d.dact == ACT["deriv_u8"]) and variant is None and v in (0, 2, 3, 6, 7):
+        # the uint8 derivative lives in the kernels with the specialised epilogue kinds; 0 = the library's own choice, which may be a DMA variant
+        v = 1 if (M < 256 or N < 128) else (4 if N >= 256 else 5)
     if b_pk is not None and (forced_pk is not None or (variant is None and M >= PACKED_MIN_M and N >= 128 and K >= 128)):
         assert b_pk.N == N and b_pk.K == K, (b_pk.N, b_pk.K, N, K)
         vp = forced_pk or _tune_packed(M, N, K, bool(a_ks), a.device, res is not None or aux is not None, v, bool(b_ks))
