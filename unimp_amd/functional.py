@@ -355,8 +355,9 @@ class MLPBlockFn(Function):
         w1g, w2g = w1.requires_grad, w2.requires_grad
         bwd = any(ctx.needs_input_grad)            # frozen tower on constant inputs (the ViT): no act'(z) output, nothing saved
         mx = gate is None and _mx_ok(w1, M) and _mx_ok(w2, M)
-        # act'(z) for the backward: uint8 (ops / common.h DERIV_U8: step 1 / 202, 0 and 1 exact) unless the MX path writes it
-        pre = torch.empty((M, F), dtype=torch.uint8 if (DERIV_U8 and not mx and F % 8 == 0) else bf16, device=x.device) if bwd else None
+        # act'(z) for the backward: uint8 (ops / common.h DERIV_U8: step 1 / 202, 0 and 1 exact) unless the MX path or the decode-row kernel
+        # (M <= 64) writes it
+        pre = torch.empty((M, F), dtype=torch.uint8 if (DERIV_U8 and not mx and F % 8 == 0 and M > 64) else bf16, device=x.device) if bwd else None
         t1, t2 = FROZEN_WT and not w1g and M > 64, FROZEN_WT and not w2g and M > 64      # M <= 64: the weight-streaming decode kernel
         if mx:      # frozen tower on the MX-fp8 path: activations quantised on the fly (e4m3 + E8M0 per 32), fp32 accumulate
             a = ops.gemm_mx(ops.mx_quantize(h), _frozen_mx(w1), bias=b1, act=act, pre=pre)
