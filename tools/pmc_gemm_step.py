@@ -36,7 +36,8 @@ for label, m, n, k, aks, bks, epi, variant, inst in CASES:
     out = torch.empty((m, n), dtype=bf, device=dev)
     kw, extra = {}, 0
     if epi == "aux":
-        kw = dict(aux=torch.rand((m, n), device=dev).to(bf), dact="deriv"); extra = m * n * 2
+        # the product's form: the stored act'(z) as uint8 (functional.DERIV_U8)
+        kw = dict(aux=torch.randint(0, 256, (m, n), device=dev, dtype=torch.uint8), dact="deriv"); extra = m * n
     elif epi == "res":
         kw = dict(bias=torch.zeros(n, device=dev, dtype=bf), res=torch.randn((m, n), device=dev).to(bf)); extra = m * n * 2
     elif epi == "act":
@@ -44,7 +45,7 @@ for label, m, n, k, aks, bks, epi, variant, inst in CASES:
     elif epi == "act_q":
         kw = dict(bias=torch.zeros(n, device=dev, dtype=bf), act="quick_gelu")
     elif epi == "out2":
-        kw = dict(bias=torch.zeros(n, device=dev, dtype=bf), act="gelu", pre=torch.empty((m, n), dtype=bf, device=dev), pre_deriv=True); extra = m * n * 2
+        kw = dict(bias=torch.zeros(n, device=dev, dtype=bf), act="gelu", pre=torch.empty((m, n), dtype=torch.uint8, device=dev), pre_deriv=True); extra = m * n
     elif epi == "rope":
         kw = dict(bias=torch.zeros(n, device=dev, dtype=bf), rope=dict(rot=80, hd=80, period=240, span=160, L=512, log2_base=13.287712379549449))
     for _ in range(4):                                  # 1 warm-up + 3
