@@ -92,7 +92,10 @@ enum { UNIMP_GEMM_AUTO = 0, UNIMP_GEMM_V1 = 1, UNIMP_GEMM_DMA256 = 2, UNIMP_GEMM
        UNIMP_GEMM_W4 = 7 /* 256 x 256 tiles, 4 waves of 128 x 128 (one wave per SIMD) */,
        UNIMP_GEMM_W8 = 8 /* 256 x 256 tiles, 8 self-interleaving waves, one barrier per half-stage */,
        UNIMP_GEMM_PP256P = 9 /* PP256 as a persistent kernel: one workgroup per CU walks its tiles, the next tile's first
-                                LDS-DMA half-stages are issued before the current tile's epilogue */ };
+                                LDS-DMA half-stages are issued before the current tile's epilogue */,
+       UNIMP_GEMM_PP256X = 10, UNIMP_GEMM_PP128X = 11, UNIMP_GEMM_PP256PX = 12
+       /* PP256 / PP128 / PP256P with ONE fragment register set: the L phase of a half-step reads that half-step's own fragments
+          (before its LDS-DMA issue) and leaves two half-stages in flight instead of one -- 48 registers fewer, same bits */ };
 int unimp_gemm_bf16_variant(const unimp_gemm_desc* d, int variant, void* stream);
 /* split-K form for outputs much smaller than the chip (weight gradients of narrow projections): `splits` K slices into
  * f32 slabs [splits][M][N] (caller-provided workspace), then an ordered reduction applying alpha*tanh(gate).  Only the

@@ -88,7 +88,7 @@ def test_gemm_layouts(ops, M, N, K, a_ks, b_ks):
     bd = (b.t().contiguous() if b_ks else b).cuda()
     got = ops.gemm(ad, bd, a_ks=a_ks, b_ks=b_ks)                  # autotuned choice
     close(got, want, name=f"gemm {M}x{N}x{K} {a_ks}{b_ks}")
-    for variant in (["v1"] if M < 256 else ["v1", "dma256", "dma128", "pp256", "pp128", "w4", "w8", "pp256p"]):   # every kernel, explicitly
+    for variant in (["v1"] if M < 256 else ["v1", "dma256", "dma128", "pp256", "pp128", "w4", "w8", "pp256p", "pp256x", "pp128x", "pp256px"]):   # every kernel, explicitly
         got = ops.gemm(ad, bd, a_ks=a_ks, b_ks=b_ks, variant=variant)
         close(got, want, name=f"gemm[{variant}] {M}x{N}x{K} {a_ks}{b_ks}")
     got32 = ops.gemm(ad, bd, a_ks=a_ks, b_ks=b_ks, out_f32=True, variant="pp256" if M >= 256 else "v1")
@@ -104,14 +104,15 @@ def test_gemm_pingpong_long_k_race_screen(ops):
         ad, bd = a.cuda(), b.cuda()
         ref = ops.gemm(ad, bd, variant="v1")
         close(ref, want, name="v1 long k")
-        for variant in ("pp256", "pp128", "dma256", "pp256p"):
+        for variant in ("pp256", "pp128", "dma256", "pp256p", "pp256x", "pp128x", "pp256px"):
             outs = [ops.gemm(ad, bd, variant=variant) for _ in range(6)]
             for o in outs:
                 assert torch.equal(o, outs[0]), f"{variant}: run-to-run mismatch at K={K}"
             close(outs[0], want, name=f"{variant} long k")
 
 
-def test_gemm_persistent_many_tiles_per_workgroup(ops):
+@pytest.mark.parametrize("pv", ["pp256p", "pp256px", "pp256x"])
+def test_gemm_persistent_many_tiles_per_workgroup(ops, pv):
     """pp256p walks several tiles per workgroup (more tiles than CUs), ragged M / N edges, each epilogue kind; results must
     equal the one-tile-per-workgroup ping-pong kernel bit for bit (same accumulation order)."""
     M, N, K = 256 * 37 + 40, 256 * 9 + 136, 32 * 21
@@ -123,18 +124,18 @@ def test_gemm_persistent_many_tiles_per_workgroup(ops):
                dict(aux=resd, dact="deriv"), dict(out_f32=True)):
         want = ops.gemm(ad, bd, variant="pp256", **kw)
         for _ in range(3):
-            got = ops.gemm(ad, bd, variant="pp256p", **kw)
-            assert torch.equal(got, want), f"pp256p != pp256 for {sorted(kw)}"
+            got = ops.gemm(ad, bd, variant=pv, **kw)
+            assert torch.equal(got, want), f"{pv} != pp256 for {sorted(kw)}"
     pre_w = torch.empty(M, N, dtype=bf16, device="cuda"); pre_g = torch.empty_like(pre_w)
     want = ops.gemm(ad, bd, variant="pp256", bias=biasd, act="gelu", pre=pre_w, pre_deriv=True)
-    got = ops.gemm(ad, bd, variant="pp256p", bias=biasd, act="gelu", pre=pre_g, pre_deriv=True)
+    got = ops.gemm(ad, bd, variant=pv, bias=biasd, act="gelu", pre=pre_g, pre_deriv=True)
     assert torch.equal(got, want) and torch.equal(pre_g, pre_w)
     for a_ks, b_ks in ((False, True), (True, True), (True, False)):
         a2 = (a[:M - 40].t().contiguous() if a_ks else a[:M - 40]).cuda()
         b2 = (b.t().contiguous() if b_ks else b).cuda()
         want = ops.gemm(a2, b2, a_ks=a_ks, b_ks=b_ks, variant="pp256")
-        got = ops.gemm(a2, b2, a_ks=a_ks, b_ks=b_ks, variant="pp256p")
-        assert torch.equal(got, want), f"pp256p != pp256 for layout {a_ks}{b_ks}"
+        got = ops.gemm(a2, b2, a_ks=a_ks, b_ks=b_ks, variant=pv)
+        assert torch.equal(got, want), f"{pv} != pp256 for layout {a_ks}{b_ks}"
 
 
 def test_gemm_variants_same_bits_under_every_forward_epilogue(ops):
@@ -150,7 +151,7 @@ def test_gemm_variants_same_bits_under_every_forward_epilogue(ops):
         bias, res = rnd(N, seed=3).cuda(), rnd(M, N, seed=4).cuda()
         for kw in (dict(), dict(bias=bias), dict(res=res), dict(res=res, gate=gate), dict(bias=bias, res=res, gate=gate), dict(gate=gate), dict(act="gelu"),
                    dict(bias=bias, act="gelu"), dict(bias=bias, act="quick_gelu"), dict(alpha=0.125, bias=bias), dict(alpha=0.125, res=res, gate=gate)):
-            outs = {v: ops.gemm(a, b, variant=v, **kw) for v in ("v1", "dma256", "dma128", "pp256", "pp128", "w8", "pp256p")}
+            outs = {v: ops.gemm(a, b, variant=v, **kw) for v in ("v1", "dma256", "dma128", "pp256", "pp128", "w8", "pp256p", "pp256x", "pp128x", "pp256px")}
             for v, o in outs.items():
                 assert torch.equal(o, outs["v1"]), f"[{M}, {N}, {K}] {sorted(kw)}: {v} differs from v1 in {int((o != outs['v1']).sum())} elements"
     M, H, hd, L = 1024, 8, 80, 512
@@ -182,7 +183,7 @@ def test_gemm_stored_derivative_uint8(ops, M, N, K, act):
     a, b, bias = rnd(M, K, seed=1).cuda(), rnd(N, K, seed=2, scale=0.2).cuda(), rnd(N, seed=3).cuda()
     ld = (N + 7) // 8 * 8
     outs = {}
-    for v in (["v1"] if M < 256 else ["v1", "pp256", "pp128", "w8", "pp256p"]):       # the kernels with the specialised epilogue kinds
+    for v in (["v1"] if M < 256 else ["v1", "pp256", "pp128", "w8", "pp256p", "pp256x", "pp128x", "pp256px"]):       # the kernels with the specialised epilogue kinds
         q = torch.full((M, ld), 255, dtype=torch.uint8, device="cuda")
         y = ops.gemm(a, b, bias=bias, act=act, pre=q[:, :N], pre_deriv=True, variant=v)
         outs[v] = (y, q)
@@ -201,7 +202,7 @@ def test_gemm_stored_derivative_uint8(ops, M, N, K, act):
     # backward: dz = (dy W2) * g through the uint8 operand
     dy, w2 = rnd(M, 96, seed=5).cuda(), rnd(96, N, seed=6, scale=0.2).cuda()
     want = (dy.float() @ w2.float()) * dec
-    for v in (["v1"] if M < 256 else ["v1", "pp256", "pp128", "w8", "pp256p"]):
+    for v in (["v1"] if M < 256 else ["v1", "pp256", "pp128", "w8", "pp256p", "pp256x", "pp128x", "pp256px"]):
         got = ops.gemm(dy, w2, b_ks=True, aux=q0[:, :N], dact="deriv", variant=v)
         close(got, want, name=f"dz through uint8 act' [{v}]")
     ref16 = ops.gemm(dy, w2, b_ks=True, aux=g16[:, :N], dact="deriv", variant="v1")
@@ -219,6 +220,19 @@ def test_gemm_stored_derivative_uint8(ops, M, N, K, act):
     e8 = float((got - truth).norm() / truth.norm())
     e16 = float((ref16.float().cpu() - truth).norm() / truth.norm())
     assert e8 <= max(2.0 * e16, 6e-3), (e8, e16)
+
+
+def test_stored_derivative_uint8_decodes_0_and_1_exactly(ops):
+    """KAT for common.h deriv_u8_get: byte 27 is EXACTLY 0 (a dead ReLU / GELU unit passes no gradient, not -7e-9 dy) and
+    byte 229 is exactly 1 (the product equals the plain GEMM bit for bit), in every kernel that serves the uint8 operand."""
+    M, N, K = 512, 512, 256
+    dy, w2 = rnd(M, K, seed=41).cuda(), rnd(K, N, seed=42, scale=0.2).cuda()
+    for v in ("v1", "pp256", "pp128", "w8", "pp256p", "pp256x", "pp128x", "pp256px"):
+        plain = ops.gemm(dy, w2, b_ks=True, variant=v)
+        zero = ops.gemm(dy, w2, b_ks=True, aux=torch.full((M, N), 27, dtype=torch.uint8, device="cuda"), dact="deriv", variant=v)
+        one = ops.gemm(dy, w2, b_ks=True, aux=torch.full((M, N), 229, dtype=torch.uint8, device="cuda"), dact="deriv", variant=v)
+        assert torch.all(zero == 0), f"{v}: byte 27 leaks {float(zero.float().abs().max())}"
+        assert torch.equal(one, plain), f"{v}: byte 229 is not exactly 1"
 
 
 def test_gemm_ragged_n_padded_rows(ops):
@@ -261,7 +275,7 @@ def test_gemm_epilogue_bias_act_pre(ops, act, M):
     N, K = 264, 136
     a, b, bias = rnd(M, K, seed=3), rnd(N, K, seed=4, scale=0.2), rnd(N, seed=5)
     z = a.float() @ b.float().t() + bias.float()
-    for variant in (["v1"] if M < 256 else ["v1", "dma128", "pp256", "pp128", "pp256p"]):
+    for variant in (["v1"] if M < 256 else ["v1", "dma128", "pp256", "pp128", "pp256p", "pp256x", "pp128x", "pp256px"]):
         pre = torch.empty(M, N, dtype=bf16, device="cuda")
         got = ops.gemm(a.cuda(), b.cuda(), bias=bias.cuda(), act=act, pre=pre, variant=variant)
         close(pre, z, name="pre")
@@ -725,7 +739,7 @@ def _adjacent_perm(hd, rot):
     return torch.where(p < rot, d, p)
 
 
-@pytest.mark.parametrize("variant", ["pp256", "pp256p"])
+@pytest.mark.parametrize("variant", ["pp256", "pp256p", "pp256x", "pp256px"])
 @pytest.mark.parametrize("nh,hd,rot,interleaved,L", [(4, 80, 80, True, 200), (6, 64, 16, True, 128), (3, 128, 128, False, 300),
                                                      (4, 80, 80, True, 2304), (2, 128, 128, False, 4100)])      # positions >= 2048
 def test_gemm_rotary_epilogue(ops, variant, nh, hd, rot, interleaved, L):

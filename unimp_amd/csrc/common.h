@@ -60,8 +60,10 @@ __device__ __forceinline__ uint32_t deriv_u8_pack4(float a, float b, float c, fl
   r = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(d, DERIV_U8_SCALE, DERIV_U8_ZERO), 3, r);
   return r;
 }
-__device__ __forceinline__ float deriv_u8_get(uint32_t w, int byte) {       // v_cvt_f32_ubyte{0..3} + one fma
-  return fmaf((float)((w >> (8 * byte)) & 0xffu), 1.f / DERIV_U8_SCALE, -DERIV_U8_ZERO / DERIV_U8_SCALE);
+// (q - 27) is exact in fp32, so q = 27 decodes to exactly 0 and q = 229 to exactly 1 (202 * fl(1 / 202) rounds to 1); the earlier
+// single-fma form `q / 202 - 27 / 202` used two separately rounded constants and gave -7e-9 for q = 27
+__device__ __forceinline__ float deriv_u8_get(uint32_t w, int byte) {       // v_cvt_f32_ubyte{0..3}, v_sub, v_mul
+  return mul_rn(add_rn((float)((w >> (8 * byte)) & 0xffu), -DERIV_U8_ZERO), 1.f / DERIV_U8_SCALE);
 }
 
 // erf-GELU with ONE exponential: Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below bf16 resolution);

@@ -28,6 +28,13 @@
 // Same k grouping inside the MFMAs as the unpacked kernel: bit-identical results.
 #include "gemm_half.h"
 
+#ifdef G3X            // second build of this file with other schedule switches, under its own symbols (Makefile: gemm3x.o)
+#define gemm3_bf16_kernel gemm3x_bf16_kernel
+#define unimp_gemm3_launch unimp_gemm3x_launch
+#define unimp_gemm3_launch_splitk unimp_gemm3x_launch_splitk
+#define launch3 launch3x
+#endif
+
 #define G3_BM 256
 #ifndef G3_NST
 #define G3_NST 4          // LDS ring depth in 32-k half-stages (4 x 32 KiB for 256 x 256 tiles; 5 = the whole 160 KiB LDS measured no faster)
@@ -94,8 +101,13 @@ __global__ __launch_bounds__(512, 2) void gemm3_bf16_kernel(Gemm2Params p) {
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifndef G3_ONESET
   bf16x8 ra0[8], rb0[NJ], ra1[8], rb1[NJ];                  // k-contiguous operands: whole fragments
   s16x4 la0[8], ha0[8], lb0[NJ], hb0[NJ], la1[8], ha1[8], lb1[NJ], hb1[NJ];   // k-strided operands: two tr halves
+#else
+  bf16x8 ra0[8], rb0[NJ];
+  s16x4 la0[8], ha0[8], lb0[NJ], hb0[NJ];
+#endif
 
   int nh = (p.K + 31) >> 5;
 
@@ -127,6 +139,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_bf16_kernel(Gemm2Params p) {
       bf16x8 fa_ = AKS ? join_halves(la##S[i], ha##S[i]) : ra##S[i];                                               \
       _Pragma("unroll") for (int j = 0; j < NJ; ++j) acc[i][j] = MFMA16(fb_[j], fa_, acc[i][j]); }                 \
     G3_PRIO(0); } while (0)
+#ifndef G3_ONESET
 // one half-step: L phase (prefetch h+3, fragments of h+1 -> RN), barrier, C phase (MFMA on RC), barrier
 #define HALF_STEP(H, SC, SN) do {                                                                                  \
     if ((H) + PD < nh) DMA((H) + PD);                                                                              \
@@ -138,12 +151,33 @@ __global__ __launch_bounds__(512, 2) void gemm3_bf16_kernel(Gemm2Params p) {
     G3_BARRIER();                                                                                                  \
     MFMAS(SC);                                                                                                     \
     G3_BARRIER(); } while (0)
+#else
+// ONE fragment register set: the L phase of half-step h reads the fragments of h ITSELF (they are complete at the lgkmcnt(0) of the
+// barrier that ends the phase, which is all the C phase needs), fragment reads first so that they land while the wave is held by its
+// LDS-DMA issue, and the DMA wait is one half-step more relaxed: half-step h+1 must have landed (the other group reads it in the next
+// interval), h+2 and h+3 stay in flight.  48 registers fewer than the two-set form.
+static_assert(G3_NST == 4, "the one-set schedule is written for a prefetch distance of 3");
+#define HALF_STEP(H, SC, SN) do {                                                                                  \
+    LOADF(0, (H));                                                                                                 \
+    if ((H) + PD < nh) { DMA((H) + PD); asm volatile("s_waitcnt vmcnt(%0)" :: "n"((PD - 1) * NEW) : "memory"); }   \
+    else if ((H) + PD - 1 < nh) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((PD - 2) * NEW) : "memory");             \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                          \
+    G3_BARRIER();                                                                                                  \
+    MFMAS(0);                                                                                                      \
+    G3_BARRIER(); } while (0)
+#endif
 
   constexpr int PD = G3_NST - 1;                        // prefetch distance in half-steps
   for (int h0 = 0; h0 < PD && h0 < nh; ++h0) DMA(h0);
+#ifndef G3_ONESET
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   G3_BARRIER();
   LOADF(0, 0);
+#else
+  if (nh >= PD) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((PD - 1) * NEW) : "memory");      // half-step 0 has landed; 1 and 2 stay in flight
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  G3_BARRIER();
+#endif
   G3_T(1);
   if (wm == 1) G3_BARRIER();                            // group B runs one phase behind group A
   for (int h = 0; h < nh; h += 2) {
@@ -233,8 +267,13 @@ extern "C" int unimp_gemm3_launch_splitk(const unimp_gemm_desc* d, int bn, int s
 #define L3(AK, BK_) do { if (bn == 256) launch3<AK, BK_, 256>(p, s, slices); else launch3<AK, BK_, 128>(p, s, slices); } while (0)
 #define L3P(AK) do { if (bn == 256) launch3<AK, false, 256, true>(p, s, 1); else launch3<AK, false, 128, true>(p, s, 1); } while (0)
   if (p.rope_rot) { launch3<false, false, 256, false, true>(p, s, 1); return 1; }      // host-validated: k-contiguous operands, 256-wide tiles
+#ifndef G3_ONESET
   if (b == 2) { if (a) L3P(true); else L3P(false); }
-  else if (!a && !b) L3(false, false); else if (!a && b) L3(false, true); else if (a && b) L3(true, true); else L3(true, false);
+  else
+#else
+  if (b == 2) return 0;      // the packed-B loads need their own look-ahead register set: served by the two-set build only
+#endif
+  if (!a && !b) L3(false, false); else if (!a && b) L3(false, true); else if (a && b) L3(true, true); else L3(true, false);
 #undef L3
 #undef L3P
   return 1;

@@ -8,6 +8,12 @@
 // Main loop, LDS images, DMA addressing: gemm3.hip / gemm_half.h.  Epilogue kinds: gemm_tile.h.
 #include "gemm_half.h"
 
+#ifdef G3X            // second build of this file with other schedule switches, under its own symbols (Makefile: gemm6x.o)
+#define gemm6_bf16_kernel gemm6x_bf16_kernel
+#define unimp_gemm6_launch unimp_gemm6x_launch
+#define launch6 launch6x
+#endif
+
 #define G3_BM 256
 #define G3_NST 4
 #ifdef G3_NO_PRIO
@@ -62,6 +68,7 @@ __global__ __launch_bounds__(512, 2) void gemm6_bf16_kernel(Gemm2Params p) {
       bf16x8 fa_ = AKS ? join_halves(la##S[i], ha##S[i]) : ra##S[i];                                               \
       _Pragma("unroll") for (int j = 0; j < NJ; ++j) acc[i][j] = MFMA16(fb_[j], fa_, acc[i][j]); }                 \
     G3_PRIO(0); } while (0)
+#ifndef G3_ONESET
 // one half-step: L phase (prefetch h+3, fragments of h+1 -> RN), barrier, C phase (MFMA on RC), barrier
 #define HALF_STEP(H, SC, SN) do {                                                                                  \
     if ((H) + PD < nh) DMA((H) + PD);                                                                              \
@@ -73,6 +80,17 @@ __global__ __launch_bounds__(512, 2) void gemm6_bf16_kernel(Gemm2Params p) {
     G3_BARRIER();                                                                                                  \
     MFMAS(SC);                                                                                                     \
     G3_BARRIER(); } while (0)
+#else
+// one fragment register set (gemm3.hip, G3_ONESET): L(h) reads the fragments of h itself, reads before the DMA issue, h+2 / h+3 in flight
+#define HALF_STEP(H, SC, SN) do {                                                                                  \
+    LOADF(0, (H));                                                                                                 \
+    if ((H) + PD < nh) { DMA((H) + PD); asm volatile("s_waitcnt vmcnt(%0)" :: "n"((PD - 1) * NEW) : "memory"); }   \
+    else if ((H) + PD - 1 < nh) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((PD - 2) * NEW) : "memory");             \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                          \
+    G3_BARRIER();                                                                                                  \
+    MFMAS(0);                                                                                                      \
+    G3_BARRIER(); } while (0)
+#endif
 
 
   int t = blockIdx.x;
@@ -82,15 +100,22 @@ __global__ __launch_bounds__(512, 2) void gemm6_bf16_kernel(Gemm2Params p) {
     // accumulators and fragment registers are scoped to one tile: declared outside the loop the compiler has to assume the
     // fragments live across the back-edge (through the whole epilogue) and spills
     f32x4 acc[8][NJ];
+#ifndef G3_ONESET
     bf16x8 ra0[8], rb0[NJ], ra1[8], rb1[NJ];                  // k-contiguous operands: whole fragments
     s16x4 la0[8], ha0[8], lb0[NJ], hb0[NJ], la1[8], ha1[8], lb1[NJ], hb1[NJ];   // k-strided operands: two tr halves
+#else
+    bf16x8 ra0[8], rb0[NJ];
+    s16x4 la0[8], ha0[8], lb0[NJ], hb0[NJ];
+#endif
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
       for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this tile's first half-stages (and the previous tile's stores)
     G3_BARRIER();                                           // ... of every wave; everybody has left the previous epilogue
+#ifndef G3_ONESET
     LOADF(0, 0);
+#endif
     if (wm == 1) G3_BARRIER();                            // group B runs one phase behind group A
     for (int h = 0; h < nh; h += 2) {
       HALF_STEP(h, 0, 1);
