@@ -310,7 +310,7 @@ def main():
     # N = 1 only: an exception on one rank of several would leave the others waiting in the leg's barrier -- the headline is not put at risk
     if world == 1 and not (args.packed or args.no_packed_leg or args.graph or args.fuse_accum or args.fp8 or args.sparse_head or GA > 1):
         try:
-            F_.PACKED = True
+            model.lang_encoder.packed = True
             for _ in range(4):                       # both row counts of the packed batches (28 672 / 30 720 at b = 64) pass the allocator once
                 one_step()
             torch.cuda.synchronize()
@@ -339,7 +339,7 @@ def main():
         except Exception as e:       # noqa: BLE001  (the headline must not depend on the opt-in leg)
             packed_leg = {"error": f"{type(e).__name__}: {e}"}
         finally:
-            F_.PACKED = False
+            model.lang_encoder.packed = False
     exposed = trainer.dp.exposed_ms() if dp_on else []
     rccl = None
     if dp_on:
@@ -415,7 +415,7 @@ def main():
                            "tflop_per_sample": round(fps["total"] / 1e12, 3),
                            "tflop_per_sample_note": "executed FLOPs (SURVEY 8d formulae); the LM head's backward runs on the labeled positions only"
                                                     if hb else "SURVEY 8d formulae, dense head backward",
-                           "hip_graph": bool(args.graph), "packed_token_order": bool(F_.PACKED), "fused_accumulation": bool(args.fuse_accum and GA > 1),
+                           "hip_graph": bool(args.graph), "packed_token_order": bool(trainer.packed), "fused_accumulation": bool(args.fuse_accum and GA > 1),
                            "head_backward": "dense" if args.dense_head_backward else "labeled rows only (zero rows of dlogits skipped; same gradients)",
                            "model_tflops_per_gpu": round(value / world * fps["total"] / 1e12, 1),
                            "mfma_frac_whole_step": round(value / world * fps["total"] / 1e12 / PEAK_BF16_TFLOPS, 4),

@@ -220,3 +220,34 @@ def test_host_logic_cpu():
     assert ((ids != lay.pad).long() == b["attention_mask"]).all()
     lab = ots.label_mask(ids.numpy(), lay.answer, lay.eoc, lay.pad, lay.media)
     assert ((lab != -100).sum(1) == 9 + 1).all()        # 9 item answers + EOS after the last answer
+
+
+def _worker_save_load(rank, world, port, q, path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from unimp_amd.train import save_checkpoint, load_checkpoint
+    torch.manual_seed(0)
+    m = torch.nn.Linear(300, 200)
+    m.weight.data.fill_(1.5 + 0 * rank)                      # replicas hold identical weights
+    save_checkpoint(path, m, barrier=True)                   # every rank calls; returns once rank 0's file exists
+    m2 = torch.nn.Linear(300, 200)
+    load_checkpoint(path, m2)                                # ... so every rank can read it straight away
+    assert torch.equal(m2.weight, m.weight) and torch.equal(m2.bias, m.bias)
+    q.put((rank, "ok"))
+    dist.destroy_process_group()
+
+
+def test_save_checkpoint_barrier_then_load_on_every_rank_world2(tmp_path):
+    """with replicated optimizer state ``save_checkpoint`` is not a collective (the reference's rank-0-writes pattern); a
+    caller that loads on every rank right after the save passes ``barrier=True``."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    path = str(tmp_path / "w.pt")
+    procs = [ctx.Process(target=_worker_save_load, args=(r, world, port, q, path)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert sorted(q.get(timeout=5) for _ in range(world)) == [(0, "ok"), (1, "ok")]

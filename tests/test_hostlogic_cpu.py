@@ -167,3 +167,35 @@ def test_pack_maps_right_padded_batches_to_row_ranges(monkeypatch):
     monkeypatch.setattr(F_, "PACK_ROUND", 8)
     with pytest.raises(ValueError):
         F_.Pack(left)
+
+
+def test_packed_flag_is_per_tower_and_qk_ln_towers_keep_the_padded_path(monkeypatch):
+    """packed token order is a property of the tower (lm._TowerBase.packed), not a process global that a second Trainer
+    flips for the first; a tower without a packed-row form (MosaicGPT with QK-LayerNorm, Llama) never packs -- under UNIMP_PACKED=1 it
+    keeps the padded path instead of raising NotImplementedError in the middle of a forward."""
+    from unimp_amd import functional as F_, lm
+    mask = torch.zeros(4, 64, dtype=torch.int64)
+    mask[:, :5] = 1
+    monkeypatch.setattr(F_, "PACK_ROUND", 8)
+    neox = lm.build_lm(lm._Cfg(model_type="gpt_neox", vocab_size=64, hidden_size=32, num_hidden_layers=1, num_attention_heads=4,
+                               intermediate_size=64, rotary_pct=1.0, rotary_emb_base=10000.0, layer_norm_eps=1e-5, max_position_embeddings=64,
+                               use_parallel_residual=False))
+    other = lm.build_lm(lm._Cfg(model_type="gpt_neox", vocab_size=64, hidden_size=32, num_hidden_layers=1, num_attention_heads=4,
+                                intermediate_size=64, rotary_pct=1.0, rotary_emb_base=10000.0, layer_norm_eps=1e-5, max_position_embeddings=64,
+                                use_parallel_residual=False))
+    neox.train(); other.train()
+    monkeypatch.setattr(F_, "PACKED", False)
+    assert neox._pack(mask, None) is None
+    neox.packed = True                                        # what Trainer(packed=True) sets
+    assert neox._pack(mask, None) is not None and other._pack(mask, None) is None
+    assert neox._pack(mask, object()) is None                 # cached decode never packs
+    neox.eval()
+    assert neox._pack(mask, None) is None
+    cfg = lm.MosaicGPTConfig()
+    assert cfg.attn_qk_ln
+    monkeypatch.setattr(F_, "PACKED", True)                   # UNIMP_PACKED=1
+    assert lm.LlamaForCausalLM.supports_packed is False
+    class _T(lm._TowerBase):
+        supports_packed = False
+        training = True
+    assert _T._pack(_T.__new__(_T), mask, None) is None

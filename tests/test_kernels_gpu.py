@@ -174,6 +174,32 @@ def test_forward_gemm_rows_do_not_depend_on_the_row_count(ops):
             assert torch.equal(got[:512], want), f"[{M}, {N}, {K}]: the first 512 rows differ from the M = 512 call in {int((got[:512] != want).sum())} elements"
 
 
+def test_forward_gemm_recomputed_inside_a_backward_pass_keeps_its_bits(ops):
+    """split-K eligibility is declared by the backward bodies (ops.backward_scope), not sniffed from the autograd engine: a
+    FORWARD GEMM that runs while autograd's backward is executing (activation checkpointing recomputes the forward there) takes the
+    forward's path and produces the forward's bits; the same call from a declared backward body may split."""
+    a, b = rnd(1024, 2560, seed=7).cuda(), rnd(512, 2560, seed=8, scale=0.05).cuda()      # the gated cross-attention's to_q: 16 tiles
+    want = ops.gemm(a, b)
+    seen = {}
+
+    class Recompute(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x * 1.0
+
+        @staticmethod
+        def backward(ctx, dy):                      # NOT a backward_scope body: this is a recomputed forward
+            seen["recomputed"] = ops.gemm(a, b)
+            return dy
+
+    x = torch.ones(4, device="cuda", requires_grad=True)
+    Recompute.apply(x).sum().backward()
+    assert torch.equal(seen["recomputed"], want)
+    assert ops._IN_BACKWARD == 0
+    inside = ops.backward_scope(lambda: ops._IN_BACKWARD)()
+    assert inside == 1 and ops._IN_BACKWARD == 0
+
+
 @pytest.mark.parametrize("M,N,K,act", [(512, 1024, 256, "gelu"), (300, 520, 192, "gelu"), (1024, 2560, 512, "quick_gelu"), (128, 264, 128, "gelu")])
 def test_gemm_stored_derivative_uint8(ops, M, N, K, act):
     """act'(z) in 8 bits (pre_deriv = 2 / dact = 6: q = round(202 g + 27)): the up-projection's second output and the backward's aux

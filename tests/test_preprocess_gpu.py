@@ -45,6 +45,30 @@ def test_ragged_batch_against_oracle(pre):
         pre()([np.zeros((4, 4), dtype=np.uint8)])
 
 
+def test_submit_while_the_compute_stream_still_owns_the_block(pre):
+    """the ring's device buffer comes from the compute stream's allocator pool.  A block the host has just freed while
+    kernels that write it are still queued must not receive the copy before those kernels ran (first use of a slot and every
+    regrow): here a [cap] byte tensor is written at the END of a long queue of GEMMs, freed, and the next submit() takes a slot of
+    exactly that size -- the preprocessed batch must equal the one computed on an idle device."""
+    from unimp_amd import ops
+    rng = np.random.default_rng(5)
+    imgs = [rng.integers(0, 256, (640, 480, 3), dtype=np.uint8) for _ in range(8)]
+    want = pre(dtype=torch.float32)(imgs).clone()
+    torch.cuda.synchronize()
+    a = torch.randn(8192, 4096, device="cuda").to(torch.bfloat16)
+    w = torch.randn(4096, 4096, device="cuda").to(torch.bfloat16)
+    for trial in range(3):
+        p = pre(dtype=torch.float32)                        # fresh ring: the first submit allocates
+        cap = max(sum(i.size for i in imgs) + (1 << 16), 1 << 20)
+        junk = torch.empty(cap, dtype=torch.uint8, device="cuda")
+        for _ in range(40):                                 # ~20 ms of queued work in front of the write
+            ops.gemm(a, w)
+        junk.fill_(0xAB)
+        del junk                                            # back to the pool while the fill is still queued
+        got = p.submit(imgs).get()
+        assert torch.equal(got, want), f"trial {trial}: {int((got != want).sum())} elements differ"
+
+
 def test_feeds_the_model_contract(pre):
     """a (b, T) list of decoded images becomes vision_x (b, T, 1, 3, 224, 224) bf16 on the device (mmrec.py:135-141)."""
     rng = np.random.default_rng(1)

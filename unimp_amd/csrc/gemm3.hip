@@ -61,6 +61,11 @@ __device__ __forceinline__ void frag_packed_asm(const void* sbase, uint32_t voff
   asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(out) : "v"(voff), "s"(sbase) : "memory");
 }
 
+// one byte per lane from 64 different lines: brings the lines into the XCD's L2 (and this CU's L1); the value is never used
+__device__ __forceinline__ void pf_touch(const void* sbase, uint32_t voff, uint32_t& sink) {
+  asm volatile("global_load_ubyte %0, %1, %2" : "=v"(sink) : "v"(voff), "s"(sbase) : "memory");
+}
+
 template <bool AKS, bool BKS, int BN, bool BPK = false, bool ROPE = false>
 __global__ __launch_bounds__(512, 2) void gemm3_bf16_kernel(Gemm2Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -158,6 +163,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_bf16_kernel(Gemm2Params p) {
 // interval), h+2 and h+3 stay in flight.  48 registers fewer than the two-set form.
 static_assert(G3_NST == 4, "the one-set schedule is written for a prefetch distance of 3");
 #define HALF_STEP(H, SC, SN) do {                                                                                  \
+    if ((H) == pf_h) pf_touch(pf_base, pf_off0, pf0); else if ((H) == pf_h + 1) pf_touch(pf_base, pf_off1, pf1);   \
     LOADF(0, (H));                                                                                                 \
     if ((H) + PD < nh) { DMA((H) + PD); asm volatile("s_waitcnt vmcnt(%0)" :: "n"((PD - 1) * NEW) : "memory"); }   \
     else if ((H) + PD - 1 < nh) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((PD - 2) * NEW) : "memory");             \
@@ -168,6 +174,33 @@ static_assert(G3_NST == 4, "the one-set schedule is written for a prefetch dista
 #endif
 
   constexpr int PD = G3_NST - 1;                        // prefetch distance in half-steps
+#ifdef G3_ONESET
+  // L2 warm-up of the epilogue's per-element input (residual tile / stored act'(z)): a CU on its own pulls ~10 B per cycle from HBM or
+  // the Infinity Cache (MI355X_MICROARCH "prologue HBM burst"), so the 128 KiB residual tile of a 256 x 256 output cost the epilogue
+  // 5+ us of exposed fetch while every matrix pipe of the CU idled (fit over K: +11 us per tile against the plain epilogue).  G3_PF_DIST
+  // half-steps before the end of K each wave touches one byte of every 128-B line of its [128 x WN] sub-tile -- two wave instructions,
+  // lane = row -- so the epilogue's own 16-byte loads find the lines in the XCD's L2.  The two result registers are only kept alive
+  // (never read); the loads are counted by the main loop's vmcnt like everything else (in order: the phase that issues one waits
+  // for one LDS-DMA more than it needs, nothing else changes).  Pure performance: no bit of the output depends on it.
+#ifndef G3_PF_DIST
+#define G3_PF_DIST 8
+#endif
+  const char* pf_base = nullptr;
+  uint32_t pf_off0 = 0, pf_off1 = 0, pf0 = 0, pf1 = 0;
+  int pf_h = -2;
+  {
+    const bool u8 = p.aux && p.dact == ACT_DERIV_U8;
+    const char* src = p.res ? (const char*)p.res : (const char*)p.aux;
+    const long ld = p.res ? p.ldres : p.ldaux, esz = (p.res || !u8) ? 2 : 1;
+    const int n = n0 + wn * WN;
+    if (src && !(p.res && p.aux) && n < p.N && ((long)p.M * ld + p.N) * esz < (1l << 32) && p.ksplit == 0) {
+      pf_base = src;
+      pf_off0 = (uint32_t)(((long)min(m0 + wm * 128 + lane, p.M - 1) * ld + n) * esz);
+      pf_off1 = (uint32_t)(((long)min(m0 + wm * 128 + 64 + lane, p.M - 1) * ld + n) * esz);
+      pf_h = max(nh - G3_PF_DIST, 0);
+    }
+  }
+#endif
   for (int h0 = 0; h0 < PD && h0 < nh; ++h0) DMA(h0);
 #ifndef G3_ONESET
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -185,6 +218,9 @@ static_assert(G3_NST == 4, "the one-set schedule is written for a prefetch dista
     if (h + 1 < nh) HALF_STEP(h + 1, 1, 0);
   }
   if (wm == 0) G3_BARRIER();                            // equalise the barrier count; all LDS reads are complete
+#ifdef G3_ONESET
+  asm volatile("" :: "v"(pf0), "v"(pf1));               // the warm-up loads' destination registers stayed reserved until here (vmcnt(0) above)
+#endif
   G3_T(2);
 #undef DMA
 #undef LOADF

@@ -66,10 +66,15 @@ class _Slot:
         self.kernel_done = torch.cuda.Event()
 
     def reserve(self, nbytes, device):
+        """make room for nbytes; True if the device buffer was (re)allocated.  A fresh block comes from the caching allocator's pool of
+        the CURRENT (compute) stream and may be one the host has just freed while kernels that use it are still queued there: the
+        caller must order the copy stream behind the compute stream before the first copy into it."""
         if self.host is None or self.host.numel() < nbytes:
             cap = max(nbytes, 2 * (self.host.numel() if self.host is not None else 0), 1 << 20)
             self.host = torch.empty(cap, dtype=torch.uint8, pin_memory=True)
             self.dev = torch.empty(cap, dtype=torch.uint8, device=device)
+            return True
+        return False
 
 
 class PendingImages:
@@ -177,7 +182,7 @@ class ImagePreprocessor:
         sl = self._ring[self._next]
         self._next = (self._next + 1) % self._depth
         sl.h2d_done.synchronize()                            # the previous copy OUT of this pinned buffer has finished (normally long ago)
-        sl.reserve(total, self.device)
+        fresh = sl.reserve(total, self.device)
         hb = sl.host.numpy()
         pos = 0
         for a in imgs:                                       # packed straight into pinned memory: no concatenate, no pageable staging
@@ -189,6 +194,12 @@ class ImagePreprocessor:
         hb[d_off:d_off + C.sizeof(descs)] = np.frombuffer(descs, dtype=np.uint8)
         cs = self._copy_stream
         cs.wait_event(sl.kernel_done)                        # the kernels that read this slot's previous device bytes are done
+        if fresh:
+            # first use / regrow: kernel_done says nothing about this block.  Whatever the compute stream still has queued on the block's
+            # previous owner must finish before the copy writes it (and must not write over the copied bytes afterwards); the block is
+            # also used on the copy stream from now on, which the allocator has to know before it hands the block out again.
+            cs.wait_stream(torch.cuda.current_stream(self.device))
+            sl.dev.record_stream(cs)
         with torch.cuda.stream(cs):
             sl.dev[:total].copy_(sl.host[:total], non_blocking=True)
             sl.h2d_done.record(cs)

@@ -144,6 +144,7 @@ class PackRowsFn(Function):
         return ops.gather_rows(x, pack.idx)
 
     @staticmethod
+    @ops.backward_scope
     def backward(ctx, dy):
         return ops.gather_rows(dy.contiguous(), ctx.pack.inv), None
 
@@ -157,6 +158,7 @@ class UnpackRowsFn(Function):
         return ops.gather_rows(x, pack.inv)
 
     @staticmethod
+    @ops.backward_scope
     def backward(ctx, dy):
         return ops.gather_rows(dy.contiguous(), ctx.pack.idx), None
 
@@ -173,6 +175,7 @@ class LayerNormFn(Function):
         return y.view(shp)
 
     @staticmethod
+    @ops.backward_scope
     def backward(ctx, dy):
         x2, w, mean, rstd = ctx.saved_tensors
         dy2 = dy.reshape(-1, ctx.shp[-1])
@@ -201,6 +204,7 @@ class LinearFn(Function):
             y.as_strided((*shp[:-1], w.shape[0]), _lead_strides(shp[:-1], ldc) + (1,), y.storage_offset())
 
     @staticmethod
+    @ops.backward_scope
     def backward(ctx, dy):
         x2, w = ctx.saved_tensors
         _no_bias_grad(ctx, ctx.b_idx, "bias")
@@ -375,6 +379,7 @@ class MLPBlockFn(Function):
         return out.view(shp)
 
     @staticmethod
+    @ops.backward_scope
     def backward(ctx, dy):
         x2, ln_w, mean, rstd, w1, w2, gate, pre, h, a, raw = ctx.saved_tensors
         _no_bias_grad(ctx, 5, "b1")
@@ -421,6 +426,7 @@ class SwiGLUBlockFn(Function):
         return out.view(shp)
 
     @staticmethod
+    @ops.backward_scope
     def backward(ctx, dy):
         x2, ln_w, rstd, w_gu, w_down, gu, h, a = ctx.saved_tensors
         dy2 = dy.reshape(-1, ctx.shp[-1])
@@ -576,6 +582,7 @@ class SelfAttnBlockFn(Function):
         return (dx.view(1, M, H), dres, dg, db, dwqkv, None, dwd, None) + (None,) * 10
 
     @staticmethod
+    @ops.backward_scope
     def backward(ctx, dy):
         if ctx.pack is not None:
             return SelfAttnBlockFn._backward_packed(ctx, dy)
@@ -825,6 +832,7 @@ class GatedXAttnFn(Function):
         return out.view(x.shape)
 
     @staticmethod
+    @ops.backward_scope
     def backward(ctx, dy):
         x2, m2, seg, ln_w, mean, rstd, wq, wkv, wo, gate, h, q, kv, o, lse = ctx.saved_tensors
         B, L, D, Sk, heads, dh, n_lat = ctx.cfg
@@ -890,6 +898,7 @@ class PerceiverAttnFn(Function):
         return out.view(G, n2, D)
 
     @staticmethod
+    @ops.backward_scope
     def backward(ctx, dy):
         x2, l2, nm_w, nl_w, mean_m, rstd_m, mean_l, rstd_l, wq, wkv, wo, kvin, hl, q, kv, o, lse = ctx.saved_tensors
         G, n1, n2, D, heads, dh = ctx.cfg
@@ -931,6 +940,7 @@ class BcastRowsFn(Function):
         return ops.bcast_rows(lat, G * lat.shape[0])
 
     @staticmethod
+    @ops.backward_scope
     def backward(ctx, dy):
         return ops.reduce_rows_periodic(dy.contiguous(), ctx.n), None
 
@@ -945,6 +955,7 @@ class EmbeddingFn(Function):
         return out.view(*ids.shape, w.shape[1])
 
     @staticmethod
+    @ops.backward_scope
     def backward(ctx, dy):
         ids, pos = ctx.saved_tensors
         dy2 = dy.reshape(-1, dy.shape[-1])
@@ -976,6 +987,7 @@ class FocalCEFn(Function):
         return loss, out3
 
     @staticmethod
+    @ops.backward_scope
     def backward(ctx, dloss, _):
         logits, labels, weights, lse, zy, out3 = ctx.saved_tensors
         gamma, rw = ctx.cfg
@@ -1009,6 +1021,7 @@ class SparseHeadLossFn(Function):
         return out3[0] / out3[1], out3
 
     @staticmethod
+    @ops.backward_scope
     def backward(ctx, dloss, _):
         h_rows, w, logits, labels, row_w, lse, zy, out3 = ctx.saved_tensors
         gamma, rw = ctx.cfg
@@ -1047,6 +1060,7 @@ class DenseHeadLossFn(Function):
         return out3[0] / out3[1], out3, logits
 
     @staticmethod
+    @ops.backward_scope
     def backward(ctx, dloss, _a, _b):
         h2, w, logits, labels, weights, lse, zy, out3, rows = ctx.saved_tensors
         gamma, rw, B, L, H = ctx.cfg

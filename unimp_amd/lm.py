@@ -68,10 +68,15 @@ def _pad8(n):
 class _TowerBase(nn.Module):
     """shared: resize_token_embeddings (HF semantics), kv_len from the attention mask, head + loss."""
     tied = False
+    packed = None              # packed token order for THIS tower: True / False (Trainer(packed=...)), None = the UNIMP_PACKED default
+    supports_packed = True     # False: the tower's blocks have no packed-row form (Llama; MosaicGPT with QK-LayerNorm)
 
     def _pack(self, attention_mask, cache):
-        """the functional.Pack of a training forward in packed token order (Trainer(packed=True)), or None"""
-        if not (F_.PACKED and cache is None and attention_mask is not None and self.training):
+        """the functional.Pack of a training forward in packed token order (Trainer(packed=True)), or None.  The flag lives on the
+        tower (a second Trainer does not change the first one's behaviour); a tower without a packed-row form keeps the padded
+        path under the environment default and is refused by Trainer(packed=True) up front."""
+        want = F_.PACKED if self.packed is None else self.packed
+        if not (want and self.supports_packed and cache is None and attention_mask is not None and self.training):
             return None
         pack = F_.Pack(attention_mask)                     # packed token order: the tower never computes the <PAD> rows
         return pack if pack.useful else None
@@ -464,6 +469,7 @@ class _LlamaModel(nn.Module):
 
 class LlamaForCausalLM(_TowerBase):
     decoder_layers_attr = "model.layers"
+    supports_packed = False
 
     def __init__(self, config):
         super().__init__()
@@ -686,6 +692,7 @@ class MosaicGPT(MptForCausalLM):
     def __init__(self, config):
         _TowerBase.__init__(self)
         self.config = config
+        self.supports_packed = not config.attn_qk_ln          # SelfAttnBlockFn's packed form has no QK-LayerNorm
         self.transformer = _MosaicBody(config)
         self.lm_head = nn.Linear(config.d_model, config.vocab_size, bias=False)
         self.lm_head.weight = self.transformer.wte.weight

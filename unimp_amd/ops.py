@@ -113,6 +113,24 @@ def _tune_gemm(M, N, K, a_ks, b_ks, device, reads_mn=False):
     return best
 
 
+_IN_BACKWARD = 0
+
+
+def backward_scope(fn):
+    """decorator for ``Function.backward`` bodies: the GEMMs they issue are backward GEMMs (dX / dW) and may run under split-K"""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*a, **k):
+        global _IN_BACKWARD
+        _IN_BACKWARD += 1
+        try:
+            return fn(*a, **k)
+        finally:
+            _IN_BACKWARD -= 1
+    return wrapped
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -350,7 +368,9 @@ def gemm(a, b, *, a_ks=False, b_ks=False, bias=None, act=None, res=None, aux=Non
     # dX form (dy [M, K] x W [K, N], k-strided weight) INSIDE a backward pass with few 256 x 256 tiles and a deep K: at the
     # reference's shipped shape (3 x 512 tokens) [1536, 2560] x K = 10240 / 7680 is 60 tiles -- the 128 x 128 kernel ran them at
     # 0.44-0.48 PFLOP/s (r3d per-shape table).  Forward GEMMs never split (their summation order must not depend on the batch size).
-    in_bwd = torch._C._current_graph_task_id() >= 0
+    in_bwd = _IN_BACKWARD > 0      # set by functional.py's Function.backward bodies (ops.backward_scope), NOT sniffed from the autograd engine:
+    #                                a forward recomputed inside a backward pass (activation checkpointing) must not take split-K paths
+    #                                the original forward did not
     dx_split = (not a_ks) and b_ks and M >= 256 and N >= 256 and K >= 5120 and tiles256 <= 128 and plain and variant is None and in_bwd
     wide = M >= 256 and N >= 256 and a_ks and b_ks   # weight-gradient form only (a forward GEMM of a small batch must not change
     #                                                  its summation order with the batch size); 256 x 256 ping-pong tiles under split-K

@@ -43,7 +43,7 @@ def get_checkpoint(model):
     return sd
 
 
-def save_checkpoint(path, model, trainer=None, epoch=0):
+def save_checkpoint(path, model, trainer=None, epoch=0, barrier=False):
     """UniMP writes only the trainable tensors (mmrec.py:873-892: ``get_checkpoint``) and never the optimizer, so its
     resume path is broken.  Same file format for the weights -- a flat ``{name: tensor}`` dict that
     ``model.load_state_dict(sd, strict=False)`` consumes -- plus, optionally, a side file with the fp32 optimizer state
@@ -52,7 +52,8 @@ def save_checkpoint(path, model, trainer=None, epoch=0):
     Calling convention under data parallelism:
       * replicated optimizer state (default): NOT a collective.  Rank 0 writes, every other rank returns at once without
         building any host copy -- the reference's pattern (mmrec.py:772-873: ``wait_for_everyone()`` then ``if args.rank == 0:``
-        save) ports as is, and a caller that wants the file to exist on return on every rank adds its own barrier.
+        save) ports as is.  ``barrier=True`` makes it a collective that every rank calls and that returns once the file exists
+        (save-then-load-on-every-rank patterns) -- without it a rank other than 0 may race rank 0's ``torch.save``.
       * sharded optimizer state (``Trainer(shard_optimizer=True)``) with a trainer given: a COLLECTIVE -- **every rank must
         call it**: the owned slices are gathered bucket by bucket, rank 0 keeps the host copy and writes, and a barrier
         closes the call so no rank runs ahead into the next step's collectives."""
@@ -60,6 +61,8 @@ def save_checkpoint(path, model, trainer=None, epoch=0):
     rank0 = not dist.is_initialized() or dist.get_rank() == 0
     sharded = trainer is not None and trainer.opt.shard is not None
     if not rank0 and not sharded:
+        if barrier and dist.is_initialized():
+            dist.barrier()
         return
     o = None
     if trainer is not None:
@@ -71,6 +74,8 @@ def save_checkpoint(path, model, trainer=None, epoch=0):
             torch.save({"epoch": epoch, "sched_step": trainer.sched_step, "optimizer": o}, path + ".resume")
     if sharded:
         dist.barrier(group=trainer.opt.shard[3])
+    elif barrier and dist.is_initialized():
+        dist.barrier()
 
 
 def load_checkpoint(path, model, trainer=None):
@@ -182,9 +187,13 @@ class Trainer:
             raise ValueError("Trainer(graph=True) needs the sync-free dense loss path (sparse_head takes a row count on the host)")
         self.use_graph, self._graph = graph, None
         self.fuse_accum, self._stash, self._last = bool(fuse_accum and grad_accum > 1), [], (None, None)
-        if packed is not None:
-            F_.PACKED = bool(packed)
-        if graph and F_.PACKED:
+        le_ = model.lang_encoder
+        if packed is not None:                   # per tower, not the module-level default: a second Trainer leaves this one alone
+            if packed and not getattr(le_, "supports_packed", True):
+                raise ValueError(f"Trainer(packed=True): {type(le_).__name__} has no packed-row form (QK-LayerNorm / Llama towers); use packed=False")
+            le_.packed = bool(packed)
+        self.packed = bool(F_.PACKED if getattr(le_, "packed", None) is None else le_.packed) and getattr(le_, "supports_packed", True)
+        if graph and self.packed:
             raise ValueError("Trainer(graph=True) cannot be combined with the packed token order (its valid-token count is a host sync per step)")
         self.grad_accum, self._micro = grad_accum, 0       # mmrec.py's --gradient_accumulation_steps (accelerator.accumulate)
         self.ids = special_ids                   # dict(answer_id, eoc_id, pad_id, media_id)
