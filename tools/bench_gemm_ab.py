@@ -24,6 +24,16 @@ SHAPES = [
     ("vit down +res     ", MV, 1024, 4096, 0, 0, "res"),
     ("vit qkv +bias     ", MV, 3072, 1024, 0, 0, "bias"),
     ("vit out +res      ", MV, 1024, 1024, 0, 0, "res"),
+    # forward GEMMs with the (frozen) weight read from a transposed copy: B k-strided, whole 512-B lines per LDS-DMA row
+    ("lm up  W^T +gelu2 ", ML, 10240, 2560, 0, 1, "gelu2"),
+    ("lm down W^T +res  ", ML, 2560, 10240, 0, 1, "res"),
+    ("lm qkv W^T +bias  ", ML, 7680, 2560, 0, 1, "bias"),
+    ("lm qkv     +bias  ", ML, 7680, 2560, 0, 0, "bias"),
+    ("lm attn-out W^T+res", ML, 2560, 2560, 0, 1, "res"),
+    ("vit up W^T +qgelu ", MV, 4096, 1024, 0, 1, "qgelu"),
+    ("vit down W^T +res ", MV, 1024, 4096, 0, 1, "res"),
+    ("vit qkv W^T +bias ", MV, 3072, 1024, 0, 1, "bias"),
+    ("vit out W^T +res  ", MV, 1024, 1024, 0, 1, "res"),
     ("xattn dW          ", 10240, 2560, ML, 1, 1, "plain"),
     ("xattn dW^T        ", 2560, 10240, ML, 1, 1, "plain"),
 ]

@@ -33,6 +33,8 @@
 #define unimp_gemm3_launch unimp_gemm3x_launch
 #define unimp_gemm3_launch_splitk unimp_gemm3x_launch_splitk
 #define launch3 launch3x
+#define g3_stamps g3x_stamps
+#define unimp_debug_g3_stamps unimp_debug_g3x_stamps
 #endif
 
 #define G3_BM 256
