@@ -268,8 +268,10 @@ def main():
     ap.add_argument("--packed", action="store_true", help="Trainer(packed=True): the language tower's row-wise kernels run on the valid tokens only "
                     "(the synthetic batches are filled 75-100 %%: 12.5 %% of the B x L rows are <PAD>); same loss / gradients; NOT the headline")
     ap.add_argument("--no-packed-leg", action="store_true", help="skip the short opt-in measurement (packed token order) that follows the timed steps")
-    ap.add_argument("--fuse-accum", action="store_true", help="Trainer(fuse_accum=True): the --grad-accum micro-batches of an optimizer step run as ONE "
-                    "pass over GA x batch samples with per-micro-batch loss normalisation (same update; fills the GEMM tiles GA times better)")
+    ap.add_argument("--no-shape-legs", action="store_true", help="skip the short legs at the reference's shipped shape (b = 3, GA 2) and b = 16 / 32")
+    ap.add_argument("--fuse-accum", action="store_true", help="(the default since round 4 whenever --grad-accum > 1; kept for old command lines) the "
+                    "micro-batches of an optimizer step run as ONE pass over GA x batch samples with per-micro-batch loss normalisation (same update)")
+    ap.add_argument("--no-fuse-accum", action="store_true", help="Trainer(fuse_accum=False): sequential micro-steps as the reference runs them")
     ap.add_argument("--graph", action="store_true", help="Trainer(graph=True): forward + loss + backward of a micro-batch replayed as one HIP graph "
                     "(small per-GPU batches are launch-bound: the reference's shipped shape --batch 3 --grad-accum 2); implies --dense-head-backward")
     ap.add_argument("--bucket-mb", type=int, default=256, help="gradient bucket size of the data-parallel exchange (MiB)")
@@ -321,7 +323,7 @@ def main():
                       lr_scheduler="cosine", warmup_steps=10, total_steps=10000, sparse_head=args.sparse_head,
                       grad_accum=args.grad_accum, dense_head_backward=args.dense_head_backward,
                       shard_optimizer=args.shard_optimizer and dp_on, bucket_bytes=args.bucket_mb << 20,
-                      force_dp_hooks=args.dp_hooks, graph=args.graph, fuse_accum=args.fuse_accum, packed=args.packed or None)
+                      force_dp_hooks=args.dp_hooks, graph=args.graph, fuse_accum=False if args.no_fuse_accum else None, packed=args.packed or None)
     if args.graph:
         args.dense_head_backward = True
     trainer.dp.record_exposed = dp_on
@@ -384,7 +386,7 @@ def main():
     # (Trainer(packed=True): no <PAD> row is computed; same loss and gradients).  Reported beside the headline, never as `value`.
     packed_leg = None
     # N = 1 only: an exception on one rank of several would leave the others waiting in the leg's barrier -- the headline is not put at risk
-    if world == 1 and not (args.packed or args.no_packed_leg or args.graph or args.fuse_accum or args.fp8 or args.sparse_head or GA > 1):
+    if world == 1 and not (args.packed or args.no_packed_leg or args.graph or args.fp8 or args.sparse_head or GA > 1):
         try:
             model.lang_encoder.packed = True
             for _ in range(4):                       # both row counts of the packed batches (28 672 / 30 720 at b = 64) pass the allocator once
@@ -416,6 +418,55 @@ def main():
             packed_leg = {"error": f"{type(e).__name__}: {e}"}
         finally:
             model.lang_encoder.packed = False
+    # third, SHORT legs: the reference's own shipped shape (unimp_task.sh:2-30: --batch_size 3 --gradient_accumulation_steps 2; the two
+    # micro-batches of an optimizer step run as one pass -- Trainer's default, same update) and SURVEY 8d's other per-GPU batches, so
+    # that the driver's record carries them beside the b = 64 headline.  Same model, fresh batch pools, HIP events around the GEMMs of
+    # the timed steps (their own roofline fraction).  N = 1, default configuration only; never `value`.
+    shape_legs = None
+    if world == 1 and not (args.no_shape_legs or args.packed or args.graph or args.fp8 or args.sparse_head or GA > 1 or nine
+                           or args.task != "rec" or args.batch != 64 or args.dp_hooks):
+        shape_legs = {}
+
+        def _leg(tr_, b_, ga_, n_steps, n_warm):
+            pool_ = [make_batch(layout, b_, T, L, seed=4321 + 1000 * i, device=dev, vision_dtype=torch.bfloat16) for i in range(min(16, (n_steps + n_warm) * ga_))]
+            k_ = [0]
+
+            def step_():
+                for _ in range(ga_):
+                    o_ = tr_.step(pool_[k_[0] % len(pool_)])
+                    k_[0] += 1
+                return o_
+            for _ in range(n_warm):
+                step_()
+            torch.cuda.synchronize()
+            ops.GEMM_PROFILE = []
+            t0_ = time.perf_counter()
+            for _ in range(n_steps):
+                l_, _ = step_()
+            torch.cuda.synchronize()
+            dt_ = time.perf_counter() - t0_
+            pr_, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
+            g_ms = sum(r[0].elapsed_time(r[1]) for r in pr_)
+            g_fl = sum(r[2] for r in pr_)
+            return {"value": round(ga_ * b_ * n_steps / dt_, 3), "unit": "samples/s", "per_gpu_batch": b_, "grad_accum": ga_, "ms_per_step": round(dt_ / n_steps * 1e3, 2),
+                    "steps": n_steps, "warmup": n_warm, "loss": float(l_), "fused_accumulation": bool(tr_.fuse_accum),
+                    "gemm_ms_per_step": round(g_ms / n_steps, 2), "roofline_frac": round(g_fl / (g_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if g_ms else None}
+        try:
+            for b_ in (32, 16):
+                shape_legs[f"b{b_}"] = _leg(trainer, b_, 1, 8, 3)
+            tr2 = Trainer(model, layout.special(), lr=2e-4, weight_decay=0.1, gamma=2.0, use_reweight=True, lr_scheduler="cosine",
+                          warmup_steps=10, total_steps=10000, grad_accum=2)
+            try:
+                shape_legs["reference_shape_b3_ga2"] = dict(_leg(tr2, 3, 2, 12, 4), note="unimp_task.sh:2-30 (--batch_size 3 --gradient_accumulation_steps 2): "
+                                                            "one optimizer step = 6 samples; the two micro-batches run as one pass (Trainer default, same update: "
+                                                            "tests/test_model_gpu.py::test_fused_accumulation_equals_sequential)")
+            finally:
+                tr2.dp.remove()
+                del tr2
+        except Exception as e:       # noqa: BLE001  (the headline must not depend on the extra legs)
+            shape_legs["error"] = f"{type(e).__name__}: {e}"
+        finally:
+            ops.GEMM_PROFILE = None
     exposed = trainer.dp.exposed_ms() if dp_on else []
     rccl = None
     if dp_on:
@@ -511,13 +562,13 @@ def main():
                            "tflop_per_sample": round(fps["total"] / 1e12, 3),
                            "tflop_per_sample_note": "executed FLOPs (SURVEY 8d formulae); the LM head's backward runs on the labeled positions only"
                                                     if hb else "SURVEY 8d formulae, dense head backward",
-                           "hip_graph": bool(args.graph), "packed_token_order": bool(trainer.packed), "fused_accumulation": bool(args.fuse_accum and GA > 1),
+                           "hip_graph": bool(args.graph), "packed_token_order": bool(trainer.packed), "fused_accumulation": bool(trainer.fuse_accum),
                            "head_backward": "dense" if args.dense_head_backward else "labeled rows only (zero rows of dlogits skipped; same gradients)",
                            "model_tflops_per_gpu": round(value / world * fps["total"] / 1e12, 1),
                            "mfma_frac_whole_step": round(value / world * fps["total"] / 1e12 / PEAK_BF16_TFLOPS, 4),
                            **({"note": "--sparse-head: the utilisation fields above still count the dense head's FLOPs"}
                               if args.sparse_head else {})},
-                "roofline": roofline, "cpu_baseline": cpu, **({"parity": parity} if parity else {}), **({"rccl": rccl} if rccl else {}), **({"packed_token_order": packed_leg} if packed_leg else {})}
+                "roofline": roofline, "cpu_baseline": cpu, **({"parity": parity} if parity else {}), **({"rccl": rccl} if rccl else {}), **({"packed_token_order": packed_leg} if packed_leg else {}), **({"other_shapes": shape_legs} if shape_legs else {})}
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if dist.is_initialized():

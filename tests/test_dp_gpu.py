@@ -18,14 +18,21 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, backend="gloo", own_device=False):
+    """backend "gloo": both ranks on cuda:0 (a 1-GPU box); backend "nccl" with own_device: rank r on cuda:r over RCCL (armed by
+    test_two_rank_rccl_step_on_two_gpus when the box has a second GPU)."""
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = rank if own_device else 0
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        assert dist.get_world_size() == world and dist.get_backend() == backend
         import _parity as P
         from unimp_amd.optim import FlatAdamW
         from unimp_amd.train import Trainer
@@ -47,6 +54,8 @@ def _worker(rank, world, port, q):
         hm = P.build_hip(cfg, om, layout)
         tr = Trainer(hm, layout.special(), lr=1e-3, lr_scheduler="constant", bucket_bytes=1 << 16)       # several buckets
         assert tr.dp.world == world and len(tr.dp.buckets) > 3
+        from unimp_amd import ops
+        assert ops.AVOID_PERSISTENT and ops._PERSISTENT_TWIN[9] == 4           # more than one rank: no persistent GEMM variant beside the collectives
         loss, _, _, _ = tr.forward_loss(batch)
         assert tr._sink is not None and tr._sink.dp is tr.dp
         tr._backward(loss)       # production backward: dW GEMMs add into the flat buffer and notify the bucketer themselves
@@ -110,6 +119,8 @@ def _worker_rccl(q, port):
         hm = P.build_hip(cfg, om, layout)
         tr = Trainer(hm, layout.special(), lr=1e-3, lr_scheduler="constant", bucket_bytes=1 << 16, force_dp_hooks=True)
         assert tr.dp.active and tr.dp.world == 1 and len(tr.dp.buckets) > 3
+        from unimp_amd import ops
+        assert not ops.AVOID_PERSISTENT                                        # one rank: the autotuned choice stands
         tr.dp.record_exposed = True
         losses = [tr.step(b)[0].item() for b in batches]
         assert tr.dp.last_launch_log == tr.dp._order + tr.dp._late_buckets and len(tr.dp.last_launch_log) == len(tr.dp.buckets)
@@ -143,11 +154,13 @@ def _worker_shard(rank, world, port, q, backend):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     try:
-        torch.cuda.set_device(0)
+        dev = rank if (backend == "nccl" and world > 1) else 0          # RCCL wants one device per rank
+        torch.cuda.set_device(dev)
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
+        assert dist.get_world_size() == world
         import _parity as P
         from unimp_amd.train import Trainer
         cfg = P.TINY
@@ -284,3 +297,96 @@ def test_bench_gpus2_starts_its_own_ranks():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "2",
                         "--no-cpu-baseline", "--model", "nonexistent"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
+
+
+# ---- armed on boxes with a second GPU (VERDICT r3 #7b): RCCL with more than one rank.  Every case starts fresh child processes (never
+# re-exec a process that touched the GPU) and skips on a 1-GPU box, so the suite stays green where only one device exists.
+def _need_two_gpus():
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL takes one device per rank)")
+
+
+def test_two_rank_rccl_step_on_two_gpus():
+    """the production data-parallel step over RCCL / xGMI: rank r on cuda:r, bucketed async all-reduce from the autograd hooks, the
+    same summed gradient on both ranks parameter by parameter, replicas bit-identical after three steps (the checks of
+    test_two_rank_step_on_one_gpu, with the real transport)."""
+    _need_two_gpus()
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, "nccl", True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(60)
+    assert all(r[1] == "ok" for r in res), res
+
+
+def test_sharded_optimizer_state_two_rank_rccl():
+    """dp.py's reduce_scatter_tensor / all_gather_into_tensor path (optim.FlatAdamW shard) with TWO RCCL ranks against the replicated
+    update: parameters equal up to the clip norm's summation order, checkpoint of the sharded state resumes bit-identically."""
+    _need_two_gpus()
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_shard, args=(r, 2, port, q, "nccl")) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=400) for _ in range(2))
+    for p in procs:
+        p.join(60)
+    assert all(r[1] == "ok" for r in res), res
+
+
+def test_bench_gpus2_over_rccl():
+    """``python bench.py --gpus 2`` with the default backend (RCCL): one JSON line whose rccl object reports the world size RCCL itself
+    reports, every bucket issued, a positive whole-job value."""
+    _need_two_gpus()
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "UNIMP_DIST_BACKEND")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for extra in ([], ["--shard-optimizer"]):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--batch", "4",
+                            "--no-cpu-baseline", "--bucket-mb", "64"] + extra, env=env, capture_output=True, text=True, timeout=1200)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        j = json.loads(lines[0])
+        rc = j["rccl"]
+        assert j["n_gpus"] == 2 and rc["backend"] == "nccl" and rc["world_size"] == 2 and j["value"] > 0
+        assert sorted(rc["issue_order"]) == list(range(rc["buckets"]))
+        assert ("sharded" in rc["optimizer_state"]) == bool(extra)
+
+
+def test_dp_hooks_on_one_rank_cost_under_two_percent():
+    """VERDICT r3 #7c: the N > 1 code path under a 1-rank RCCL group (`bench.py --dp-hooks`: bucketed async all-reduce from the hooks,
+    stream hand-off, finish()) against the plain N = 1 run of the same command in the same test: the hooks may cost at most 2 % of the
+    step (measured 0.2-1.3 %; box noise between two runs of the SAME command is ~0.5 %).  b = 16, 8 steps each, run twice, best of two."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0")
+
+    def run(extra):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "8", "--warmup", "4", "--batch", "16", "--no-cpu-baseline",
+                            "--no-roofline", "--no-packed-leg", "--no-shape-legs"] + extra, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    plain, hooks = [], []
+    for _ in range(2):
+        plain.append(run([])["ms_per_step"])
+        j = run(["--dp-hooks"])
+        hooks.append(j["ms_per_step"])
+        assert j["rccl"]["world_size"] == 1 and j["rccl"]["backend"] == "nccl"
+    print(f"\n[dp hooks, 1-rank RCCL] plain {plain} ms, hooks {hooks} ms per step")
+    assert min(hooks) <= 1.02 * min(plain), (plain, hooks)

@@ -345,8 +345,10 @@ def test_flamingo_over_mpt_generate_cached_equals_rescoring():
     assert k.shape[0] == 3 and torch.equal(k[:, :n], ids.expand(3, -1))
 
 
-def test_gradient_accumulation_equals_one_step_on_the_same_batch():
-    """grad_accum = 2 over two identical micro-batches is one optimizer step with that batch's gradient ((g + g) / 2)."""
+@pytest.mark.parametrize("fuse", [None, False])
+def test_gradient_accumulation_equals_one_step_on_the_same_batch(fuse):
+    """grad_accum = 2 over two identical micro-batches is one optimizer step with that batch's gradient ((g + g) / 2), in the default
+    (fused: both micro-batches in one pass) and in the sequential form."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     import _parity as P
@@ -357,7 +359,7 @@ def test_gradient_accumulation_equals_one_step_on_the_same_batch():
     res = {}
     for ga in (1, 2):
         hm = P.build_hip(cfg, om, layout)
-        tr = Trainer(hm, layout.special(), lr=1e-2, lr_scheduler="constant", grad_accum=ga)
+        tr = Trainer(hm, layout.special(), lr=1e-2, lr_scheduler="constant", grad_accum=ga, fuse_accum=fuse)
         before = tr.opt.master.clone()
         for _ in range(ga):
             tr.step(batch)
@@ -384,7 +386,8 @@ def test_scheduler_and_accumulation_stepping(P):
     om, layout = P.build_oracle(cfg)
     hm = P.build_hip(cfg, om, layout)
     GA, warm, total, base = 2, 4, 24, 3e-4
-    tr = Trainer(hm, layout.special(), lr=base, lr_scheduler="cosine", warmup_steps=warm // GA, total_steps=total // GA, grad_accum=GA)
+    tr = Trainer(hm, layout.special(), lr=base, lr_scheduler="cosine", warmup_steps=warm // GA, total_steps=total // GA, grad_accum=GA,
+                 fuse_accum=False)                       # the sequential form: 1 / GA rides in the optimizer's gradient scale
     ref_opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=base)
     ref = transformers.get_cosine_schedule_with_warmup(ref_opt, num_warmup_steps=warm // GA, num_training_steps=total // GA)
     used, scales = [], []
@@ -672,13 +675,15 @@ def test_fused_accumulation_equals_sequential(P, reweight):
         res[mode] = (losses, grads, tr.opt.master.clone())
         tr.dp.remove()
     (ls, gs, ms), (lf, gf, mf) = res["sequential"], res["fused"]
+    assert Trainer(P.build_hip(cfg, om, layout), layout.special(), grad_accum=2).fuse_accum            # the default with grad_accum > 1
+    assert not Trainer(P.build_hip(cfg, om, layout), layout.special(), grad_accum=2, graph=True, dense_head_backward=True).fuse_accum
     assert len(gs) == len(gf) == 2
     for k in range(2):
         want = 0.5 * (ls[2 * k] + ls[2 * k + 1])                  # accelerate: each micro-batch loss / GA
         assert abs(lf[2 * k + 1] - want) <= 2e-3 * abs(want), (lf, ls)
         e = P.rel_l2(gf[k], gs[k])
         assert e <= 2e-2, (k, e)
-    assert lf[0] is None and lf[2] == lf[1]                       # buffered micro-steps return the previous optimizer step's loss
+    assert lf[0] == 0.0 and lf[2] == lf[1]                        # buffered micro-steps return the previous optimizer step's loss (zero before the first)
     assert P.rel_l2(mf, ms) <= 5e-3                               # fp32 masters after two AdamW steps (Adam amplifies tiny gradients' noise)
 
 

@@ -515,9 +515,9 @@ extern "C" int unimp_gemm_bf16_variant(const unimp_gemm_desc* d, int variant, vo
         d->rope_period <= 0 || d->rope_period % d->rope_hd || d->rope_span % d->rope_hd || d->rope_span > d->rope_period || !(d->rope_log2_base > 0.f))
       return unimp_set_error(UNIMP_ERR_ARG, "gemm: rotary epilogue needs rot % 8 == 0 <= hd, hd % 8 == 0, period / span multiples of hd, L > 0, base > 1");
     if (d->M >= (1 << 24)) return unimp_set_error(UNIMP_ERR_SHAPE, "gemm: rotary epilogue needs M < 2^24");
-    bool kern = (variant == UNIMP_GEMM_PP256 || variant == UNIMP_GEMM_PP256P || variant == UNIMP_GEMM_PP256X || variant == UNIMP_GEMM_PP256PX) && !d->a_kstrided && !d->b_kstrided;
+    bool kern = (variant == UNIMP_GEMM_PP256 || variant == UNIMP_GEMM_PP256P || variant == UNIMP_GEMM_PP256X || variant == UNIMP_GEMM_PP256PX) && !d->a_kstrided && d->b_kstrided != 2;
     if (!kern || d->res || d->aux || d->pre || d->act || d->dact || d->accumulate || d->gate || d->out_f32 || (d->N & 7) || (d->ldc & 7) || d->M < 256 || d->N < 128)
-      return unimp_set_error(UNIMP_ERR_UNSUPPORTED, "gemm: the rotary epilogue is served by variants pp256 / pp256p on k-contiguous operands with a plain (alpha, bias) bf16 epilogue, N % 8 == 0, ldc % 8 == 0");
+      return unimp_set_error(UNIMP_ERR_UNSUPPORTED, "gemm: the rotary epilogue is served by variants pp256 / pp256p (and their one-set forms) with a k-contiguous A operand, an unpacked B operand and a plain (alpha, bias) bf16 epilogue, N % 8 == 0, ldc % 8 == 0");
   }
   switch (variant) {
     case UNIMP_GEMM_V1: launch_v1(d, stream); break;

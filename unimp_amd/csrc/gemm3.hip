@@ -26,6 +26,7 @@
 // reads + 16 KiB of DMA writes instead of 96 + 32 KiB: with B through the LDS the LDS pipe (128 B/clk) is as busy as the matrix
 // pipe (128 KiB per 1024 MFMA cycles), which is what held every schedule of this family at 52-57 % MFMA utilisation.
 // Same k grouping inside the MFMAs as the unpacked kernel: bit-identical results.
+#include <stdlib.h>
 #include "gemm_half.h"
 
 #ifdef G3X            // second build of this file with other schedule switches, under its own symbols (Makefile: gemm3x.o)
@@ -63,13 +64,10 @@ __device__ __forceinline__ void frag_packed_asm(const void* sbase, uint32_t voff
   asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(out) : "v"(voff), "s"(sbase) : "memory");
 }
 
-// one byte per lane from 64 different lines: brings the lines into the XCD's L2 (and this CU's L1); the value is never used
-__device__ __forceinline__ void pf_touch(const void* sbase, uint32_t voff, uint32_t& sink) {
-  asm volatile("global_load_ubyte %0, %1, %2" : "=v"(sink) : "v"(voff), "s"(sbase) : "memory");
-}
-
-template <bool AKS, bool BKS, int BN, bool BPK = false, bool ROPE = false>
+// EPI: -1 = epilogue kind chosen per tile at run time (every form); EK_ROPE / EK_PLAIN / EK_ACT / EK_GELU2 / EK_AUX / EK_RES = that kind only
+template <bool AKS, bool BKS, int BN, bool BPK = false, int EPI = -1>
 __global__ __launch_bounds__(512, 2) void gemm3_bf16_kernel(Gemm2Params p) {
+  constexpr bool ROPE = EPI == EK_ROPE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   G3_T(0);
 #ifdef G3_STAMP
@@ -165,7 +163,6 @@ __global__ __launch_bounds__(512, 2) void gemm3_bf16_kernel(Gemm2Params p) {
 // interval), h+2 and h+3 stay in flight.  48 registers fewer than the two-set form.
 static_assert(G3_NST == 4, "the one-set schedule is written for a prefetch distance of 3");
 #define HALF_STEP(H, SC, SN) do {                                                                                  \
-    if ((H) == pf_h) pf_touch(pf_base, pf_off0, pf0); else if ((H) == pf_h + 1) pf_touch(pf_base, pf_off1, pf1);   \
     LOADF(0, (H));                                                                                                 \
     if ((H) + PD < nh) { DMA((H) + PD); asm volatile("s_waitcnt vmcnt(%0)" :: "n"((PD - 1) * NEW) : "memory"); }   \
     else if ((H) + PD - 1 < nh) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((PD - 2) * NEW) : "memory");             \
@@ -176,33 +173,6 @@ static_assert(G3_NST == 4, "the one-set schedule is written for a prefetch dista
 #endif
 
   constexpr int PD = G3_NST - 1;                        // prefetch distance in half-steps
-#ifdef G3_ONESET
-  // L2 warm-up of the epilogue's per-element input (residual tile / stored act'(z)): a CU on its own pulls ~10 B per cycle from HBM or
-  // the Infinity Cache (MI355X_MICROARCH "prologue HBM burst"), so the 128 KiB residual tile of a 256 x 256 output cost the epilogue
-  // 5+ us of exposed fetch while every matrix pipe of the CU idled (fit over K: +11 us per tile against the plain epilogue).  G3_PF_DIST
-  // half-steps before the end of K each wave touches one byte of every 128-B line of its [128 x WN] sub-tile -- two wave instructions,
-  // lane = row -- so the epilogue's own 16-byte loads find the lines in the XCD's L2.  The two result registers are only kept alive
-  // (never read); the loads are counted by the main loop's vmcnt like everything else (in order: the phase that issues one waits
-  // for one LDS-DMA more than it needs, nothing else changes).  Pure performance: no bit of the output depends on it.
-#ifndef G3_PF_DIST
-#define G3_PF_DIST 8
-#endif
-  const char* pf_base = nullptr;
-  uint32_t pf_off0 = 0, pf_off1 = 0, pf0 = 0, pf1 = 0;
-  int pf_h = -2;
-  {
-    const bool u8 = p.aux && p.dact == ACT_DERIV_U8;
-    const char* src = p.res ? (const char*)p.res : (const char*)p.aux;
-    const long ld = p.res ? p.ldres : p.ldaux, esz = (p.res || !u8) ? 2 : 1;
-    const int n = n0 + wn * WN;
-    if (src && !(p.res && p.aux) && n < p.N && ((long)p.M * ld + p.N) * esz < (1l << 32) && p.ksplit == 0) {
-      pf_base = src;
-      pf_off0 = (uint32_t)(((long)min(m0 + wm * 128 + lane, p.M - 1) * ld + n) * esz);
-      pf_off1 = (uint32_t)(((long)min(m0 + wm * 128 + 64 + lane, p.M - 1) * ld + n) * esz);
-      pf_h = max(nh - G3_PF_DIST, 0);
-    }
-  }
-#endif
   for (int h0 = 0; h0 < PD && h0 < nh; ++h0) DMA(h0);
 #ifndef G3_ONESET
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -220,9 +190,6 @@ static_assert(G3_NST == 4, "the one-set schedule is written for a prefetch dista
     if (h + 1 < nh) HALF_STEP(h + 1, 1, 0);
   }
   if (wm == 0) G3_BARRIER();                            // equalise the barrier count; all LDS reads are complete
-#ifdef G3_ONESET
-  asm volatile("" :: "v"(pf0), "v"(pf1));               // the warm-up loads' destination registers stayed reserved until here (vmcnt(0) above)
-#endif
   G3_T(2);
 #undef DMA
 #undef LOADF
@@ -246,7 +213,7 @@ static_assert(G3_NST == 4, "the one-set schedule is written for a prefetch dista
     __builtin_amdgcn_s_waitcnt(0xc07f); } while (0)
   // the epilogue kind is chosen once per tile; every global load goes out before the first store (see gemm_tile.h)
   const int em = m0 + wm * 128, en = n0 + wn * WN;
-  const int kind = ROPE ? EK_ROPE : epi_kind(p, fast);
+  const int kind = EPI >= 0 ? EPI : epi_kind(p, fast);
   EpiPre<WN> pre0, pre1;
   bf16x8 biasv = epi_bias<WN>(p, lane, en, kind);
   epi_fetch<WN>(p, lane, em, en, kind, pre0);
@@ -255,23 +222,32 @@ static_assert(G3_NST == 4, "the one-set schedule is written for a prefetch dista
   G3_T(5);
   epi_fetch<WN>(p, lane, em + 64, en, kind, pre1);
   if (kind != EK_GENERIC) epi_inputs_ready();
-  epi_pass_kind<WN, 64, ROPE>(p, er, lane, em, en, gate, fast, kind, pre0, biasv);
+  if (EPI >= 0 && !ROPE) epi_pass_fixed<WN, EPI < 0 ? 0 : EPI>(p, er, lane, em, en, gate, pre0, biasv);
+  else epi_pass_kind<WN, 64, ROPE>(p, er, lane, em, en, gate, fast, kind, pre0, biasv);
   __builtin_amdgcn_s_waitcnt(0xc07f);
   G3_T(6);
   EPI_STAGE(1);
   G3_T(7);
-  epi_pass_kind<WN, 64, ROPE>(p, er, lane, em + 64, en, gate, fast, kind, pre1, biasv);
+  if (EPI >= 0 && !ROPE) epi_pass_fixed<WN, EPI < 0 ? 0 : EPI>(p, er, lane, em + 64, en, gate, pre1, biasv);
+  else epi_pass_kind<WN, 64, ROPE>(p, er, lane, em + 64, en, gate, fast, kind, pre1, biasv);
 #undef EPI_STAGE
   G3_T(3);
 }
 
-template <bool AKS, bool BKS, int BN, bool BPK = false, bool ROPE = false>
+// UNIMP_GEMM_FIXED_EPI=0: every launch takes the run-time-dispatch kernel (A/B and debugging; same bits either way)
+static bool getenv_no_fixed() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("UNIMP_GEMM_FIXED_EPI"); v = (e && e[0] == '0') ? 1 : 0; }
+  return v == 1;
+}
+
+template <bool AKS, bool BKS, int BN, bool BPK = false, int EPI = -1>
 static void launch3(const Gemm2Params& p, hipStream_t s, int slices = 1) {
   static bool attr_set = false;
   // the epilogue stages the tile through wave-private LDS regions: 8 waves x 64 rows x (BN / 4) floats
   constexpr size_t lds_ring = G3_NST * (G3_BM * 64 + (BPK ? 0 : BN * 64)), lds_epi = 8 * 64 * (BN / 4) * 4;
   constexpr size_t lds = lds_ring > lds_epi ? lds_ring : lds_epi;
-  auto kern = gemm3_bf16_kernel<AKS, BKS, BN, BPK, ROPE>;
+  auto kern = gemm3_bf16_kernel<AKS, BKS, BN, BPK, EPI>;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
   hipLaunchKernelGGL(kern, dim3(p.nbm * p.nbn, slices), dim3(512), lds, s, p);
 }
@@ -304,7 +280,24 @@ extern "C" int unimp_gemm3_launch_splitk(const unimp_gemm_desc* d, int bn, int s
   int a = d->a_kstrided, b = d->b_kstrided;
 #define L3(AK, BK_) do { if (bn == 256) launch3<AK, BK_, 256>(p, s, slices); else launch3<AK, BK_, 128>(p, s, slices); } while (0)
 #define L3P(AK) do { if (bn == 256) launch3<AK, false, 256, true>(p, s, 1); else launch3<AK, false, 128, true>(p, s, 1); } while (0)
-  if (p.rope_rot) { launch3<false, false, 256, false, true>(p, s, 1); return 1; }      // host-validated: k-contiguous operands, 256-wide tiles
+  if (p.rope_rot) {       // host-validated: k-contiguous A, 256-wide tiles; B k-contiguous or k-strided (the transposed copy of a frozen projection)
+    if (b == 1) launch3<false, true, 256, false, EK_ROPE>(p, s, 1); else launch3<false, false, 256, false, EK_ROPE>(p, s, 1);
+    return 1;
+  }
+  // fixed-kind instantiations for the forms the training step spends its time in (256-wide tiles, k-contiguous A, unpacked B, no split-K)
+  if (bn == 256 && !a && b != 2 && slices == 1 && !getenv_no_fixed()) {
+    const int ek = epi_kind_host(p);
+#define L3F(K_) do { if (b) launch3<false, true, 256, false, K_>(p, s, 1); else launch3<false, false, 256, false, K_>(p, s, 1); return 1; } while (0)
+    switch (ek) {
+      case EK_PLAIN: L3F(EK_PLAIN);
+      case EK_ACT:   L3F(EK_ACT);
+      case EK_GELU2: L3F(EK_GELU2);
+      case EK_RES:   L3F(EK_RES);
+      case EK_AUX:   if (b) { launch3<false, true, 256, false, EK_AUX>(p, s, 1); return 1; } break;      // dX through the activation: W is read k-strided
+      default: break;
+    }
+#undef L3F
+  }
 #ifndef G3_ONESET
   if (b == 2) { if (a) L3P(true); else L3P(false); }
   else

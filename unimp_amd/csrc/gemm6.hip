@@ -201,7 +201,7 @@ extern "C" int unimp_gemm6_launch(const unimp_gemm_desc* d, void* stream) {
   p.nbn = (d->N + 255) / 256;
   hipStream_t s = (hipStream_t)stream;
   int a = d->a_kstrided, b = d->b_kstrided;
-  if (p.rope_rot) { launch6<false, false, true>(p, s); return 1; }       // host-validated: k-contiguous operands
+  if (p.rope_rot) { if (b == 1) launch6<false, true, true>(p, s); else launch6<false, false, true>(p, s); return 1; }   // host-validated: k-contiguous A
   if (!a && !b) launch6<false, false>(p, s); else if (!a && b) launch6<false, true>(p, s);
   else if (a && b) launch6<true, true>(p, s); else launch6<true, false>(p, s);
   return 1;

@@ -159,7 +159,8 @@ __device__ __forceinline__ void epi_pass(const Gemm2Params& p, const char* er, i
 // there (it cannot count in-flight stores across branches), which also waits for the previous row group's store to be
 // acknowledged.  EK_PLAIN / EK_ACT have no per-row-group input and run as a rolled loop; EK_AUX / EK_RES unroll their <= 8
 // row groups around the prefetched registers.
-enum { EK_PLAIN = 0, EK_ACT = 1, EK_AUX = 2, EK_RES = 3, EK_GENERIC = 4, EK_ROPE = 5 /* EK_PLAIN + rotary pairs (QKV projection) */ };
+enum { EK_PLAIN = 0, EK_ACT = 1, EK_AUX = 2, EK_RES = 3, EK_GENERIC = 4, EK_ROPE = 5 /* EK_PLAIN + rotary pairs (QKV projection) */,
+       EK_GELU2 = 6 /* EK_ACT with act == GELU and the uint8 derivative as second output, both fixed at compile time (the LM's up-projection) */ };
 __device__ __forceinline__ int epi_kind(const Gemm2Params& p, bool fast) {
   if (!fast || p.accumulate || (p.aux && p.res)) return EK_GENERIC;
   // the specialised kinds serve the stored derivative in its 8-bit form only (what the MLP blocks use); a bf16 derivative or a raw
@@ -228,6 +229,11 @@ __device__ __forceinline__ void epi8k(const Gemm2Params& p, float (&v)[8], int m
       }
     }
   }
+  if (KIND == EK_GELU2) {                       // one activation, no switch: a quarter of EK_ACT's code per row group
+    float dv[8];
+    act_fwd_deriv_n<8>(ACT_GELU, v, dv);
+    *(uint2*)((uint8_t*)p.pre + (long)m * p.ldpre + n) = uint2{deriv_u8_pack4(dv[0], dv[1], dv[2], dv[3]), deriv_u8_pack4(dv[4], dv[5], dv[6], dv[7])};
+  }
   if (KIND == EK_ACT) {
     if (p.pre) {                                // epi_kind: the second output of this kind is the uint8 derivative
       float dv[8];
@@ -288,12 +294,33 @@ __device__ __forceinline__ void epi_groups(const Gemm2Params& p, const char* er,
   } else if (KIND == EK_ROPE) {           // one rolled copy: the kernels must stay inside the instruction cache
 #pragma unroll 1
     for (int u = 0; u < NIT; ++u) EPI_GROUP(u, bf16x8{});
+  } else if (KIND == EK_GELU2) {          // fixed-kind kernels only: four row groups in flight (the erf-GELU pair is a long dependent chain)
+#pragma unroll 4
+    for (int u = 0; u < NIT; ++u) EPI_GROUP(u, bf16x8{});
   } else {
 #pragma unroll 2
     for (int u = 0; u < NIT; ++u) EPI_GROUP(u, bf16x8{});
   }
 #undef EPI_GROUP
 }
+// Kernel instantiations with the epilogue kind FIXED at compile time (gemm3.hip, template parameter EPI >= 0): the host has checked the
+// kind's conditions (epi_kind_host) plus N % 8 == 0, so neither the run-time kind dispatch nor the generic element-wise form is compiled
+// in -- 8-15 KiB of code instead of 62, which leaves room to unroll the activation kinds for instruction-level parallelism.
+template <int WN, int KIND, int ROWS = 64>
+__device__ __forceinline__ void epi_pass_fixed(const Gemm2Params& p, const char* er, int lane, int mbase, int nbase, float gate,
+                                               const EpiPre<WN, ROWS>& e, bf16x8 biasv) {
+  epi_groups<WN, KIND, ROWS>(p, er, lane, mbase, nbase, gate, e, biasv);
+}
+// host-side twin of epi_kind() + the fixed kinds' extra conditions; returns the EPI template value to launch, -1 = the generic kernel
+static inline int epi_kind_host(const Gemm2Params& p) {
+  bool fast = ((p.ldc | p.ldres | p.ldaux | p.ldpre) & 7) == 0;
+  if (!fast || (p.N & 7) || p.accumulate || (p.aux && p.res) || p.rope_rot) return -1;
+  if (p.aux) return (p.dact == ACT_DERIV_U8 && !p.act && !p.pre) ? EK_AUX : -1;
+  if (p.res) return (!p.act && !(p.pre && p.pre_deriv)) ? EK_RES : -1;
+  if (p.pre) return (p.pre_deriv == 2 && p.act == ACT_GELU) ? EK_GELU2 : -1;
+  return p.act ? EK_ACT : EK_PLAIN;
+}
+
 // one pass of the chosen kind
 // ROPE: the kernel instantiation that serves the rotary epilogue (and nothing else: the host validated a plain alpha / bias
 // epilogue, N % 8 == 0) -- a separate instantiation because the ordinary kernels sit within 1 KiB of the instruction cache.

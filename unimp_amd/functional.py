@@ -313,10 +313,15 @@ def _frozen_pk(w, b_ks=False):
 # wait on L2 latency every half-step where the LDS-DMA ring does not -- so it is NOT the default (it also costs a second copy
 # of the frozen weights per orientation)
 FROZEN_PK = _os.environ.get("UNIMP_FROZEN_PK", "0") == "1"
-_FW = int(_os.environ.get("UNIMP_FROZEN_WT", "0"))   # opt-in: +0.8 % on the step, but a k-strided weight operand is summed in a different
-# order inside the MFMA by the 128x128 and the 256-row kernels, so a sample's bits would depend on which variant its batch size tuned to
-FROZEN_WT = _FW >= 1      # use the transposed copy for frozen MLP weights (costs one extra copy of them in HBM)
-FROZEN_WT_ATTN = _FW >= 2    # same for the frozen qkv / attention-out projections
+# Forward GEMMs of FROZEN layers read a cached transposed copy W^T [in, out] of the weight (default since round 4; UNIMP_FROZEN_WT=0: off,
+# =1: MLP weights only).  A k-strided B operand is staged in whole 512-byte rows per LDS-DMA instruction where the k-contiguous [out, in]
+# form is fetched as 64-byte pieces of 16 different rows: +1.5 ... +4.8 % on every forward shape of the towers (tools/bench_gemm_ab.py,
+# profiles/r04_gemm_ab_forms.txt), and EVERY kernel variant sums the two forms in the same order -- the same bits as the [out, in] form on
+# all nine variants (tools/check_ks_bits.py; round 3 kept this opt-in on the belief that the 128 x 128 kernel differed).  Costs one
+# extra copy of the frozen weights in HBM (4b-instruct: 5.6 GB of 288).
+_FW = int(_os.environ.get("UNIMP_FROZEN_WT", "2"))
+FROZEN_WT = _FW >= 1      # frozen MLP weights (LM, ViT)
+FROZEN_WT_ATTN = _FW >= 2    # frozen qkv / attention-out projections (LM, ViT), incl. the row-permuted copy of the rotary epilogue
 
 
 # ----------------------------------------------------------------------------------------------- MX-fp8 frozen towers (F4)
@@ -470,16 +475,16 @@ class SelfAttnBlockFn(Function):
         mx = _mx_ok(wqkv, B * L) and _mx_ok(wd, B * L)
         # rotary epilogue: frozen projection, bf16 path, a kernel variant that serves it, positions 0 .. L-1 per sequence
         fused = None
-        if (ROPE_EPILOGUE and rope is not None and len(rope) > 3 and not mx and not tq and not wqkv.requires_grad and not FROZEN_PK
+        if (ROPE_EPILOGUE and rope is not None and len(rope) > 3 and not mx and not wqkv.requires_grad and not FROZEN_PK
                 and (bqkv is None or not bqkv.requires_grad) and rope[2] % 8 == 0 and hd % 8 == 0 and B * L < (1 << 24)
-                and ops.attn_generation() >= 2 and ops.gemm_rope_variant(B * L, 3 * H, H, False, x.device) is not None):
+                and ops.attn_generation() >= 2 and ops.gemm_rope_variant(B * L, 3 * H, H, tq, x.device) is not None):
             rot = rope[2]
             fused = dict(rot=rot, hd=hd, period=3 * hd if interleaved else 3 * H, span=2 * hd if interleaved else 2 * H, L=L,
                          log2_base=math.log2(rope[3]))
         if fused is not None:
             wp = _frozen_rope_perm(wqkv, nh, hd, fused["rot"], interleaved)
             bp = _frozen_rope_perm(bqkv, nh, hd, fused["rot"], interleaved) if bqkv is not None else None
-            qkv = ops.gemm(h, wp, bias=bp, rope=fused)
+            qkv = ops.gemm(h, _frozen_t(wp) if tq else wp, b_ks=tq, bias=bp, rope=fused)
         else:
             qkv = ops.gemm_mx(ops.mx_quantize(h), _frozen_mx(wqkv), bias=bqkv) if mx else \
                 ops.gemm(h, _frozen_t(wqkv) if tq else wqkv, b_ks=tq, bias=bqkv, b_pk=None if tq else _frozen_pk(wqkv))
@@ -521,23 +526,25 @@ class SelfAttnBlockFn(Function):
         x2 = x.reshape(M, H)
         r2 = x2 if res is None else res.reshape(M, H)
         h, mean, rstd = ops.layernorm_fwd(x2, ln_w, ln_b, eps, rms=rms)
+        tq = FROZEN_WT_ATTN and not wqkv.requires_grad and M >= 1024       # the padded path's criteria on the packed row count
+        td = FROZEN_WT_ATTN and not wd.requires_grad and M >= 1024
         fused = None
         if (ROPE_EPILOGUE and rope is not None and len(rope) > 3 and not wqkv.requires_grad and not FROZEN_PK
                 and (bqkv is None or not bqkv.requires_grad) and rope[2] % 8 == 0 and hd % 8 == 0 and M < (1 << 24)
-                and ops.attn_generation() >= 2 and ops.gemm_rope_variant(M, 3 * H, H, False, x.device) is not None):
+                and ops.attn_generation() >= 2 and ops.gemm_rope_variant(M, 3 * H, H, tq, x.device) is not None):
             fused = dict(rot=rope[2], hd=hd, period=3 * hd if interleaved else 3 * H, span=2 * hd if interleaved else 2 * H, L=L,
                          log2_base=math.log2(rope[3]), pos=pack.pos)
         if fused is not None:
             wp = _frozen_rope_perm(wqkv, nh, hd, fused["rot"], interleaved)
             bp = _frozen_rope_perm(bqkv, nh, hd, fused["rot"], interleaved) if bqkv is not None else None
-            qkv = ops.gemm(h, wp, bias=bp, rope=fused)
+            qkv = ops.gemm(h, _frozen_t(wp) if tq else wp, b_ks=tq, bias=bp, rope=fused)
         else:
-            qkv = ops.gemm(h, wqkv, bias=bqkv)
+            qkv = ops.gemm(h, _frozen_t(wqkv) if tq else wqkv, b_ks=tq, bias=bqkv)
         q, k, v, hs, offs = _split_qkv(qkv, 1, M, nh, hd, interleaved)
         if rope is not None and fused is None:
             ops.rope_(qkv, L, nh, hs, rope[2], offs, rope[0], rope[1], pos=pack.pos)
         o, lse = ops.attn_fwd(q, k, v, q_scale, ops.MASK_CAUSAL if causal else ops.MASK_NONE, alibi=alibi, q_rows=pack.rows, k_rows=pack.rows)
-        out = ops.gemm(o.view(M, H), wd, bias=bd, res=r2)
+        out = ops.gemm(o.view(M, H), _frozen_t(wd) if td else wd, b_ks=td, bias=bd, res=r2)
         ctx.save_for_backward(x2, ln_w, mean, rstd, wqkv, wd, qkv, o, lse, kv_len, h if wqkv.requires_grad else None,
                               rope[0] if rope is not None else None, rope[1] if rope is not None else None, alibi)
         ctx.cfg = (B, L, H, nh, hd, interleaved, causal, rms, q_scale, rope[2] if rope is not None else 0, res is None, ln_b is not None)

@@ -75,7 +75,7 @@ def _tune_gemm(M, N, K, a_ks, b_ks, device, reads_mn=False):
         return v
     if not GEMM_AUTOTUNE or torch.cuda.is_current_stream_capturing():
         return 0
-    cands = [1] if (M < 512 or N < 128 or K < 128) else ([1, 4, 5, 8, 9] if reads_mn == "out2" else [1, 4, 5, 2, 3, 8, 9])   # "out2": the uint8 derivative
+    cands = [1] if (M < 512 or N < 128 or K < 128) else ([1, 4, 5, 8, 9, 10, 11] if reads_mn == "out2" else [1, 4, 5, 2, 3, 8, 9, 10, 11])   # "out2": the uint8 derivative
     if len(cands) == 1:
         _GEMM_CHOICE[key] = cands[0]
         return cands[0]
@@ -112,6 +112,14 @@ def _tune_gemm(M, N, K, a_ks, b_ks, device, reads_mn=False):
         _save_tune_table(_TUNE_FILE)
     return best
 
+
+# Data parallelism with more than one rank (set by train.Trainer): RCCL's all-reduce kernels take a handful of CUs for the whole backward
+# pass.  A persistent GEMM (one workgroup per CU walking its tiles: variants pp256p / pp256px) then has CUs whose workgroup shares its CU
+# and finishes last -- measured 1.55-1.64x on the kernel beside a 16-workgroup streaming kernel, against 1.1-1.4x for the one-tile-per-
+# workgroup kernels, whose tiles the dispatcher simply hands to whichever CU is free (profiles/r03_interference_rccl_footprint.txt).  The
+# autotuned choice is mapped to the non-persistent twin with the same main loop; every variant produces the same bits.
+AVOID_PERSISTENT = False
+_PERSISTENT_TWIN = {9: 4, 12: 10}
 
 _IN_BACKWARD = 0
 
@@ -224,7 +232,7 @@ def _tune_packed(M, N, K, a_ks, device, reads_mn, unpacked_variant, b_ks):
 TAIL_SPLIT = os.environ.get("UNIMP_GEMM_TAIL_SPLIT", "1") != "0"
 
 
-ROPE_VARIANTS = (4, 9)          # pp256 / pp256p: the kernels with a rotary-epilogue instantiation (gemm3.hip, gemm6.hip)
+ROPE_VARIANTS = (4, 9, 10, 12)  # pp256 / pp256p and their one-set forms: the kernels with a rotary-epilogue instantiation (gemm3.hip, gemm6.hip)
 
 
 ROPE_MIN_M = 256                # rows (one tile row) from which the QKV projection takes the rotary epilogue: low enough that a training
@@ -239,9 +247,7 @@ def gemm_rope_variant(M, N, K, b_ks, device):
     arithmetic runs (ping-pong or persistent ping-pong)."""
     if M < ROPE_MIN_M or N < 128 or N % 8 or M >= 1 << 24:
         return None
-    if b_ks:
-        return None
-    v = _tune_gemm(M, N, K, False, False, device, False)
+    v = _tune_gemm(M, N, K, False, bool(b_ks), device, False)          # b_ks: the transposed copy of a frozen projection (same bits)
     return v if v in ROPE_VARIANTS else 4
 
 
@@ -402,6 +408,8 @@ def gemm(a, b, *, a_ks=False, b_ks=False, bias=None, act=None, res=None, aux=Non
                                                                       _tune_gemm(M, N, K, bool(a_ks), bool(b_ks), a.device,
                                                                                  True if (res is not None or aux is not None) else
                                                                                  ("out2" if pre is not None else False)))
+    if AVOID_PERSISTENT and variant is None and v in _PERSISTENT_TWIN:
+        v = _PERSISTENT_TWIN[v]
     if (d.pre_deriv == 2 or d.dact == ACT["deriv_u8"]) and variant is None and v in (0, 2, 3, 6, 7):
         # the uint8 derivative lives in the kernels with the specialised epilogue kinds; 0 = the library's own choice, which may be a DMA variant
         v = 1 if (M < 256 or N < 128) else (4 if N >= 256 else 5)

@@ -151,7 +151,7 @@ class Trainer:
     def __init__(self, model, special_ids, lr=2e-4, weight_decay=0.1, gamma=2.0, use_reweight=True, max_grad_norm=1.0,
                  lr_scheduler="cosine", warmup_steps=0, total_steps=1000, bucket_bytes=256 << 20, process_group=None,
                  sparse_head=False, grad_accum=1, mask_lm_head=False, force_dp_hooks=False, dense_head_backward=False,
-                 shard_optimizer=False, direct_wgrad=True, graph=False, fuse_accum=False, packed=None):
+                 shard_optimizer=False, direct_wgrad=True, graph=False, fuse_accum=None, packed=None):
         """packed (None: the UNIMP_PACKED environment default, off): packed token order in the language tower -- LayerNorm and the
         QKV / out / MLP / gated feed-forward projections run on the VALID tokens only ([1, M, H], M = the valid count rounded up to 2048
         rows), the attention kernels take the sequences as row ranges of the packed buffers (functional.Pack, include/unimp_hip.h
@@ -159,15 +159,16 @@ class Trainer:
         computes the <PAD> rows too (collate_rec.py:38-74 pads to the longest sequence of the batch); nothing reads them: loss and
         gradients are those of the padded run (tests/test_model_gpu.py::test_packed_token_order_equals_padded), logits at <PAD>
         positions become those of a zero hidden state.  GPT-NeoX, MPT and OPT towers; one extra host sync per step (the valid count).
-        fuse_accum (off by default; needs grad_accum > 1): run the GA micro-batches of an optimizer step as ONE forward /
-        backward pass.  The reference accumulates because 3 samples are what fits its GPUs (unimp_task.sh:2-30: --batch_size 3,
+        fuse_accum (None = ON whenever grad_accum > 1 and graph is off; False restores the sequential micro-steps): run the GA
+        micro-batches of an optimizer step as ONE forward / backward pass.  The reference accumulates because 3 samples are what fits its GPUs (unimp_task.sh:2-30: --batch_size 3,
         --gradient_accumulation_steps 2); on 288 GB the activations of all GA micro-batches fit, and one pass over GA x B samples
         fills the GEMM tiles GA times better (a micro-batch of 3 x 512 tokens is 6 tile rows: measured, the step is GPU-bound at
         0.57 PFLOP/s in the GEMMs, not launch-bound).  SAME optimizer step: the loss keeps its per-micro-batch normalisation
         (mmrec.py:213 divides by the labeled positions of the micro-batch, accelerate averages the GA losses) through per-sample
         weights w_b * N_total / (GA * N_mb(b)) computed on the device -- gradients equal the sequential ones up to summation order
         (tests/test_model_gpu.py::test_fused_accumulation_equals_sequential).  ``step()`` buffers the micro-batches and returns
-        the previous optimizer step's (loss, stats) until the GA-th arrives; micro-batches of different lengths are right-padded.
+        the previous optimizer step's (loss, stats) until the GA-th arrives (before the first optimizer step: a zero loss and zero stats -- never
+        None, ``loss.item()`` in a logging loop keeps working); micro-batches of different lengths are right-padded.
         graph (off by default): replay the forward + loss + backward of a micro-batch as ONE HIP graph.  At the reference's
         shipped shape (--batch 3 --grad-accum 2, unimp_task.sh:2-30) a micro-step is ~3 000 launches of kernels that run for
         10-40 us each: the host, not the GPU, sets the pace.  The first micro-step with a given set of batch shapes runs eagerly
@@ -186,7 +187,9 @@ class Trainer:
         if graph and sparse_head:
             raise ValueError("Trainer(graph=True) needs the sync-free dense loss path (sparse_head takes a row count on the host)")
         self.use_graph, self._graph = graph, None
-        self.fuse_accum, self._stash, self._last = bool(fuse_accum and grad_accum > 1), [], (None, None)
+        if fuse_accum is None:
+            fuse_accum = grad_accum > 1 and not graph
+        self.fuse_accum, self._stash, self._last = bool(fuse_accum and grad_accum > 1), [], None
         le_ = model.lang_encoder
         if packed is not None:                   # per tower, not the module-level default: a second Trainer leaves this one alone
             if packed and not getattr(le_, "supports_packed", True):
@@ -216,6 +219,8 @@ class Trainer:
             late = list({id(w): w for w in late + self._masked}.values())
         self.dp = GradBucketer(self.opt, bucket_bytes=bucket_bytes, process_group=process_group, late_params=late,
                                force_hooks=force_dp_hooks)
+        if self.dp.active and self.dp.world > 1:
+            ops.AVOID_PERSISTENT = True       # collectives share the CUs with backward: no persistent GEMM variant (ops.AVOID_PERSISTENT)
         self.sched, self.base_lr, self.warmup, self.total = lr_scheduler, lr, warmup_steps, total_steps
         self.sched_step = 0
         # the weight-gradient GEMMs add straight into the flat gradient buffer (functional.WGRAD_SINK); under data parallelism
@@ -252,6 +257,9 @@ class Trainer:
     def _fused_step(self, batch):
         self._stash.append(batch)
         if len(self._stash) < self.grad_accum:
+            if self._last is None:         # nothing computed yet: placeholders of the right type (focal_ce's stats vector)
+                dev = batch["lang_x"].device
+                self._last = (torch.zeros((), device=dev), torch.zeros(3, device=dev))   # stats = [loss_sum, n_labeled, ce_sum]
             return self._last
         fused, self._stash = self._fused_batch(self._stash), []
         loss, stats = self._micro_step(fused)

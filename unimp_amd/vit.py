@@ -50,12 +50,16 @@ class ResidualAttentionBlock(nn.Module):
         ws = (self.attn.in_proj_weight, self.attn.out_proj.weight, self.mlp.c_fc.weight, self.mlp.c_proj.weight)
         mx = all(F_._mx_ok(w, h.shape[0]) for w in ws)          # opt-in MX-fp8 path for the frozen tower (functional.FP8_FROZEN)
 
-        def lin(x, w, **kw):
-            return ops.gemm_mx(ops.mx_quantize(x), F_._frozen_mx(w), **kw) if mx else ops.gemm(x, w, b_pk=F_._frozen_pk(w), **kw)
+        def lin(x, w, attn=False, **kw):
+            if mx:
+                return ops.gemm_mx(ops.mx_quantize(x), F_._frozen_mx(w), **kw)
+            if (F_.FROZEN_WT_ATTN if attn else F_.FROZEN_WT) and not w.requires_grad and x.shape[0] > 64:
+                return ops.gemm(x, F_._frozen_t(w), b_ks=True, **kw)        # W^T copy: whole rows per LDS-DMA instruction, same bits
+            return ops.gemm(x, w, b_pk=F_._frozen_pk(w), **kw)
         a, _, _ = ops.layernorm_fwd(h, self.ln_1.weight, self.ln_1.bias, self.ln_1.eps)
-        qkv = lin(a, self.attn.in_proj_weight, bias=self.attn.in_proj_bias).view(N, S, 3, self.heads, hd)
+        qkv = lin(a, self.attn.in_proj_weight, attn=True, bias=self.attn.in_proj_bias).view(N, S, 3, self.heads, hd)
         o, _ = ops.attn_fwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], hd ** -0.5, ops.MASK_NONE)
-        h = lin(o.view(N * S, D), self.attn.out_proj.weight, bias=self.attn.out_proj.bias, res=h)
+        h = lin(o.view(N * S, D), self.attn.out_proj.weight, attn=True, bias=self.attn.out_proj.bias, res=h)
         a, _, _ = ops.layernorm_fwd(h, self.ln_2.weight, self.ln_2.bias, self.ln_2.eps)
         f = lin(a, self.mlp.c_fc.weight, bias=self.mlp.c_fc.bias, act=self.act)
         return lin(f, self.mlp.c_proj.weight, bias=self.mlp.c_proj.bias, res=h)
