@@ -29,14 +29,37 @@
 #include <stdlib.h>
 #include "gemm_half.h"
 
-#ifdef G3X            // second build of this file with other schedule switches, under its own symbols (Makefile: gemm3x.o)
+#if defined(G3X) && defined(G3_AFULL)   // third build (Makefile: gemm3a.o): the one-set schedule with the A operand staged in whole 128-byte rows
+#define gemm3_bf16_kernel gemm3a_bf16_kernel
+#define unimp_gemm3_launch unimp_gemm3a_launch
+#define unimp_gemm3_launch_splitk unimp_gemm3a_launch_splitk
+#define launch3 launch3a
+#define g3_stamps g3a_stamps
+#define unimp_debug_g3_stamps unimp_debug_g3a_stamps
+#define getenv_no_fixed getenv_no_fixed_a
+#elif defined(G3X)    // second build of this file with other schedule switches, under its own symbols (Makefile: gemm3x.o)
 #define gemm3_bf16_kernel gemm3x_bf16_kernel
 #define unimp_gemm3_launch unimp_gemm3x_launch
 #define unimp_gemm3_launch_splitk unimp_gemm3x_launch_splitk
 #define launch3 launch3x
 #define g3_stamps g3x_stamps
 #define unimp_debug_g3_stamps unimp_debug_g3x_stamps
+#define getenv_no_fixed getenv_no_fixed_x
 #endif
+#if defined(G3_AFULL) && !defined(G3_ONESET)
+#error "G3_AFULL builds on the one-set schedule"
+#endif
+// G3_AFULL: a k-contiguous A operand ([M][K] activations -- every forward and dX GEMM) is staged in 64-k stages of WHOLE 128-byte rows
+// (8 rows x 128 B per LDS-DMA instruction) through a ring of its own, instead of 32-k half-stages whose instructions fetch 64-byte
+// halves of 16 different rows: every 128-byte line is requested once, by one instruction, where the half-stage form asks for it twice,
+// a half-step apart (the B operand read k-strided gained 2-5 % from the same change of access shape: tools/bench_gemm_ab.py W^T rows).
+//   LDS (160 KiB): A ring 3 stages x [256 rows][64 k] = 96 KiB, B ring 4 half-stages x [BN][32 k] = 64 KiB (BN = 256).
+//   A stage s (k = 64 s ..) lives in slot s % 3 as the v1 kernel's KC image (common.h kc_off: 16-byte chunk XOR (row >> 1) & 7,
+//   conflict-free ds_read_b128); half-step h reads chunks 4 (h & 1) .. + 3 of stage h >> 1.  DMA of stage s + 2 is issued in L(2 s):
+//   its slot's last readers ran L(2 s - 1) (both groups, two and one intervals earlier); it is needed in L(2 s + 4), four half-steps on.
+//   vmcnt: per wave an even half-step issues 4 (A) + NB (B) instructions, an odd one NB; after L(h)'s issues everything younger than
+//   B(h + 1) may stay in flight = 4 + 2 NB in steady state (either parity), 2 NB / NB / 0 over the last four half-steps.
+// Same k grouping inside every MFMA as the other builds: bit-identical results.
 
 #define G3_BM 256
 #ifndef G3_NST
@@ -173,6 +196,57 @@ static_assert(G3_NST == 4, "the one-set schedule is written for a prefetch dista
 #endif
 
   constexpr int PD = G3_NST - 1;                        // prefetch distance in half-steps
+#ifdef G3_AFULL
+  if constexpr (!AKS && !BPK) {
+    constexpr int A_STG = G3_BM * 128, A_RING = 3 * A_STG, NB = BN / 128, NFULL = 4 + 2 * NB;
+    uint32_t aoffF[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int P = (wave * 4 + i) * 64 + lane, row = P >> 3, cpos = P & 7, c = cpos ^ ((row >> 1) & 7);
+      aoffF[i] = (uint32_t)(((long)min(m0 + row, p.M - 1) * p.lda + c * 8) * 2);
+    }
+    const uint32_t a_dst0 = smem_lds + wave * 4096;
+    const int a_lane = kc_off(wm * 128 + (lane & 15), lane >> 4);
+#define DMA_A(S) do { const char* ub_ = (const char*)p.A + (long)(S) * 128;                                         \
+      uint32_t d_ = __builtin_amdgcn_readfirstlane(a_dst0 + ((S) % 3) * A_STG);                                        \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) glds16_s(ub_, aoffF[i], d_ + i * 1024); } while (0)
+#define DMA_B(H) dma_issue<BKS, BN>(p.B, p.ldb, (H), p.K, smem + A_RING + ((H) % 4) * B_SUB, wave, boff)
+#define LOADF_AF(H) do { const char* bb_ = smem + A_RING + ((H) % 4) * B_SUB;                                       \
+      uint32_t ubb_ = smem_lds + A_RING + ((H) % 4) * B_SUB;                                                           \
+      _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                             \
+        if (BKS) frag_ks32_asm<BN>(lbB + ubb_, j, lb0[j], hb0[j]);                                                 \
+        else rb0[j] = frag_kc32(bb_, wn * WN + j * 16); }                                                          \
+      const char* ab_ = smem + (((H) >> 1) % 3) * A_STG + (a_lane ^ (((H) & 1) << 6));                             \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i) ra0[i] = *(const bf16x8*)(ab_ + i * 2048); } while (0)
+#define HALF_STEP_AF(H, EVEN) do {                                                                                 \
+      LOADF_AF(H);                                                                                                 \
+      if ((EVEN) && (H) + 4 < nh) DMA_A(((H) >> 1) + 2);                                                           \
+      if ((H) + 3 < nh) DMA_B((H) + 3);                                                                            \
+      if ((H) + 4 < nh) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NFULL) : "memory");                              \
+      else if ((H) + 4 == nh) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NB) : "memory");                       \
+      else if ((H) + 3 == nh) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NB) : "memory");                           \
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                        \
+      G3_BARRIER();                                                                                                \
+      MFMAS(0);                                                                                                    \
+      G3_BARRIER(); } while (0)
+    // host-checked: K % 64 == 0, K >= 256 (nh >= 8, even)
+    DMA_A(0); DMA_B(0); DMA_A(1); DMA_B(1); DMA_B(2);
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NFULL) : "memory");       // stage 0 / half-stage 0 have landed; A(1), B(1), B(2) stay in flight
+    G3_BARRIER();
+    G3_T(1);
+    if (wm == 1) G3_BARRIER();
+    for (int h = 0; h < nh; h += 2) {
+      HALF_STEP_AF(h, true);
+      HALF_STEP_AF(h + 1, false);
+    }
+    if (wm == 0) G3_BARRIER();
+    G3_T(2);
+#undef DMA_A
+#undef DMA_B
+#undef LOADF_AF
+#undef HALF_STEP_AF
+  } else {
+#endif
   for (int h0 = 0; h0 < PD && h0 < nh; ++h0) DMA(h0);
 #ifndef G3_ONESET
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -191,6 +265,9 @@ static_assert(G3_NST == 4, "the one-set schedule is written for a prefetch dista
   }
   if (wm == 0) G3_BARRIER();                            // equalise the barrier count; all LDS reads are complete
   G3_T(2);
+#ifdef G3_AFULL
+  }
+#endif
 #undef DMA
 #undef LOADF
 #undef MFMAS
@@ -245,7 +322,12 @@ template <bool AKS, bool BKS, int BN, bool BPK = false, int EPI = -1>
 static void launch3(const Gemm2Params& p, hipStream_t s, int slices = 1) {
   static bool attr_set = false;
   // the epilogue stages the tile through wave-private LDS regions: 8 waves x 64 rows x (BN / 4) floats
+#ifdef G3_AFULL
+  constexpr size_t lds_ring = (!AKS && !BPK) ? 3 * (G3_BM * 128) + 4 * (BN * 64) : G3_NST * (G3_BM * 64 + (BPK ? 0 : BN * 64));
+  constexpr size_t lds_epi = 8 * 64 * (BN / 4) * 4;
+#else
   constexpr size_t lds_ring = G3_NST * (G3_BM * 64 + (BPK ? 0 : BN * 64)), lds_epi = 8 * 64 * (BN / 4) * 4;
+#endif
   constexpr size_t lds = lds_ring > lds_epi ? lds_ring : lds_epi;
   auto kern = gemm3_bf16_kernel<AKS, BKS, BN, BPK, EPI>;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
@@ -258,7 +340,14 @@ extern "C" int unimp_gemm3_launch_splitk(const unimp_gemm_desc* d, int bn, int s
 extern "C" int unimp_gemm3_launch(const unimp_gemm_desc* d, int bn, void* stream) {
   return unimp_gemm3_launch_splitk(d, bn, 1, nullptr, stream);
 }
+#ifdef G3_AFULL
+extern "C" int unimp_gemm3x_launch_splitk(const unimp_gemm_desc* d, int bn, int splits, float* slabs, void* stream);
+#endif
 extern "C" int unimp_gemm3_launch_splitk(const unimp_gemm_desc* d, int bn, int splits, float* slabs, void* stream) {
+#ifdef G3_AFULL
+  // the whole-row A staging serves a k-contiguous A with K a multiple of the 64-k stage; everything else runs the plain one-set build (same bits)
+  if (d->a_kstrided || d->b_kstrided == 2 || (d->K & 63) || d->K < 256 || splits > 1) return unimp_gemm3x_launch_splitk(d, bn, splits, slabs, stream);
+#endif
   Gemm2Params p;
   p.A = (const bf16*)d->A; p.B = (const bf16*)d->B; p.C = d->C;
   p.M = d->M; p.N = d->N; p.K = d->K; p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;

@@ -244,6 +244,165 @@ __global__ __launch_bounds__(64 * WMW * WNW) void gemm_mx_kernel(MxP p) {
   }
 }
 
+// ---- ping-pong form of the 256 x 256 tile (round 4).  The kernel above runs its 8 waves in lockstep: everybody issues the LDS-DMA, everybody
+// reads 24 KiB of fragments, everybody issues its 32 MFMAs, vmcnt(0), __syncthreads() -- the matrix pipes idle through the first two.
+// Here the two waves of a SIMD (w and w + 4: group A = waves 0-3, group B = waves 4-7) run ONE PHASE APART like the bf16 ping-pong GEMM
+// (gemm3.hip): per 128-byte K-step an L phase (fragment + scale reads of the step) and a C phase (32 block-scaled MFMAs = 1024 cycles),
+// raw s_barrier between phases, B one interval behind A.  Two LDS stages of a whole K-step each (2 x 66 KiB; the instruction eats K = 128
+// at once, so a stage cannot be cut in half): step s + 1 can only be fetched once BOTH groups have read step s - 1 out of its stage,
+// i.e. from interval 2 s on -- group A issues its share of the DMA in L(s) after its own reads and waits for it behind its C(s) MFMAs,
+// group B issues its share at the head of C(s - 1) (the same interval) and waits at the end of its L(s): every wait sits one phase of
+// >= 1000 cycles behind its issue, nothing reads a stage in the phase that retires it.  Same MFMA order per output: same bits as above.
+#define MXP_FENCE() do { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); } while (0)
+#define MXP_BARRIER() do { MXP_FENCE(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); MXP_FENCE(); } while (0)
+__global__ __launch_bounds__(512, 2) void gemm_mx_pp_kernel(MxP p) {
+  constexpr int BM = 256, BN = 256, NWAVE = 8, MI = 8, NJ = 4;
+  constexpr int STAGE = (BM + BN) * 128 + (BM + BN) * 4;
+  constexpr int ND = (BM + BN) * 8 / 64 / NWAVE;                        // 8 data DMA instructions per wave and K-step
+  constexpr int NS = 1;                                                   // 512 rows of scale words = 8 instructions of 64 rows: one per wave
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = lane_id(), r16 = l & 15, g = l >> 4;
+  const int wm = wave >> 2, wn = wave & 3;                                // wm doubles as the ping-pong group
+  int nwg = p.nbm * p.nbn;
+  int id = xcd_remap(blockIdx.x, nwg);
+  constexpr int GM = 4;
+  int per_group = GM * p.nbn, grp = id / per_group, first_m = grp * GM, gsz = min(p.nbm - first_m, GM);
+  int in_g = id - grp * per_group;
+  const int tm = first_m + in_g % gsz, tn = in_g / gsz;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  uint32_t d_off[ND];
+#pragma unroll
+  for (int t = 0; t < ND; ++t) {
+    int s = 64 * (wave * ND + t) + l;
+    int row = s >> 3, c = (s & 7) ^ ((row >> 1) & 7);
+    bool isb = row >= BM;
+    int gr = isb ? min(n0 + row - BM, p.N - 1) : min(m0 + row, p.M - 1);
+    d_off[t] = (uint32_t)((long)gr * (isb ? p.ldb : p.lda) + c * 16);
+  }
+  uint32_t s_off;
+  {
+    int row = 64 * wave + l;
+    bool isb = row >= BM;
+    int gr = isb ? min(n0 + row - BM, p.N - 1) : min(m0 + row, p.M - 1);
+    s_off = (uint32_t)((long)gr * (isb ? p.ldsb : p.ldsa));
+  }
+  const uint32_t smem_lds = (uint32_t)(uintptr_t)LDS_PTR(char, smem);
+  const bool wave_b = wave * ND * 8 >= BM;                                // this wave's data rows belong to B (waves 4-7), its scale rows too
+  auto dma_step = [&](int ks, int stage) {
+    const uint8_t* base = (wave_b ? p.B : p.A) + (long)ks * 128;
+#pragma unroll
+    for (int t = 0; t < ND; ++t)
+      mx_glds16(base, d_off[t], __builtin_amdgcn_readfirstlane(smem_lds + stage * STAGE + (wave * ND + t) * 1024));
+    mx_glds4((wave_b ? p.sB : p.sA) + (long)ks * 4, s_off, __builtin_amdgcn_readfirstlane(smem_lds + stage * STAGE + (BM + BN) * 128 + wave * 256));
+  };
+
+  f32x4 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  i32x8 afr[MI], bfr[NJ];
+  int sav[MI], sbv[NJ];
+  // per-lane LDS offsets of fragment 0 (chunk g of the row; chunk 4 + g is the same address with bit 6 flipped; row + 16 i = + 2048 i)
+  const int a_lane = kc_off(wm * 128 + r16, g), b_lane = kc_off(BM + wn * 64 + r16, g);
+  const int sa_lane = (BM + BN) * 128 + (wm * 128 + r16) * 4, sb_lane = (BM + BN) * 128 + (BM + wn * 64 + r16) * 4;
+#define MXP_LOADF(ST) do { const char* sb_ = smem + (ST) * STAGE;                                                     \
+    _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                               \
+      u32x4 b0 = *(const u32x4*)(sb_ + b_lane + j * 2048), b1 = *(const u32x4*)(sb_ + (b_lane ^ 64) + j * 2048);   \
+      bfr[j] = i32x8{(int)b0[0], (int)b0[1], (int)b0[2], (int)b0[3], (int)b1[0], (int)b1[1], (int)b1[2], (int)b1[3]};  \
+      sbv[j] = (int)(*(const uint32_t*)(sb_ + sb_lane + j * 64) >> (8 * g)); }                                     \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                                               \
+      u32x4 a0 = *(const u32x4*)(sb_ + a_lane + i * 2048), a1 = *(const u32x4*)(sb_ + (a_lane ^ 64) + i * 2048);   \
+      afr[i] = i32x8{(int)a0[0], (int)a0[1], (int)a0[2], (int)a0[3], (int)a1[0], (int)a1[1], (int)a1[2], (int)a1[3]};  \
+      sav[i] = (int)(*(const uint32_t*)(sb_ + sa_lane + i * 64) >> (8 * g)); } } while (0)
+#define MXP_MFMAS() do { __builtin_amdgcn_s_setprio(1);                                                            \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                                 \
+      _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                               \
+        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bfr[j], afr[i], acc[i][j], 0, 0, 0, sbv[j], 0, sav[i]);  \
+    __builtin_amdgcn_s_setprio(0); } while (0)
+
+  const int nk = p.K >> 7;
+  dma_step(0, 0);
+  if (nk > 1) { dma_step(1, 1); asm volatile("s_waitcnt vmcnt(%0)" :: "n"(ND + NS) : "memory"); }      // step 0 has landed, step 1 stays in flight
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  MXP_BARRIER();
+  if (wm == 0) {
+    for (int s = 0; s < nk; ++s) {                         // group A: L(s) at interval 2 s, C(s) at 2 s + 1
+      MXP_LOADF(s & 1);
+      if (s >= 1 && s + 1 < nk) dma_step(s + 1, (s + 1) & 1);       // the other stage: both groups read step s - 1 out of it two and one intervals ago
+      MXP_BARRIER();
+      MXP_MFMAS();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of step s + 1 (issued one phase ago) has landed
+      MXP_BARRIER();
+    }
+    MXP_BARRIER();
+  } else {
+    MXP_BARRIER();                                         // group B runs one interval behind
+    for (int s = 0; s < nk; ++s) {                         // L(s) at interval 2 s + 1, C(s) at 2 s + 2
+      MXP_LOADF(s & 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the share of step s + 1 issued at the head of C(s - 1) (the prologue for s = 0)
+      MXP_BARRIER();
+      if (s + 2 < nk) dma_step(s + 2, s & 1);              // both groups have read step s out of this stage (intervals 2 s, 2 s + 1)
+      MXP_MFMAS();
+      MXP_BARRIER();
+    }
+  }
+#undef MXP_LOADF
+#undef MXP_MFMAS
+
+  // ---- epilogue: as gemm_mx_kernel<2, 4, 8, 4>
+  constexpr int WNC = 16 * NJ, FP = WNC + 4, CPRW = WNC / 8;
+  static_assert(NWAVE * 32 * FP * 4 <= 2 * STAGE, "epilogue staging fits");
+  float* ewf = (float*)(smem + wave * (32 * FP * 4));
+  const int em = m0 + wm * 16 * MI, en = n0 + wn * WNC;
+  const bool vec = !((p.ldc | p.ldres | p.ldaux | p.ldpre) & 7);
+#pragma unroll
+  for (int pass = 0; pass < MI / 2; ++pass) {
+#pragma unroll
+    for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) *(f32x4*)(ewf + (16 * i2 + r16) * FP + 16 * j + 4 * g) = acc[2 * pass + i2][j];
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 32 * CPRW / 64; ++it) {
+      int idx = l + 64 * it;
+      int r = idx / CPRW, c = idx - r * CPRW;
+      int gm = em + 32 * pass + r, gn = en + c * 8;
+      if (gm >= p.M || gn >= p.N) continue;
+      float v[8], d[8];
+      f32x4 x0 = *(const f32x4*)(ewf + r * FP + c * 8), x1 = *(const f32x4*)(ewf + r * FP + c * 8 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] = x0[e]; v[4 + e] = x1[e]; }
+      bool full = vec && gn + 8 <= p.N;
+      if (p.bias) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) if (gn + e < p.N) v[e] += bf2f(p.bias[gn + e]);
+      }
+      if (p.act) {
+        if (p.pre) {
+          act_fwd_deriv_n<8>(p.act, v, d);
+          if (full) { bf16x8 o; for (int e = 0; e < 8; ++e) o[e] = f2bf(d[e]); *(bf16x8*)(p.pre + (long)gm * p.ldpre + gn) = o; }
+          else for (int e = 0; e < 8; ++e) if (gn + e < p.N) p.pre[(long)gm * p.ldpre + gn + e] = f2bf(d[e]);
+        } else act_fwd_n<8>(p.act, v);
+      }
+      if (p.aux) {
+        if (full) { bf16x8 a = *(const bf16x8*)(p.aux + (long)gm * p.ldaux + gn); for (int e = 0; e < 8; ++e) v[e] *= bf2f(a[e]); }
+        else for (int e = 0; e < 8; ++e) if (gn + e < p.N) v[e] *= bf2f(p.aux[(long)gm * p.ldaux + gn + e]);
+      }
+      if (p.res) {
+        if (full) { bf16x8 a = *(const bf16x8*)(p.res + (long)gm * p.ldres + gn); for (int e = 0; e < 8; ++e) v[e] += bf2f(a[e]); }
+        else for (int e = 0; e < 8; ++e) if (gn + e < p.N) v[e] += bf2f(p.res[(long)gm * p.ldres + gn + e]);
+      }
+      if (full) { bf16x8 o; for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]); *(bf16x8*)(p.C + (long)gm * p.ldc + gn) = o; }
+      else for (int e = 0; e < 8; ++e) if (gn + e < p.N) p.C[(long)gm * p.ldc + gn + e] = f2bf(v[e]);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 extern "C" int unimp_gemm_mxfp8(const unimp_mx_gemm_desc* d, void* stream) {
   if (!d || !d->A || !d->B || !d->scale_a || !d->scale_b || !d->C) return unimp_set_error(UNIMP_ERR_ARG, "gemm_mxfp8: null pointer");
   if (d->M <= 0 || d->N <= 0) return UNIMP_OK;
@@ -264,7 +423,14 @@ extern "C" int unimp_gemm_mxfp8(const unimp_mx_gemm_desc* d, void* stream) {
   static const int force = [] { const char* e = getenv("UNIMP_MX_TILE"); return e ? atoi(e) : 0; }();
   long t256 = (long)((d->M + 255) / 256) * ((d->N + 255) / 256);
   bool big = force ? force == 256 : t256 >= 512;
-  if (big) {
+  static const int no_pp = [] { const char* e = getenv("UNIMP_MX_PP"); return e && e[0] == '0'; }();       // UNIMP_MX_PP=0: the lockstep kernel (A/B)
+  if (big && !no_pp) {
+    p.nbm = (d->M + 255) / 256; p.nbn = (d->N + 255) / 256;
+    constexpr int lds = 2 * ((256 + 256) * 128 + (256 + 256) * 4);
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_mx_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
+    hipLaunchKernelGGL(gemm_mx_pp_kernel, dim3(p.nbm * p.nbn), dim3(512), lds, (hipStream_t)stream, p);
+  } else if (big) {
     p.nbm = (d->M + 255) / 256; p.nbn = (d->N + 255) / 256;
     hipLaunchKernelGGL((gemm_mx_kernel<2, 4, 8, 4>), dim3(p.nbm * p.nbn), dim3(512), 0, (hipStream_t)stream, p);
   } else {
