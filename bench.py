@@ -268,6 +268,7 @@ def main():
     ap.add_argument("--packed", action="store_true", help="Trainer(packed=True): the language tower's row-wise kernels run on the valid tokens only "
                     "(the synthetic batches are filled 75-100 %%: 12.5 %% of the B x L rows are <PAD>); same loss / gradients; NOT the headline")
     ap.add_argument("--no-packed-leg", action="store_true", help="skip the short opt-in measurement (packed token order) that follows the timed steps")
+    ap.add_argument("--no-cfg5-leg", action="store_true", help="skip the short leg on BASELINE config 5's model (9b, frozen towers on the MX-fp8 GEMM)")
     ap.add_argument("--no-shape-legs", action="store_true", help="skip the short legs at the reference's shipped shape (b = 3, GA 2) and b = 16 / 32")
     ap.add_argument("--fuse-accum", action="store_true", help="(the default since round 4 whenever --grad-accum > 1; kept for old command lines) the "
                     "micro-batches of an optimizer step run as ONE pass over GA x batch samples with per-micro-batch loss normalisation (same update)")
@@ -547,6 +548,57 @@ def main():
             cpu = cpu_baseline(T, L, layout, fps, args.cpu_full_steps, before_full_steps=_parity_leg)
             if parity is None and not (args.no_parity or nine or args.fp8 or args.task != "rec"):
                 parity = {"skipped": "the full-depth oracle was not built (--cpu-full-steps 0, or less than 56 GB of host memory available)"}
+        # last leg (N = 1, default configuration): BASELINE config 5's model with its frozen towers on the MX-fp8 GEMM ("9B Flamingo ... fp8 MFMA
+        # weights"; mmrec.py:515-524), so that the driver's record carries an fp8 number beside the bf16 headline.  The headline's model,
+        # trainer and batch pools are released first; everything the JSON line needs from them is taken before.
+        cfg_flags = {"packed": bool(trainer.packed), "fused": bool(trainer.fuse_accum)}
+        cfg5_leg = None
+        if world == 1 and not (args.no_cfg5_leg or args.packed or args.graph or args.fp8 or args.sparse_head or GA > 1 or nine
+                               or args.task != "rec" or args.batch != 64 or args.dp_hooks):
+            try:
+                trainer.dp.remove()
+                del pool[:]
+                trainer.opt = None
+                trainer = model = None
+                import gc
+                gc.collect()
+                torch.cuda.empty_cache()
+                F_.FP8_FROZEN = True
+                m9, lay9 = build_cfg2(dev, lang="anas-awadalla/mpt-7b", every=4)
+                tr9 = Trainer(m9, lay9.special(), lr=2e-4, weight_decay=0.1, gamma=2.0, use_reweight=True, lr_scheduler="cosine", warmup_steps=10, total_steps=10000)
+                b9, n9 = 24, 6
+                pool9 = [make_batch(lay9, b9, T, L, seed=8642 + 1000 * i, device=dev, vision_dtype=torch.bfloat16) for i in range(n9 + 3)]
+                for i in range(3):
+                    tr9.step(pool9[i])
+                torch.cuda.synchronize()
+                ops.GEMM_PROFILE = []
+                t9 = time.perf_counter()
+                for i in range(n9):
+                    l9, _ = tr9.step(pool9[3 + i])
+                torch.cuda.synchronize()
+                dt9 = time.perf_counter() - t9
+                pr9, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
+                mx9 = [r for r in pr9 if r[3][-1] == "mxfp8"]
+                bf9 = [r for r in pr9 if r[3][-1] != "mxfp8"]
+                mx_ms, mx_fl = sum(r[0].elapsed_time(r[1]) for r in mx9), sum(r[2] for r in mx9)
+                bf_ms, bf_fl = sum(r[0].elapsed_time(r[1]) for r in bf9), sum(r[2] for r in bf9)
+                f9 = flops_per_sample(T, L, lay9.vocab, H=4096, F=16384, lm_layers=32, n_xattn=8, head_bwd_rows=10)
+                cfg5_leg = {"value": round(b9 * n9 / dt9, 3), "unit": "samples/s", "ms_per_step": round(dt9 / n9 * 1e3, 2), "per_gpu_batch": b9, "steps": n9, "warmup": 3,
+                            "loss": float(l9), "tflop_per_sample": round(f9["total"] / 1e12, 3),
+                            "dtype": "bf16 (trainable blocks, activations, attention) + MX-fp8 e4m3 frozen-tower GEMMs (E8M0 block scales)",
+                            "mx_gemms": {"achieved": round(mx_fl / (mx_ms * 1e-3) / 1e12, 2) if mx_ms else None, "peak": PEAK_MXFP8_TFLOPS, "unit": "TFLOP/s",
+                                         "frac": round(mx_fl / (mx_ms * 1e-3) / 1e12 / PEAK_MXFP8_TFLOPS, 4) if mx_ms else None, "ms_per_step": round(mx_ms / n9, 2),
+                                         "launches_per_step": len(mx9) // n9},
+                            "bf16_gemms": {"achieved": round(bf_fl / (bf_ms * 1e-3) / 1e12, 2) if bf_ms else None, "frac": round(bf_fl / (bf_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if bf_ms else None,
+                                           "ms_per_step": round(bf_ms / n9, 2)},
+                            "config": "cfg5's model family: 9b Flamingo (ViT-L/14 + MPT-7B dims, gated cross-attention every 4th block; mmrec.py:515-524), single-task rec, "
+                                      f"T = {T}, L = {L}, full optimizer step; NOT the headline"}
+                tr9.dp.remove()
+            except Exception as e:       # noqa: BLE001  (the headline must not depend on the extra leg)
+                cfg5_leg = {"error": f"{type(e).__name__}: {e}"}
+            finally:
+                F_.FP8_FROZEN = False
+                ops.GEMM_PROFILE = None
         line = {"metric": "train samples/sec (user sequences) at 4B-instruct", "value": round(value, 3), "unit": "samples/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -562,13 +614,13 @@ def main():
                            "tflop_per_sample": round(fps["total"] / 1e12, 3),
                            "tflop_per_sample_note": "executed FLOPs (SURVEY 8d formulae); the LM head's backward runs on the labeled positions only"
                                                     if hb else "SURVEY 8d formulae, dense head backward",
-                           "hip_graph": bool(args.graph), "packed_token_order": bool(trainer.packed), "fused_accumulation": bool(trainer.fuse_accum),
+                           "hip_graph": bool(args.graph), "packed_token_order": cfg_flags["packed"], "fused_accumulation": cfg_flags["fused"],
                            "head_backward": "dense" if args.dense_head_backward else "labeled rows only (zero rows of dlogits skipped; same gradients)",
                            "model_tflops_per_gpu": round(value / world * fps["total"] / 1e12, 1),
                            "mfma_frac_whole_step": round(value / world * fps["total"] / 1e12 / PEAK_BF16_TFLOPS, 4),
                            **({"note": "--sparse-head: the utilisation fields above still count the dense head's FLOPs"}
                               if args.sparse_head else {})},
-                "roofline": roofline, "cpu_baseline": cpu, **({"parity": parity} if parity else {}), **({"rccl": rccl} if rccl else {}), **({"packed_token_order": packed_leg} if packed_leg else {}), **({"other_shapes": shape_legs} if shape_legs else {})}
+                "roofline": roofline, "cpu_baseline": cpu, **({"parity": parity} if parity else {}), **({"rccl": rccl} if rccl else {}), **({"packed_token_order": packed_leg} if packed_leg else {}), **({"other_shapes": shape_legs} if shape_legs else {}), **({"cfg5_fp8": cfg5_leg} if cfg5_leg else {})}
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if dist.is_initialized():

@@ -18,6 +18,7 @@ SHAPES = [
     ("lm dX(down) x aux ", ML, 10240, 2560, 0, 1, "aux"),
     ("lm qkv +rope      ", ML, 7680, 2560, 0, 0, "rope"),
     ("lm dX(qkv)        ", ML, 2560, 7680, 0, 1, "plain"),
+    ("vit-like qkv +rope", MV, 3072, 1024, 0, 0, "rope64"),
     ("lm attn-out +res  ", ML, 2560, 2560, 0, 0, "res"),
     ("lm dX(attn-out)   ", ML, 2560, 2560, 0, 1, "plain"),
     ("vit up +qgelu     ", MV, 4096, 1024, 0, 0, "qgelu"),
@@ -46,7 +47,7 @@ def make(M, N, K, aks, bks, epi):
     out = torch.empty((M, N), dtype=bf, device="cuda")
     kw = dict(a_ks=bool(aks), b_ks=bool(bks), out=out)
     extra = []
-    if epi in ("bias", "gelu2", "res", "qgelu", "rope"):
+    if epi in ("bias", "gelu2", "res", "qgelu", "rope", "rope64"):
         kw["bias"] = torch.randn(N, device="cuda", generator=g).to(bf)
     if epi == "gelu2":
         pre = torch.empty((M, N), dtype=torch.uint8, device="cuda")
@@ -59,6 +60,8 @@ def make(M, N, K, aks, bks, epi):
         kw.update(res=torch.randn((M, N), device="cuda", generator=g).to(bf))
     if epi == "rope":
         kw.update(rope=dict(rot=80, hd=80, period=240, span=160, L=512, log2_base=13.287712379549449))     # NeoX 4b: rotary_pct 1.0, [h][q,k,v]
+    if epi == "rope64":        # a K = 1024 problem with the rotary epilogue (16 heads of 64, [h][q,k,v]): the short-K case of the persistent kernels
+        kw.update(rope=dict(rot=64, hd=64, period=192, span=128, L=257, log2_base=13.287712379549449))
     return a, b, kw, out, extra
 
 
@@ -77,7 +80,7 @@ for name, M, N, K, aks, bks, epi in SHAPES:
         continue
     a, b, kw, out, extra = make(M, N, K, aks, bks, epi)
     fl = 2.0 * M * N * K
-    vs = [v for v in VARIANTS if not (epi == "rope" and v in ("w8", "pp128", "pp128x"))]
+    vs = [v for v in VARIANTS if not (epi.startswith("rope") and v in ("w8", "pp128", "pp128x", "pp128a"))]
     ref, same, times = None, {}, {v: [] for v in vs}
     for v in vs:
         try:

@@ -72,7 +72,7 @@ fi
 
 if has prof; then
   # 3. kernel stats of the default bench command: whole process (--stats) and the timed steps only (markers)
-  leg prof 900 $O/prof.log rocprofv3 --kernel-trace --stats -d $O/stats -o st --output-format csv -- python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-roofline --no-packed-leg --no-shape-legs
+  leg prof 900 $O/prof.log rocprofv3 --kernel-trace --stats -d $O/stats -o st --output-format csv -- python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-roofline --no-packed-leg --no-shape-legs --no-cfg5-leg
   leg window 300 $O/window.txt python tools/trace_window.py "$(find $O/stats -name '*kernel_trace.csv' | head -1)" 6 $O/${R}_bench_b64_timed_steps.csv
   keep window $O/${R}_bench_b64_timed_steps.csv ${R}_bench_b64_timed_steps.csv
   keep prof "$(find $O/stats -name '*kernel_stats.csv' | head -1)" ${R}_bench_b64_kernel_stats.csv

@@ -76,6 +76,8 @@ def _tune_gemm(M, N, K, a_ks, b_ks, device, reads_mn=False):
     if not GEMM_AUTOTUNE or torch.cuda.is_current_stream_capturing():
         return 0
     cands = [1] if (M < 512 or N < 128 or K < 128) else ([1, 4, 5, 8, 9, 10, 11] if reads_mn == "out2" else [1, 4, 5, 2, 3, 8, 9, 10, 11])   # "out2": the uint8 derivative
+    if len(cands) > 1 and not a_ks and K % 64 == 0 and K >= 256:
+        cands += [13, 14]                       # whole-row A staging (k-contiguous A, 64-k stages); other forms would only re-run the X kernels
     if len(cands) == 1:
         _GEMM_CHOICE[key] = cands[0]
         return cands[0]
@@ -232,7 +234,7 @@ def _tune_packed(M, N, K, a_ks, device, reads_mn, unpacked_variant, b_ks):
 TAIL_SPLIT = os.environ.get("UNIMP_GEMM_TAIL_SPLIT", "1") != "0"
 
 
-ROPE_VARIANTS = (4, 9, 10, 12)  # pp256 / pp256p and their one-set forms: the kernels with a rotary-epilogue instantiation (gemm3.hip, gemm6.hip)
+ROPE_VARIANTS = (4, 9, 10, 12, 13)  # pp256 / pp256p, their one-set forms and the whole-row-A form: the kernels with a rotary-epilogue instantiation (gemm3.hip, gemm6.hip)
 
 
 ROPE_MIN_M = 256                # rows (one tile row) from which the QKV projection takes the rotary epilogue: low enough that a training
