@@ -22,6 +22,8 @@ def _worker(rank, world, port, q, backend="gloo", own_device=False):
     """backend "gloo": both ranks on cuda:0 (a 1-GPU box); backend "nccl" with own_device: rank r on cuda:r over RCCL (armed by
     test_two_rank_rccl_step_on_two_gpus when the box has a second GPU)."""
     import sys
+    import faulthandler
+    faulthandler.dump_traceback_later(200, exit=True)          # a hung rank reports where it hangs and EXITS (a surviving child would keep pytest alive)
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -91,7 +93,7 @@ def test_two_rank_step_on_one_gpu():
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(daemon=True, target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=240) for _ in range(world))
@@ -102,6 +104,8 @@ def test_two_rank_step_on_one_gpu():
 
 def _worker_rccl(q, port):
     import sys
+    import faulthandler
+    faulthandler.dump_traceback_later(200, exit=True)          # a hung rank reports where it hangs and EXITS (a surviving child would keep pytest alive)
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -150,6 +154,8 @@ def _worker_rccl(q, port):
 
 def _worker_shard(rank, world, port, q, backend):
     import sys
+    import faulthandler
+    faulthandler.dump_traceback_later(200, exit=True)          # a hung rank reports where it hangs and EXITS (a surviving child would keep pytest alive)
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -244,7 +250,7 @@ def test_sharded_optimizer_state_matches_replicated(backend, world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_shard, args=(r, world, port, q, backend)) for r in range(world)]
+    procs = [ctx.Process(daemon=True, target=_worker_shard, args=(r, world, port, q, backend)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=300) for _ in range(world))
@@ -262,7 +268,7 @@ def test_one_rank_rccl_process_group():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_worker_rccl, args=(q, _free_port()))
+    p = ctx.Process(daemon=True, target=_worker_rccl, args=(q, _free_port()))
     p.start()
     res = q.get(timeout=300)
     p.join(60)
@@ -315,7 +321,7 @@ def test_two_rank_rccl_step_on_two_gpus():
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, "nccl", True)) for r in range(world)]
+    procs = [ctx.Process(daemon=True, target=_worker, args=(r, world, port, q, "nccl", True)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=300) for _ in range(world))
@@ -332,7 +338,7 @@ def test_sharded_optimizer_state_two_rank_rccl():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_shard, args=(r, 2, port, q, "nccl")) for r in range(2)]
+    procs = [ctx.Process(daemon=True, target=_worker_shard, args=(r, 2, port, q, "nccl")) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=400) for _ in range(2))

@@ -103,6 +103,8 @@ if has micro; then
   keep mx $O/mx.log ${R}_mx_gemm.txt
   leg attn 600 $O/attn.log python tools/bench_attn2.py
   keep attn $O/attn.log ${R}_attention_microbench.txt
+  leg loader 900 $O/loader.log python tools/bench_loader.py 8 8
+  keep loader $O/loader.log ${R}_loader_throughput.txt
 fi
 
 if has pmc; then

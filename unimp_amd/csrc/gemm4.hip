@@ -30,7 +30,7 @@ __device__ __forceinline__ void mfma_agpr(f32x4& c, bf16x8 a, bf16x8 b) {
   asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
 
-#ifdef G4_STAMP      // debug build: cycle stamps of one block's waves (tools/stamp_gemm4.py); LDS bytes [128 KiB, +8 KiB) hold them
+#ifdef G4_STAMP      // debug build: cycle stamps of one block's waves (round-2 tool, removed; see docs/history); LDS bytes [128 KiB, +8 KiB) hold them
 __device__ unsigned long long g4_stamps[4 * 64 * 4];
 extern "C" int unimp_debug_g4_stamps(void* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g4_stamps), sizeof(g4_stamps)); }
 #define STAMP(H, K_) do { if (blockIdx.x == 300 && (H) < 64) { unsigned long long t_;                               \

@@ -249,7 +249,7 @@ def linear(x, w, b=None, ldc=None):
 def _frozen_t(w):
     """k-strided copy W^T [in, out] of a FROZEN weight, cached on the parameter and rebuilt when the weight is written to
     (load_state_dict copies in place and bumps `_version`).  The forward MLP GEMMs run 5-8 % faster with the weight operand
-    in that form (tools/bench_forms.py); trainable weights keep the reference layout -- a copy would have to follow every
+    in that form (tools/bench_gemm_ab.py, the W^T rows); trainable weights keep the reference layout -- a copy would have to follow every
     optimizer step."""
     c = getattr(w, "_unimp_wt", None)
     if c is None or c[0] != w._version or c[1].data_ptr() == 0:
