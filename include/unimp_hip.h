@@ -95,7 +95,6 @@ enum { UNIMP_GEMM_AUTO = 0, UNIMP_GEMM_V1 = 1, UNIMP_GEMM_DMA256 = 2, UNIMP_GEMM
                                 LDS-DMA half-stages are issued before the current tile's epilogue */,
        UNIMP_GEMM_PP256A = 13, UNIMP_GEMM_PP128A = 14 /* PP256X / PP128X with a k-contiguous A operand staged in whole 128-byte rows
           (64-k stages, a ring of its own); other operand forms run the X kernels */,
-       UNIMP_GEMM_PP256D = 15 /* PP256A whose fixed-epilogue-kind kernels store straight from the accumulators (no LDS round trip) */,
        UNIMP_GEMM_PP256X = 10, UNIMP_GEMM_PP128X = 11, UNIMP_GEMM_PP256PX = 12
        /* PP256 / PP128 / PP256P with ONE fragment register set: the L phase of a half-step reads that half-step's own fragments
           (before its LDS-DMA issue) and leaves two half-stages in flight instead of one -- 48 registers fewer, same bits */ };

@@ -23,7 +23,7 @@ def _worker(rank, world, port, q, backend="gloo", own_device=False):
     test_two_rank_rccl_step_on_two_gpus when the box has a second GPU)."""
     import sys
     import faulthandler
-    faulthandler.dump_traceback_later(200, exit=True)          # a hung rank reports where it hangs and EXITS (a surviving child would keep pytest alive)
+    faulthandler.dump_traceback_later(540, exit=True)          # a hung rank reports where it hangs and EXITS (a surviving child would keep pytest alive)
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -96,7 +96,7 @@ def test_two_rank_step_on_one_gpu():
     procs = [ctx.Process(daemon=True, target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=240) for _ in range(world))
+    res = sorted(q.get(timeout=600) for _ in range(world))
     for p in procs:
         p.join(60)
     assert all(r[1] == "ok" for r in res), res
@@ -105,7 +105,7 @@ def test_two_rank_step_on_one_gpu():
 def _worker_rccl(q, port):
     import sys
     import faulthandler
-    faulthandler.dump_traceback_later(200, exit=True)          # a hung rank reports where it hangs and EXITS (a surviving child would keep pytest alive)
+    faulthandler.dump_traceback_later(540, exit=True)          # a hung rank reports where it hangs and EXITS (a surviving child would keep pytest alive)
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -155,7 +155,7 @@ def _worker_rccl(q, port):
 def _worker_shard(rank, world, port, q, backend):
     import sys
     import faulthandler
-    faulthandler.dump_traceback_later(200, exit=True)          # a hung rank reports where it hangs and EXITS (a surviving child would keep pytest alive)
+    faulthandler.dump_traceback_later(540, exit=True)          # a hung rank reports where it hangs and EXITS (a surviving child would keep pytest alive)
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -253,7 +253,7 @@ def test_sharded_optimizer_state_matches_replicated(backend, world):
     procs = [ctx.Process(daemon=True, target=_worker_shard, args=(r, world, port, q, backend)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=300) for _ in range(world))
+    res = sorted(q.get(timeout=600) for _ in range(world))
     for p in procs:
         p.join(60)
     assert all(r[1] == "ok" for r in res), res
@@ -270,7 +270,7 @@ def test_one_rank_rccl_process_group():
     q = ctx.Queue()
     p = ctx.Process(daemon=True, target=_worker_rccl, args=(q, _free_port()))
     p.start()
-    res = q.get(timeout=300)
+    res = q.get(timeout=600)
     p.join(60)
     assert res[0] == "ok", res[1]
 
@@ -324,7 +324,7 @@ def test_two_rank_rccl_step_on_two_gpus():
     procs = [ctx.Process(daemon=True, target=_worker, args=(r, world, port, q, "nccl", True)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=300) for _ in range(world))
+    res = sorted(q.get(timeout=600) for _ in range(world))
     for p in procs:
         p.join(60)
     assert all(r[1] == "ok" for r in res), res
@@ -341,7 +341,7 @@ def test_sharded_optimizer_state_two_rank_rccl():
     procs = [ctx.Process(daemon=True, target=_worker_shard, args=(r, 2, port, q, "nccl")) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=400) for _ in range(2))
+    res = sorted(q.get(timeout=600) for _ in range(2))
     for p in procs:
         p.join(60)
     assert all(r[1] == "ok" for r in res), res

@@ -88,7 +88,7 @@ def test_gemm_layouts(ops, M, N, K, a_ks, b_ks):
     bd = (b.t().contiguous() if b_ks else b).cuda()
     got = ops.gemm(ad, bd, a_ks=a_ks, b_ks=b_ks)                  # autotuned choice
     close(got, want, name=f"gemm {M}x{N}x{K} {a_ks}{b_ks}")
-    for variant in (["v1"] if M < 256 else ["v1", "dma256", "dma128", "pp256", "pp128", "w4", "w8", "pp256p", "pp256x", "pp128x", "pp256px", "pp256a", "pp128a", "pp256d"]):   # every kernel, explicitly
+    for variant in (["v1"] if M < 256 else ["v1", "dma256", "dma128", "pp256", "pp128", "w4", "w8", "pp256p", "pp256x", "pp128x", "pp256px", "pp256a", "pp128a"]):   # every kernel, explicitly
         got = ops.gemm(ad, bd, a_ks=a_ks, b_ks=b_ks, variant=variant)
         close(got, want, name=f"gemm[{variant}] {M}x{N}x{K} {a_ks}{b_ks}")
     got32 = ops.gemm(ad, bd, a_ks=a_ks, b_ks=b_ks, out_f32=True, variant="pp256" if M >= 256 else "v1")
@@ -104,14 +104,14 @@ def test_gemm_pingpong_long_k_race_screen(ops):
         ad, bd = a.cuda(), b.cuda()
         ref = ops.gemm(ad, bd, variant="v1")
         close(ref, want, name="v1 long k")
-        for variant in ("pp256", "pp128", "dma256", "pp256p", "pp256x", "pp128x", "pp256px", "pp256a", "pp128a", "pp256d"):
+        for variant in ("pp256", "pp128", "dma256", "pp256p", "pp256x", "pp128x", "pp256px", "pp256a", "pp128a"):
             outs = [ops.gemm(ad, bd, variant=variant) for _ in range(6)]
             for o in outs:
                 assert torch.equal(o, outs[0]), f"{variant}: run-to-run mismatch at K={K}"
             close(outs[0], want, name=f"{variant} long k")
 
 
-@pytest.mark.parametrize("pv", ["pp256p", "pp256px", "pp256x", "pp256a", "pp256d"])
+@pytest.mark.parametrize("pv", ["pp256p", "pp256px", "pp256x", "pp256a"])
 def test_gemm_persistent_many_tiles_per_workgroup(ops, pv):
     """pp256p walks several tiles per workgroup (more tiles than CUs), ragged M / N edges, each epilogue kind; results must
     equal the one-tile-per-workgroup ping-pong kernel bit for bit (same accumulation order)."""
@@ -151,7 +151,7 @@ def test_gemm_variants_same_bits_under_every_forward_epilogue(ops):
         bias, res = rnd(N, seed=3).cuda(), rnd(M, N, seed=4).cuda()
         for kw in (dict(), dict(bias=bias), dict(res=res), dict(res=res, gate=gate), dict(bias=bias, res=res, gate=gate), dict(gate=gate), dict(act="gelu"),
                    dict(bias=bias, act="gelu"), dict(bias=bias, act="quick_gelu"), dict(alpha=0.125, bias=bias), dict(alpha=0.125, res=res, gate=gate)):
-            outs = {v: ops.gemm(a, b, variant=v, **kw) for v in ("v1", "dma256", "dma128", "pp256", "pp128", "w8", "pp256p", "pp256x", "pp128x", "pp256px", "pp256a", "pp128a", "pp256d")}
+            outs = {v: ops.gemm(a, b, variant=v, **kw) for v in ("v1", "dma256", "dma128", "pp256", "pp128", "w8", "pp256p", "pp256x", "pp128x", "pp256px", "pp256a", "pp128a")}
             for v, o in outs.items():
                 assert torch.equal(o, outs["v1"]), f"[{M}, {N}, {K}] {sorted(kw)}: {v} differs from v1 in {int((o != outs['v1']).sum())} elements"
     M, H, hd, L = 1024, 8, 80, 512
@@ -209,7 +209,7 @@ def test_gemm_stored_derivative_uint8(ops, M, N, K, act):
     a, b, bias = rnd(M, K, seed=1).cuda(), rnd(N, K, seed=2, scale=0.2).cuda(), rnd(N, seed=3).cuda()
     ld = (N + 7) // 8 * 8
     outs = {}
-    for v in (["v1"] if M < 256 else ["v1", "pp256", "pp128", "w8", "pp256p", "pp256x", "pp128x", "pp256px", "pp256a", "pp128a", "pp256d"]):       # the kernels with the specialised epilogue kinds
+    for v in (["v1"] if M < 256 else ["v1", "pp256", "pp128", "w8", "pp256p", "pp256x", "pp128x", "pp256px", "pp256a", "pp128a"]):       # the kernels with the specialised epilogue kinds
         q = torch.full((M, ld), 255, dtype=torch.uint8, device="cuda")
         y = ops.gemm(a, b, bias=bias, act=act, pre=q[:, :N], pre_deriv=True, variant=v)
         outs[v] = (y, q)
@@ -228,7 +228,7 @@ def test_gemm_stored_derivative_uint8(ops, M, N, K, act):
     # backward: dz = (dy W2) * g through the uint8 operand
     dy, w2 = rnd(M, 96, seed=5).cuda(), rnd(96, N, seed=6, scale=0.2).cuda()
     want = (dy.float() @ w2.float()) * dec
-    for v in (["v1"] if M < 256 else ["v1", "pp256", "pp128", "w8", "pp256p", "pp256x", "pp128x", "pp256px", "pp256a", "pp128a", "pp256d"]):
+    for v in (["v1"] if M < 256 else ["v1", "pp256", "pp128", "w8", "pp256p", "pp256x", "pp128x", "pp256px", "pp256a", "pp128a"]):
         got = ops.gemm(dy, w2, b_ks=True, aux=q0[:, :N], dact="deriv", variant=v)
         close(got, want, name=f"dz through uint8 act' [{v}]")
     ref16 = ops.gemm(dy, w2, b_ks=True, aux=g16[:, :N], dact="deriv", variant="v1")
@@ -253,7 +253,7 @@ def test_stored_derivative_uint8_decodes_0_and_1_exactly(ops):
     byte 229 is exactly 1 (the product equals the plain GEMM bit for bit), in every kernel that serves the uint8 operand."""
     M, N, K = 512, 512, 256
     dy, w2 = rnd(M, K, seed=41).cuda(), rnd(K, N, seed=42, scale=0.2).cuda()
-    for v in ("v1", "pp256", "pp128", "w8", "pp256p", "pp256x", "pp128x", "pp256px", "pp256a", "pp128a", "pp256d"):
+    for v in ("v1", "pp256", "pp128", "w8", "pp256p", "pp256x", "pp128x", "pp256px", "pp256a", "pp128a"):
         plain = ops.gemm(dy, w2, b_ks=True, variant=v)
         zero = ops.gemm(dy, w2, b_ks=True, aux=torch.full((M, N), 27, dtype=torch.uint8, device="cuda"), dact="deriv", variant=v)
         one = ops.gemm(dy, w2, b_ks=True, aux=torch.full((M, N), 229, dtype=torch.uint8, device="cuda"), dact="deriv", variant=v)
@@ -301,7 +301,7 @@ def test_gemm_epilogue_bias_act_pre(ops, act, M):
     N, K = 264, 136
     a, b, bias = rnd(M, K, seed=3), rnd(N, K, seed=4, scale=0.2), rnd(N, seed=5)
     z = a.float() @ b.float().t() + bias.float()
-    for variant in (["v1"] if M < 256 else ["v1", "dma128", "pp256", "pp128", "pp256p", "pp256x", "pp128x", "pp256px", "pp256a", "pp128a", "pp256d"]):
+    for variant in (["v1"] if M < 256 else ["v1", "dma128", "pp256", "pp128", "pp256p", "pp256x", "pp128x", "pp256px", "pp256a", "pp128a"]):
         pre = torch.empty(M, N, dtype=bf16, device="cuda")
         got = ops.gemm(a.cuda(), b.cuda(), bias=bias.cuda(), act=act, pre=pre, variant=variant)
         close(pre, z, name="pre")
@@ -765,7 +765,7 @@ def _adjacent_perm(hd, rot):
     return torch.where(p < rot, d, p)
 
 
-@pytest.mark.parametrize("variant", ["pp256", "pp256p", "pp256x", "pp256px", "pp256a", "pp256d"])
+@pytest.mark.parametrize("variant", ["pp256", "pp256p", "pp256x", "pp256px", "pp256a"])
 @pytest.mark.parametrize("nh,hd,rot,interleaved,L", [(4, 80, 80, True, 200), (6, 64, 16, True, 128), (3, 128, 128, False, 300),
                                                      (4, 80, 80, True, 2304), (2, 128, 128, False, 4100)])      # positions >= 2048
 def test_gemm_rotary_epilogue(ops, variant, nh, hd, rot, interleaved, L):

@@ -29,15 +29,7 @@
 #include <stdlib.h>
 #include "gemm_half.h"
 
-#if defined(G3X) && defined(G3_AFULL) && defined(G3_DIRECT)   // fourth build (gemm3d.o): the third with the register-direct epilogue
-#define gemm3_bf16_kernel gemm3d_bf16_kernel
-#define unimp_gemm3_launch unimp_gemm3d_launch
-#define unimp_gemm3_launch_splitk unimp_gemm3d_launch_splitk
-#define launch3 launch3d
-#define g3_stamps g3d_stamps
-#define unimp_debug_g3_stamps unimp_debug_g3d_stamps
-#define getenv_no_fixed getenv_no_fixed_d
-#elif defined(G3X) && defined(G3_AFULL)   // third build (Makefile: gemm3a.o): the one-set schedule with the A operand staged in whole 128-byte rows
+#if defined(G3X) && defined(G3_AFULL)   // third build (Makefile: gemm3a.o): the one-set schedule with the A operand staged in whole 128-byte rows
 #define gemm3_bf16_kernel gemm3a_bf16_kernel
 #define unimp_gemm3_launch unimp_gemm3a_launch
 #define unimp_gemm3_launch_splitk unimp_gemm3a_launch_splitk
@@ -99,11 +91,6 @@ __device__ __forceinline__ void frag_packed_asm(const void* sbase, uint32_t voff
 template <bool AKS, bool BKS, int BN, bool BPK = false, int EPI = -1>
 __global__ __launch_bounds__(512, 2) void gemm3_bf16_kernel(Gemm2Params p) {
   constexpr bool ROPE = EPI == EK_ROPE;
-#ifdef G3_DIRECT
-  constexpr bool DIRECT = EPI >= 0 && !BPK;     // fixed-kind kernels: register-direct epilogue (gemm_tile.h epi_direct), B fragment rows permuted for it
-#else
-  constexpr bool DIRECT = false;
-#endif
   extern __shared__ __attribute__((aligned(16))) char smem[];
   G3_T(0);
 #ifdef G3_STAMP
@@ -163,13 +150,13 @@ __global__ __launch_bounds__(512, 2) void gemm3_bf16_kernel(Gemm2Params p) {
     dma_issue<AKS, G3_BM>(p.A, p.lda, (H), p.K, b_, wave, aoff);                                                   \
     if (!BPK) dma_issue<BKS, BN>(p.B, p.ldb, (H), p.K, b_ + A_SUB, wave, boff); } while (0)
   const uint32_t smem_lds = (uint32_t)(uintptr_t)LDS_PTR(char, smem);
-  const uint32_t lbA = AKS ? ks32_lane_base<G3_BM>(wm * 128) : 0u, lbB = (BKS && !BPK) ? (DIRECT ? ks32_lane_base_p<BN>(wn * WN) : ks32_lane_base<BN>(wn * WN)) : 0u;
+  const uint32_t lbA = AKS ? ks32_lane_base<G3_BM>(wm * 128) : 0u, lbB = (BKS && !BPK) ? ks32_lane_base<BN>(wn * WN) : 0u;
 #define LOADF(S, H) do { const char* b_ = smem + ((H) % G3_NST) * SUB;                                                  \
     uint32_t ub_ = smem_lds + ((H) % G3_NST) * SUB;                                                                     \
     _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                               \
       if (BPK) frag_packed_asm(pk_base + ((long)j * pk_nh + (H)) * 1024, pk_lane, rb##S[j]);                       \
       else if (BKS) frag_ks32_asm<BN>(lbB + ub_ + A_SUB, j, lb##S[j], hb##S[j]);                                   \
-      else rb##S[j] = DIRECT ? frag_kc32p(b_ + A_SUB, wn * WN + j * 16) : frag_kc32(b_ + A_SUB, wn * WN + j * 16); }   \
+      else rb##S[j] = frag_kc32(b_ + A_SUB, wn * WN + j * 16); }                                                   \
     _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                \
       if (AKS) frag_ks32_asm<G3_BM>(lbA + ub_, i, la##S[i], ha##S[i]);                                             \
       else ra##S[i] = frag_kc32(b_, wm * 128 + i * 16); } } while (0)
@@ -228,7 +215,7 @@ static_assert(G3_NST == 4, "the one-set schedule is written for a prefetch dista
       uint32_t ubb_ = smem_lds + A_RING + ((H) % 4) * B_SUB;                                                           \
       _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                             \
         if (BKS) frag_ks32_asm<BN>(lbB + ubb_, j, lb0[j], hb0[j]);                                                 \
-        else rb0[j] = DIRECT ? frag_kc32p(bb_, wn * WN + j * 16) : frag_kc32(bb_, wn * WN + j * 16); }             \
+        else rb0[j] = frag_kc32(bb_, wn * WN + j * 16); }                                                          \
       const char* ab_ = smem + (((H) >> 1) % 3) * A_STG + (a_lane ^ (((H) & 1) << 6));                             \
       _Pragma("unroll") for (int i = 0; i < 8; ++i) ra0[i] = *(const bf16x8*)(ab_ + i * 2048); } while (0)
 #define HALF_STEP_AF(H, EVEN) do {                                                                                 \
@@ -288,12 +275,6 @@ static_assert(G3_NST == 4, "the one-set schedule is written for a prefetch dista
 
   float gate = 1.f;
   if (p.gate) gate = tanhf(bf2f(*p.gate));
-  if constexpr (DIRECT) {       // fixed-kind kernels: straight from the accumulators (gemm_tile.h epi_direct)
-    G3_T(4); G3_T(5); G3_T(6); G3_T(7);
-    epi_direct<EPI < 0 ? 0 : EPI, NJ>(p, acc, lane, m0 + wm * 128, n0 + wn * WN, gate);
-    G3_T(3);
-    return;
-  }
   // ---- epilogue through LDS (see gemm2.hip): wave-private [64][WN] f32 region, 16-B units XOR-swizzled by row
   constexpr int ESTR = WN * 4, UNITS = WN / 4;
   char* er = smem + wave * (64 * ESTR);

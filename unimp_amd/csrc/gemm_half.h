@@ -9,11 +9,6 @@ __device__ __forceinline__ bf16x8 frag_kc32(const char* tile, int r0) {
   int l = lane_id();
   return *(const bf16x8*)(tile + kc32_off(r0 + (l & 15), l >> 4));
 }
-// the same fragment with its 16 rows in the order of gemm_tile.h's register-direct epilogue (row groups of four as 0, 2, 1, 3)
-__device__ __forceinline__ bf16x8 frag_kc32p(const char* tile, int r0) {
-  int l = lane_id(), i = l & 15;
-  return *(const bf16x8*)(tile + kc32_off(r0 + ((i & 3) | ((i & 4) << 1) | ((i & 8) >> 1)), l >> 4));
-}
 template <int ROWS>
 __device__ __forceinline__ int ks32_off(int krow, int col) {
   return krow * (ROWS * 2) + ((((col >> 4) ^ ks_h(krow)) << 5) | ((col & 15) << 1));
@@ -32,14 +27,6 @@ __device__ __forceinline__ uint32_t ks32_lane_base(int c0) {
   int l = lane_id();
   int g = l >> 4, q = (l >> 2) & 3, p = l & 3;
   return (uint32_t)ks32_off<ROWS>(g * 8 + q, c0 + 4 * p);
-}
-// transposed form of the permuted fragment: the lanes with l & 3 == p fetch the four columns that land on output lanes 4 p .. 4 p + 3,
-// so the column groups are fetched in the order 0, 2, 1, 3
-template <int ROWS>
-__device__ __forceinline__ uint32_t ks32_lane_base_p(int c0) {
-  int l = lane_id();
-  int g = l >> 4, q = (l >> 2) & 3, p = l & 3, pp = ((p & 1) << 1) | (p >> 1);
-  return (uint32_t)ks32_off<ROWS>(g * 8 + q, c0 + 4 * pp);
 }
 template <int ROWS>
 __device__ __forceinline__ void frag_ks32_asm(uint32_t a0, int i, s16x4& lo, s16x4& hi) {

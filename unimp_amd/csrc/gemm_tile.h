@@ -311,53 +311,6 @@ __device__ __forceinline__ void epi_pass_fixed(const Gemm2Params& p, const char*
                                                const EpiPre<WN, ROWS>& e, bf16x8 biasv) {
   epi_groups<WN, KIND, ROWS>(p, er, lane, mbase, nbase, gate, e, biasv);
 }
-// ---- register-direct epilogue of the fixed-kind kernels (G3_DIRECT): no LDS round trip.
-// The swapped MFMA leaves a lane with 4 consecutive n of one m per 16 x 16 tile (fragment rows 4 q .. 4 q + 3, q = lane >> 4).  The B
-// fragments of these kernels are read with their 16 rows PERMUTED by groups of four -- row group order (0, 2, 1, 3): frag_kc32p /
-// ks32_lane_base_p -- so lane q owns columns {0-3, 8-11, 4-7, 12-15}[q]; one v_permlane32_swap per register between the accumulators of
-// two adjacent column tiles then gives every lane 8 CONSECUTIVE columns of its row (lanes 0-31 finish tile 2 jp, lanes 32-63 tile
-// 2 jp + 1: column n0 + 32 jp + 8 q), which is exactly what epi8k<KIND> eats: 16-byte loads / stores, 64 contiguous bytes per row and
-// instruction.  Replaces 32 ds_write_b128 + 32 ds_read_b128 + the waits between them per wave and tile by 64 swaps (cdna guide T21).
-// The permutation only relabels n: every output element is still the same k-ordered sum -- same bits as the LDS-staged form.
-__device__ __forceinline__ void swap32(float& a, float& b) {          // a[lanes 32-63] <-> b[lanes 0-31]
-  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-  a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
-}
-template <int KIND, int NJ>
-__device__ __forceinline__ void epi_direct(const Gemm2Params& p, f32x4 (&acc)[8][NJ], int lane, int em, int en, float gate) {
-  static_assert(NJ % 2 == 0, "column tiles are finished in pairs");
-  const int q = lane >> 4, r16 = lane & 15;
-  const bool interior = em + 128 <= p.M && en + 16 * NJ <= p.N;      // wave-uniform: the branch-free path (no per-row guards -> counted waits)
-#pragma unroll
-  for (int jp = 0; jp < NJ / 2; ++jp) {
-    const int n = en + 32 * jp + 8 * q;
-    const bool ncol = n < p.N;                                         // N % 8 == 0 (host): a lane's 8 columns are all in or all out
-    bf16x8 biasv = bf16x8{};
-    if (p.bias && ncol) biasv = *(const bf16x8*)(p.bias + n);
-    bf16x8 xv[8];
-    if (KIND == EK_AUX || KIND == EK_RES) {                            // all eight row chunks of this column pair first, then the stores
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int m = min(em + 16 * i + r16, p.M - 1), nn = ncol ? n : 0;
-        if (KIND == EK_AUX) { uint2 w = *(const uint2*)((const uint8_t*)p.aux + (long)m * p.ldaux + nn);
-          union { uint2 qq[2]; bf16x8 b; } cv; cv.qq[0] = w; cv.qq[1] = uint2{0, 0}; xv[i] = cv.b; }
-        else xv[i] = *(const bf16x8*)(p.res + (long)m * p.ldres + nn);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const f32x4 a = acc[i][2 * jp], b = acc[i][2 * jp + 1];
-      float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-#pragma unroll
-      for (int r = 0; r < 4; ++r) swap32(v[r], v[4 + r]);
-      const int m = em + 16 * i + r16;
-      if (interior || (m < p.M && ncol)) epi8k<KIND>(p, v, m, n, gate, (KIND == EK_AUX || KIND == EK_RES) ? xv[i] : bf16x8{}, biasv);
-    }
-  }
-}
-// B-fragment reads with the row-group permutation above
-__device__ __forceinline__ int perm16(int i) { return (i & 3) | ((i & 4) << 1) | ((i & 8) >> 1); }
-
 // host-side twin of epi_kind() + the fixed kinds' extra conditions; returns the EPI template value to launch, -1 = the generic kernel
 static inline int epi_kind_host(const Gemm2Params& p) {
   bool fast = ((p.ldc | p.ldres | p.ldaux | p.ldpre) & 7) == 0;

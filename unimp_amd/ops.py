@@ -20,7 +20,7 @@ bf16 = torch.bfloat16
 GEMM_PROFILE = None      # bench.py sets this to a list: (start_event, end_event, flops) per GEMM launch
 GEMM_AUTOTUNE = True     # time the kernel variants once per (M, N, K, layout) on scratch operands and keep the fastest
 GEMM_VARIANTS = {"auto": 0, "v1": 1, "dma256": 2, "dma128": 3, "pp256": 4, "pp128": 5, "skinny": 6, "w4": 7, "w8": 8, "pp256p": 9,
-                 "pp256x": 10, "pp128x": 11, "pp256px": 12, "pp256a": 13, "pp128a": 14, "pp256d": 15}
+                 "pp256x": 10, "pp128x": 11, "pp256px": 12, "pp256a": 13, "pp128a": 14}
 _GEMM_CHOICE = {}
 # The autotune table is DATA: the one the published numbers were measured with is committed (profiles/gemm_autotune_gfx950.json,
 # keyed by (M, N, K, a k-strided, b k-strided, epilogue reads an [M, N] input)) and loaded by default, so the variant per shape --
