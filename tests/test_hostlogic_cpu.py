@@ -115,6 +115,22 @@ def test_eval_text_metrics_hand_computed():
     assert abs(r["rouge1"] - 5 / 6) < 1e-12 and abs(r["rouge2"] - 0.6) < 1e-12 and abs(r["rougeL"] - 5 / 6) < 1e-12
     r = E.rouge_f(["a b c d"], ["d c b a"])                   # same words, reversed: unigrams 1.0, bigrams 0, LCS 1 -> 0.25
     assert r["rouge1"] == 1.0 and r["rouge2"] == 0.0 and r["rougeL"] == 0.25
+    # METEOR (eval_exp.py:65,146), exact + Porter-stem stages, nltk's alpha 0.9 / beta 3 / gamma 0.5.  Porter's published examples first:
+    for w, st in (("caresses", "caress"), ("ponies", "poni"), ("agreed", "agre"), ("plastered", "plaster"), ("motoring", "motor"), ("hopping", "hop"),
+                  ("filing", "file"), ("happy", "happi"), ("sky", "sky"), ("relational", "relat"), ("rational", "ration"), ("digitizer", "digit"),
+                  ("electrical", "electr"), ("replacement", "replac"), ("adoption", "adopt"), ("controll", "control"), ("roll", "roll"), ("sing", "sing")):
+        assert E._porter_stem(w) == st, (w, E._porter_stem(w), st)
+    # identical sentences: 6 matches in one chunk -> F = 1, penalty 0.5 (1/6)^3 -> 0.99769 (the value nltk documents for this case)
+    assert abs(E.meteor(["the cat sat on the mat"], ["the cat sat on the mat"]) - (1 - 0.5 / 216)) < 1e-12
+    # "the cats sat on the mat" vs "the cat is sitting on the mat": exact the / on / the / mat, stem cats ~ cat (sat / sitting do not share a
+    # stem): m = 5, P = 5/6, R = 5/7, F = PR / (0.9 P + 0.1 R), two chunks -> penalty 0.5 (2/5)^3
+    P_, R_ = 5 / 6, 5 / 7
+    want = P_ * R_ / (0.9 * P_ + 0.1 * R_) * (1 - 0.5 * (2 / 5) ** 3)
+    assert abs(E.meteor(["the cats sat on the mat"], ["the cat is sitting on the mat"]) - want) < 1e-12
+    # the same six words in another order: every word matches, but the greedy alignment (walk the hypothesis from its end, take the LAST free
+    # equal reference word) pairs the4 -> the4 and the1 -> the0: (0,3) (1,0) (2,5) (3,2) (4,4) (5,1), no two adjacent -> 6 chunks, penalty 0.5
+    assert abs(E.meteor(["on the mat sat the cat"], ["the cat sat on the mat"]) - 0.5) < 1e-12
+    assert E.meteor(["x y"], ["a b"]) == 0.0 and E.meteor([""], ["a"]) == 0.0
     # eval_img_sel.py:96-113: the SET of generated words
     assert E.selection_scores("Select? s_0 s_2 s_2", [0, 1]) == {"recall": 0.5, "precision": 0.5, "f1": 0.5}
     assert E.selection_scores("Select?", [1]) == {"recall": 0.0, "precision": 0, "f1": 0.0}

@@ -14,8 +14,8 @@ the weight reads of the decode step).
 
 The text metrics of eval_exp come from the third-party ``evaluate`` hub (bleu / rouge / meteor; not installed, not under
 /root/reference): BLEU's unigram modified precision and ROUGE F-measures are restated from their published definitions
-(``bleu1_precision``, ``rouge_f``: PARITY UNPINNED, anchored by hand-computed cases in tests/test_hostlogic_cpu.py); METEOR needs
-WordNet data and is not built."""
+(``bleu1_precision``, ``rouge_f``: PARITY UNPINNED, anchored by hand-computed cases in tests/test_hostlogic_cpu.py); METEOR's exact
+and Porter-stem matching stages are built (``meteor``, round 4), its WordNet-synonym stage is not (no WordNet data offline)."""
 import collections
 import re
 
@@ -238,9 +238,133 @@ def rouge_f(predictions, references):
     return {k: float(np.mean(v)) if v else 0.0 for k, v in out.items()}
 
 
+# ---- METEOR (eval_exp.py:65,146: evaluate's "meteor" = nltk.translate.meteor_score with alpha 0.9, beta 3, gamma 0.5) ---------------
+# nltk aligns hypothesis and reference words in three stages: exact match, Porter-stem match, WordNet-synonym match.  The first two are
+# restated here (Porter's 1980 algorithm; nltk / WordNet are not in the image and not under /root/reference, so: PARITY UNPINNED, and a
+# LOWER bound of nltk's score whenever a synonym pair would have matched).  Per pair: m matched unigrams, P = m / |hyp|, R = m / |ref|,
+# F = P R / (alpha P + (1 - alpha) R), penalty = gamma (chunks / m)^beta, score = F (1 - penalty); corpus value = mean over the pairs.
+def _porter_stem(w):
+    """M. F. Porter, "An algorithm for suffix stripping" (1980), steps 1a-5b; w lower-case."""
+    if len(w) <= 2:
+        return w
+    vow = "aeiou"
+
+    def cons(s, i):
+        return s[i] not in vow and not (s[i] == "y" and i > 0 and cons(s, i - 1))
+
+    def m(s):
+        n, i, L = 0, 0, len(s)
+        while i < L and cons(s, i):
+            i += 1
+        while i < L:
+            while i < L and not cons(s, i):
+                i += 1
+            if i >= L:
+                break
+            n += 1
+            while i < L and cons(s, i):
+                i += 1
+        return n
+
+    def has_vowel(s):
+        return any(not cons(s, i) for i in range(len(s)))
+
+    def dbl(s):
+        return len(s) >= 2 and s[-1] == s[-2] and cons(s, len(s) - 1)
+
+    def cvc(s):
+        return len(s) >= 3 and cons(s, len(s) - 3) and not cons(s, len(s) - 2) and cons(s, len(s) - 1) and s[-1] not in "wxy"
+    if w.endswith("sses"):
+        w = w[:-2]
+    elif w.endswith("ies"):
+        w = w[:-2]
+    elif not w.endswith("ss") and w.endswith("s"):
+        w = w[:-1]
+    again = False
+    if w.endswith("eed"):
+        if m(w[:-3]) > 0:
+            w = w[:-1]
+    elif w.endswith("ed") and has_vowel(w[:-2]):
+        w, again = w[:-2], True
+    elif w.endswith("ing") and has_vowel(w[:-3]):
+        w, again = w[:-3], True
+    if again:
+        if w.endswith(("at", "bl", "iz")):
+            w += "e"
+        elif dbl(w) and w[-1] not in "lsz":
+            w = w[:-1]
+        elif m(w) == 1 and cvc(w):
+            w += "e"
+    if w.endswith("y") and has_vowel(w[:-1]):
+        w = w[:-1] + "i"
+    for suf, rep in (("ational", "ate"), ("tional", "tion"), ("enci", "ence"), ("anci", "ance"), ("izer", "ize"), ("abli", "able"),
+                     ("alli", "al"), ("entli", "ent"), ("eli", "e"), ("ousli", "ous"), ("ization", "ize"), ("ation", "ate"), ("ator", "ate"),
+                     ("alism", "al"), ("iveness", "ive"), ("fulness", "ful"), ("ousness", "ous"), ("aliti", "al"), ("iviti", "ive"),
+                     ("biliti", "ble")):
+        if w.endswith(suf):
+            if m(w[:-len(suf)]) > 0:
+                w = w[:-len(suf)] + rep
+            break
+    for suf, rep in (("icate", "ic"), ("ative", ""), ("alize", "al"), ("iciti", "ic"), ("ical", "ic"), ("ful", ""), ("ness", "")):
+        if w.endswith(suf):
+            if m(w[:-len(suf)]) > 0:
+                w = w[:-len(suf)] + rep
+            break
+    for suf in ("al", "ance", "ence", "er", "ic", "able", "ible", "ant", "ement", "ment", "ent", "ion", "ou", "ism", "ate", "iti", "ous",
+                "ive", "ize"):
+        if w.endswith(suf):
+            stem = w[:-len(suf)]
+            if m(stem) > 1 and (suf != "ion" or (stem and stem[-1] in "st")):
+                w = stem
+            break
+    if w.endswith("e"):
+        stem = w[:-1]
+        if m(stem) > 1 or (m(stem) == 1 and not cvc(stem)):
+            w = stem
+    if m(w) > 1 and dbl(w) and w.endswith("l"):
+        w = w[:-1]
+    return w
+
+
+def _meteor_align(hyp, ref):
+    """nltk's greedy staged alignment: exact matches first, then stems, each stage walking the hypothesis from its END and taking the LAST
+    still-unmatched equal reference word (meteor_score._match_enums); returns the sorted list of (hyp index, ref index) pairs."""
+    pairs, uh, ur = [], list(enumerate(hyp)), list(enumerate(ref))
+    for key in (lambda x: x, _porter_stem):
+        i = len(uh) - 1
+        while i >= 0:
+            j = len(ur) - 1
+            while j >= 0:
+                if key(uh[i][1]) == key(ur[j][1]):
+                    pairs.append((uh[i][0], ur[j][0]))
+                    uh.pop(i)
+                    ur.pop(j)
+                    break
+                j -= 1
+            i -= 1
+    return sorted(pairs)
+
+
+def meteor(predictions, references, alpha=0.9, beta=3.0, gamma=0.5):
+    """mean METEOR of the pairs (exact + stem stages; module comment above)."""
+    scores = []
+    for p, r in zip(predictions, references):
+        hyp, ref = _tok13a(p.lower()), _tok13a(r.lower())
+        al = _meteor_align(hyp, ref)
+        n = len(al)
+        if n == 0 or not hyp or not ref:
+            scores.append(0.0)
+            continue
+        prec, rec = n / len(hyp), n / len(ref)
+        fmean = prec * rec / (alpha * prec + (1 - alpha) * rec)
+        chunks = 1 + sum(1 for (h0, r0), (h1, r1) in zip(al[:-1], al[1:]) if not (h1 == h0 + 1 and r1 == r0 + 1))
+        scores.append(fmean * (1 - gamma * (chunks / n) ** beta))
+    return float(np.mean(scores)) if scores else 0.0
+
+
 @torch.no_grad()
 def eval_model_exp(model, samples, tokenizer, max_new_tokens=256, num_beams=5, image_preprocessor=None, device="cuda", users_per_batch=1):
-    """eval_exp.py:31-205: rating + explanation generation.  Returns mae, rmse, bleu (unigram precision), rouge1 / rouge2 / rougeL."""
+    """eval_exp.py:31-205: rating + explanation generation.  Returns mae, rmse, bleu (unigram precision), rouge1 / rouge2 / rougeL, meteor."""
     abs_err, sq_err, gen_exps, real_exps = [], [], [], []
 
     def on_user(s, texts):
@@ -256,6 +380,7 @@ def eval_model_exp(model, samples, tokenizer, max_new_tokens=256, num_beams=5, i
         return {}
     out = {"mae": float(np.mean(abs_err)), "rmse": float(np.sqrt(np.mean(sq_err))), "bleu": bleu1_precision(gen_exps, real_exps)}
     out.update(rouge_f(gen_exps, real_exps))
+    out["meteor"] = meteor(gen_exps, real_exps)
     return out
 
 
