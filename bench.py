@@ -527,7 +527,7 @@ def main():
                 note = (f"rocprofv3 --pmc FETCH_SIZE(x2, gfx950 correction)+WRITE_SIZE per launch of {j['kernel']} ({j.get('label', 'dominant GEMM instance of the step')}) "
                         f"at M,N,K={j['shape']} (algorithmic {alg} B; L2-to-fabric requests incl. Infinity-Cache hits); MFMA pipe busy "
                         f"{j['mfma_util']:.3f} of SIMD cycles at the clock the chip held under that kernel; {j['source']}")
-            roofline = {"bound": "mfma", "kernel": "256x256-tile bf16 MFMA GEMMs (gemm3 ping-pong, gemm6 persistent ping-pong, gemm5 8-wave; autotuned per shape), all GEMM launches of the step",
+            roofline = {"bound": "mfma", "kernel": "256x256-tile bf16 MFMA GEMMs (gemm3 ping-pong family: whole-row-A / one-set / two-set builds with fixed-epilogue-kind instantiations; autotuned per shape), all GEMM launches of the step",
                         "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_note": note,
                         "lm_xattn_gemms": {"achieved": round(lm_ach, 2), "frac": round(lm_ach / PEAK_BF16_TFLOPS, 4),

@@ -598,7 +598,8 @@ def test_graphed_micro_step_equals_eager(P, ga):
     res = {}
     for mode in ("eager", "graph"):
         hm = P.build_hip(cfg, om, layout)
-        tr = Trainer(hm, layout.special(), lr=1e-3, lr_scheduler="constant", grad_accum=ga, dense_head_backward=True, graph=mode == "graph")
+        tr = Trainer(hm, layout.special(), lr=1e-3, lr_scheduler="constant", grad_accum=ga, dense_head_backward=True, graph=mode == "graph",
+                     fuse_accum=False)        # both modes run the micro-steps one by one (the eager default would fuse them into one pass)
         losses, masters = [], []
         for i, b in enumerate(batches):
             loss, stats = tr.step(b)
@@ -619,12 +620,14 @@ def test_graphed_micro_step_equals_eager(P, ga):
 
 
 def test_fp8_loss_curve_tracks_bf16(P, monkeypatch):
-    """cfg5's training dynamics with fp8 frozen towers: 60 optimizer steps on the same 8 batches (cycled), bf16 HIP against fp8 HIP
+    """cfg5's training dynamics with fp8 frozen towers: 48 optimizer steps on the same 8 batches (cycled), bf16 HIP against fp8 HIP
     from identical initial weights.  The trainable blocks stay bf16 in both; the quantised frozen towers perturb activations and
     the gradients that flow back through them by a few per cent per step.  Asserted: both curves fall, the fp8 curve stays within
-    25 % of the bf16 curve at every step, and the mean loss of the last 8 steps agrees within 10 %.  (Two 60-step runs of a model this
-    small part chaotically: ANY bit-level change of a backward kernel moves the largest gap between 0.06 and 0.15 -- the bounds
-    leave room for that; what the test screens for is an fp8 path that stops learning or drifts away.)"""
+    10 % of the bf16 curve at every step (measured: <= 2.6 %), and the mean loss of the last 8 steps agrees within 5 % (measured 0.2 %).
+    Round 4: the run stops at step 48.  At this learning rate the toy model's training goes unstable near step 58 in BOTH precisions
+    (bf16: 3.70 then 21.70 at steps 58 / 59, fp8: 29.97 / 22.29 -- tools/scratch/fp8curve.py); which step the spike lands on moves with
+    any bit-level change, and a spike one step apart read as a 7 x "gap" under the old 60-step bound.  That is the optimizer's chaos,
+    not the fp8 path; the cfg5-width run against a measured chaos floor is test_widths_gpu.py::test_cfg5_width_fp8_loss_curve_...."""
     from unimp_amd import functional as F_
     from unimp_amd.train import Trainer
     cfg = P.TINY_MX
@@ -635,14 +638,14 @@ def test_fp8_loss_curve_tracks_bf16(P, monkeypatch):
         monkeypatch.setattr(F_, "FP8_FROZEN", flag)
         hm = P.build_hip(cfg, om, layout)
         tr = Trainer(hm, layout.special(), lr=2e-3, lr_scheduler="constant", gamma=2.0)
-        curves[flag] = [tr.step(batches[i % 8])[0].item() for i in range(60)]
+        curves[flag] = [tr.step(batches[i % 8])[0].item() for i in range(48)]
         tr.dp.remove()
     a, b = curves[False], curves[True]
     dev = max(abs(x - y) / abs(x) for x, y in zip(a, b))
     tail_a, tail_b = sum(a[-8:]) / 8, sum(b[-8:]) / 8
-    print(f"\\n[fp8 loss curve] bf16 {a[0]:.3f} -> {tail_a:.3f}; fp8 {b[0]:.3f} -> {tail_b:.3f}; max relative gap over 60 steps {dev:.3e}")
+    print(f"\\n[fp8 loss curve] bf16 {a[0]:.3f} -> {tail_a:.3f}; fp8 {b[0]:.3f} -> {tail_b:.3f}; max relative gap over 48 steps {dev:.3e}")
     assert tail_a < 0.7 * a[0] and tail_b < 0.7 * b[0]
-    assert dev <= 0.25 and abs(tail_a - tail_b) <= 0.10 * tail_a
+    assert dev <= 0.10 and abs(tail_a - tail_b) <= 0.05 * tail_a
 
 
 @pytest.mark.parametrize("reweight", [True, False])
