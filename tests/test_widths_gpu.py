@@ -282,17 +282,18 @@ FP8_VS_MODEL = 0.75              # HIP-vs-model error as a fraction of HIP-vs-fp
 
 def test_cfg5_width_fp8_loss_curve_against_the_chaos_floor(P, monkeypatch):
     """the fp8 loss-curve test at cfg5's WIDTH (MPT-7B dims, 2 of 32 blocks, one gated block, L = 1024) instead of
-    the toy tower, with its bound taken from a measured noise floor instead of a flat 25 %.  Three 40-step runs from identical weights on
-    the same 4 batches (cycled): bf16 (A), bf16 with ONE trainable weight moved by one bf16 ulp (B: how far two bf16 runs drift apart by
-    themselves -- the chaos floor of this model and schedule), fp8 frozen towers (C).  Asserted: every curve falls; step 0 of C (same
-    weights, forward only differs) is within 2 % of A's loss (the e4m3 error model puts the logits of this width at 1.1e-1 rel-L2, which
-    moves a 74 k-way focal loss by well under that); the largest relative gap C-vs-A stays within max(4 x the floor B-vs-A, 3 %); the mean
-    of the last 8 steps within max(2 x the floor's, 2 %)."""
+    the toy tower, with bounds read off a measured noise floor instead of a flat 25 %.  Three 16-step runs from identical weights, a FRESH
+    batch every step (at this width the model memorises a b = 1 batch in one visit: a cycled pool's loss is 0.000 from the second pass on,
+    tools/scratch/fp8curve_cfg5.py): bf16 (A), bf16 with ONE trainable weight moved by one bf16 ulp (B: how far two bf16 runs part by
+    themselves -- the chaos floor, measured 5e-4), fp8 frozen towers (C).  The fp8 effect is NOT chaos: it perturbs every step's forward
+    by the e4m3 error (logits 1.1e-1 rel-L2 at this width, test_cfg5_fp8_vs_error_model), which moves a 74 k-way focal loss by 0.1-1.8 %
+    per step (measured).  Asserted: step 0 (same weights) within 0.5 %; every step within 4 %; mean gap within 2 %; and the floor itself
+    below 0.5 % (if two bf16 runs part further, the comparison means nothing)."""
     from unimp_amd import functional as F_
     from unimp_amd.train import Trainer
     cfg = P.CFG5_SLIM
     om, layout = P.build_oracle(cfg)
-    batches = [{k: v.cuda() for k, v in P.make_batch(cfg, layout, seed=950 + i).items()} for i in range(4)]
+    batches = [{k: v.cuda() for k, v in P.make_batch(cfg, layout, seed=950 + i).items()} for i in range(16)]
     curves = {}
     for name, fp8, nudge in (("A", False, False), ("B", False, True), ("C", True, False)):
         monkeypatch.setattr(F_, "FP8_FROZEN", fp8)
@@ -302,20 +303,18 @@ def test_cfg5_width_fp8_loss_curve_against_the_chaos_floor(P, monkeypatch):
             with torch.no_grad():
                 v = w.view(-1)[:1].view(torch.int16)
                 v += 1                                               # one ulp of one bf16 weight
-        tr = Trainer(hm, layout.special(), lr=1e-3, lr_scheduler="constant", gamma=2.0)
-        curves[name] = [tr.step(batches[i % 4])[0].item() for i in range(40)]
+        tr = Trainer(hm, layout.special(), lr=5e-5, lr_scheduler="constant", gamma=2.0)
+        curves[name] = [tr.step(b)[0].item() for b in batches]
         tr.dp.remove()
         del tr, hm
         torch.cuda.empty_cache()
     monkeypatch.setattr(F_, "FP8_FROZEN", False)
     a, b, c = curves["A"], curves["B"], curves["C"]
-    gap = lambda x, y: max(abs(p_ - q_) / abs(p_) for p_, q_ in zip(x, y))
-    tail = lambda x: sum(x[-8:]) / 8
-    floor, dev = gap(a, b), gap(a, c)
-    tfloor, tdev = abs(tail(a) - tail(b)) / tail(a), abs(tail(a) - tail(c)) / tail(a)
-    print(f"\n[cfg5 width, fp8 loss curve] bf16 {a[0]:.3f} -> {tail(a):.3f}; fp8 {c[0]:.3f} -> {tail(c):.3f}; step-0 gap {abs(a[0] - c[0]) / a[0]:.2e}; "
-          f"largest gap fp8 vs bf16 {dev:.3e} (chaos floor, one-ulp nudge: {floor:.3e}); tail means {tdev:.2e} (floor {tfloor:.2e})")
-    assert tail(a) < 0.8 * a[0] and tail(c) < 0.8 * c[0]
-    assert abs(a[0] - c[0]) <= 2e-2 * a[0]
-    assert dev <= max(4 * floor, 3e-2), (dev, floor)
-    assert tdev <= max(2 * tfloor, 2e-2), (tdev, tfloor)
+    rel = lambda x, y: [abs(p_ - q_) / abs(p_) for p_, q_ in zip(x, y)]
+    floor, gaps = rel(a, b), rel(a, c)
+    print(f"\n[cfg5 width, fp8 loss curve] bf16 {' '.join(f'{x:.2f}' for x in a)}\n                              fp8  {' '.join(f'{x:.2f}' for x in c)}\n"
+          f"  step-0 gap {gaps[0]:.2e}; largest gap fp8 vs bf16 {max(gaps):.2e}, mean {sum(gaps) / len(gaps):.2e}; chaos floor (one-ulp nudge) largest {max(floor):.2e}")
+    assert min(a) > 1.0, "a loss near zero makes relative gaps meaningless: the batches must stay fresh"
+    assert max(floor) <= 5e-3, floor
+    assert gaps[0] <= 5e-3, gaps[0]
+    assert max(gaps) <= 4e-2 and sum(gaps) / len(gaps) <= 2e-2, gaps

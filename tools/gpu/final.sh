@@ -7,7 +7,7 @@ cd $GRAFT_REPO_ROOT
 R=${ROUND:-r04}
 O=gpurun_out/final; mkdir -p $O profiles
 LEGS="${@:-tune bench prof micro pmc pytest}"
-: > $O/rc.txt
+echo "# final.sh legs: $LEGS ($(date -u +%FT%TZ))" >> $O/rc.txt
 declare -A RC
 leg() {            # leg <name> <timeout> <stdout file> <command...>: run, record rc
   local name=$1 to=$2 out=$3; shift 3
@@ -19,7 +19,8 @@ keep() {           # keep <leg name> <src> <dst under profiles/>: copy a summary
   if [ "${RC[$name]}" != "0" ]; then echo "keep: $3 NOT copied (leg $name rc=${RC[$name]})" >> $O/rc.txt; return 1; fi
   if [ ! -s "$src" ]; then echo "keep: $3 NOT copied ($src empty or missing)" >> $O/rc.txt; return 1; fi
   if grep -q "Traceback (most recent call last)" "$src"; then echo "keep: $3 NOT copied ($src holds a traceback)" >> $O/rc.txt; return 1; fi
-  cp "$src" "$dst"; echo "keep: $3 <- $src" >> $O/rc.txt
+  cp "$src" "$dst"; mkdir -p $O/profiles; cp "$src" "$O/profiles/$3"       # profiles/ on the box is not merged back: the mirror under gpurun_out/ is
+  echo "keep: $3 <- $src" >> $O/rc.txt
 }
 has() { case " $LEGS " in *" $1 "*) return 0;; *) return 1;; esac; }
 T=$PWD/$O/gemm_autotune_gfx950.json
@@ -67,7 +68,7 @@ for f in sorted(glob.glob("gpurun_out/final/bench_*.json")):
     except Exception as e:
         print(f, "UNREADABLE", e)
 EOF
-  cp $O/bench_lines.txt profiles/${R}_bench_lines_final.txt; echo "keep: ${R}_bench_lines_final.txt (failed legs are marked inside)" >> $O/rc.txt
+  cp $O/bench_lines.txt profiles/${R}_bench_lines_final.txt; mkdir -p $O/profiles; cp $O/bench_lines.txt $O/profiles/${R}_bench_lines_final.txt; echo "keep: ${R}_bench_lines_final.txt (failed legs are marked inside)" >> $O/rc.txt
 fi
 
 if has prof; then
@@ -126,7 +127,7 @@ if has pmc; then
     leg pmca_$tag 600 $O/pmca_$tag.log rocprofv3 --kernel-trace --pmc $pm -d $O/pmca_$tag -o pmc --output-format csv -- python3 tools/pmc_attn.py
     [ "${RC[pmca_$tag]}" = "0" ] || RC[pmca]=1
   done
-  leg pmca_sum 300 $O/${R}_pmc_attention.csv python tools/pmc_summary.py $O/pmca_SQ_VALU_MFMA_BUSY_CYCLES $O/pmca_SQ_LDS_BANK_CONFLICT $O/pmca_SQ_WAVE_CYCLES
+  leg pmca_sum 300 $O/${R}_pmc_attention.csv python tools/pmc_summary.py $O/pmca_SQ_VALU_MFMA_BUSY_CYCLES $O/pmca_SQ_LDS_BANK_CONFLICT $O/pmca_SQ_WAVE_CYCLES --match attn
   [ "${RC[pmca]}" = "0" ] || RC[pmca_sum]=1
   keep pmca_sum $O/${R}_pmc_attention.csv ${R}_pmc_attention.csv
 fi
