@@ -112,7 +112,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_bf16_kernel(Gemm2Params p) {
   }
   int nwg = p.nbm * p.nbn;
   int id = xcd_remap(blockIdx.x, nwg);
-  constexpr int GM = 4;
+  const int GM = p.gm > 0 ? p.gm : 4;
   int per_group = GM * p.nbn;
   int grp_ = id / per_group;
   int first_m = grp_ * GM;
@@ -358,6 +358,7 @@ extern "C" int unimp_gemm3_launch_splitk(const unimp_gemm_desc* d, int bn, int s
   p.nbm = (d->M + G3_BM - 1) / G3_BM;
   p.nbn = (d->N + bn - 1) / bn;
   p.ksplit = 0;
+  { static int gm = -1; if (gm < 0) { const char* e = getenv("UNIMP_GEMM_GM"); gm = e ? atoi(e) : 0; } p.gm = gm; }
   int slices = 1;
   if (splits > 1) {
     p.ksplit = ((d->K + splits - 1) / splits + 63) & ~63;

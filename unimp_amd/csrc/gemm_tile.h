@@ -16,6 +16,7 @@ struct Gemm2Params {
   int act, dact, out_f32, accumulate, pre_deriv;
   int nbm, nbn;
   int ksplit;                       // > 0 (gemm3 only): blockIdx.y reduces k in [y*ksplit, (y+1)*ksplit) into f32 slab y of C
+  int gm;                           // gemm3 only: tile rows per raster group (0 = the default 4); UNIMP_GEMM_GM, measurement knob
   int rope_rot, rope_hd, rope_period, rope_span, rope_L;      // rotary epilogue (EK_PLAIN only; include/unimp_hip.h), rope_rot == 0: none
   float rope_step, rope_invL;       // 2 log2(base) / rope_rot;  1 / rope_L
   const int* rope_tab;              // null: position = m % rope_L; else position = rope_tab[m] (packed rows)
