@@ -152,16 +152,45 @@ __device__ __forceinline__ void act_fwd_n(int act, float (&v)[N]) {             
     default: break;
   }
 }
+// erf-GELU and its derivative over N / 2 element pairs, STAGE by stage across the pairs (same operations per element as gelu_parts2 /
+// the loop it replaces -- same bits): each pair's arithmetic is one dependent chain (|x| -> rcp -> five Horner steps -> ...), and written
+// pair after pair hipcc emitted it that way, an s_nop behind every packed fma whose result the next instruction needs (112 s_nop per 64
+// outputs in the up-projection's epilogue, round 4 ISA).  Stage-major source order puts N / 2 independent instructions between a result
+// and its use.
+template <int N>
+__device__ __forceinline__ void gelu_fwd_deriv_staged(float (&v)[N], float (&d)[N]) {
+  constexpr int P = N / 2;
+  f32x2 x[P], z[P], t[P], e[P], poly[P], c[P];
+#pragma unroll
+  for (int i = 0; i < P; ++i) { x[i] = f32x2{v[2 * i], v[2 * i + 1]}; z[i] = f32x2{fabsf(x[i][0]), fabsf(x[i][1])} * 0.70710678118654752f; }
+#pragma unroll
+  for (int i = 0; i < P; ++i) t[i] = rcp2(z[i] * 0.3275911f + 1.0f);
+#pragma unroll
+  for (int i = 0; i < P; ++i) e[i] = exp2_2(z[i] * z[i] * -1.4426950408889634f);
+#pragma unroll
+  for (int i = 0; i < P; ++i) poly[i] = -1.453152027f + t[i] * 1.061405429f;
+#pragma unroll
+  for (int i = 0; i < P; ++i) poly[i] = 1.421413741f + t[i] * poly[i];
+#pragma unroll
+  for (int i = 0; i < P; ++i) poly[i] = -0.284496736f + t[i] * poly[i];
+#pragma unroll
+  for (int i = 0; i < P; ++i) poly[i] = 0.254829592f + t[i] * poly[i];
+#pragma unroll
+  for (int i = 0; i < P; ++i) poly[i] = t[i] * poly[i];
+#pragma unroll
+  for (int i = 0; i < P; ++i) { f32x2 ea = 1.0f - poly[i] * e[i]; c[i] = f32x2{copysignf(ea[0], x[i][0]), copysignf(ea[1], x[i][1])} * 0.5f + 0.5f; }
+#pragma unroll
+  for (int i = 0; i < P; ++i) {
+    f32x2 dd = c[i] + x[i] * 0.3989422804014327f * e[i], y = x[i] * c[i];
+    v[2 * i] = y[0]; v[2 * i + 1] = y[1]; d[2 * i] = dd[0]; d[2 * i + 1] = dd[1];
+  }
+}
 template <int N>
 __device__ __forceinline__ void act_fwd_deriv_n(int act, float (&v)[N], float (&d)[N]) {  // d = act'(v), then v = act(v)
   static_assert(N % 2 == 0, "pairs");
   switch (act) {
     case ACT_GELU:
-#pragma unroll
-      for (int r = 0; r < N; r += 2) {
-        f32x2 x = {v[r], v[r + 1]}, c, e; gelu_parts2(x, c, e);
-        f32x2 dd = c + x * 0.3989422804014327f * e; x *= c;
-        v[r] = x[0]; v[r + 1] = x[1]; d[r] = dd[0]; d[r + 1] = dd[1]; }
+      gelu_fwd_deriv_staged<N>(v, d);
       break;
     case ACT_QUICKGELU: case ACT_SILU: {
       float k = act == ACT_SILU ? 1.0f : 1.702f;
