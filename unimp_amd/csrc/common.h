@@ -140,10 +140,15 @@ __device__ __forceinline__ void act_fwd_n(int act, float (&v)[N]) {             
 #pragma unroll
       for (int r = 0; r < N; r += 2) { f32x2 x = {v[r], v[r + 1]}, c, e; gelu_parts2(x, c, e); x *= c; v[r] = x[0]; v[r + 1] = x[1]; }
       break;
-    case ACT_QUICKGELU: case ACT_SILU: {
+    case ACT_QUICKGELU: case ACT_SILU: {          // stage by stage across the pairs (as gelu_fwd_deriv_staged below): exp2 -> + 1 -> rcp -> x *
       float k = act == ACT_SILU ? 1.0f : 1.702f;
+      f32x2 x[N / 2], sg[N / 2];
 #pragma unroll
-      for (int r = 0; r < N; r += 2) { f32x2 x = {v[r], v[r + 1]}; x *= sigmoid2(x, k); v[r] = x[0]; v[r + 1] = x[1]; }
+      for (int i = 0; i < N / 2; ++i) { x[i] = f32x2{v[2 * i], v[2 * i + 1]}; sg[i] = exp2_2(x[i] * (-k * 1.4426950408889634f)); }
+#pragma unroll
+      for (int i = 0; i < N / 2; ++i) sg[i] = rcp2(sg[i] + 1.0f);
+#pragma unroll
+      for (int i = 0; i < N / 2; ++i) { x[i] *= sg[i]; v[2 * i] = x[i][0]; v[2 * i + 1] = x[i][1]; }
       break; }
     case ACT_RELU:
 #pragma unroll
