@@ -279,7 +279,9 @@ __device__ __forceinline__ void epi8k(const Gemm2Params& p, float (&v)[8], int m
     *(bf16x8*)((bf16*)p.C + (long)m * p.ldc + n) = o;
   }
 }
-template <int WN, int KIND, int ROWS = 64>
+// FIXED: called from a fixed-kind kernel (room to unroll); false = the run-time-dispatch kernels, which hold every kind and must stay
+// inside the instruction cache (tests/test_cabi_cpu.py): their activation kind runs as a rolled loop
+template <int WN, int KIND, int ROWS = 64, bool FIXED = false>
 __device__ __forceinline__ void epi_groups(const Gemm2Params& p, const char* er, int lane, int mbase, int nbase, float gate,
                                            const EpiPre<WN, ROWS>& e, bf16x8 biasv) {
   constexpr int ESTR = WN * 4, UNITS = WN / 4, LPR = EpiPre<WN, ROWS>::LPR, RPI = EpiPre<WN, ROWS>::RPI, NIT = EpiPre<WN, ROWS>::NIT;
@@ -306,8 +308,11 @@ __device__ __forceinline__ void epi_groups(const Gemm2Params& p, const char* er,
   } else if (KIND == EK_GELU2) {          // fixed-kind kernels only: four row groups in flight (the erf-GELU pair is a long dependent chain)
 #pragma unroll 4
     for (int u = 0; u < NIT; ++u) EPI_GROUP(u, bf16x8{});
-  } else {
+  } else if (FIXED) {
 #pragma unroll 2
+    for (int u = 0; u < NIT; ++u) EPI_GROUP(u, bf16x8{});
+  } else {
+#pragma unroll 1
     for (int u = 0; u < NIT; ++u) EPI_GROUP(u, bf16x8{});
   }
 #undef EPI_GROUP
@@ -318,7 +323,7 @@ __device__ __forceinline__ void epi_groups(const Gemm2Params& p, const char* er,
 template <int WN, int KIND, int ROWS = 64>
 __device__ __forceinline__ void epi_pass_fixed(const Gemm2Params& p, const char* er, int lane, int mbase, int nbase, float gate,
                                                const EpiPre<WN, ROWS>& e, bf16x8 biasv) {
-  epi_groups<WN, KIND, ROWS>(p, er, lane, mbase, nbase, gate, e, biasv);
+  epi_groups<WN, KIND, ROWS, true>(p, er, lane, mbase, nbase, gate, e, biasv);
 }
 // host-side twin of epi_kind() + the fixed kinds' extra conditions; returns the EPI template value to launch, -1 = the generic kernel
 static inline int epi_kind_host(const Gemm2Params& p) {
