@@ -548,6 +548,7 @@ ATTN_CASES = [
     (1, 2, 512, 512, 80, 1), (2, 2, 130, 130, 128, 1), (2, 8, 100, 192, 64, 2), (1, 2, 96, 96, 64, 1),
     (2, 2, 1024, 1024, 128, 1),      # cfg5's workload: MPT head dim 128 over an image-generation sequence (L = 1024)
     (1, 4, 1000, 1000, 80, 1), (1, 2, 257, 257, 80, 0), (1, 8, 512, 1024, 64, 2),     # cfg4: 16 images x 64 latents
+    (1, 3, 257, 257, 64, 0),         # the ViT-L/14 form (B = 1: no kv_len): last key seeds the softmax state, 9 waves per block
 ]
 
 

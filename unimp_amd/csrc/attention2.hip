@@ -160,7 +160,11 @@ __device__ __forceinline__ void a2_key_range_kvl(const AttnP& p, int b, int qr, 
   else { int t = p.seg[(long)b * p.SqS + qr]; if (t > 0) { lo = (t - 1) * p.seg_len; hi = min(t * p.seg_len, p.Sk); } }
 }
 
-template <int D, int NW, bool ALIBI>
+// TAIL (host: no mask, no kv_len, no ALiBi, Sk % 64 == 1 -- the ViT's 256 patches + CLS): the tile loop runs over the Sk / 64 FULL
+// tiles and the last key SEEDS the online-softmax state instead of costing a fifth tile with one live column: m = q . k_last,
+// l = 1, O = v_last (p = exp2(0) = 1 exactly, so the seed row enters O unrounded).  The dot product is a 64-term fp32 FMA chain
+// on the same bf16 products the matrix pipe forms.
+template <int D, int NW, bool ALIBI, bool TAIL = false>
 __global__ __launch_bounds__(64 * NW) void attn_fwd2_kernel(AttnP p, int row_base, int nx) {
   using C = A2Cfg<D>;
   constexpr int CPR = C::CPR, PK = C::PK, PV = C::PV, KS = C::KS, ND = C::ND, NI = C::NI, STAGE = C::STAGE;
@@ -182,7 +186,8 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd2_kernel(AttnP p, int row_bas
   {
     int q_last = min(qblk0 + 32 * NW - 1, p.Sq - 1);
     int kvl = p.kv_len ? p.kv_len[b] : p.Sk;
-    if (p.mask_mode == UNIMP_MASK_NONE) kt_hi = (kvl + 63) >> 6;
+    if (TAIL) kt_hi = kvl >> 6;
+    else if (p.mask_mode == UNIMP_MASK_NONE) kt_hi = (kvl + 63) >> 6;
     else if (p.mask_mode == UNIMP_MASK_CAUSAL) kt_hi = (min(q_last + 1, kvl) + 63) >> 6;
     else {
       int t0 = p.seg[(long)b * p.SqS + qblk0], t1 = p.seg[(long)b * p.SqS + q_last];
@@ -243,12 +248,46 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd2_kernel(AttnP p, int row_bas
   for (int nd = 0; nd < ND; ++nd)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[nd][r] = 0.f;
+  bf16x8 kx[KS]; bf16x4 vx[ND][4];
+  if (TAIL) {                                                 // the last key / value row, the lane's own dims (half-wave-uniform addresses)
+    const bf16* kr = (const bf16*)(kb + (long)(p.Sk - 1) * k_sb);
+    const bf16* vr = (const bf16*)(vb + (long)(p.Sk - 1) * v_sb);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) kx[ks] = *(const bf16x8*)(kr + ks * 16 + hi5 * 8);
+#pragma unroll
+    for (int nd = 0; nd < ND; ++nd)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) vx[nd][g] = *(const bf16x4*)(vr + min(32 * nd + 8 * g + 4 * hi5, D - 4));
+  }
 
   if (kt_lo < kt_hi) dma_tile(kt_lo, 0);
+  if (TAIL) {
+    float sx = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sx = fmaf(bf2f(qf[ks][j]), bf2f(kx[ks][j]), sx);
+    sx += __shfl_xor(sx, 32, 64);
+    if (hi > 0) {                                             // rows past Sq keep the empty state
+      m = sx * sc2;
+      lsum = hi5 == 0 ? 1.f : 0.f;
+#pragma unroll
+      for (int nd = 0; nd < ND; ++nd)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[nd][4 * g + e] = bf2f(vx[nd][g][e]);
+    }
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) a2_pin(qf[ks]);
   a2_pin(lo); a2_pin(hi);
+  if (TAIL) {
+    a2_pin(m); a2_pin(lsum);
+#pragma unroll
+    for (int nd = 0; nd < ND; ++nd) a2_pin(o[nd]);
+  }
   __syncthreads();
 
   // per-lane LDS read offsets (bytes) inside a stage
@@ -761,6 +800,16 @@ static void launch_fwd2(const AttnP& p, hipStream_t s) {
   // is 9 waves of rows = 2 blocks of 5 instead of 3 blocks of 4 with a third nearly empty one
   int w = (p.Sq + 31) / 32;
   int b4 = (w + 3) / 4, b5 = (w + 4) / 5;
+  if constexpr (D == 64 && !ALIBI) {
+    // the ViT (S = 257, every key visible): the last key seeds the softmax state (TAIL: 4 tiles instead of 5) and the 9 waves of
+    // query rows go out as 3 blocks of 3 (no idle tenth wave slot).  Measured at 512 images x 16 heads (profiles/r04_vit_attention_ab.txt):
+    // 446 us before; TAIL with 5 / 9 / 3 waves per block 405 / 413 / 361 us.  UNIMP_ATTN_VIT=0: the general path.
+    static const bool vit = [] { const char* e = getenv("UNIMP_ATTN_VIT"); return !e || atoi(e) != 0; }();
+    if (vit && p.mask_mode == UNIMP_MASK_NONE && !p.kv_len && !p.k_off && !p.q_off && (p.Sk & 63) == 1 && p.Sk > 64 && w == 9) {
+      hipLaunchKernelGGL((attn_fwd2_kernel<D, 3, false, true>), dim3(3 * p.H * p.B), dim3(192), 0, s, p, 0, 3);
+      return;
+    }
+  }
   if (b5 * 5 < b4 * 4) hipLaunchKernelGGL((attn_fwd2_kernel<D, 5, ALIBI>), dim3(b5 * p.H * p.B), dim3(320), 0, s, p, 0, b5);
   else hipLaunchKernelGGL((attn_fwd2_kernel<D, 4, ALIBI>), dim3(b4 * p.H * p.B), dim3(256), 0, s, p, 0, b4);
 }
