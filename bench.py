@@ -488,7 +488,7 @@ def main():
             if mxp:       # --fp8: the MX GEMMs get their own roofline (5 PF peak); the main object keeps the bf16 GEMMs
                 mx_ms, mx_fl = sum(r[0].elapsed_time(r[1]) for r in mxp), sum(r[2] for r in mxp)
                 mx_ach = mx_fl / (mx_ms * 1e-3) / 1e12
-                mx_roof = {"bound": "mfma", "kernel": "gemm_mx_kernel (MX-fp8 e4m3 + E8M0, frozen-tower GEMMs, forward + dX)", "achieved": round(mx_ach, 2),
+                mx_roof = {"bound": "mfma", "kernel": "gemm_mx_pp_kernel (MX-fp8 e4m3 + E8M0; the frozen language tower's GEMMs, forward + dX; fixed epilogue kinds)", "achieved": round(mx_ach, 2),
                            "peak": PEAK_MXFP8_TFLOPS, "unit": "TFLOP/s", "frac": round(mx_ach / PEAK_MXFP8_TFLOPS, 4),
                            "launches_per_step": len(mxp) // prof_steps, "ms_per_step": round(mx_ms / prof_steps, 2)}
                 prof = [r for r in prof if r[3][-1] != "mxfp8"]
@@ -585,7 +585,7 @@ def main():
                 f9 = flops_per_sample(T, L, lay9.vocab, H=4096, F=16384, lm_layers=32, n_xattn=8, head_bwd_rows=10)
                 cfg5_leg = {"value": round(b9 * n9 / dt9, 3), "unit": "samples/s", "ms_per_step": round(dt9 / n9 * 1e3, 2), "per_gpu_batch": b9, "steps": n9, "warmup": 3,
                             "loss": float(l9), "tflop_per_sample": round(f9["total"] / 1e12, 3),
-                            "dtype": "bf16 (trainable blocks, activations, attention) + MX-fp8 e4m3 frozen-tower GEMMs (E8M0 block scales)",
+                            "dtype": "bf16 (trainable blocks, activations, attention, the ViT's K = 1024 projections) + MX-fp8 e4m3 GEMMs of the frozen language tower (E8M0 block scales)",
                             "mx_gemms": {"achieved": round(mx_fl / (mx_ms * 1e-3) / 1e12, 2) if mx_ms else None, "peak": PEAK_MXFP8_TFLOPS, "unit": "TFLOP/s",
                                          "frac": round(mx_fl / (mx_ms * 1e-3) / 1e12 / PEAK_MXFP8_TFLOPS, 4) if mx_ms else None, "ms_per_step": round(mx_ms / n9, 2),
                                          "launches_per_step": len(mx9) // n9},
@@ -602,7 +602,7 @@ def main():
         line = {"metric": "train samples/sec (user sequences) at 4B-instruct", "value": round(value, 3), "unit": "samples/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "bf16 (trainable blocks, activations, attention) + MX-fp8 e4m3 frozen-tower GEMMs" if args.fp8 else "bf16", "data": "synthetic",
+                "dtype": "bf16 (trainable blocks, activations, attention, ViT) + MX-fp8 e4m3 GEMMs of the frozen language tower" if args.fp8 else "bf16", "data": "synthetic",
                 "config": {"workload": ("cfg5 model in bf16: 9b Flamingo (ViT-L/14 + MPT-7B dims, xattn every 4), " if nine else
                                         "cfg2: 4b-instruct Flamingo (ViT-L/14 + GPT-NeoX-3B RedPajama dims, xattn every 2), ") +
                                        ("image-token generation task (2 history images, 257 labeled code tokens), " if args.task == "img_gen" else "single-task rec, ") + "full optimizer step" + (", LM head on labeled rows only" if args.sparse_head else ""), "per_gpu_batch": B, "grad_accum": GA, "global_batch": GA * B * world,

@@ -22,7 +22,7 @@ extern "C" {
 
 /* bumped whenever a signature, a descriptor layout or a buffer-size requirement changes incompatibly (2: round-2 additions --
  * layernorm_bwd(wgrad_accumulate), dot_bf16's fp32[1+1024] scratch, grown gemm / attention descriptors; 3: round 3) */
-#define UNIMP_ABI_VERSION 4
+#define UNIMP_ABI_VERSION 5
 enum { UNIMP_OK = 0, UNIMP_ERR_ARG = 1, UNIMP_ERR_SHAPE = 2, UNIMP_ERR_ALIGN = 3, UNIMP_ERR_LAUNCH = 4,
        UNIMP_ERR_UNSUPPORTED = 5 };
 enum { UNIMP_ACT_NONE = 0, UNIMP_ACT_GELU = 1, UNIMP_ACT_QUICKGELU = 2, UNIMP_ACT_RELU = 3, UNIMP_ACT_SILU = 4,
@@ -253,6 +253,9 @@ typedef struct unimp_mx_gemm_desc {
   const void* bias; const void* res; const void* aux; void* pre;
   int64_t lda, ldb, ldsa, ldsb, ldc, ldres, ldaux, ldpre;
   int32_t M, N, K, act;
+  int32_t deriv_u8;                         /* != 0: the derivative act'(z) written to `pre` / read from `aux` is the uint8 form the bf16
+                                             * GEMM descriptor selects with pre_deriv = 2 / dact = UNIMP_ACT_DERIV_U8: one byte per element,
+                                             * ldpre / ldaux in bytes */
 } unimp_mx_gemm_desc;
 int unimp_mx_quantize(const void* x, int64_t ldx, void* q, int64_t ldq, void* scales, int64_t lds, int rows, int K, void* stream);
 int unimp_gemm_mxfp8(const unimp_mx_gemm_desc* d, void* stream);

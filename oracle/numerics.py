@@ -75,15 +75,16 @@ class _MXLinear(torch.autograd.Function):
 
 
 @contextlib.contextmanager
-def mx_frozen(min_rows=65):
-    """inside: every F.linear on a FROZEN weight (requires_grad False) whose two dimensions are multiples of 128, applied to more
-    than 64 rows, runs as an emulated MX-fp8 product (functional._mx_ok's rule); everything else stays fp32."""
+def mx_frozen(min_rows=65, min_dim=2048):
+    """inside: every F.linear on a FROZEN weight (requires_grad False) whose two dimensions are multiples of 128 and at least
+    ``min_dim`` (the product's FP8_MIN_DIM: the ViT-L/14's 1024-wide projections stay bf16), applied to more than 64 rows, runs as an
+    emulated MX-fp8 product (functional._mx_ok's rule); everything else stays fp32."""
     import torch.nn.functional as F
     real = F.linear
 
     def linear(x, w, b=None):
         rows = x.numel() // x.shape[-1]
-        if (not w.requires_grad) and w.dim() == 2 and w.shape[0] % 128 == 0 and w.shape[1] % 128 == 0 and rows >= min_rows:
+        if (not w.requires_grad) and w.dim() == 2 and w.shape[0] % 128 == 0 and w.shape[1] % 128 == 0 and rows >= min_rows and min(w.shape) >= min_dim:
             return _MXLinear.apply(x, w, b)
         return real(x, w, b)
     F.linear = linear

@@ -1138,6 +1138,36 @@ def test_gemm_mxfp8_vs_dequantised_reference(ops, M, N, K):
     close(y2, want.float() * aux.float().cpu() + res.float().cpu(), rel=2 ** -6, name="mx aux+res")
 
 
+def test_gemm_mxfp8_ping_pong_kernel_epilogue_kinds(ops):
+    """The 256 x 256 ping-pong MX kernel (>= 512 tiles) with the bf16 family's fixed epilogue kinds (PLAIN, RES, GELU + uint8 act'(z),
+    x uint8 act'(z)) and its general epilogue (bf16 derivative forms): each against fp32 arithmetic on the dequantised operands, the
+    GELU output bit-equal between the fixed kind and the general form (same accumulators, same activation code), the uint8 derivative
+    within its quantisation step of the bf16 one, ragged M."""
+    M, N, K = 4096 + 40, 8192, 512
+    a = ops.mx_quantize(rnd(M, K, seed=1).cuda())
+    b = ops.mx_quantize(rnd(N, K, scale=0.5, seed=2).cuda())
+    want = (a.dequantize().double() @ b.dequantize().double().t()).float().cpu()
+    bias, res = rnd(N, seed=3).cuda(), rnd(M, N, seed=5).cuda()
+    close(ops.gemm_mx(a, b).float().cpu(), want, rel=2 ** -7, name="mx pp plain")
+    close(ops.gemm_mx(a, b, bias=bias).float().cpu(), want + bias.float().cpu(), rel=2 ** -7, name="mx pp bias")
+    close(ops.gemm_mx(a, b, res=res).float().cpu(), want + res.float().cpu(), rel=2 ** -7, name="mx pp res")
+    close(ops.gemm_mx(a, b, bias=bias, res=res).float().cpu(), want + bias.float().cpu() + res.float().cpu(), rel=2 ** -7, name="mx pp bias+res")
+    pre16 = torch.empty((M, N), dtype=bf16, device="cuda")
+    pre8 = torch.empty((M, N), dtype=torch.uint8, device="cuda")
+    y16 = ops.gemm_mx(a, b, act="gelu", pre=pre16)                  # general epilogue (bf16 derivative)
+    y8 = ops.gemm_mx(a, b, act="gelu", pre=pre8)                    # EK_GELU2
+    assert torch.equal(y16, y8)
+    close(y8.float().cpu(), torch.nn.functional.gelu(want), rel=2 ** -6, name="mx pp gelu")
+    d8 = (pre8.float() - 27.0) / 202.0
+    assert float((d8 - pre16.float()).abs().max()) <= 0.5 / 202 + 2 ** -8, float((d8 - pre16.float()).abs().max())
+    dy = ops.mx_quantize(rnd(M, K, seed=7).cuda())
+    g16 = ops.gemm_mx(dy, b, aux=pre16).float().cpu()               # general
+    g8 = ops.gemm_mx(dy, b, aux=pre8).float().cpu()                 # EK_AUX
+    w2 = (dy.dequantize().double() @ b.dequantize().double().t()).float().cpu()
+    close(g16, w2 * pre16.float().cpu(), rel=2 ** -6, name="mx pp aux bf16")
+    close(g8, w2 * d8.cpu(), rel=2 ** -6, name="mx pp aux u8")
+
+
 # ------------------------------------------------------------------------------------------------- packed-B ping-pong GEMM
 @pytest.mark.parametrize("M,N,K", [(1024, 2560, 2560), (1096, 520, 1000), (2048, 10240, 2560), (1304, 2560, 10240 + 40), (1024, 264, 96)])
 @pytest.mark.parametrize("b_ks", [False, True])

@@ -436,6 +436,28 @@ def test_compact_head_backward_equals_dense(P):
             assert P.rel_l2(res[False][3][n], g) <= 4e-3, (n, P.rel_l2(res[False][3][n], g))
 
 
+def test_labeled_rows_without_a_blocking_nonzero():
+    """Trainer._labeled_rows_begin / _end (count read behind an event, after the forward is queued) return exactly the flat rows
+    b * L + j that ``nonzero()`` on the shifted label mask gives, in the same order -- including no labeled position at all and
+    a label in the last column (position L - 1 has no next token: never a scored row)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from unimp_amd.train import Trainer
+    tr = Trainer.__new__(Trainer)
+    tr._cnt_host = None
+    g = torch.Generator().manual_seed(5)
+    for B, L, frac in [(3, 17, 0.2), (8, 512, 0.02), (2, 9, 0.0), (1, 5, 1.0)]:
+        labels = torch.where(torch.rand(B, L, generator=g) < frac, torch.randint(0, 100, (B, L), generator=g), torch.full((B, L), -100)).cuda()
+        bj = (labels[:, 1:] != -100).nonzero()
+        want = bj[:, 0] * L + bj[:, 1]
+        pend = tr._labeled_rows_begin(labels)
+        torch.mm(torch.randn(512, 512, device="cuda"), torch.randn(512, 512, device="cuda"))     # work queued between begin and end
+        got = tr._labeled_rows_end(pend)
+        assert got.dtype == torch.int64 and got.is_contiguous() and torch.equal(got, want), (B, L, frac)
+        cpu = tr._labeled_rows_end(tr._labeled_rows_begin(labels.cpu()))
+        assert torch.equal(cpu, want.cpu())
+
+
 def test_direct_weight_gradients_equal_autograd_path(P):
     """Single rank: the dW GEMMs accumulate into the flat gradient buffer themselves (functional.WGRAD_SINK, epilogue
     ``accumulate``) instead of returning a temporary for autograd's ``.grad +=``.  Same gradients up to one bf16 rounding
@@ -516,6 +538,7 @@ def test_fp8_frozen_towers_track_the_bf16_path(P, monkeypatch):
     from unimp_amd import functional as F_, ops
     from unimp_amd.train import Trainer
     cfg = P.TINY_MX
+    monkeypatch.setattr(F_, "FP8_MIN_DIM", 128)          # the toy widths (128 / 256) on the MX kernel: LM and ViT (default 2048: LM widths only)
     om, layout = P.build_oracle(cfg)
     batch = P.make_batch(cfg, layout)
     _, want_loss, _, _ = P.oracle_step(om, layout, batch)
@@ -631,6 +654,7 @@ def test_fp8_loss_curve_tracks_bf16(P, monkeypatch):
     from unimp_amd import functional as F_
     from unimp_amd.train import Trainer
     cfg = P.TINY_MX
+    monkeypatch.setattr(F_, "FP8_MIN_DIM", 128)
     om, layout = P.build_oracle(cfg)
     batches = [{k: v.cuda() for k, v in P.make_batch(cfg, layout, seed=900 + i).items()} for i in range(8)]
     curves = {}

@@ -1,8 +1,9 @@
 """Kernel-time statistics of the TIMED steps of bench.py only: cuts a rocprofv3 --kernel-trace CSV to the region between the two
 marker kernels bench.py launches around its timed loop (unimp_marker_kernel with grid 101 x 64 and 102 x 64 threads), so model
 construction, autotuning and warm-up are not in the numbers ("nobody knows what the step really pays").
-usage: trace_window.py KERNEL_TRACE.csv STEPS [OUT.csv]   -> per-kernel calls / total / average inside the window, grouped
-totals (GEMM / attention / norm / optimizer / ATen / other) per step, and the window's wall time per step."""
+usage: trace_window.py KERNEL_TRACE.csv STEPS [OUT.csv] [gaps]   -> per-kernel calls / total / average inside the window, grouped
+totals (GEMM / attention / norm / optimizer / ATen / other) per step, and the window's wall time per step; with a fourth argument
+also where the device idles: the largest gaps between consecutive kernels of the window and the kernels on either side."""
 import collections
 import csv
 import sys
@@ -59,3 +60,23 @@ if out:
         w.writerow(["Name", "CallsPerStep", "MsPerStep", "AverageUs", "Percentage"])
         for n, (c, ns) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
             w.writerow([n, round(c / steps, 2), round(ns / 1e6 / steps, 4), round(ns / 1e3 / c, 2), round(100.0 * ns / busy, 3)])
+
+if len(sys.argv) > 4:
+    ks = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r[name_k]) for r in rows
+                 if int(r["Start_Timestamp"]) >= t0 and int(r["End_Timestamp"]) <= t1 and "unimp_marker_kernel" not in r[name_k]))
+    gaps, end = [], ks[0][1]
+    for i in range(1, len(ks)):
+        if ks[i][0] > end:
+            gaps.append((ks[i][0] - end, i))
+        end = max(end, ks[i][1])
+    tot = sum(g for g, _ in gaps)
+    print(f"# idle inside the window: {tot / 1e6 / steps:.3f} ms per step in {len(gaps) / steps:.0f} gaps per step; "
+          f"gaps > 20 us: {sum(g for g, _ in gaps if g > 20000) / 1e6 / steps:.3f} ms, 5-20 us: {sum(g for g, _ in gaps if 5000 < g <= 20000) / 1e6 / steps:.3f} ms, "
+          f"< 5 us: {sum(g for g, _ in gaps if g <= 5000) / 1e6 / steps:.3f} ms")
+    by = collections.defaultdict(lambda: [0, 0])
+    for g, i in gaps:
+        k = (ks[i - 1][2][:50], ks[i][2][:50])
+        by[k][0] += 1
+        by[k][1] += g
+    for (a, b), (c, ns) in sorted(by.items(), key=lambda kv: -kv[1][1])[:25]:
+        print(f"#   {ns / 1e6 / steps:7.3f} ms/step  {c / steps:6.1f} gaps/step  avg {ns / 1e3 / c:7.1f} us   after [{a}]  before [{b}]")

@@ -38,7 +38,7 @@ class MxGemmDesc(C.Structure):
     _fields_ = [("A", c_p), ("B", c_p), ("scale_a", c_p), ("scale_b", c_p), ("C", c_p),
                 ("bias", c_p), ("res", c_p), ("aux", c_p), ("pre", c_p)] + \
                [(n, c_l) for n in ("lda", "ldb", "ldsa", "ldsb", "ldc", "ldres", "ldaux", "ldpre")] + \
-               [("M", c_i), ("N", c_i), ("K", c_i), ("act", c_i)]
+               [("M", c_i), ("N", c_i), ("K", c_i), ("act", c_i), ("deriv_u8", c_i)]
 
 
 # name -> argtypes (every entry point returns int status)
@@ -83,7 +83,7 @@ _SIGS = {
     "unimp_image_resize_normalize": [c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_p],
 }
 
-ABI_VERSION = 4          # must equal UNIMP_ABI_VERSION of include/unimp_hip.h the library was built from
+ABI_VERSION = 5          # must equal UNIMP_ABI_VERSION of include/unimp_hip.h the library was built from
 
 _lib = None
 

@@ -15,10 +15,12 @@
 //                     LDS-DMA (data + scale words; the XOR swizzle of the 128-byte rows is applied to the DMA's source address),
 //                     epilogue through LDS in 16-byte row chunks: + bias, GELU / ReLU with the derivative as a second output,
 //                     x aux (activation backward), + residual, bf16 out.
-// First version of this path: correct and measured (tools/bench_mx.py), not yet schedule-tuned like the bf16 GEMMs.
+// Round 4: the 256 x 256 tile runs as a ping-pong kernel (gemm_mx_pp_kernel) whose epilogue is the bf16 family's fixed-kind code (gemm_tile.h;
+// uint8 act'(z)); the tower's launches run at 0.45 of the 5 PF peak inside the train step (profiles/r04_mx_step_shapes.txt).
 #include <stdlib.h>
 #include "common.h"
 #include "unimp_hip.h"
+#include "gemm_tile.h"
 
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 
@@ -81,7 +83,81 @@ struct MxP {
   bf16* C; long ldc;
   const bf16* bias; const bf16* res; long ldres; const bf16* aux; long ldaux; bf16* pre; long ldpre;
   int M, N, K, act, nbm, nbn;
+  int deriv_u8;              // the stored derivative act'(z) (`pre` written / `aux` read) is the 8-bit form of the bf16 GEMMs (common.h)
 };
+
+// ---- general epilogue (every option behind a run-time branch) through a wave-private f32 staging area, 32 rows per pass, then 16-byte
+// chunks of 8 consecutive columns.  acc[i][j]: row m = 16 i + r16 (the swapped product puts A's row on the lane), columns n = 16 j + 4 g + e
+template <int MI, int NJ, int NWAVE, int STAGE>
+__device__ __forceinline__ void mx_epilogue_general(const MxP& p, const f32x4 (&acc)[MI][NJ], char* smem, int wave, int em, int en) {
+  constexpr int WNC = 16 * NJ, FP = WNC + 4, CPRW = WNC / 8;          // wave tile width, row pitch in floats, 8-column chunks per row
+  static_assert(NWAVE * 32 * FP * 4 <= 2 * STAGE, "epilogue staging fits");
+  const int l = lane_id(), r16 = l & 15, g = l >> 4;
+  float* ewf = (float*)(smem + wave * (32 * FP * 4));
+  const bool vec = !((p.ldc | p.ldres | p.ldaux | p.ldpre) & 7);
+#pragma unroll
+  for (int pass = 0; pass < MI / 2; ++pass) {
+#pragma unroll
+    for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) *(f32x4*)(ewf + (16 * i2 + r16) * FP + 16 * j + 4 * g) = acc[2 * pass + i2][j];
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 32 * CPRW / 64; ++it) {
+      int idx = l + 64 * it;                    // 32 rows x CPRW chunks of 8 columns
+      int r = idx / CPRW, c = idx - r * CPRW;
+      int gm = em + 32 * pass + r, gn = en + c * 8;
+      if (gm >= p.M || gn >= p.N) continue;
+      float v[8], d[8];
+      f32x4 x0 = *(const f32x4*)(ewf + r * FP + c * 8), x1 = *(const f32x4*)(ewf + r * FP + c * 8 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] = x0[e]; v[4 + e] = x1[e]; }
+      bool full = vec && gn + 8 <= p.N;
+      if (p.bias) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) if (gn + e < p.N) v[e] += bf2f(p.bias[gn + e]);
+      }
+      if (p.act) {
+        if (p.pre) {
+          act_fwd_deriv_n<8>(p.act, v, d);
+          if (p.deriv_u8) {
+            uint32_t w0 = deriv_u8_pack4(d[0], d[1], d[2], d[3]), w1 = deriv_u8_pack4(d[4], d[5], d[6], d[7]);
+            uint8_t* dst = (uint8_t*)p.pre + (long)gm * p.ldpre + gn;
+            if (full) *(uint2*)dst = uint2{w0, w1};
+            else for (int e = 0; e < 8; ++e) if (gn + e < p.N) dst[e] = (uint8_t)(((e < 4 ? w0 : w1) >> (8 * (e & 3))) & 0xffu);
+          } else if (full) { bf16x8 o; for (int e = 0; e < 8; ++e) o[e] = f2bf(d[e]); *(bf16x8*)(p.pre + (long)gm * p.ldpre + gn) = o; }
+          else for (int e = 0; e < 8; ++e) if (gn + e < p.N) p.pre[(long)gm * p.ldpre + gn + e] = f2bf(d[e]);
+        } else act_fwd_n<8>(p.act, v);
+      }
+      if (p.aux) {
+        if (p.deriv_u8) {
+          const uint8_t* src = (const uint8_t*)p.aux + (long)gm * p.ldaux + gn;
+          if (full) { uint2 w = *(const uint2*)src; for (int e = 0; e < 8; ++e) v[e] *= deriv_u8_get(e < 4 ? w.x : w.y, e & 3); }
+          else for (int e = 0; e < 8; ++e) if (gn + e < p.N) v[e] *= deriv_u8_get(src[e], 0);
+        } else if (full) { bf16x8 a = *(const bf16x8*)(p.aux + (long)gm * p.ldaux + gn); for (int e = 0; e < 8; ++e) v[e] *= bf2f(a[e]); }
+        else for (int e = 0; e < 8; ++e) if (gn + e < p.N) v[e] *= bf2f(p.aux[(long)gm * p.ldaux + gn + e]);
+      }
+      if (p.res) {
+        if (full) { bf16x8 a = *(const bf16x8*)(p.res + (long)gm * p.ldres + gn); for (int e = 0; e < 8; ++e) v[e] += bf2f(a[e]); }
+        else for (int e = 0; e < 8; ++e) if (gn + e < p.N) v[e] += bf2f(p.res[(long)gm * p.ldres + gn + e]);
+      }
+      if (full) { bf16x8 o; for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]); *(bf16x8*)(p.C + (long)gm * p.ldc + gn) = o; }
+      else for (int e = 0; e < 8; ++e) if (gn + e < p.N) p.C[(long)gm * p.ldc + gn + e] = f2bf(v[e]);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// the bf16 GEMM family's parameter block for the shared fixed-kind epilogues (gemm_tile.h): alpha = 1, no gate, bf16 output
+__device__ __forceinline__ Gemm2Params mx_as_gemm2(const MxP& p) {
+  Gemm2Params q = {};
+  q.C = p.C; q.M = p.M; q.N = p.N; q.K = p.K; q.ldc = p.ldc;
+  q.bias = p.bias; q.res = p.res; q.ldres = p.ldres; q.aux = p.aux; q.ldaux = p.ldaux; q.pre = p.pre; q.ldpre = p.ldpre;
+  q.alpha = 1.f; q.act = p.act; q.dact = p.deriv_u8 ? ACT_DERIV_U8 : ACT_DERIV; q.pre_deriv = p.pre ? (p.deriv_u8 ? 2 : 1) : 0;
+  return q;
+}
 
 __device__ __forceinline__ void mx_glds16(const void* sbase, uint32_t voff, uint32_t lds_dst) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
@@ -191,57 +267,7 @@ __global__ __launch_bounds__(64 * WMW * WNW) void gemm_mx_kernel(MxP p) {
     __syncthreads();
   }
 
-  // ---- epilogue through a wave-private f32 staging area, 32 rows per pass, then 16-byte chunks of 8 consecutive columns.
-  // acc[i][j]: row m = 16 i + r16 (the swapped product puts A's row on the lane), columns n = 16 j + 4 g + e
-  constexpr int WNC = 16 * NJ, FP = WNC + 4, CPRW = WNC / 8;          // wave tile width, row pitch in floats, 8-column chunks per row
-  static_assert(NWAVE * 32 * FP * 4 <= 2 * STAGE, "epilogue staging fits");
-  float* ewf = (float*)(smem + wave * (32 * FP * 4));
-  const int em = m0 + wm * 16 * MI, en = n0 + wn * WNC;
-  const bool vec = !((p.ldc | p.ldres | p.ldaux | p.ldpre) & 7);
-#pragma unroll
-  for (int pass = 0; pass < MI / 2; ++pass) {
-#pragma unroll
-    for (int i2 = 0; i2 < 2; ++i2)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) *(f32x4*)(ewf + (16 * i2 + r16) * FP + 16 * j + 4 * g) = acc[2 * pass + i2][j];
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int it = 0; it < 32 * CPRW / 64; ++it) {
-      int idx = l + 64 * it;                    // 32 rows x CPRW chunks of 8 columns
-      int r = idx / CPRW, c = idx - r * CPRW;
-      int gm = em + 32 * pass + r, gn = en + c * 8;
-      if (gm >= p.M || gn >= p.N) continue;
-      float v[8], d[8];
-      f32x4 x0 = *(const f32x4*)(ewf + r * FP + c * 8), x1 = *(const f32x4*)(ewf + r * FP + c * 8 + 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { v[e] = x0[e]; v[4 + e] = x1[e]; }
-      bool full = vec && gn + 8 <= p.N;
-      if (p.bias) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) if (gn + e < p.N) v[e] += bf2f(p.bias[gn + e]);
-      }
-      if (p.act) {
-        if (p.pre) {
-          act_fwd_deriv_n<8>(p.act, v, d);
-          if (full) { bf16x8 o; for (int e = 0; e < 8; ++e) o[e] = f2bf(d[e]); *(bf16x8*)(p.pre + (long)gm * p.ldpre + gn) = o; }
-          else for (int e = 0; e < 8; ++e) if (gn + e < p.N) p.pre[(long)gm * p.ldpre + gn + e] = f2bf(d[e]);
-        } else act_fwd_n<8>(p.act, v);
-      }
-      if (p.aux) {
-        if (full) { bf16x8 a = *(const bf16x8*)(p.aux + (long)gm * p.ldaux + gn); for (int e = 0; e < 8; ++e) v[e] *= bf2f(a[e]); }
-        else for (int e = 0; e < 8; ++e) if (gn + e < p.N) v[e] *= bf2f(p.aux[(long)gm * p.ldaux + gn + e]);
-      }
-      if (p.res) {
-        if (full) { bf16x8 a = *(const bf16x8*)(p.res + (long)gm * p.ldres + gn); for (int e = 0; e < 8; ++e) v[e] += bf2f(a[e]); }
-        else for (int e = 0; e < 8; ++e) if (gn + e < p.N) v[e] += bf2f(p.res[(long)gm * p.ldres + gn + e]);
-      }
-      if (full) { bf16x8 o; for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]); *(bf16x8*)(p.C + (long)gm * p.ldc + gn) = o; }
-      else for (int e = 0; e < 8; ++e) if (gn + e < p.N) p.C[(long)gm * p.ldc + gn + e] = f2bf(v[e]);
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-  }
+  mx_epilogue_general<MI, NJ, NWAVE, STAGE>(p, acc, smem, wave, m0 + wm * 16 * MI, n0 + wn * 16 * NJ);
 }
 
 // ---- ping-pong form of the 256 x 256 tile (round 4).  The kernel above runs its 8 waves in lockstep: everybody issues the LDS-DMA, everybody
@@ -255,6 +281,10 @@ __global__ __launch_bounds__(64 * WMW * WNW) void gemm_mx_kernel(MxP p) {
 // >= 1000 cycles behind its issue, nothing reads a stage in the phase that retires it.  Same MFMA order per output: same bits as above.
 #define MXP_FENCE() do { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); } while (0)
 #define MXP_BARRIER() do { MXP_FENCE(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); MXP_FENCE(); } while (0)
+// EPI: -1 = the general epilogue above; EK_PLAIN / EK_GELU2 / EK_AUX / EK_RES = that fixed kind of the bf16 family (gemm_tile.h epi_groups: inputs
+// prefetched before the first store, uint8 act'(z), no option branches) -- the accumulator layout is the bf16 kernels', so the staging and
+// the store loops are shared code and an epilogue costs here what it costs there.
+template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_mx_pp_kernel(MxP p) {
   constexpr int BM = 256, BN = 256, NWAVE = 8, MI = 8, NJ = 4;
   constexpr int STAGE = (BM + BN) * 128 + (BM + BN) * 4;
@@ -351,55 +381,34 @@ __global__ __launch_bounds__(512, 2) void gemm_mx_pp_kernel(MxP p) {
 #undef MXP_LOADF
 #undef MXP_MFMAS
 
-  // ---- epilogue: as gemm_mx_kernel<2, 4, 8, 4>
-  constexpr int WNC = 16 * NJ, FP = WNC + 4, CPRW = WNC / 8;
-  static_assert(NWAVE * 32 * FP * 4 <= 2 * STAGE, "epilogue staging fits");
-  float* ewf = (float*)(smem + wave * (32 * FP * 4));
-  const int em = m0 + wm * 16 * MI, en = n0 + wn * WNC;
-  const bool vec = !((p.ldc | p.ldres | p.ldaux | p.ldpre) & 7);
-#pragma unroll
-  for (int pass = 0; pass < MI / 2; ++pass) {
-#pragma unroll
-    for (int i2 = 0; i2 < 2; ++i2)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) *(f32x4*)(ewf + (16 * i2 + r16) * FP + 16 * j + 4 * g) = acc[2 * pass + i2][j];
+  const int em = m0 + wm * 16 * MI, en = n0 + wn * 16 * NJ;
+  if constexpr (EPI < 0) {
+    mx_epilogue_general<MI, NJ, NWAVE, STAGE>(p, acc, smem, wave, em, en);
+  } else {
+    // the loop ended with a barrier behind every group's last fragment read: the stages are free.  Wave-private [64][64] f32 region,
+    // 16-byte units XOR-swizzled by row, two 64-row passes (gemm3.hip's epilogue, same helpers)
+    constexpr int WN = 16 * NJ, ESTR = WN * 4, UNITS = WN / 4;
+    static_assert(NWAVE * 64 * ESTR <= 2 * STAGE, "epilogue staging fits");
+    const Gemm2Params q = mx_as_gemm2(p);
+    char* er = smem + wave * (64 * ESTR);
+#define MXP_STAGE(PASS) do {                                                                                      \
+    _Pragma("unroll") for (int i2 = 0; i2 < 4; ++i2)                                                               \
+      _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                           \
+        int row = i2 * 16 + r16, u = j * 4 + g;                                                                    \
+        *(f32x4*)(er + row * ESTR + ((u ^ (row & (UNITS - 1))) << 4)) = acc[(PASS) * 4 + i2][j];                   \
+      }                                                                                                            \
+    __builtin_amdgcn_s_waitcnt(0xc07f); } while (0)
+    EpiPre<WN> pre0, pre1;
+    bf16x8 biasv = epi_bias<WN>(q, l, en, EPI);
+    epi_fetch<WN>(q, l, em, en, EPI, pre0);
+    MXP_STAGE(0);
+    epi_fetch<WN>(q, l, em + 64, en, EPI, pre1);
+    epi_inputs_ready();
+    epi_pass_fixed<WN, EPI < 0 ? 0 : EPI>(q, er, l, em, en, 1.f, pre0, biasv);
     __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int it = 0; it < 32 * CPRW / 64; ++it) {
-      int idx = l + 64 * it;
-      int r = idx / CPRW, c = idx - r * CPRW;
-      int gm = em + 32 * pass + r, gn = en + c * 8;
-      if (gm >= p.M || gn >= p.N) continue;
-      float v[8], d[8];
-      f32x4 x0 = *(const f32x4*)(ewf + r * FP + c * 8), x1 = *(const f32x4*)(ewf + r * FP + c * 8 + 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { v[e] = x0[e]; v[4 + e] = x1[e]; }
-      bool full = vec && gn + 8 <= p.N;
-      if (p.bias) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) if (gn + e < p.N) v[e] += bf2f(p.bias[gn + e]);
-      }
-      if (p.act) {
-        if (p.pre) {
-          act_fwd_deriv_n<8>(p.act, v, d);
-          if (full) { bf16x8 o; for (int e = 0; e < 8; ++e) o[e] = f2bf(d[e]); *(bf16x8*)(p.pre + (long)gm * p.ldpre + gn) = o; }
-          else for (int e = 0; e < 8; ++e) if (gn + e < p.N) p.pre[(long)gm * p.ldpre + gn + e] = f2bf(d[e]);
-        } else act_fwd_n<8>(p.act, v);
-      }
-      if (p.aux) {
-        if (full) { bf16x8 a = *(const bf16x8*)(p.aux + (long)gm * p.ldaux + gn); for (int e = 0; e < 8; ++e) v[e] *= bf2f(a[e]); }
-        else for (int e = 0; e < 8; ++e) if (gn + e < p.N) v[e] *= bf2f(p.aux[(long)gm * p.ldaux + gn + e]);
-      }
-      if (p.res) {
-        if (full) { bf16x8 a = *(const bf16x8*)(p.res + (long)gm * p.ldres + gn); for (int e = 0; e < 8; ++e) v[e] += bf2f(a[e]); }
-        else for (int e = 0; e < 8; ++e) if (gn + e < p.N) v[e] += bf2f(p.res[(long)gm * p.ldres + gn + e]);
-      }
-      if (full) { bf16x8 o; for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]); *(bf16x8*)(p.C + (long)gm * p.ldc + gn) = o; }
-      else for (int e = 0; e < 8; ++e) if (gn + e < p.N) p.C[(long)gm * p.ldc + gn + e] = f2bf(v[e]);
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
+    MXP_STAGE(1);
+    epi_pass_fixed<WN, EPI < 0 ? 0 : EPI>(q, er, l, em + 64, en, 1.f, pre1, biasv);
+#undef MXP_STAGE
   }
 }
 
@@ -418,7 +427,8 @@ extern "C" int unimp_gemm_mxfp8(const unimp_mx_gemm_desc* d, void* stream) {
   p.C = (bf16*)d->C; p.ldc = d->ldc;
   p.bias = (const bf16*)d->bias; p.res = (const bf16*)d->res; p.ldres = d->ldres; p.aux = (const bf16*)d->aux; p.ldaux = d->ldaux;
   p.pre = (bf16*)d->pre; p.ldpre = d->ldpre;
-  p.M = d->M; p.N = d->N; p.K = d->K; p.act = d->act;
+  p.M = d->M; p.N = d->N; p.K = d->K; p.act = d->act; p.deriv_u8 = d->deriv_u8 != 0;
+  if (p.deriv_u8 && p.pre && !p.act) return unimp_set_error(UNIMP_ERR_ARG, "gemm_mxfp8: deriv_u8 with `pre` needs an activation (pre = act'(z))");
   // 256 x 256 tiles once they fill the chip (>= 2 rounds of 256 CUs), 128 x 128 otherwise; env UNIMP_MX_TILE=128|256 forces one (A/B)
   static const int force = [] { const char* e = getenv("UNIMP_MX_TILE"); return e ? atoi(e) : 0; }();
   long t256 = (long)((d->M + 255) / 256) * ((d->N + 255) / 256);
@@ -426,10 +436,27 @@ extern "C" int unimp_gemm_mxfp8(const unimp_mx_gemm_desc* d, void* stream) {
   static const int no_pp = [] { const char* e = getenv("UNIMP_MX_PP"); return e && e[0] == '0'; }();       // UNIMP_MX_PP=0: the lockstep kernel (A/B)
   if (big && !no_pp) {
     p.nbm = (d->M + 255) / 256; p.nbn = (d->N + 255) / 256;
+    // fixed epilogue kinds (UNIMP_MX_FIXED_EPI=0: the general epilogue everywhere, A/B): the conditions of the bf16 family's epi_kind_host
+    static const int no_fixed = [] { const char* e = getenv("UNIMP_MX_FIXED_EPI"); return e && e[0] == '0'; }();
+    int kind = -1;
+    if (!no_fixed && !((p.ldc | p.ldres | p.ldaux | p.ldpre) & 7) && !(p.N & 7) && !(p.aux && p.res)) {
+      if (p.aux) kind = (p.deriv_u8 && !p.act && !p.pre) ? EK_AUX : -1;
+      else if (p.res) kind = (!p.act && !p.pre) ? EK_RES : -1;
+      else if (p.pre) kind = (p.deriv_u8 && p.act == ACT_GELU) ? EK_GELU2 : -1;
+      else kind = p.act ? -1 : EK_PLAIN;
+    }
+#define MXPP(E_) do { auto kern = gemm_mx_pp_kernel<E_>; static bool attr_set = false;                                                    \
+      if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }   \
+      hipLaunchKernelGGL(kern, dim3(p.nbm * p.nbn), dim3(512), lds, (hipStream_t)stream, p); } while (0)
     constexpr int lds = 2 * ((256 + 256) * 128 + (256 + 256) * 4);
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_mx_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
-    hipLaunchKernelGGL(gemm_mx_pp_kernel, dim3(p.nbm * p.nbn), dim3(512), lds, (hipStream_t)stream, p);
+    switch (kind) {
+      case EK_PLAIN: MXPP(EK_PLAIN); break;
+      case EK_GELU2: MXPP(EK_GELU2); break;
+      case EK_AUX:   MXPP(EK_AUX); break;
+      case EK_RES:   MXPP(EK_RES); break;
+      default:       MXPP(-1); break;
+    }
+#undef MXPP
   } else if (big) {
     p.nbm = (d->M + 255) / 256; p.nbn = (d->N + 255) / 256;
     hipLaunchKernelGGL((gemm_mx_kernel<2, 4, 8, 4>), dim3(p.nbm * p.nbn), dim3(512), 0, (hipStream_t)stream, p);

@@ -328,10 +328,19 @@ FROZEN_WT_ATTN = _FW >= 2    # frozen qkv / attention-out projections (LM, ViT),
 FP8_FROZEN = _os.environ.get("UNIMP_FP8", "0") == "1"   # opt-in (bench.py --fp8): frozen Linear layers of the towers run on the MX-fp8 GEMM
 
 
+# A weight takes the MX path only if BOTH its dimensions reach FP8_MIN_DIM (each is the contraction depth of the forward or of dX).  At
+# K = 1024 a 256 x 256 MX tile is 8 K-steps of 128 bytes -- prologue and epilogue outweigh the loop -- and the bf16 ping-pong kernel is the
+# faster one: the ViT-L/14's four projections ran at 0.53-1.11 PF on the MX kernel against 0.86-1.22 PF in bf16, before the cost of
+# quantising their activations (profiles/r04_mx_step_shapes.txt).  So "fp8 frozen towers" means the language tower (4096 x 4096 ... 16384);
+# UNIMP_FP8_MIN_DIM=128 restores MX everywhere (the tiny-tower tests do).
+FP8_MIN_DIM = int(_os.environ.get("UNIMP_FP8_MIN_DIM", "2048"))
+
+
 def _mx_ok(w, M):
-    """the MX path serves a FROZEN weight whose two dimensions are multiples of 128 (contraction of the forward and of dX), for
-    row counts the decode kernel does not take"""
-    return FP8_FROZEN and not w.requires_grad and M > 64 and w.shape[0] % 128 == 0 and w.shape[1] % 128 == 0
+    """the MX path serves a FROZEN weight whose two dimensions are multiples of 128 (contraction of the forward and of dX) and at
+    least FP8_MIN_DIM, for row counts the decode kernel does not take"""
+    return (FP8_FROZEN and not w.requires_grad and M > 64 and w.shape[0] % 128 == 0 and w.shape[1] % 128 == 0
+            and min(w.shape[0], w.shape[1]) >= FP8_MIN_DIM)
 
 
 def _frozen_mx(w, transposed=False):
@@ -364,9 +373,8 @@ class MLPBlockFn(Function):
         w1g, w2g = w1.requires_grad, w2.requires_grad
         bwd = any(ctx.needs_input_grad)            # frozen tower on constant inputs (the ViT): no act'(z) output, nothing saved
         mx = gate is None and _mx_ok(w1, M) and _mx_ok(w2, M)
-        # act'(z) for the backward: uint8 (ops / common.h DERIV_U8: step 1 / 202, 0 and 1 exact) unless the MX path or the decode-row kernel
-        # (M <= 64) writes it
-        pre = torch.empty((M, F), dtype=torch.uint8 if (DERIV_U8 and not mx and F % 8 == 0 and M > 64) else bf16, device=x.device) if bwd else None
+        # act'(z) for the backward: uint8 (ops / common.h DERIV_U8: step 1 / 202, 0 and 1 exact) unless the decode-row kernel (M <= 64) writes it
+        pre = torch.empty((M, F), dtype=torch.uint8 if (DERIV_U8 and F % 8 == 0 and M > 64) else bf16, device=x.device) if bwd else None
         t1, t2 = FROZEN_WT and not w1g and M > 64, FROZEN_WT and not w2g and M > 64      # M <= 64: the weight-streaming decode kernel
         if mx:      # frozen tower on the MX-fp8 path: activations quantised on the fly (e4m3 + E8M0 per 32), fp32 accumulate
             a = ops.gemm_mx(ops.mx_quantize(h), _frozen_mx(w1), bias=b1, act=act, pre=pre)

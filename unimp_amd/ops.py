@@ -845,7 +845,8 @@ def mx_quantize(x):
 
 
 def gemm_mx(a, b, *, bias=None, act=None, pre=None, aux=None, res=None, out=None):
-    """C[M, N] (bf16) = epi(A B^T) for MxTensors a [M, K], b [N, K]; epilogue as unimp_gemm_mxfp8."""
+    """C[M, N] (bf16) = epi(A B^T) for MxTensors a [M, K], b [N, K]; epilogue as unimp_gemm_mxfp8.  A uint8 ``pre`` / ``aux`` is the
+    8-bit stored derivative of the bf16 GEMMs (act'(z), step 1 / 202); they cannot be mixed with bf16 ones in one call."""
     M, N, K = a.q.shape[0], b.q.shape[0], a.K
     assert b.K == K, (a.q.shape, b.q.shape)
     if out is None:
@@ -861,11 +862,15 @@ def gemm_mx(a, b, *, bias=None, act=None, pre=None, aux=None, res=None, out=None
     if pre is not None:
         d.pre, d.ldpre = pre.data_ptr(), pre.stride(0)
     d.M, d.N, d.K, d.act = M, N, K, ACT[act]
+    u8 = [t.dtype == torch.uint8 for t in (pre, aux) if t is not None]
+    assert all(u8) or not any(u8), "gemm_mx: pre and aux must both be uint8 or both bf16"
+    d.deriv_u8 = int(bool(u8) and u8[0])
     if GEMM_PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     check(_lib.lib().unimp_gemm_mxfp8(C.byref(d), _stream()), "gemm_mxfp8")
     if GEMM_PROFILE is not None:
         e1.record()
-        GEMM_PROFILE.append((e0, e1, 2.0 * M * N * K, (M, N, K, 0, 0, "mxfp8")))
+        epi = "+".join(n for n, t in (("bias", bias), ("act", act), ("pre", pre), ("aux", aux), ("res", res)) if t is not None) or "plain"
+        GEMM_PROFILE.append((e0, e1, 2.0 * M * N * K, (M, N, K, epi, 0, "mxfp8")))
     return out

@@ -9,6 +9,7 @@
 Loss normalisation is per rank and gradients are averaged across ranks (mean of per-rank token means), as
 in the reference.  Samples/s accounting = GA * batch * world / step_time (mmrec.py:267-272).
 """
+import os
 import time
 import torch
 
@@ -147,6 +148,9 @@ class _WgradSink:
             self.dp._on_grad(self.views[w.data_ptr()][0])
 
 
+_ROWS_SYNC = os.environ.get("UNIMP_ROWS_SYNC", "0") == "1"      # A/B knob: the blocking nonzero() of rounds 1-3
+
+
 class Trainer:
     def __init__(self, model, special_ids, lr=2e-4, weight_decay=0.1, gamma=2.0, use_reweight=True, max_grad_norm=1.0,
                  lr_scheduler="cosine", warmup_steps=0, total_steps=1000, bucket_bytes=256 << 20, process_group=None,
@@ -190,6 +194,7 @@ class Trainer:
         if fuse_accum is None:
             fuse_accum = grad_accum > 1 and not graph
         self.fuse_accum, self._stash, self._last = bool(fuse_accum and grad_accum > 1), [], None
+        self._mb_index, self._cnt_host = {}, None
         le_ = model.lang_encoder
         if packed is not None:                   # per tower, not the module-level default: a second Trainer leaves this one alone
             if packed and not getattr(le_, "supports_packed", True):
@@ -247,9 +252,12 @@ class Trainer:
         ids = torch.cat([padded(b["lang_x"], pad) for b in batches])
         labels, _ = ops.label_mask(ids, self.ids["answer_id"], self.ids["eoc_id"], self.ids["pad_id"], self.ids["media_id"], want_media_time=False)
         n_b = (labels[:, 1:] != -100).sum(1).float()                                   # labeled positions per sample
-        sizes = [b["lang_x"].shape[0] for b in batches]
-        n_mb = torch.stack([x.sum() for x in n_b.split(sizes)]).clamp_min(1.0)         # ... per micro-batch
-        norm = (n_b.sum().clamp_min(1.0) / (len(batches) * n_mb)).repeat_interleave(torch.tensor(sizes, device=ids.device))
+        sizes = tuple(b["lang_x"].shape[0] for b in batches)
+        mb = self._mb_index.get(sizes)                    # sample -> micro-batch index; built once per size tuple (no per-step H2D / sync)
+        if mb is None:
+            mb = self._mb_index[sizes] = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes)).to(ids.device)
+        n_mb = torch.zeros(len(sizes), device=ids.device).index_add_(0, mb, n_b).clamp_min(1.0)   # ... per micro-batch (small integers: exact)
+        norm = (n_b.sum().clamp_min(1.0) / (len(batches) * n_mb))[mb]
         w = torch.cat([b["weights"].float() for b in batches])        # the task weights apply with and without --use_reweight (mmrec.py:203)
         return dict(vision_x=torch.cat([b["vision_x"] for b in batches]), lang_x=ids,
                     attention_mask=torch.cat([padded(b["attention_mask"], 0) for b in batches]), weights=w * norm)
@@ -288,13 +296,41 @@ class Trainer:
             out = self.model(vision_x=vx, lang_x=ids, attention_mask=batch["attention_mask"], labels=None)
             loss, stats = F_.focal_ce(out["logits"], labels, batch["weights"], self.gamma, self.use_reweight)
             return loss, stats, out, labels
-        bj = (labels[:, 1:] != -100).nonzero()                           # host sync: how many positions are scored
-        rows = (bj[:, 0] * ids.shape[1] + bj[:, 1]).contiguous()
+        pending = self._labeled_rows_begin(labels)                        # queued BEFORE the forward, read after it is queued
         out = self.model(vision_x=vx, lang_x=ids, attention_mask=batch["attention_mask"], labels=None, head_rows="hidden")
+        rows = self._labeled_rows_end(pending)                            # host wait: only for the count, long done by now
         w = self.model.lang_encoder.get_output_embeddings().weight
         loss, stats, logits = F_.dense_head_loss(out.hidden_rows, w, labels, batch["weights"], rows, self.gamma, self.use_reweight)
         out.logits, out.hidden_rows = logits, None                       # the reference's dense output["logits"] (mmrec.py:190)
         return loss, stats, out, labels
+
+    def _labeled_rows_begin(self, labels):
+        """The compact head backward needs the scored positions as flat row indices b * L + j (position j predicts the labeled token
+        j + 1) and their COUNT on the host.  ``nonzero()`` would stop the host right here, at the top of the step, until the device has
+        drained the previous step -- and the device then idles while the host queues the first kernels of this one (6 % of the
+        step at the reference's b = 3 x GA 2).  Instead the indices are formed at a fixed size (stable sort of the mask: scored
+        positions first, ascending), the count goes to pinned memory behind an event, and the host reads it only after the
+        model forward has been queued."""
+        B, L = labels.shape
+        m = torch.zeros(B, L, dtype=torch.uint8, device=labels.device)
+        m[:, :-1] = labels[:, 1:] != -100
+        flat = m.view(-1)
+        if not labels.is_cuda or _ROWS_SYNC:
+            return flat.nonzero().view(-1), None
+        order = torch.sort(flat, descending=True, stable=True).indices
+        if self._cnt_host is None:
+            self._cnt_host = torch.empty(1, dtype=torch.int64, pin_memory=True)
+        self._cnt_host.copy_(flat.sum(dtype=torch.int64).view(1), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return order, ev
+
+    def _labeled_rows_end(self, pending):
+        order, ev = pending
+        if ev is None:
+            return order
+        ev.synchronize()
+        return order[:int(self._cnt_host[0])]
 
     def _mask_lm_head_grads(self):
         if not self._masked:
@@ -344,9 +380,10 @@ class Trainer:
         return g["loss"], g["stats"]
 
     def step(self, batch):
-        """returns (loss, stats) device tensors.  The default loss path (and sparse_head) takes the number of labeled positions on
-        the host right after the label-mask kernel -- ONE host synchronisation per micro-step, before the model forward;
-        ``dense_head_backward=True`` (and ``graph=True``, which implies it) has none."""
+        """returns (loss, stats) device tensors.  The default loss path takes the number of labeled positions on the host: ONE host
+        wait per micro-step, for a count that is queued before the model forward and read after it (_labeled_rows_begin: the
+        device does not idle); ``sparse_head`` needs it before the forward; ``dense_head_backward=True`` (and ``graph=True``, which
+        implies it) has none."""
         self.model.train()
         if self.fuse_accum:
             return self._fused_step(batch)
