@@ -102,6 +102,8 @@ if has micro; then
   keep vendor $O/vendor.log ${R}_vendor_gemm.txt
   leg mx 300 $O/mx.log python tools/bench_mx.py
   keep mx $O/mx.log ${R}_mx_gemm.txt
+  leg mx_step 600 $O/mx_step.log python tools/mx_step_shapes.py
+  keep mx_step $O/mx_step.log ${R}_mx_step_shapes_final.txt
   leg attn 600 $O/attn.log python tools/bench_attn2.py
   keep attn $O/attn.log ${R}_attention_microbench.txt
   leg loader 900 $O/loader.log python tools/bench_loader.py 8 8

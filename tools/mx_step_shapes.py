@@ -1,6 +1,6 @@
 """Per-shape table of the MX-fp8 GEMM launches inside the cfg5-family train step (9b Flamingo, frozen towers in MX-fp8): ms per step, TFLOP/s, share."""
 import collections, os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from unimp_amd import ops, functional as F_
 from unimp_amd.synthetic import make_batch
