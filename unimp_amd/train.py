@@ -318,7 +318,7 @@ class Trainer:
         if not labels.is_cuda or _ROWS_SYNC:
             return flat.nonzero().view(-1), None
         order = torch.sort(flat, descending=True, stable=True).indices
-        if self._cnt_host is None:
+        if getattr(self, "_cnt_host", None) is None:
             self._cnt_host = torch.empty(1, dtype=torch.int64, pin_memory=True)
         self._cnt_host.copy_(flat.sum(dtype=torch.int64).view(1), non_blocking=True)
         ev = torch.cuda.Event()
