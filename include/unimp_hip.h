@@ -117,6 +117,10 @@ int unimp_gemm_bf16_splitk(const unimp_gemm_desc* d, int splits, float* slabs, v
 int unimp_layernorm_fwd(const void* x, int64_t ldx, const void* gamma, const void* beta, void* y, int64_t ldy,
                         float* mean, float* rstd, int rows, int D, float eps, int rms,
                         int grp, int grp_stride, int grp_off, void* stream);
+/* the same row arithmetic with the normalised row leaving as an MX-fp8 operand (e4m3 bytes [rows][D], ldyq in bytes; E8M0 [rows][D/32]):
+ * the bytes unimp_mx_quantize makes of the bf16 row -- LayerNorm feeding a frozen projection on the MX GEMM (F4).  D % 32 == 0. */
+int unimp_layernorm_fwd_mx(const void* x, int64_t ldx, const void* gamma, const void* beta, void* yq, int64_t ldyq, void* scales,
+                           int64_t ldsc, float* mean, float* rstd, int rows, int D, float eps, int rms, void* stream);
 int unimp_layernorm_bwd(const void* dy, int64_t lddy, const void* dy2, int64_t lddy2, const void* x, int64_t ldx, const void* gamma,
                         const float* mean, const float* rstd, const void* dres, int64_t lddres,
                         void* dx, int64_t lddx, void* dgamma, void* dbeta, float* partial, int partial_blocks,
@@ -256,6 +260,10 @@ typedef struct unimp_mx_gemm_desc {
   int32_t deriv_u8;                         /* != 0: the derivative act'(z) written to `pre` / read from `aux` is the uint8 form the bf16
                                              * GEMM descriptor selects with pre_deriv = 2 / dact = UNIMP_ACT_DERIV_U8: one byte per element,
                                              * ldpre / ldaux in bytes */
+  int32_t reserved0;
+  void* scale_c; int64_t ldsc;              /* scale_c != NULL: C leaves as an MX operand for the NEXT product -- e4m3 bytes [M][N] (ldc in bytes)
+                                             * + E8M0 [M][N/32], quantised along N exactly as unimp_mx_quantize would quantise the bf16 result
+                                             * (same bytes); N % 32 == 0.  The bf16 round trip and the quantiser pass disappear. */
 } unimp_mx_gemm_desc;
 int unimp_mx_quantize(const void* x, int64_t ldx, void* q, int64_t ldq, void* scales, int64_t lds, int rows, int K, void* stream);
 int unimp_gemm_mxfp8(const unimp_mx_gemm_desc* d, void* stream);

@@ -131,8 +131,9 @@ def test_kernel_register_budgets():
             assert r["Occupancy"] >= 2, (k, r)
     mx = remarks("mx.hip", vg)
     big = [r for k, r in mx.items() if "gemm_mx_kernelILi2ELi4ELi8ELi4" in k or "gemm_mx_pp_kernel" in k]
-    # the lockstep 256 x 256 kernel + the ping-pong kernel with the general epilogue and its four fixed kinds (PLAIN, GELU2, AUX, RES)
-    assert len(big) == 6 and all(b["ScratchSize"] == 0 and b["VGPRs"] + b.get("AGPRs", 0) <= 256 for b in big), big
+    # the lockstep 256 x 256 kernel + the ping-pong kernel with the general epilogue, its four fixed kinds (PLAIN, GELU2, AUX, RES) and the two with
+    # the fused MX output (GELU2 -> MX, AUX -> MX)
+    assert len(big) == 8 and all(b["ScratchSize"] == 0 and b["VGPRs"] + b.get("AGPRs", 0) <= 256 for b in big), big
 
 
 def test_gemm_kernel_code_fits_the_instruction_cache():

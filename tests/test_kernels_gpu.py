@@ -1168,6 +1168,43 @@ def test_gemm_mxfp8_ping_pong_kernel_epilogue_kinds(ops):
     close(g8, w2 * d8.cpu(), rel=2 ** -6, name="mx pp aux u8")
 
 
+@pytest.mark.parametrize("M,N,K", [(4096 + 40, 8192, 512), (300, 256, 256)])
+def test_gemm_mxfp8_fused_mx_output_equals_quantising_the_bf16_result(ops, M, N, K):
+    """unimp_mx_gemm_desc.scale_c: the result leaves the GEMM as the next product's MX operand.  Must be the SAME BYTES (elements and
+    scales) as mx_quantize of the bf16 result it replaces -- on the ping-pong kernel's two fused kinds (GELU + uint8 GELU', x uint8
+    GELU'), on its general epilogue (bias + residual) and on the 128 x 128 kernel (the small shape), ragged M."""
+    a = ops.mx_quantize(rnd(M, K, seed=1).cuda())
+    b = ops.mx_quantize(rnd(N, K, scale=0.5, seed=2).cuda())
+    bias, res = rnd(N, seed=3).cuda(), rnd(M, N, seed=5).cuda()
+
+    def same(kw):
+        want = ops.mx_quantize(ops.gemm_mx(a, b, **{k: (v.clone() if k == "pre" else v) for k, v in kw.items()}))
+        got = ops.gemm_mx(a, b, out_mx=True, **kw)
+        assert torch.equal(got.scales, want.scales), kw.keys()
+        assert torch.equal(got.q, want.q), kw.keys()
+    pre8 = torch.empty((M, N), dtype=torch.uint8, device="cuda")
+    same(dict(act="gelu", pre=pre8))
+    same(dict(bias=bias, act="gelu", pre=pre8))
+    same(dict(aux=pre8))
+    same(dict(bias=bias, res=res))
+    same(dict())
+
+
+@pytest.mark.parametrize("rows,D", [(300, 4096), (129, 2560), (70, 1024), (33, 96), (5, 1536), (40, 3072)])
+def test_layernorm_fwd_mx_equals_quantising_the_bf16_rows(ops, rows, D):
+    """unimp_layernorm_fwd_mx: the normalised rows leave as an MX operand -- same element bytes, same scales, same statistics as
+    mx_quantize(layernorm_fwd(x)); full and ragged chunk maps (D = 4096 / 2560 / 1024 are the FULL forms), LayerNorm and RMSNorm."""
+    x = rnd(rows, D, scale=2.0, seed=rows).cuda()
+    x[0, :32] = 0
+    g, b = (1 + 0.1 * rnd(D, seed=2)).cuda(), (0.1 * rnd(D, seed=3)).cuda()
+    for rms, beta in ((False, b), (False, None), (True, None)):
+        y, mean, rstd = ops.layernorm_fwd(x, g, beta, 1e-5, rms=rms)
+        want = ops.mx_quantize(y)
+        got, mean2, rstd2 = ops.layernorm_fwd_mx(x, g, beta, 1e-5, rms=rms)
+        assert torch.equal(got.scales, want.scales) and torch.equal(got.q, want.q), (rms, beta is None)
+        assert torch.equal(rstd, rstd2) and (rms or torch.equal(mean, mean2))
+
+
 # ------------------------------------------------------------------------------------------------- packed-B ping-pong GEMM
 @pytest.mark.parametrize("M,N,K", [(1024, 2560, 2560), (1096, 520, 1000), (2048, 10240, 2560), (1304, 2560, 10240 + 40), (1024, 264, 96)])
 @pytest.mark.parametrize("b_ks", [False, True])

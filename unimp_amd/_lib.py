@@ -38,7 +38,7 @@ class MxGemmDesc(C.Structure):
     _fields_ = [("A", c_p), ("B", c_p), ("scale_a", c_p), ("scale_b", c_p), ("C", c_p),
                 ("bias", c_p), ("res", c_p), ("aux", c_p), ("pre", c_p)] + \
                [(n, c_l) for n in ("lda", "ldb", "ldsa", "ldsb", "ldc", "ldres", "ldaux", "ldpre")] + \
-               [("M", c_i), ("N", c_i), ("K", c_i), ("act", c_i), ("deriv_u8", c_i)]
+               [("M", c_i), ("N", c_i), ("K", c_i), ("act", c_i), ("deriv_u8", c_i), ("reserved0", c_i), ("scale_c", c_p), ("ldsc", c_l)]
 
 
 # name -> argtypes (every entry point returns int status)
@@ -47,6 +47,7 @@ _SIGS = {
     "unimp_gemm_bf16_variant": [C.POINTER(GemmDesc), c_i, c_p],
     "unimp_gemm_bf16_splitk": [C.POINTER(GemmDesc), c_i, c_p, c_p],
     "unimp_layernorm_fwd": [c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_p, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_p],
+    "unimp_layernorm_fwd_mx": [c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_p, c_i, c_i, c_f, c_i, c_p],
     "unimp_layernorm_bwd": [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_i,
                             c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "unimp_rope_halfsplit": [c_p, c_l, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p],

@@ -84,7 +84,38 @@ struct MxP {
   const bf16* bias; const bf16* res; long ldres; const bf16* aux; long ldaux; bf16* pre; long ldpre;
   int M, N, K, act, nbm, nbn;
   int deriv_u8;              // the stored derivative act'(z) (`pre` written / `aux` read) is the 8-bit form of the bf16 GEMMs (common.h)
+  uint8_t* sC; long ldsc;    // != null: C is written as an MX operand (e4m3 bytes at C, ldc in bytes, + E8M0 per 32 columns here)
 };
+
+// ---- fused MX output: 8 consecutive columns of one row, held by one lane; the 32-column scale block spans 4 ADJACENT lanes of the same row (both
+// epilogue forms below hand consecutive 8-column chunks of a row to consecutive lanes, 8 chunks per 64-column wave tile).  The value is rounded
+// to bf16 first, so the bytes are exactly what mx_quantize_kernel makes of the bf16 tensor this replaces.
+template <int CTRL> __device__ __forceinline__ float mx_quad(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ void mx_store8(const MxP& p, const float (&v)[8], int m, int n) {
+  float w[8], amax = 0.f;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) { w[r] = bf2f(f2bf(v[r])); amax = fmaxf(amax, fabsf(w[r])); }
+  amax = fmaxf(amax, mx_quad<0xB1>(amax));                       // quad_perm [1, 0, 3, 2]: lane ^ 1
+  amax = fmaxf(amax, mx_quad<0x4E>(amax));                       // quad_perm [2, 3, 0, 1]: lane ^ 2
+  int eb = (int)((__float_as_uint(amax) >> 23) & 0xff);
+  int sbyte = max(eb - 8, 0);
+  if (!(amax == amax) || eb == 255) sbyte = 254;
+  float inv = __uint_as_float((uint32_t)(254 - sbyte) << 23);
+  if (sbyte == 254) inv = 1.17549435e-38f;
+  uint32_t out[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    float a = fminf(fmaxf(w[4 * h] * inv, -448.f), 448.f), b = fminf(fmaxf(w[4 * h + 1] * inv, -448.f), 448.f);
+    float c = fminf(fmaxf(w[4 * h + 2] * inv, -448.f), 448.f), d = fminf(fmaxf(w[4 * h + 3] * inv, -448.f), 448.f);
+    int pk = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    pk = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, pk, true);
+    out[h] = (uint32_t)pk;
+  }
+  *(uint2*)((uint8_t*)p.C + (long)m * p.ldc + n) = uint2{out[0], out[1]};
+  if (!(n & 31)) p.sC[(long)m * p.ldsc + (n >> 5)] = (uint8_t)sbyte;
+}
 
 // ---- general epilogue (every option behind a run-time branch) through a wave-private f32 staging area, 32 rows per pass, then 16-byte
 // chunks of 8 consecutive columns.  acc[i][j]: row m = 16 i + r16 (the swapped product puts A's row on the lane), columns n = 16 j + 4 g + e
@@ -142,11 +173,45 @@ __device__ __forceinline__ void mx_epilogue_general(const MxP& p, const f32x4 (&
         if (full) { bf16x8 a = *(const bf16x8*)(p.res + (long)gm * p.ldres + gn); for (int e = 0; e < 8; ++e) v[e] += bf2f(a[e]); }
         else for (int e = 0; e < 8; ++e) if (gn + e < p.N) v[e] += bf2f(p.res[(long)gm * p.ldres + gn + e]);
       }
-      if (full) { bf16x8 o; for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]); *(bf16x8*)(p.C + (long)gm * p.ldc + gn) = o; }
+      if (p.sC) mx_store8(p, v, gm, gn);                   // host: N % 32 == 0, so the 4 lanes of a scale block are in range together
+      else if (full) { bf16x8 o; for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]); *(bf16x8*)(p.C + (long)gm * p.ldc + gn) = o; }
       else for (int e = 0; e < 8; ++e) if (gn + e < p.N) p.C[(long)gm * p.ldc + gn + e] = f2bf(v[e]);
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// fixed kinds with the fused MX output (the frozen MLP: up-projection + GELU + uint8 GELU' -> MX, and dX x GELU' -> MX): the arithmetic of
+// gemm_tile.h's epi8k<EK_GELU2> / <EK_AUX> (bias by add_rn, unit alpha / gate skipped), then mx_store8 instead of the bf16 store
+enum { MXK_GELU2_MX = 100, MXK_AUX_MX = 101 };
+template <int WN, int KIND>
+__device__ __forceinline__ void mx_out_groups(const MxP& p, const char* er, int lane, int mbase, int nbase, const EpiPre<WN>& e, bf16x8 biasv) {
+  constexpr int ESTR = WN * 4, UNITS = WN / 4, LPR = EpiPre<WN>::LPR, RPI = EpiPre<WN>::RPI, NIT = EpiPre<WN>::NIT;
+  const int cg = lane % LPR, n = nbase + cg * 8;
+  if (n >= p.N) return;
+#pragma unroll
+  for (int u = 0; u < NIT; ++u) {                  // fully unrolled: e.xv[u] must stay in registers
+    int row = u * RPI + lane / LPR, m = mbase + row, sw = row & (UNITS - 1);
+    f32x4 x0 = *(const f32x4*)(er + row * ESTR + (((2 * cg) ^ sw) << 4));
+    f32x4 x1 = *(const f32x4*)(er + row * ESTR + (((2 * cg + 1) ^ sw) << 4));
+    if (m < p.M) {
+      float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+      if (p.bias) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = add_rn(v[r], bf2f(biasv[r]));
+      }
+      if (KIND == EK_GELU2) {
+        float dv[8];
+        act_fwd_deriv_n<8>(ACT_GELU, v, dv);
+        *(uint2*)((uint8_t*)p.pre + (long)m * p.ldpre + n) = uint2{deriv_u8_pack4(dv[0], dv[1], dv[2], dv[3]), deriv_u8_pack4(dv[4], dv[5], dv[6], dv[7])};
+      } else {
+        union { bf16x8 b; uint2 q[2]; } cv; cv.b = e.xv[u];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] *= deriv_u8_get(r < 4 ? cv.q[0].x : cv.q[0].y, r & 3);
+      }
+      mx_store8(p, v, m, n);
+    }
   }
 }
 
@@ -398,16 +463,19 @@ __global__ __launch_bounds__(512, 2) void gemm_mx_pp_kernel(MxP p) {
         *(f32x4*)(er + row * ESTR + ((u ^ (row & (UNITS - 1))) << 4)) = acc[(PASS) * 4 + i2][j];                   \
       }                                                                                                            \
     __builtin_amdgcn_s_waitcnt(0xc07f); } while (0)
+    constexpr int KIND = EPI == MXK_GELU2_MX ? EK_GELU2 : (EPI == MXK_AUX_MX ? EK_AUX : EPI);
     EpiPre<WN> pre0, pre1;
-    bf16x8 biasv = epi_bias<WN>(q, l, en, EPI);
-    epi_fetch<WN>(q, l, em, en, EPI, pre0);
+    bf16x8 biasv = epi_bias<WN>(q, l, en, KIND);
+    epi_fetch<WN>(q, l, em, en, KIND, pre0);
     MXP_STAGE(0);
-    epi_fetch<WN>(q, l, em + 64, en, EPI, pre1);
+    epi_fetch<WN>(q, l, em + 64, en, KIND, pre1);
     epi_inputs_ready();
-    epi_pass_fixed<WN, EPI < 0 ? 0 : EPI>(q, er, l, em, en, 1.f, pre0, biasv);
+    if constexpr (EPI >= 100) mx_out_groups<WN, KIND>(p, er, l, em, en, pre0, biasv);
+    else epi_pass_fixed<WN, KIND < 0 ? 0 : KIND>(q, er, l, em, en, 1.f, pre0, biasv);
     __builtin_amdgcn_s_waitcnt(0xc07f);
     MXP_STAGE(1);
-    epi_pass_fixed<WN, EPI < 0 ? 0 : EPI>(q, er, l, em + 64, en, 1.f, pre1, biasv);
+    if constexpr (EPI >= 100) mx_out_groups<WN, KIND>(p, er, l, em + 64, en, pre1, biasv);
+    else epi_pass_fixed<WN, KIND < 0 ? 0 : KIND>(q, er, l, em + 64, en, 1.f, pre1, biasv);
 #undef MXP_STAGE
   }
 }
@@ -428,6 +496,8 @@ extern "C" int unimp_gemm_mxfp8(const unimp_mx_gemm_desc* d, void* stream) {
   p.bias = (const bf16*)d->bias; p.res = (const bf16*)d->res; p.ldres = d->ldres; p.aux = (const bf16*)d->aux; p.ldaux = d->ldaux;
   p.pre = (bf16*)d->pre; p.ldpre = d->ldpre;
   p.M = d->M; p.N = d->N; p.K = d->K; p.act = d->act; p.deriv_u8 = d->deriv_u8 != 0;
+  p.sC = (uint8_t*)d->scale_c; p.ldsc = d->ldsc;
+  if (p.sC && ((d->N & 31) || (d->ldc & 7))) return unimp_set_error(UNIMP_ERR_SHAPE, "gemm_mxfp8: MX output needs N %% 32 == 0 and ldc %% 8 == 0 (bytes)");
   if (p.deriv_u8 && p.pre && !p.act) return unimp_set_error(UNIMP_ERR_ARG, "gemm_mxfp8: deriv_u8 with `pre` needs an activation (pre = act'(z))");
   // 256 x 256 tiles once they fill the chip (>= 2 rounds of 256 CUs), 128 x 128 otherwise; env UNIMP_MX_TILE=128|256 forces one (A/B)
   static const int force = [] { const char* e = getenv("UNIMP_MX_TILE"); return e ? atoi(e) : 0; }();
@@ -444,6 +514,7 @@ extern "C" int unimp_gemm_mxfp8(const unimp_mx_gemm_desc* d, void* stream) {
       else if (p.res) kind = (!p.act && !p.pre) ? EK_RES : -1;
       else if (p.pre) kind = (p.deriv_u8 && p.act == ACT_GELU) ? EK_GELU2 : -1;
       else kind = p.act ? -1 : EK_PLAIN;
+      if (p.sC) kind = kind == EK_GELU2 ? MXK_GELU2_MX : (kind == EK_AUX ? MXK_AUX_MX : -1);     // other MX-output forms: the general epilogue
     }
 #define MXPP(E_) do { auto kern = gemm_mx_pp_kernel<E_>; static bool attr_set = false;                                                    \
       if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }   \
@@ -454,6 +525,8 @@ extern "C" int unimp_gemm_mxfp8(const unimp_mx_gemm_desc* d, void* stream) {
       case EK_GELU2: MXPP(EK_GELU2); break;
       case EK_AUX:   MXPP(EK_AUX); break;
       case EK_RES:   MXPP(EK_RES); break;
+      case MXK_GELU2_MX: MXPP(MXK_GELU2_MX); break;
+      case MXK_AUX_MX:   MXPP(MXK_AUX_MX); break;
       default:       MXPP(-1); break;
     }
 #undef MXPP

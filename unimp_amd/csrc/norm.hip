@@ -38,11 +38,18 @@ __device__ __forceinline__ void load_raw(const bf16* __restrict__ p, const int (
   for (int c = 0; c < MAXC; ++c) t[c] = *(const bf16x8*)(p + off[c]);
 }
 
-template <int MAXC, bool FULL>
+// MXOUT: the normalised row leaves as an MX-fp8 operand (e4m3 bytes at y, ldy in bytes; one E8M0 scale per 32 consecutive elements at
+// `sc`) -- exactly the bytes mx_quantize_kernel (mx.hip) makes of the bf16 row this replaces: the 32-element block is the 8-element
+// chunks of 4 ADJACENT lanes, its amax one quad exchange.  D % 32 == 0.
+template <int CTRL> __device__ __forceinline__ float ln_quad(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+template <int MAXC, bool FULL, bool MXOUT = false>
 __device__ __forceinline__ void ln_fwd_rows(const bf16* __restrict__ x, long ldx, const bf16* __restrict__ gamma,
                                             const bf16* __restrict__ beta, bf16* __restrict__ y, long ldy,
                                             float* __restrict__ mean, float* __restrict__ rstd, int rows, int D,
-                                            float eps, int rms, int grp, int grp_stride, int grp_off) {
+                                            float eps, int rms, int grp, int grp_stride, int grp_off,
+                                            uint8_t* __restrict__ sc = nullptr, long ldsc = 0) {
   int lane = lane_id();
   int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   int nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -75,11 +82,17 @@ __device__ __forceinline__ void ln_fwd_rows(const bf16* __restrict__ x, long ldx
 #pragma unroll
     for (int c = 0; c < MAXC; ++c)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { float d = m.ok[c] ? v[c][j] - mu : 0.f; q += d * d; }
+      for (int j = 0; j < 8; ++j) {
+        float d = m.ok[c] ? v[c][j] - mu : 0.f;
+        // the FULL bf16 instantiations compile to packed d * d products followed by sequential adds (no fma); this one would contract to
+        // scalar fmas and differ in the last bit of rstd (the ragged forms contract in both): spelled out so that both outputs of a shape
+        // come from the same statistics (tests/test_kernels_gpu.py compares them bitwise for every (MAXC, FULL) pair)
+        if (MXOUT && FULL) q = add_rn(q, mul_rn(d, d)); else q += d * d;
+      }
     float var = wave_sum(q) * inv_d;
     float rs = rsqrtf(var + eps);
     if (lane == 0) { if (mean) mean[r] = mu; rstd[r] = rs; }
-    bf16* yo = y + map_row(r, grp, grp_stride, grp_off) * ldy;
+    bf16* yo = MXOUT ? (bf16*)((uint8_t*)y + (long)r * ldy) : y + map_row(r, grp, grp_stride, grp_off) * ldy;
     // gamma / beta stay in their bf16 load registers until the chunk that uses them (LN_KEEP_RAW: left to itself the
     // scheduler widens all of them to fp32 as soon as they land - 80 more live registers, half the waves per SIMD)
 #pragma unroll
@@ -88,7 +101,31 @@ __device__ __forceinline__ void ln_fwd_rows(const bf16* __restrict__ x, long ldx
       bf16x8 o;
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] = f2bf((v[c][j] - mu) * rs * bf2f(g[c][j]) + bf2f(b[c][j]));
-      if (m.ok[c]) *(bf16x8*)(yo + m.off[c]) = o;
+      if (MXOUT) {
+        float w[8], amax = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { w[j] = bf2f(o[j]); amax = fmaxf(amax, fabsf(w[j])); }
+        amax = fmaxf(amax, ln_quad<0xB1>(amax));                 // lane ^ 1
+        amax = fmaxf(amax, ln_quad<0x4E>(amax));                 // lane ^ 2
+        int eb = (int)((__float_as_uint(amax) >> 23) & 0xff);
+        int sbyte = max(eb - 8, 0);
+        if (!(amax == amax) || eb == 255) sbyte = 254;
+        float inv = __uint_as_float((uint32_t)(254 - sbyte) << 23);
+        if (sbyte == 254) inv = 1.17549435e-38f;
+        uint32_t pk[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          float a0 = fminf(fmaxf(w[4 * h] * inv, -448.f), 448.f), a1 = fminf(fmaxf(w[4 * h + 1] * inv, -448.f), 448.f);
+          float a2 = fminf(fmaxf(w[4 * h + 2] * inv, -448.f), 448.f), a3 = fminf(fmaxf(w[4 * h + 3] * inv, -448.f), 448.f);
+          int t = __builtin_amdgcn_cvt_pk_fp8_f32(a0, a1, 0, false);
+          t = __builtin_amdgcn_cvt_pk_fp8_f32(a2, a3, t, true);
+          pk[h] = (uint32_t)t;
+        }
+        if (m.ok[c]) {
+          *(uint2*)((uint8_t*)yo + m.off[c]) = uint2{pk[0], pk[1]};          // yo advanced in BYTES: ldy is the byte pitch (see the kernel)
+          if (!(lane & 3)) sc[(long)r * ldsc + (m.off[c] >> 5)] = (uint8_t)sbyte;
+        }
+      } else if (m.ok[c]) *(bf16x8*)(yo + m.off[c]) = o;
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -100,6 +137,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int rows, int D,
                                                      float eps, int rms, int grp, int grp_stride, int grp_off) {
   ln_fwd_rows<MAXC, FULL>(x, ldx, gamma, beta, y, ldy, mean, rstd, rows, D, eps, rms, grp, grp_stride, grp_off);
+}
+
+template <int MAXC, bool FULL>
+__global__ __launch_bounds__(256) void ln_fwd_mx_kernel(const bf16* __restrict__ x, long ldx, const bf16* __restrict__ gamma,
+                                                        const bf16* __restrict__ beta, uint8_t* __restrict__ yq, long ldyq,
+                                                        uint8_t* __restrict__ sc, long ldsc, float* __restrict__ mean,
+                                                        float* __restrict__ rstd, int rows, int D, float eps, int rms) {
+  ln_fwd_rows<MAXC, FULL, true>(x, ldx, gamma, beta, (bf16*)yq, ldyq, mean, rstd, rows, D, eps, rms, 0, 0, 0, sc, ldsc);
 }
 
 // dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat))      [LayerNorm]
@@ -266,6 +311,22 @@ extern "C" int unimp_layernorm_fwd(const void* x, int64_t ldx, const void* gamma
 #undef LN_FWD_
 #undef LN_FWD
   return unimp_check_launch("layernorm_fwd");
+}
+
+extern "C" int unimp_layernorm_fwd_mx(const void* x, int64_t ldx, const void* gamma, const void* beta, void* yq, int64_t ldyq, void* scales,
+                                      int64_t ldsc, float* mean, float* rstd, int rows, int D, float eps, int rms, void* stream) {
+  if (!x || !gamma || !yq || !scales || !rstd) return unimp_set_error(UNIMP_ERR_ARG, "layernorm_fwd_mx: null pointer");
+  if (rows <= 0) return UNIMP_OK;
+  if ((D & 31) || D > 4096 || (ldx & 7) || (ldyq & 7)) return unimp_set_error(UNIMP_ERR_SHAPE, "layernorm_fwd_mx: need D%32==0, D<=4096, ldx%8==0, ldyq%8==0");
+  hipStream_t s = (hipStream_t)stream;
+  dim3 g(ln_grid(rows)), b(256);
+#define LN_MX_(MC, FU) hipLaunchKernelGGL((ln_fwd_mx_kernel<MC, FU>), g, b, 0, s, (const bf16*)x, (long)ldx, (const bf16*)gamma, (const bf16*)beta, \
+                                      (uint8_t*)yq, (long)ldyq, (uint8_t*)scales, (long)ldsc, mean, rstd, rows, D, eps, rms)
+#define LN_MX(MC) do { if (D == MC * 512) LN_MX_(MC, true); else LN_MX_(MC, false); } while (0)
+  if (D <= 1024) LN_MX(2); else if (D <= 2560) LN_MX(5); else LN_MX(8);
+#undef LN_MX_
+#undef LN_MX
+  return unimp_check_launch("layernorm_fwd_mx");
 }
 
 extern "C" int unimp_layernorm_bwd(const void* dy, int64_t lddy, const void* dy2, int64_t lddy2, const void* x, int64_t ldx, const void* gamma,

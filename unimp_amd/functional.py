@@ -334,6 +334,7 @@ FP8_FROZEN = _os.environ.get("UNIMP_FP8", "0") == "1"   # opt-in (bench.py --fp8
 # quantising their activations (profiles/r04_mx_step_shapes.txt).  So "fp8 frozen towers" means the language tower (4096 x 4096 ... 16384);
 # UNIMP_FP8_MIN_DIM=128 restores MX everywhere (the tiny-tower tests do).
 FP8_MIN_DIM = int(_os.environ.get("UNIMP_FP8_MIN_DIM", "2048"))
+MX_FUSED_OUT = _os.environ.get("UNIMP_MX_FUSED_OUT", "1") != "0"     # MLP-internal activations leave their GEMM as MX operands (A/B knob; same bits)
 
 
 def _mx_ok(w, M):
@@ -368,18 +369,23 @@ class MLPBlockFn(Function):
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
         r2 = x2 if res is None else res.reshape(-1, shp[-1])
-        h, mean, rstd = ops.layernorm_fwd(x2, ln_w, ln_b, eps)
         M, F = x2.shape[0], w1.shape[0]
         w1g, w2g = w1.requires_grad, w2.requires_grad
         bwd = any(ctx.needs_input_grad)            # frozen tower on constant inputs (the ViT): no act'(z) output, nothing saved
         mx = gate is None and _mx_ok(w1, M) and _mx_ok(w2, M)
+        ln_mx = mx and MX_FUSED_OUT and shp[-1] % 32 == 0 and shp[-1] <= 4096
+        h, mean, rstd = ops.layernorm_fwd_mx(x2, ln_w, ln_b, eps) if ln_mx else ops.layernorm_fwd(x2, ln_w, ln_b, eps)
         # act'(z) for the backward: uint8 (ops / common.h DERIV_U8: step 1 / 202, 0 and 1 exact) unless the decode-row kernel (M <= 64) writes it
         pre = torch.empty((M, F), dtype=torch.uint8 if (DERIV_U8 and F % 8 == 0 and M > 64) else bf16, device=x.device) if bwd else None
         t1, t2 = FROZEN_WT and not w1g and M > 64, FROZEN_WT and not w2g and M > 64      # M <= 64: the weight-streaming decode kernel
         if mx:      # frozen tower on the MX-fp8 path: activations quantised on the fly (e4m3 + E8M0 per 32), fp32 accumulate
-            a = ops.gemm_mx(ops.mx_quantize(h), _frozen_mx(w1), bias=b1, act=act, pre=pre)
+            # the up-projection's output only feeds the down-projection (both frozen): it leaves its GEMM already quantised
+            # (MX_FUSED_OUT: the bytes mx_quantize would make of the bf16 tensor, without that tensor and without the quantiser pass)
+            fused = MX_FUSED_OUT and F % 32 == 0
+            a = ops.gemm_mx(h if ln_mx else ops.mx_quantize(h), _frozen_mx(w1), bias=b1, act=act, pre=pre, out_mx=fused)
             raw = None
-            out = ops.gemm_mx(ops.mx_quantize(a), _frozen_mx(w2), bias=b2, res=r2)
+            out = ops.gemm_mx(a if fused else ops.mx_quantize(a), _frozen_mx(w2), bias=b2, res=r2)
+            a = None
         else:
             a = ops.gemm(h, _frozen_t(w1) if t1 else w1, b_ks=t1, bias=b1, act=act, pre=pre, pre_deriv=bwd,   # pre <- act'(z): backward needs no transcendental
                          b_pk=None if t1 or M <= 64 else _frozen_pk(w1))
@@ -402,9 +408,10 @@ class MLPBlockFn(Function):
             dy2 = dy2.contiguous()
         dgate = _gate_grad(dy2, raw, gate) if gate is not None and _need(ctx, 8) else None
         if ctx.mx:      # dX through the frozen MLP on the MX path: the same e4m3 weights, quantised along the other dimension
-            dpre = ops.gemm_mx(ops.mx_quantize(dy2), _frozen_mx(w2, True), aux=pre)
+            fused = MX_FUSED_OUT and w2.shape[1] % 32 == 0
+            dpre = ops.gemm_mx(ops.mx_quantize(dy2), _frozen_mx(w2, True), aux=pre, out_mx=fused)
             dw1 = dw2 = None
-            dh = ops.gemm_mx(ops.mx_quantize(dpre), _frozen_mx(w1, True))
+            dh = ops.gemm_mx(dpre if fused else ops.mx_quantize(dpre), _frozen_mx(w1, True))
         else:
             dpre = ops.gemm(dy2, w2, b_ks=True, gate=gate, aux=pre, dact="deriv", b_pk=_frozen_pk(w2, True))   # [M,F]  (dy tanh(g) W2) * act'(z)
             dw2 = _dw(ctx, 6, w2, dy2, a, gate=gate)
@@ -477,10 +484,11 @@ class SelfAttnBlockFn(Function):
         hd = H // nh
         x2 = x.reshape(B * L, H)
         r2 = x2 if res is None else res.reshape(B * L, H)
-        h, mean, rstd = ops.layernorm_fwd(x2, ln_w, ln_b, eps, rms=rms)
+        mx = _mx_ok(wqkv, B * L) and _mx_ok(wd, B * L)
+        ln_mx = mx and MX_FUSED_OUT and H % 32 == 0 and H <= 4096            # the normalised rows only feed the frozen MX projection: they leave LayerNorm quantised
+        h, mean, rstd = ops.layernorm_fwd_mx(x2, ln_w, ln_b, eps, rms=rms) if ln_mx else ops.layernorm_fwd(x2, ln_w, ln_b, eps, rms=rms)
         tq = FROZEN_WT_ATTN and not wqkv.requires_grad and B * L >= 1024
         td = FROZEN_WT_ATTN and not wd.requires_grad and B * L >= 1024
-        mx = _mx_ok(wqkv, B * L) and _mx_ok(wd, B * L)
         # rotary epilogue: frozen projection, bf16 path, a kernel variant that serves it, positions 0 .. L-1 per sequence
         fused = None
         if (ROPE_EPILOGUE and rope is not None and len(rope) > 3 and not mx and not wqkv.requires_grad and not FROZEN_PK
@@ -494,7 +502,7 @@ class SelfAttnBlockFn(Function):
             bp = _frozen_rope_perm(bqkv, nh, hd, fused["rot"], interleaved) if bqkv is not None else None
             qkv = ops.gemm(h, _frozen_t(wp) if tq else wp, b_ks=tq, bias=bp, rope=fused)
         else:
-            qkv = ops.gemm_mx(ops.mx_quantize(h), _frozen_mx(wqkv), bias=bqkv) if mx else \
+            qkv = ops.gemm_mx(h if ln_mx else ops.mx_quantize(h), _frozen_mx(wqkv), bias=bqkv) if mx else \
                 ops.gemm(h, _frozen_t(wqkv) if tq else wqkv, b_ks=tq, bias=bqkv, b_pk=None if tq else _frozen_pk(wqkv))
         q, k, v, hs, offs = _split_qkv(qkv, B, L, nh, hd, interleaved)
         qk_raw = qk_stats = None

@@ -444,6 +444,20 @@ def layernorm_fwd(x, gamma, beta, eps, *, rms=False, out=None, grp=0, grp_stride
     return out, mean, rstd
 
 
+def layernorm_fwd_mx(x, gamma, beta, eps, *, rms=False):
+    """LayerNorm whose output leaves as an MxTensor (quantised along D): the bytes of ``mx_quantize(layernorm_fwd(x)[0])`` without the
+    bf16 tensor and the quantiser pass.  returns (MxTensor, mean, rstd)."""
+    x, ldx = _mat(x)
+    rows, D = x.shape
+    q = torch.empty((rows, D), dtype=torch.uint8, device=x.device)
+    sc = torch.empty((rows, D // 32), dtype=torch.uint8, device=x.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(_lib.lib().unimp_layernorm_fwd_mx(_dev(x).data_ptr(), ldx, _p(gamma), _p(beta), q.data_ptr(), q.stride(0), sc.data_ptr(), sc.stride(0),
+                                             mean.data_ptr(), rstd.data_ptr(), rows, D, eps, int(rms), _stream()), "layernorm_fwd_mx")
+    return MxTensor(q, sc), mean, rstd
+
+
 _PARTIAL_BLOCKS = 512       # 2 blocks per CU: the wgrad variant holds 244 VGPRs (occupancy 2), 256 blocks left half the SIMDs with one wave
 
 
@@ -844,14 +858,23 @@ def mx_quantize(x):
     return MxTensor(q, sc)
 
 
-def gemm_mx(a, b, *, bias=None, act=None, pre=None, aux=None, res=None, out=None):
+def gemm_mx(a, b, *, bias=None, act=None, pre=None, aux=None, res=None, out=None, out_mx=False):
     """C[M, N] (bf16) = epi(A B^T) for MxTensors a [M, K], b [N, K]; epilogue as unimp_gemm_mxfp8.  A uint8 ``pre`` / ``aux`` is the
-    8-bit stored derivative of the bf16 GEMMs (act'(z), step 1 / 202); they cannot be mixed with bf16 ones in one call."""
+    8-bit stored derivative of the bf16 GEMMs (act'(z), step 1 / 202); they cannot be mixed with bf16 ones in one call.
+    ``out_mx``: return the result as an MxTensor quantised along N (the operand of the next product) -- the same bytes as
+    ``mx_quantize(gemm_mx(...))`` without the bf16 tensor and the quantiser pass (N % 32 == 0)."""
     M, N, K = a.q.shape[0], b.q.shape[0], a.K
     assert b.K == K, (a.q.shape, b.q.shape)
-    if out is None:
+    sc_out = None
+    if out_mx:
+        assert out is None and N % 32 == 0, (N,)
+        out = torch.empty((M, N), dtype=torch.uint8, device=a.q.device)
+        sc_out = torch.empty((M, N // 32), dtype=torch.uint8, device=a.q.device)
+    elif out is None:
         out = torch.empty((M, N), dtype=bf16, device=a.q.device)
     d = MxGemmDesc()
+    if sc_out is not None:
+        d.scale_c, d.ldsc = sc_out.data_ptr(), sc_out.stride(0)
     d.A, d.B, d.scale_a, d.scale_b, d.C = a.q.data_ptr(), b.q.data_ptr(), a.scales.data_ptr(), b.scales.data_ptr(), _dev(out).data_ptr()
     d.lda, d.ldb, d.ldsa, d.ldsb, d.ldc = a.q.stride(0), b.q.stride(0), a.scales.stride(0), b.scales.stride(0), out.stride(0)
     d.bias = _p(bias)
@@ -872,5 +895,5 @@ def gemm_mx(a, b, *, bias=None, act=None, pre=None, aux=None, res=None, out=None
     if GEMM_PROFILE is not None:
         e1.record()
         epi = "+".join(n for n, t in (("bias", bias), ("act", act), ("pre", pre), ("aux", aux), ("res", res)) if t is not None) or "plain"
-        GEMM_PROFILE.append((e0, e1, 2.0 * M * N * K, (M, N, K, epi, 0, "mxfp8")))
-    return out
+        GEMM_PROFILE.append((e0, e1, 2.0 * M * N * K, (M, N, K, epi + ("->mx" if out_mx else ""), 0, "mxfp8")))
+    return MxTensor(out, sc_out) if out_mx else out
