@@ -534,13 +534,25 @@ __global__ __launch_bounds__(256) void attn_dq2_kernel(AttnP p, int nx) {
         }
         const int key0 = kbase + 4 * hi5;
         bf16x8 dsf[2];
+        // two copies of the element loop behind a wave-uniform BRANCH: with the mask as a select inside one loop it compiled to 4
+        // compare / select instructions per element on every block (64 of the 140 vector instructions of a 32-key block), although
+        // only the blocks on the diagonal or at a sequence end need it; each copy still consumes s[r] / dp[r] as it goes (registers)
+        if (full) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          int key = key0 + 8 * (r >> 2) + (r & 3);
-          float sv = ALIBI ? s[r] + ab * (float)key : s[r];
-          float pr = EXP2(fmaf(sv, sc2, -lse2));
-          if (!full) pr = (key >= lo && key < hi) ? pr : 0.f;
-          dsf[r >> 3][r & 7] = f2bf(pr * (dp[r] - dl) * p.scale);
+          for (int r = 0; r < 16; ++r) {
+            float sv = ALIBI ? s[r] + ab * (float)(key0 + 8 * (r >> 2) + (r & 3)) : s[r];
+            float pr = EXP2(fmaf(sv, sc2, -lse2));
+            dsf[r >> 3][r & 7] = f2bf(pr * (dp[r] - dl) * p.scale);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            int key = key0 + 8 * (r >> 2) + (r & 3);
+            float sv = ALIBI ? s[r] + ab * (float)key : s[r];
+            float pr = EXP2(fmaf(sv, sc2, -lse2));
+            pr = (key >= lo && key < hi) ? pr : 0.f;
+            dsf[r >> 3][r & 7] = f2bf(pr * (dp[r] - dl) * p.scale);
+          }
         }
 #pragma unroll
         for (int nd = 0; nd < ND; ++nd)
