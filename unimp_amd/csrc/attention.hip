@@ -498,27 +498,41 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p, int nx) {
   TileCopy<32, DQK, STR> rq, rdo;
   rq.init(p.q_ss, p.D); rdo.init(p.do_ss, p.D);
   if (DQK != DV) lds_zero(smem, 2 * STAGE);
-  auto stage_aux = [&](char* st, int qt) {
+  // per-row lse / delta / key range of a query tile (first 32 threads): the global LOADS are issued with the tile's Q / dO loads at the
+  // top of an iteration and fly under its MFMAs; only the LDS stores wait at the bottom.  (As one step at the bottom, the loads were issued
+  // and waited for after the MFMAs: one exposed memory latency per query tile, in a kernel whose tile is ~0.4 us of arithmetic.)
+  // Head dim 64 keeps the late form: the four values live across the MFMAs cost it its fourth wave per SIMD (128 -> 136 registers).
+  constexpr bool EARLY_AUX = DQK != 64;
+  struct Aux { float lse, dl; int lo, hi; };               // values of ONE iteration (not loop-carried: that would keep them live everywhere)
+  auto aux_load = [&](int qt) {
+    Aux a;
+    a.lse = 0.f; a.dl = 0.f; a.lo = 0; a.hi = 0;
     if (threadIdx.x < 32) {
-      float* st_lse = (float*)(st + 2 * 32 * STR);
       int qr = qt * 32 + threadIdx.x;
       long sidx = ((long)b * p.H + h) * p.SqS + min(qr, p.Sq - 1);
-      st_lse[threadIdx.x] = p.lse[sidx] * LOG2E;
-      st_lse[32 + threadIdx.x] = p.delta[sidx];
-      int lo, hi;
-      key_range(p, b, qr, lo, hi);
-      ((int*)st_lse)[64 + threadIdx.x] = lo; ((int*)st_lse)[96 + threadIdx.x] = hi;
+      a.lse = p.lse[sidx]; a.dl = p.delta[sidx];
+      key_range(p, b, qr, a.lo, a.hi);
+    }
+    return a;
+  };
+  auto aux_store = [&](char* st, const Aux& a) {
+    if (threadIdx.x < 32) {
+      float* st_lse = (float*)(st + 2 * 32 * STR);
+      st_lse[threadIdx.x] = a.lse * LOG2E;
+      st_lse[32 + threadIdx.x] = a.dl;
+      ((int*)st_lse)[64 + threadIdx.x] = a.lo; ((int*)st_lse)[96 + threadIdx.x] = a.hi;
       // all 32 rows of this query tile see every key of the block -> the waves skip the per-element mask
-      unsigned long long okm = __ballot(lo <= kfirst && hi > klast);
+      unsigned long long okm = __ballot(a.lo <= kfirst && a.hi > klast);
       if (threadIdx.x == 0) ((int*)st_lse)[128] = (okm & 0xffffffffull) == 0xffffffffull;
     }
   };
   if (qt_a < qt_b) {
     rq.g2r(qb + (long)qt_a * 32 * p.q_ss, p.Sq - qt_a * 32);
     rdo.g2r(dob + (long)qt_a * 32 * p.do_ss, p.Sq - qt_a * 32);
+    Aux a0 = aux_load(qt_a);
     rq.r2s(smem);
     rdo.r2s(smem + 32 * STR);
-    stage_aux(smem, qt_a);
+    aux_store(smem, a0);
   }
   __syncthreads();
   for (int qt = qt_a; qt < qt_b; ++qt) {
@@ -533,6 +547,8 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p, int nx) {
       rq.g2r(qb + (long)(qt + 1) * 32 * p.q_ss, p.Sq - (qt + 1) * 32);
       rdo.g2r(dob + (long)(qt + 1) * 32 * p.do_ss, p.Sq - (qt + 1) * 32);
     }
+    Aux an;
+    if (EARLY_AUX && more) an = aux_load(qt + 1);
     if (key0 < p.Sk) {
     f32x4 s[KU][2], dp[KU][2];              // [key block u][query block qb2]: lane holds S[q = 16*qb2 + 4g + r][key = l&15]
 #pragma unroll
@@ -597,7 +613,8 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p, int nx) {
     if (more) {
       rq.r2s(nx);
       rdo.r2s(nx + 32 * STR);
-      stage_aux(nx, qt + 1);
+      if (!EARLY_AUX) an = aux_load(qt + 1);
+      aux_store(nx, an);
     }
     __syncthreads();
   }

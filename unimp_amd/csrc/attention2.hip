@@ -465,6 +465,9 @@ __global__ __launch_bounds__(256) void attn_dq2_kernel(AttnP p, int nx) {
     }
   };
 
+  // the first tile's DMA goes out BEFORE the wave's own Q / dO / O row loads: the delta row sums below wait for those loads, and a
+  // DMA issued after them paid a second, serial memory latency before the first tile (a block sweeps only 2-8 tiles at L = 512)
+  if (kt_lo < kt_hi) dma_tile(kt_lo, 0);
   bf16x8 qf[KS], dof[KS];
   int lo, hi;
   float lse2, dl;
@@ -502,7 +505,6 @@ __global__ __launch_bounds__(256) void attn_dq2_kernel(AttnP p, int nx) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[nd][r] = 0.f;
 
-  if (kt_lo < kt_hi) dma_tile(kt_lo, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) { a2_pin(qf[ks]); a2_pin(dof[ks]); }
