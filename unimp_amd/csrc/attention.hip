@@ -46,6 +46,16 @@ __device__ __forceinline__ void key_range(const AttnP& p, int b, int qr, int& lo
   else { int t = p.seg[(long)b * p.SqS + qr]; if (t > 0) { lo = (t - 1) * p.seg_len; hi = min(t * p.seg_len, p.Sk); } }
 }
 
+// the same with the batch row's key count already in a register: inside a tile loop the p.kv_len[b] of key_range() is a scalar load +
+// s_waitcnt lgkmcnt(0) per iteration (the compiler cannot hoist it past the loop's stores)
+__device__ __forceinline__ void key_range_kvl(const AttnP& p, int b, int qr, int kvl, int& lo, int& hi) {
+  lo = 0; hi = 0;
+  if (qr >= p.Sq) return;
+  if (p.mask_mode == UNIMP_MASK_NONE) { hi = kvl; }
+  else if (p.mask_mode == UNIMP_MASK_CAUSAL) { hi = min(qr + 1, kvl); }
+  else { int t = p.seg[(long)b * p.SqS + qr]; if (t > 0) { lo = (t - 1) * p.seg_len; hi = min(t * p.seg_len, p.Sk); } }
+}
+
 // cooperative [rows x DPAD] bf16 tile load into LDS with row stride STR bytes; zero fill outside (nrows, D)
 template <int ROWS, int DPAD, int STR>
 __device__ __forceinline__ void load_tile(char* lds, const bf16* __restrict__ base, long row_stride, int row0, int nrows, int D) {
@@ -452,11 +462,22 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(AttnP p) {
   }
 }
 
+#ifdef ATTN_STAMP     // debug build (tools/stamp_attn.py): where a dK/dV block's time goes -- wave 0's s_memtime cycles per loop segment, summed over its tiles
+__device__ unsigned long long attn_stamps[16384 * 12];
+extern "C" int unimp_debug_attn_stamps(void* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(attn_stamps), sizeof(attn_stamps)); }
+#define AT_NOW() __builtin_amdgcn_s_memtime()
+#define AT_SEG(K_) do { unsigned long long t_ = AT_NOW(); at_acc[K_] += t_ - at_last; at_last = t_; } while (0)
+#else
+#define AT_SEG(K_) do {} while (0)
+#endif
 // ------------------------------------------------------------------------------------------- dK, dV
 // block = 64 * KU keys: each wave owns 16 * KU keys (KU 16-key blocks whose K / V fragments live in registers) and sweeps the
 // query tiles (32 rows, double-buffered Q / dO images + per-row lse / delta / key range); P and dS stay in registers.
 template <int DQK, int DV, bool ALIBI, int KU = 2>
 __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p, int nx) {
+#ifdef ATTN_STAMP
+  unsigned long long at_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, at_t0 = __builtin_amdgcn_s_memrealtime(), at_c0 = AT_NOW(), at_last = 0;
+#endif
   constexpr int KPW = 16 * KU, KPB = 4 * KPW;               // keys per wave (KU blocks of 16) and per workgroup
   constexpr int STR = attn_pitch(DQK * 2), NKS = DQK / 32, ND = DV / 16;
   constexpr int STAGE = 2 * 32 * STR + 32 * 16 + 16;
@@ -503,6 +524,8 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p, int nx) {
   // and waited for after the MFMAs: one exposed memory latency per query tile, in a kernel whose tile is ~0.4 us of arithmetic.)
   // Head dim 64 keeps the late form: the four values live across the MFMAs cost it its fourth wave per SIMD (128 -> 136 registers).
   constexpr bool EARLY_AUX = DQK != 64;
+  const int kvl_b = p.kv_len ? p.kv_len[b] : p.Sk;          // once per block, not once per query tile (stamps: the scalar load + wait was
+                                                            // inside the largest segment of the loop)
   struct Aux { float lse, dl; int lo, hi; };               // values of ONE iteration (not loop-carried: that would keep them live everywhere)
   auto aux_load = [&](int qt) {
     Aux a;
@@ -511,7 +534,7 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p, int nx) {
       int qr = qt * 32 + threadIdx.x;
       long sidx = ((long)b * p.H + h) * p.SqS + min(qr, p.Sq - 1);
       a.lse = p.lse[sidx]; a.dl = p.delta[sidx];
-      key_range(p, b, qr, a.lo, a.hi);
+      key_range_kvl(p, b, qr, kvl_b, a.lo, a.hi);
     }
     return a;
   };
@@ -535,6 +558,10 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p, int nx) {
     aux_store(smem, a0);
   }
   __syncthreads();
+#ifdef ATTN_STAMP
+  at_last = AT_NOW();
+  const unsigned long long at_c1 = at_last;
+#endif
   for (int qt = qt_a; qt < qt_b; ++qt) {
     char* st = smem + ((qt - qt_a) & 1) * STAGE;
     char* nx = smem + ((qt - qt_a + 1) & 1) * STAGE;
@@ -549,6 +576,7 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p, int nx) {
     }
     Aux an;
     if (EARLY_AUX && more) an = aux_load(qt + 1);
+    AT_SEG(0);                                               // next tile's global loads issued
     if (key0 < p.Sk) {
     f32x4 s[KU][2], dp[KU][2];              // [key block u][query block qb2]: lane holds S[q = 16*qb2 + 4g + r][key = l&15]
 #pragma unroll
@@ -571,6 +599,10 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p, int nx) {
       for (int r = 0; r < 4; ++r) { lse_r[qb2][r] = a[r]; dl_r[qb2][r] = d[r]; }
     }
     bool all_visible = st_lo[64] != 0;        // word 128 of the aux block
+#ifdef ATTN_STAMP
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); asm volatile("" :: "v"(s[0][0][0]), "v"(dp[0][0][0]));
+#endif
+    AT_SEG(1);                                               // S, dP products done (their fragment reads + 12 MFMAs), row constants read
 #pragma unroll
     for (int u = 0; u < KU; ++u) {
       int key = key0 + u * 16 + (l & 15);
@@ -603,6 +635,10 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p, int nx) {
       }
       pf[u] = pack8(s[u][0], s[u][1]); dsf[u] = pack8(dp[u][0], dp[u][1]);
     }
+#ifdef ATTN_STAMP
+    asm volatile("" :: "v"(pf[0]), "v"(dsf[0]));
+#endif
+    AT_SEG(2);                                               // exponentials, dS, packing
 #pragma unroll
     for (int nd = 0; nd < ND; ++nd) {
       bf16x8 dot_f = lfrag_tr_perm<STR>(dos_t, 0, nd * 16), qt_f = lfrag_tr_perm<STR>(qs_t, 0, nd * 16);
@@ -610,14 +646,26 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p, int nx) {
       for (int u = 0; u < KU; ++u) { dv[u][nd] = MFMA16(dot_f, pf[u], dv[u][nd]); dk[u][nd] = MFMA16(qt_f, dsf[u], dk[u][nd]); }
     }
     }
+#ifdef ATTN_STAMP
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); asm volatile("" :: "v"(dv[0][0][0]), "v"(dk[0][0][0]));
+#endif
+    AT_SEG(3);                                               // dV, dK products (transposed fragment reads + 10 MFMAs)
     if (more) {
       rq.r2s(nx);
       rdo.r2s(nx + 32 * STR);
       if (!EARLY_AUX) an = aux_load(qt + 1);
       aux_store(nx, an);
     }
+#ifdef ATTN_STAMP
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+    AT_SEG(4);                                               // wait for the next tile's loads + LDS stores
     __syncthreads();
+    AT_SEG(5);                                               // barrier
   }
+#ifdef ATTN_STAMP
+  const unsigned long long at_c2 = AT_NOW();
+#endif
   // epilogue through a wave-private LDS region (the loop ended with a barrier): accumulator layout (lane: key = l & 15 of
   // block u, 4 consecutive d) -> whole 16-byte chunks of consecutive key rows; 8-byte stores straight from the accumulators
   // touched 16 different rows per instruction (store-issue bound: ~80 us of this kernel at the LM shape)
@@ -689,6 +737,14 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p, int nx) {
       }
     }
   }
+#ifdef ATTN_STAMP
+  if (threadIdx.x == 0 && blockIdx.x < 16384) {
+    unsigned long long* o = attn_stamps + (long)blockIdx.x * 12;
+    for (int i = 0; i < 6; ++i) o[i] = at_acc[i];
+    o[6] = at_c1 - at_c0; o[7] = at_c2 - at_c1; o[8] = AT_NOW() - at_c2; o[9] = qt_b - qt_a;
+    o[10] = at_t0; o[11] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------- host
