@@ -82,9 +82,10 @@ def _worker(rank, world, port, q):
     dp.finish()
     logs = [None] * world
     dist.all_gather_object(logs, dp.last_launch_log)
-    assert logs[0] == logs[1] == sorted(logs[0]) and len(logs[0]) == len(dp.buckets), logs
+    assert all(lg == logs[0] for lg in logs) and logs[0] == sorted(logs[0]) and len(logs[0]) == len(dp.buckets), logs
+    tot = float(sum(r + 1 for r in range(world)))
     assert torch.equal(ps[0][1].grad.float(), torch.full((300,), 1.0))           # only rank 0 contributed
-    assert torch.equal(ps[4][1].grad.float(), torch.full((2048,), 3.0))
+    assert torch.equal(ps[4][1].grad.float(), torch.full((2048,), tot))
     # --- a stray gradient tensor (foreign code set .grad = None before backward): folded into the view inside the hook,
     # before its bucket is reduced, so it is averaged like every other gradient
     opt.flat_g.zero_()
@@ -93,7 +94,7 @@ def _worker(rank, world, port, q):
     loss.backward()
     dp.finish()
     assert ps[2][1].grad.data_ptr() == opt.flat_g[opt.layout[2][2]:].data_ptr()
-    assert torch.equal(ps[2][1].grad.float(), torch.full((1000,), 3.0))
+    assert torch.equal(ps[2][1].grad.float(), torch.full((1000,), tot))
     q.put((rank, "ok"))
     dist.destroy_process_group()
 
@@ -153,7 +154,7 @@ def _worker_order(rank, world, port, q):
     assert seen[3][:2] == [2, 3], seen                            # when r3's hook (registered after the bucketer's) runs, r5 and r4 are out
     logs = [None] * world
     dist.all_gather_object(logs, dp.last_launch_log)
-    assert logs[0] == logs[1]
+    assert all(lg == logs[0] for lg in logs)
     q.put((rank, "ok"))
     dist.destroy_process_group()
 
@@ -196,6 +197,84 @@ def test_bucketed_allreduce_world2():
         assert p.exitcode == 0
     got = sorted(q.get(timeout=5) for _ in range(world))
     assert got == [(0, "ok"), (1, "ok")]
+
+
+def _worker_shard_layout(rank, world, port, q):
+    """optim.FlatAdamW's sharded layout + dp.GradBucketer's sharded exchange at W ranks, on CPU tensors (construction and the
+    collectives are host logic; the AdamW kernel itself is the -m gpu tests' business): bucket padding to W x 64 elements, the owned
+    slices partition every bucket, parameters never straddle a bucket, every rank issues the same bucket order, and after the exchange
+    each rank's owned slice holds the sum over the ranks."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from unimp_amd.dp import GradBucketer
+    from unimp_amd.optim import FlatAdamW
+    torch.manual_seed(0)
+    sizes = [(300,), (64, 70), (1000,), (5,), (2048,), (7, 33), (4096,), (129,), (3, 3, 3)]
+    named = [((f"gated_cross_attn_layer.w{i}" if i % 2 else f"p{i}"), torch.nn.Parameter(torch.randn(sz).to(torch.bfloat16))) for i, sz in enumerate(sizes)]
+    opt = FlatAdamW(named, shard=(rank, world, 2048, None), device="cpu")
+    q_ = world * FlatAdamW.ALIGN
+    assert len(opt.buckets) >= 3 and opt.buckets[0][0] == 0 and opt.buckets[-1][1] == opt.total
+    for (s0, e0), (s1, e1) in zip(opt.buckets[:-1], opt.buckets[1:]):
+        assert e0 == s1
+    for (s_, e_), (lo, hi, so) in zip(opt.buckets, opt.owned):
+        assert (e_ - s_) % q_ == 0 and hi - lo == (e_ - s_) // world and lo == s_ + rank * (hi - lo)
+    for n, p, o, k in opt.layout:                      # a parameter lives inside ONE bucket
+        assert sum(1 for s_, e_ in opt.buckets if s_ <= o and o + k <= e_) == 1, n
+    assert opt.master.numel() == sum(hi - lo for lo, hi, _ in opt.owned) == opt.total // world
+    owned_all = [None] * world
+    dist.all_gather_object(owned_all, [(lo, hi) for lo, hi, _ in opt.owned])
+    for bi, (s_, e_) in enumerate(opt.buckets):        # the W owned slices tile the bucket in rank order
+        edges = [owned_all[r][bi] for r in range(world)]
+        assert edges[0][0] == s_ and edges[-1][1] == e_ and all(a[1] == b[0] for a, b in zip(edges[:-1], edges[1:]))
+    dp = GradBucketer(opt, bucket_bytes=4096)
+    assert dp.sharded and [tuple(b[:2]) for b in dp.buckets] == list(opt.buckets) and dp.active
+    x = torch.full((), float(rank + 1))
+    loss = sum((p.float() * x).sum() for n, p in named if n != "p3")           # p3 gets no gradient: flushed by finish()
+    loss.backward()
+    assert dp.finish() == 1.0 / world
+    logs = [None] * world
+    dist.all_gather_object(logs, dp.last_launch_log)
+    assert all(lg == logs[0] for lg in logs) and sorted(logs[0]) == list(range(len(dp.buckets))), logs
+    tot = float(sum(r + 1 for r in range(world)))
+    for n, p, o, k in opt.layout:                      # gloo has no reduce-scatter: the whole bucket is reduced, the owned slice is what is used
+        want = 0.0 if n == "p3" else tot
+        for lo, hi, _ in opt.owned:
+            a, b = max(lo, o), min(hi, o + k)
+            if a < b:
+                assert torch.equal(opt.flat_g[a:b].float(), torch.full((b - a,), want)), n
+    q.put((rank, "ok"))
+    dist.destroy_process_group()
+
+
+def _spawn(target, world, extra=()):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=target, args=(r, world, port, q) + tuple(extra)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert sorted(q.get(timeout=5) for _ in range(world)) == [(r, "ok") for r in range(world)]
+
+
+def test_bucketed_allreduce_world8():
+    """VERDICT r4 #7a: the target is 8 ranks.  The world-2 plumbing test (bucket boundaries, hook-driven launches, unused-parameter
+    flush, 1/W, one collective order on every rank, stray gradients) with eight gloo ranks."""
+    _spawn(_worker, 8)
+
+
+def test_issue_order_world8():
+    _spawn(_worker_order, 8)
+
+
+def test_sharded_layout_and_exchange_world8():
+    _spawn(_worker_shard_layout, 8)
+
+
+def test_sharded_layout_and_exchange_world2():
+    _spawn(_worker_shard_layout, 2)
 
 
 def test_host_logic_cpu():

@@ -618,11 +618,16 @@ def test_checkpoint_matches_reference_get_checkpoint(tmp_path, golden_dir):
 
 def test_cfg2_full_depth_forward_vs_oracle(cfg2):
     """north_star's parity figure at cfg2's FULL depth (mmrec.py:177-213): the 24-layer ViT, the 6-layer Perceiver and the
-    32-layer LM with its 16 gated cross-attention blocks, the same bf16-representable weights on both sides, ONE b = 1 batch, forward +
-    weighted focal loss.  bench.full_depth_parity is the function the bench line's `parity` object comes from.  Bounds:
-      labels bit-exact; loss rel <= 1e-3 (north_star); logits rel-L2 <= 1.15 x the storage-precision model's own deviation from fp32
-      (oracle/numerics.py -- bf16 storage at the product's HBM points; the reduced-depth tests measure 0.98-1.00) and <= 2e-2 absolute;
-      argmax identical wherever the top-2 margin exceeds 8 sigma of the measured logit error, and on >= 90 % of all valid positions."""
+    32-layer LM with its 16 gated cross-attention blocks, the same bf16-representable weights on both sides, forward + weighted focal
+    loss on FOUR distinct b = 1 batches (bench.full_depth_parity is the function the bench line's `parity` object comes from; the bench
+    runs eight).  A batch carries ~10 labeled positions, so its loss error is a random draw of a few 1e-4 (sigma_logit ~ 0.016 over 10
+    positions): the bounds are re-based on the storage-precision model's OWN loss deviation on the same batches instead of a bare 1e-3
+    on one draw:
+      labels bit-exact; mean and pooled loss error <= 1e-3 (north_star); worst batch <= max(1.5e-3, 3 x the storage model's worst batch);
+      logits rel-L2 <= 1.05 x the storage-precision model's own deviation from fp32 overall (measured 1.001), <= 1.10 x per batch,
+      and <= 2e-2 absolute; argmax identical wherever the top-2 margin exceeds 8 sigma of the measured logit error, on >= 90 % of all
+      valid positions, and on EVERY position of a head with planted winners; the ViT forward's two paths (257th key seeding the softmax /
+      the general five tiles) both sit at the storage model's distance from fp32."""
     import psutil
     if psutil.virtual_memory().available < 40 * 2 ** 30:
         pytest.skip("the full-depth fp32 oracle needs ~20 GB of host memory for its weights plus activations")
@@ -634,17 +639,22 @@ def test_cfg2_full_depth_forward_vs_oracle(cfg2):
     keep = {k: v.clone() for k, v in model.state_dict().items()}         # the module-scoped model goes back to its own weights afterwards
     tr = Trainer(model, layout.special(), lr=1e-4)
     try:
-        r = bench.full_depth_parity(om, model, tr, layout, 8, 512, torch.device("cuda"))
+        r = bench.full_depth_parity(om, model, tr, layout, 8, 512, torch.device("cuda"), n_batches=4)
     finally:
         tr.dp.remove()
         model.load_state_dict(keep)
         del om
     print("\n[cfg2 full depth] " + ", ".join(f"{k} {v}" for k, v in r.items() if k not in ("config", "note")))
-    assert r["labels_equal"]
-    assert r["loss_rel"] <= 1e-3, r
-    assert r["logits_rel_l2"] <= 2e-2 and r["storage_model_ratio"] <= 1.15, r
+    assert r["n_batches"] == 4 and r["labels_equal"]
+    assert r["loss_rel_mean"] <= 1e-3 and r["loss_rel_pooled"] <= 1e-3, r
+    assert r["loss_rel_max"] <= max(1.5e-3, 3 * r["loss_rel_storage_model_max"]), r
+    assert r["logits_rel_l2"] <= 2e-2 and r["storage_model_ratio"] <= 1.05 and max(r["storage_model_ratio_per_batch"]) <= 1.10, r
     assert r["argmax_sure_positions"] > 0 and r["argmax_sure_equal"], r
     assert r["argmax_rate"] >= 0.90, r
+    pw = r["planted_winner_head"]
+    assert pw["plant_took"] > 0.9 and pw["min_margin_over_sigma"] > 8 and pw["argmax_equal"] == pw["positions"], pw
+    ab = r["vit_257th_key_ab"]               # both ViT forward paths sit on the storage model: neither is "the" accurate one
+    assert max(ab["logits_rel_l2_seeded"], ab["logits_rel_l2_general"]) <= 1.10 * r["storage_model_rel_l2"] * max(r["storage_model_ratio_per_batch"]) + 2e-3, ab
 
 
 def test_generate_with_trainable_gated_blocks_and_autograd_on(cfg2):

@@ -808,6 +808,15 @@ int unimp_attn_bwd2_dispatch(const AttnP& p, int which, void* stream) {
   return unimp_check_launch("attn_bwd2");
 }
 
+// UNIMP_ATTN_VIT / unimp_attn_set_vit_tail: -1 = not read yet, 0 = the general forward path for S = 257, 1 = the seeded form (default)
+static int g_attn_vit_tail = -1;
+extern "C" int unimp_attn_set_vit_tail(int on) {
+  if (g_attn_vit_tail < 0) { const char* e = getenv("UNIMP_ATTN_VIT"); g_attn_vit_tail = (!e || atoi(e) != 0) ? 1 : 0; }
+  int old = g_attn_vit_tail;
+  g_attn_vit_tail = on ? 1 : 0;
+  return old;
+}
+
 template <int D, bool ALIBI>
 static void launch_fwd2(const AttnP& p, hipStream_t s) {
   // a wave owns 32 query rows; 4 or 5 waves per block, whichever wastes fewer wave slots: S = 257 (the ViT: 256 patches + CLS)
@@ -818,7 +827,8 @@ static void launch_fwd2(const AttnP& p, hipStream_t s) {
     // the ViT (S = 257, every key visible): the last key seeds the softmax state (TAIL: 4 tiles instead of 5) and the 9 waves of
     // query rows go out as 3 blocks of 3 (no idle tenth wave slot).  Measured at 512 images x 16 heads (profiles/r04_vit_attention_ab.txt):
     // 446 us before; TAIL with 5 / 9 / 3 waves per block 405 / 413 / 361 us.  UNIMP_ATTN_VIT=0: the general path.
-    static const bool vit = [] { const char* e = getenv("UNIMP_ATTN_VIT"); return !e || atoi(e) != 0; }();
+    if (g_attn_vit_tail < 0) { const char* e = getenv("UNIMP_ATTN_VIT"); g_attn_vit_tail = (!e || atoi(e) != 0) ? 1 : 0; }
+    const bool vit = g_attn_vit_tail != 0;
     if (vit && p.mask_mode == UNIMP_MASK_NONE && !p.kv_len && !p.k_off && !p.q_off && (p.Sk & 63) == 1 && p.Sk > 64 && w == 9) {
       hipLaunchKernelGGL((attn_fwd2_kernel<D, 3, false, true>), dim3(3 * p.H * p.B), dim3(192), 0, s, p, 0, 3);
       return;

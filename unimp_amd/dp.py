@@ -158,3 +158,7 @@ class GradBucketer:
     def remove(self):
         for h in self._hooks:
             h.remove()
+        self._hooks = []
+        cb, self.on_remove = getattr(self, "on_remove", None), None
+        if cb is not None:
+            cb()

@@ -364,7 +364,12 @@ def meteor(predictions, references, alpha=0.9, beta=3.0, gamma=0.5):
 
 @torch.no_grad()
 def eval_model_exp(model, samples, tokenizer, max_new_tokens=256, num_beams=5, image_preprocessor=None, device="cuda", users_per_batch=1):
-    """eval_exp.py:31-205: rating + explanation generation.  Returns mae, rmse, bleu (unigram precision), rouge1 / rouge2 / rougeL, meteor."""
+    """eval_exp.py:31-205: rating + explanation generation.  Returns mae, rmse, bleu (unigram precision), rouge1 / rouge2 / rougeL and
+    ``meteor_exact_stem``.  The last one is NOT the reference's "meteor" and must not be compared with eval_exp.py numbers: evaluate's
+    metric tokenises with nltk ``word_tokenize``, stems with nltk's PorterStemmer in its NLTK_EXTENSIONS mode and adds a WordNet synonym
+    stage; here the exact + (1980 Porter) stem stages run on whitespace tokens (no nltk / WordNet data offline) -- a lower bound with
+    another tokenisation, hence another key.  ``unpinned_metrics`` lists the keys whose definition is a restatement
+    without a pin on the reference's library."""
     abs_err, sq_err, gen_exps, real_exps = [], [], [], []
 
     def on_user(s, texts):
@@ -380,7 +385,8 @@ def eval_model_exp(model, samples, tokenizer, max_new_tokens=256, num_beams=5, i
         return {}
     out = {"mae": float(np.mean(abs_err)), "rmse": float(np.sqrt(np.mean(sq_err))), "bleu": bleu1_precision(gen_exps, real_exps)}
     out.update(rouge_f(gen_exps, real_exps))
-    out["meteor"] = meteor(gen_exps, real_exps)
+    out["meteor_exact_stem"] = meteor(gen_exps, real_exps)
+    out["unpinned_metrics"] = ["bleu", "rouge1", "rouge2", "rougeL", "meteor_exact_stem"]
     return out
 
 

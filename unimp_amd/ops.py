@@ -334,6 +334,7 @@ def gemm(a, b, *, a_ks=False, b_ks=False, bias=None, act=None, res=None, aux=Non
                 gemm(a, b[:, :cut], out=out[:, :cut], _splits=0, **kw)
                 gemm(a, b[:, cut:], out=out[:, cut:], _splits=S, **kw)
             return out
+    tuned_rope = False               # the rotary path resolves its variant through the tuner too: the persistent-twin mapping applies to it
     d = GemmDesc()
     d.A, d.B, d.C = a.data_ptr(), b.data_ptr(), _dev(out).data_ptr()
     d.M, d.N, d.K = M, N, K
@@ -365,6 +366,7 @@ def gemm(a, b, *, a_ks=False, b_ks=False, bias=None, act=None, res=None, aux=Non
             d.rope_pos = rope["pos"].data_ptr()
         _splits = 0
         if variant is None:
+            tuned_rope = True
             variant = gemm_rope_variant(M, N, K, b_ks, a.device)
             if variant is None:
                 raise _lib.UnimpHipError("gemm: no rotary-epilogue kernel for this problem (ops.gemm_rope_variant); run rope_ as a separate pass")
@@ -410,7 +412,7 @@ def gemm(a, b, *, a_ks=False, b_ks=False, bias=None, act=None, res=None, aux=Non
                                                                       _tune_gemm(M, N, K, bool(a_ks), bool(b_ks), a.device,
                                                                                  True if (res is not None or aux is not None) else
                                                                                  ("out2" if pre is not None else False)))
-    if AVOID_PERSISTENT and variant is None and v in _PERSISTENT_TWIN:
+    if AVOID_PERSISTENT and (variant is None or tuned_rope) and v in _PERSISTENT_TWIN:
         v = _PERSISTENT_TWIN[v]
     if (d.pre_deriv == 2 or d.dact == ACT["deriv_u8"]) and variant is None and v in (0, 2, 3, 6, 7):
         # the uint8 derivative lives in the kernels with the specialised epilogue kinds; 0 = the library's own choice, which may be a DMA variant

@@ -44,7 +44,7 @@ def get_checkpoint(model):
     return sd
 
 
-def save_checkpoint(path, model, trainer=None, epoch=0, barrier=False):
+def save_checkpoint(path, model, trainer=None, epoch=0, barrier=False, group=None):
     """UniMP writes only the trainable tensors (mmrec.py:873-892: ``get_checkpoint``) and never the optimizer, so its
     resume path is broken.  Same file format for the weights -- a flat ``{name: tensor}`` dict that
     ``model.load_state_dict(sd, strict=False)`` consumes -- plus, optionally, a side file with the fp32 optimizer state
@@ -59,24 +59,32 @@ def save_checkpoint(path, model, trainer=None, epoch=0, barrier=False):
         call it**: the owned slices are gathered bucket by bucket, rank 0 keeps the host copy and writes, and a barrier
         closes the call so no rank runs ahead into the next step's collectives."""
     import torch.distributed as dist
-    rank0 = not dist.is_initialized() or dist.get_rank() == 0
+    if group is None and trainer is not None:
+        group = trainer.dp.pg                          # the Trainer may run on a subgroup: WORLD would wait for ranks that never call
+    rank0 = not dist.is_initialized() or dist.get_rank(group) == 0
     sharded = trainer is not None and trainer.opt.shard is not None
     if not rank0 and not sharded:
         if barrier and dist.is_initialized():
-            dist.barrier()
+            dist.barrier(group=group)
         return
     o = None
     if trainer is not None:
         o = trainer.opt.state_dict(to_host=rank0)      # sharded: a collective; only rank 0 keeps the per-parameter host copies
+    err = None
     if rank0:                                          # replicas hold identical weights: one writer
-        sd = {k: v.detach().to("cpu") for k, v in get_checkpoint(model).items()}
-        torch.save(sd, path)
-        if o is not None:
-            torch.save({"epoch": epoch, "sched_step": trainer.sched_step, "optimizer": o}, path + ".resume")
+        try:
+            sd = {k: v.detach().to("cpu") for k, v in get_checkpoint(model).items()}
+            torch.save(sd, path)
+            if o is not None:
+                torch.save({"epoch": epoch, "sched_step": trainer.sched_step, "optimizer": o}, path + ".resume")
+        except BaseException as e:                     # the barrier below must still be reached, or every other rank hangs in it
+            err = e
     if sharded:
         dist.barrier(group=trainer.opt.shard[3])
     elif barrier and dist.is_initialized():
-        dist.barrier()
+        dist.barrier(group=group)
+    if err is not None:
+        raise err
 
 
 def load_checkpoint(path, model, trainer=None):
@@ -149,6 +157,24 @@ class _WgradSink:
 
 
 _ROWS_SYNC = os.environ.get("UNIMP_ROWS_SYNC", "0") == "1"      # A/B knob: the blocking nonzero() of rounds 1-3
+# fuse_accum=None (auto): fused accumulation holds the activations of GA x B samples at once, so the automatic choice takes it only
+# while GA x B x L stays within this many tokens (b = 64 x L = 512, the bench's headline shape, is 32 768 tokens and needs ~150 GB at
+# cfg2); beyond it the micro-batches run one after the other as the reference does.  fuse_accum=True is never second-guessed.
+FUSE_TOKEN_BUDGET = int(os.environ.get("UNIMP_FUSE_TOKENS", str(48 * 1024)))
+
+
+class StepOut(tuple):
+    """what ``Trainer.step`` returns: unpacks as ``(loss, stats)`` like before, and carries ``pending`` -- True when the call only
+    BUFFERED its micro-batch (fused accumulation before the GA-th micro-batch): no forward ran, ``loss`` / ``stats`` are then the
+    previous optimizer step's values (NaN / zeros before the first one), not this micro-batch's.  A logging loop ported from
+    mmrec.py:259-296 must skip pending results (``if not out.pending: meter.update(...)``)."""
+    pending = False
+
+    def __new__(cls, loss, stats, pending=False):
+        t = super().__new__(cls, (loss, stats))
+        t.pending = bool(pending)
+        return t
+
 
 
 class Trainer:
@@ -163,16 +189,21 @@ class Trainer:
         computes the <PAD> rows too (collate_rec.py:38-74 pads to the longest sequence of the batch); nothing reads them: loss and
         gradients are those of the padded run (tests/test_model_gpu.py::test_packed_token_order_equals_padded), logits at <PAD>
         positions become those of a zero hidden state.  GPT-NeoX, MPT and OPT towers; one extra host sync per step (the valid count).
-        fuse_accum (None = ON whenever grad_accum > 1 and graph is off; False restores the sequential micro-steps): run the GA
+        fuse_accum (None = automatic: ON when grad_accum > 1, graph is off and GA x B x L of the first micro-batch fits
+        ``FUSE_TOKEN_BUDGET`` tokens -- activation memory scales with GA x B, beyond the budget the micro-steps run one after the
+        other; True = always; False = the sequential micro-steps of the reference): run the GA
         micro-batches of an optimizer step as ONE forward / backward pass.  The reference accumulates because 3 samples are what fits its GPUs (unimp_task.sh:2-30: --batch_size 3,
         --gradient_accumulation_steps 2); on 288 GB the activations of all GA micro-batches fit, and one pass over GA x B samples
         fills the GEMM tiles GA times better (a micro-batch of 3 x 512 tokens is 6 tile rows: measured, the step is GPU-bound at
         0.57 PFLOP/s in the GEMMs, not launch-bound).  SAME optimizer step: the loss keeps its per-micro-batch normalisation
         (mmrec.py:213 divides by the labeled positions of the micro-batch, accelerate averages the GA losses) through per-sample
         weights w_b * N_total / (GA * N_mb(b)) computed on the device -- gradients equal the sequential ones up to summation order
-        (tests/test_model_gpu.py::test_fused_accumulation_equals_sequential).  ``step()`` buffers the micro-batches and returns
-        the previous optimizer step's (loss, stats) until the GA-th arrives (before the first optimizer step: a zero loss and zero stats -- never
-        None, ``loss.item()`` in a logging loop keeps working); micro-batches of different lengths are right-padded.
+        (tests/test_model_gpu.py::test_fused_accumulation_equals_sequential).  CONTRACT CHANGE against the sequential loop: ``step()`` only
+        BUFFERS the first GA - 1 micro-batches of an optimizer step -- it returns a ``StepOut`` with ``pending=True`` whose loss / stats are
+        the PREVIOUS optimizer step's (a NaN loss and zero stats before the first one: a meter that averages them without looking at
+        ``pending`` goes NaN instead of being silently skewed); the GA-th call runs the fused pass and returns its loss.  Micro-batches of
+        different lengths are right-padded.  When the loader ends inside a group, call ``flush()`` (accelerate steps at the end of
+        the dataloader: ``sync_with_dataloader``) -- otherwise the buffered micro-batches would join the next epoch's first group.
         graph (off by default): replay the forward + loss + backward of a micro-batch as ONE HIP graph.  At the reference's
         shipped shape (--batch 3 --grad-accum 2, unimp_task.sh:2-30) a micro-step is ~3 000 launches of kernels that run for
         10-40 us each: the host, not the GPU, sets the pace.  The first micro-step with a given set of batch shapes runs eagerly
@@ -191,8 +222,11 @@ class Trainer:
         if graph and sparse_head:
             raise ValueError("Trainer(graph=True) needs the sync-free dense loss path (sparse_head takes a row count on the host)")
         self.use_graph, self._graph = graph, None
-        if fuse_accum is None:
-            fuse_accum = grad_accum > 1 and not graph
+        if fuse_accum and graph:
+            raise ValueError("Trainer(fuse_accum=True, graph=True): the fused pass is not graph-captured (it would silently ignore graph=True); "
+                             "pick one -- graph=True replays each micro-batch, fuse_accum=True runs the GA micro-batches as one pass")
+        # None: decided at the first micro-batch, when B and L are known (_fuse_decide)
+        self._fuse_auto = fuse_accum is None and grad_accum > 1 and not graph
         self.fuse_accum, self._stash, self._last = bool(fuse_accum and grad_accum > 1), [], None
         self._mb_index, self._cnt_host = {}, None
         le_ = model.lang_encoder
@@ -225,12 +259,21 @@ class Trainer:
         self.dp = GradBucketer(self.opt, bucket_bytes=bucket_bytes, process_group=process_group, late_params=late,
                                force_hooks=force_dp_hooks)
         if self.dp.active and self.dp.world > 1:
-            ops.AVOID_PERSISTENT = True       # collectives share the CUs with backward: no persistent GEMM variant (ops.AVOID_PERSISTENT)
+            # collectives share the CUs with backward: no persistent GEMM variant (ops.AVOID_PERSISTENT).  The flag is process-wide (the GEMM
+            # call sites do not know their trainer); close() / dp.remove() puts back what this trainer found
+            prev = ops.AVOID_PERSISTENT
+            ops.AVOID_PERSISTENT = True
+            self.dp.on_remove = lambda: setattr(ops, "AVOID_PERSISTENT", prev)
         self.sched, self.base_lr, self.warmup, self.total = lr_scheduler, lr, warmup_steps, total_steps
         self.sched_step = 0
         # the weight-gradient GEMMs add straight into the flat gradient buffer (functional.WGRAD_SINK); under data parallelism
         # the sink plays the post-accumulate hook for the bucketer
         self._sink = _WgradSink(self.opt, exclude=late, dp=self.dp if self.dp.active else None) if direct_wgrad else None
+
+    def close(self):
+        """detach from the process: gradient hooks removed, ops.AVOID_PERSISTENT restored (a later single-rank Trainer in the same
+        process gets the persistent GEMM variants back)"""
+        self.dp.remove()
 
     def current_lr(self):
         if self.sched == "cosine":
@@ -262,21 +305,56 @@ class Trainer:
         return dict(vision_x=torch.cat([b["vision_x"] for b in batches]), lang_x=ids,
                     attention_mask=torch.cat([padded(b["attention_mask"], 0) for b in batches]), weights=w * norm)
 
-    def _fused_step(self, batch):
-        self._stash.append(batch)
-        if len(self._stash) < self.grad_accum:
-            if self._last is None:         # nothing computed yet: placeholders of the right type (focal_ce's stats vector)
-                dev = batch["lang_x"].device
-                self._last = (torch.zeros((), device=dev), torch.zeros(3, device=dev))   # stats = [loss_sum, n_labeled, ce_sum]
-            return self._last
-        fused, self._stash = self._fused_batch(self._stash), []
-        loss, stats = self._micro_step(fused)
+    def _fuse_decide(self, batch):
+        """automatic fuse_accum: take the fused pass only while its activations (GA x B x L tokens) stay inside FUSE_TOKEN_BUDGET"""
+        B, L = batch["lang_x"].shape
+        self.fuse_accum = self.grad_accum * B * L <= FUSE_TOKEN_BUDGET
+        self._fuse_auto = False
+
+    def _fused_pass(self, batches, scale=1.0):
+        loss, stats = self._micro_step(self._fused_batch(batches))
         self._mask_lm_head_grads()
-        gscale = self.dp.finish()
+        gscale = self.dp.finish() * scale
         self.opt.step(lr=self.current_lr(), grad_scale=gscale)
         self.sched_step += 1
         self._last = (loss, stats)
-        return self._last
+        return StepOut(loss, stats)
+
+    def _fused_step(self, batch):
+        self._stash.append(batch)
+        if len(self._stash) < self.grad_accum:
+            if self._last is None:         # nothing computed yet: NaN loss (not a fake 0.0), stats of the right shape (focal_ce's [loss_sum, n_labeled, ce_sum])
+                dev = batch["lang_x"].device
+                self._last = (torch.full((), float("nan"), device=dev), torch.zeros(3, device=dev))
+            return StepOut(self._last[0], self._last[1], pending=True)
+        batches, self._stash = self._stash, []
+        return self._fused_pass(batches)
+
+    def flush(self, mean_over="ga"):
+        """optimizer step over the micro-batches of an INCOMPLETE accumulation group (the loader ended inside it); a no-op returning None
+        when nothing is pending.  accelerate does the same at the end of the dataloader (``sync_with_dataloader``: the last batch
+        sets ``sync_gradients``), and it has divided every micro-batch loss by the full GA (``Accelerator.backward``), so the
+        reference's partial group steps with sum(grad_i) / GA: that is ``mean_over="ga"``, the default.  ``mean_over="stashed"``
+        averages over the k micro-batches actually seen (sum(grad_i) / k)."""
+        if mean_over not in ("ga", "stashed"):
+            raise ValueError(mean_over)
+        if self.fuse_accum:
+            k = len(self._stash)
+            if k == 0:
+                return None
+            batches, self._stash = self._stash, []
+            # _fused_batch normalises by the k micro-batches it is given (mean over k); the reference's partial group is k / GA of that
+            return self._fused_pass(batches, scale=(k / self.grad_accum) if mean_over == "ga" else 1.0)
+        k = self._micro % self.grad_accum if (self.grad_accum > 1 or self.use_graph) else 0
+        if k == 0:
+            return None
+        self._mask_lm_head_grads()
+        gscale = self.dp.finish() / (self.grad_accum if mean_over == "ga" else k)
+        self.dp.sync = True
+        self.opt.step(lr=self.current_lr(), grad_scale=gscale)
+        self.sched_step += 1
+        self._micro = 0
+        return StepOut(*self._last) if self._last is not None else None
 
     def forward_loss(self, batch):
         ids = batch["lang_x"]
@@ -385,6 +463,8 @@ class Trainer:
         device does not idle); ``sparse_head`` needs it before the forward; ``dense_head_backward=True`` (and ``graph=True``, which
         implies it) has none."""
         self.model.train()
+        if self._fuse_auto:
+            self._fuse_decide(batch)
         if self.fuse_accum:
             return self._fused_step(batch)
         micro = self._graphed_micro_step if self.use_graph else self._micro_step
@@ -395,16 +475,17 @@ class Trainer:
             self._micro += 1
             self.dp.sync = False          # hooks only fold gradients; finish() issues the exchange (a replayed graph runs no hook)
             loss, stats = micro(batch)
+            self._last = (loss, stats)
             if self._micro % self.grad_accum == 0:
                 self._mask_lm_head_grads()
                 gscale = self.dp.finish() / self.grad_accum
                 self.dp.sync = True
                 self.opt.step(lr=self.current_lr(), grad_scale=gscale)
                 self.sched_step += 1
-            return loss, stats
+            return StepOut(loss, stats)
         loss, stats = micro(batch)
         self._mask_lm_head_grads()
         gscale = self.dp.finish()
         self.opt.step(lr=self.current_lr(), grad_scale=gscale)
         self.sched_step += 1
-        return loss, stats
+        return StepOut(loss, stats)
