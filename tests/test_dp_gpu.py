@@ -262,12 +262,20 @@ def _worker_shard(rank, world, port, q, backend):
         assert l0.item() == l1.item()
         pr = {n: p.detach().float() for n, p in ref.model.named_parameters() if p.requires_grad}
         n_diff = n_all = 0
+        # W = 2: a + b is the same bf16 whatever the exchange's chunking, only the clip norm's order differs.  W > 2: the two trainers cut
+        # the flat buffer into different buckets, gloo's ring sums a bucket's elements in a chunk-dependent order, and the summed bf16
+        # gradients differ in their last bit here and there -- Adam's FIRST step is lr * g / (|g| + eps), so an element whose gradient is
+        # rounding noise around zero may move by up to 2 lr the other way.  Bounded: at most 2.5 lr, on at most 0.5 % of the elements.
+        lr_ = 1e-3
         for n, p in shd.model.named_parameters():
             if p.requires_grad:
                 d = (p.detach().float() - pr[n]).abs()
-                assert d.max().item() <= 2 ** -7 * pr[n].abs().clamp_min(1e-3).max().item() and d.max().item() <= 2e-5, (n, d.max().item())
-                n_diff += int((d > 0).sum()); n_all += d.numel()
-        assert n_diff <= 1e-4 * n_all, (n_diff, n_all)
+                if world <= 2:
+                    assert d.max().item() <= 2 ** -7 * pr[n].abs().clamp_min(1e-3).max().item() and d.max().item() <= 2e-5, (n, d.max().item())
+                else:
+                    assert d.max().item() <= 2.5 * lr_ + 2 ** -7 * pr[n].abs().max().item(), (n, d.max().item())
+                n_diff += int((d > (0 if world <= 2 else 2e-5)).sum()); n_all += d.numel()
+        assert n_diff <= (1e-4 if world <= 2 else 5e-3) * n_all, (n_diff, n_all)
         for b in batches[1:]:
             l0, _ = ref.step(b)
             l1, _ = shd.step(b)
@@ -303,7 +311,7 @@ def _worker_shard(rank, world, port, q, backend):
         for (n, p1), (_, p2) in zip(shd.model.named_parameters(), fresh_r.model.named_parameters()):
             if p1.requires_grad:
                 d = (p1.detach().float() - p2.detach().float()).abs().max().item()
-                assert d <= 2e-5 + 2 ** -7 * p1.detach().float().abs().max().item(), (n, d)          # sharded -> replicated: clip-norm order only
+                assert d <= (2e-5 if world <= 2 else 2.5e-3) + 2 ** -7 * p1.detach().float().abs().max().item(), (n, d)   # sharded -> replicated: clip-norm order (W > 2: + the ring's summation order)
         q.put((rank, "ok", worst))
     except Exception:                                                      # noqa: BLE001
         import traceback

@@ -88,7 +88,8 @@ def test_gemm_layouts(ops, M, N, K, a_ks, b_ks):
     bd = (b.t().contiguous() if b_ks else b).cuda()
     got = ops.gemm(ad, bd, a_ks=a_ks, b_ks=b_ks)                  # autotuned choice
     close(got, want, name=f"gemm {M}x{N}x{K} {a_ks}{b_ks}")
-    for variant in (["v1"] if M < 256 else ["v1", "dma256", "dma128", "pp256", "pp128", "w4", "w8", "pp256p", "pp256x", "pp128x", "pp256px", "pp256a", "pp128a"]):   # every kernel, explicitly
+    w4x = ["w4x"] if (not a_ks and K % 64 == 0 and K >= 128) else []         # gemm7.hip: k-contiguous A, whole 64-k stages
+    for variant in (["v1"] if M < 256 else ["v1", "dma256", "dma128", "pp256", "pp128", "w4", "w8", "pp256p", "pp256x", "pp128x", "pp256px", "pp256a", "pp128a"] + w4x):   # every kernel, explicitly
         got = ops.gemm(ad, bd, a_ks=a_ks, b_ks=b_ks, variant=variant)
         close(got, want, name=f"gemm[{variant}] {M}x{N}x{K} {a_ks}{b_ks}")
     got32 = ops.gemm(ad, bd, a_ks=a_ks, b_ks=b_ks, out_f32=True, variant="pp256" if M >= 256 else "v1")
@@ -136,6 +137,55 @@ def test_gemm_persistent_many_tiles_per_workgroup(ops, pv):
         want = ops.gemm(a2, b2, a_ks=a_ks, b_ks=b_ks, variant="pp256")
         got = ops.gemm(a2, b2, a_ks=a_ks, b_ks=b_ks, variant=pv)
         assert torch.equal(got, want), f"{pv} != pp256 for layout {a_ks}{b_ks}"
+
+
+@pytest.mark.parametrize("M,N,K", [(256 * 5 + 40, 256 * 3 + 136, 64 * 21), (1024, 2560, 2560), (2048, 768, 64 * 37), (512, 512, 128), (300, 264, 192)])
+@pytest.mark.parametrize("b_ks", [False, True])
+def test_gemm_w4x_equals_pingpong_bit_for_bit(ops, M, N, K, b_ks):
+    """gemm7.hip (variant w4x, round 5): one wave per SIMD, 128 x 128 per wave, 64-k stages, every instruction of the main loop placed by hand
+    (two fragment register sets, LDS-DMA two stages ahead, two barriers per 128 MFMAs).  Same k grouping inside every MFMA and the same k
+    order per accumulator as the ping-pong kernels, same epilogue code: the results must be the ping-pong kernel's BIT FOR BIT under every
+    epilogue kind, with a k-contiguous and a k-strided B, ragged M / N edges, the shortest K it serves (two stages) and long odd stage
+    counts (the ring's hazards: repeated launches must agree).  Forms it does not serve are refused, not mis-served."""
+    a, b = rnd(M, K, seed=21), rnd(N, K, seed=22, scale=0.2)
+    bias, res = rnd(N, seed=23), rnd(M, N, seed=24)
+    ad, bd, biasd, resd = a.cuda(), (b.t().contiguous() if b_ks else b).cuda(), bias.cuda(), res.cuda()
+    gate = torch.tensor([0.3], dtype=bf16, device="cuda")
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    aux8 = torch.randint(0, 256, (M, N), dtype=torch.uint8, device="cuda", generator=g)
+    kws = [dict(), dict(bias=biasd), dict(bias=biasd, act="gelu"), dict(bias=biasd, act="quick_gelu"), dict(res=resd), dict(bias=biasd, res=resd, gate=gate),
+           dict(aux=resd, dact="deriv"), dict(out_f32=True), dict(alpha=0.125, bias=biasd), dict(gate=gate)]
+    if N % 8 == 0:
+        kws.append(dict(aux=aux8, dact="deriv"))
+    for kw in kws:
+        want = ops.gemm(ad, bd, b_ks=b_ks, variant="pp256", **kw)
+        for _ in range(3):
+            got = ops.gemm(ad, bd, b_ks=b_ks, variant="w4x", **kw)
+            assert torch.equal(got, want), f"w4x != pp256 for {sorted(kw)} ({int((got != want).sum())} elements)"
+    close(ops.gemm(ad, bd, b_ks=b_ks, variant="w4x"), a.float() @ b.float().t(), name="w4x vs fp32")
+    if N % 8 == 0:
+        pre_w = torch.empty(M, N, dtype=torch.uint8, device="cuda"); pre_g = torch.empty_like(pre_w)
+        want = ops.gemm(ad, bd, b_ks=b_ks, variant="pp256", bias=biasd, act="gelu", pre=pre_w, pre_deriv=True)
+        got = ops.gemm(ad, bd, b_ks=b_ks, variant="w4x", bias=biasd, act="gelu", pre=pre_g, pre_deriv=True)
+        assert torch.equal(got, want) and torch.equal(pre_g, pre_w)
+        acc_w = ops.gemm(ad, bd, b_ks=b_ks, variant="pp256").clone(); acc_g = acc_w.clone()
+        ops.gemm(ad, bd, b_ks=b_ks, variant="pp256", out=acc_w, accumulate=True)
+        ops.gemm(ad, bd, b_ks=b_ks, variant="w4x", out=acc_g, accumulate=True)
+        assert torch.equal(acc_g, acc_w)
+    if M % 8 == 0:
+        with pytest.raises(Exception):                                   # a k-strided A is refused (UNIMP_ERR_UNSUPPORTED), not mis-served
+            ops.gemm(ad.t().contiguous(), bd, a_ks=True, b_ks=b_ks, variant="w4x")
+
+
+def test_gemm_w4x_rotary_epilogue_equals_pingpong(ops):
+    M, H, hd, L = 1024, 8, 80, 512
+    a, b, bias = rnd(M, H * hd, seed=7).cuda(), rnd(3 * H * hd, H * hd, seed=8, scale=0.05).cuda(), rnd(3 * H * hd, seed=9).cuda()
+    rope = dict(rot=hd, hd=hd, period=3 * hd, span=2 * hd, L=L, log2_base=float(np.log2(10000.0)))
+    for bk in (False, True):
+        bb = b.t().contiguous() if bk else b
+        want = ops.gemm(a, bb, b_ks=bk, bias=bias, rope=rope, variant="pp256")
+        got = ops.gemm(a, bb, b_ks=bk, bias=bias, rope=rope, variant="w4x")
+        assert torch.equal(got, want), int((got != want).sum())
 
 
 def test_gemm_variants_same_bits_under_every_forward_epilogue(ops):

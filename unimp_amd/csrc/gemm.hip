@@ -397,6 +397,10 @@ extern "C" int unimp_gemm6_launch(const unimp_gemm_desc* d, void* stream);      
 extern "C" int unimp_gemm3x_launch(const unimp_gemm_desc* d, int bn, void* stream);  // gemm3.hip built with G3_ONESET: one fragment register set
 extern "C" int unimp_gemm6x_launch(const unimp_gemm_desc* d, void* stream);          // gemm6.hip built with G3_ONESET
 extern "C" int unimp_gemm3a_launch(const unimp_gemm_desc* d, int bn, void* stream);  // gemm3.hip built with G3_ONESET + G3_AFULL: A staged in whole 128-byte rows
+extern "C" int unimp_gemm3b_launch(const unimp_gemm_desc* d, int bn, void* stream);  // gemm3a with the K tail peeled (G3_PEEL)
+extern "C" int unimp_gemm7_launch(const unimp_gemm_desc* d, void* stream);           // gemm7.hip: one wave per SIMD, hand-ordered two-set main loop, 64-k stages
+extern "C" int unimp_gemm7n_launch(const unimp_gemm_desc* d, void* stream);          // ... staging loads nt
+extern "C" int unimp_gemm7s_launch(const unimp_gemm_desc* d, void* stream);          // ... staging loads sc1
 
 static int check_operand(const void* p, long ld, int ks, int rows) {
   if (((uintptr_t)p & 15) != 0) return UNIMP_ERR_ALIGN;
@@ -509,14 +513,15 @@ extern "C" int unimp_gemm_bf16_variant(const unimp_gemm_desc* d, int variant, vo
   if (d->b_kstrided == 2 && variant != UNIMP_GEMM_PP256 && variant != UNIMP_GEMM_PP128)
     return unimp_set_error(UNIMP_ERR_UNSUPPORTED, "gemm: a pre-packed B operand is served by the ping-pong kernels only (variants pp256 / pp128)");
   if (((d->pre && d->pre_deriv == 2) || d->dact == ACT_DERIV_U8) &&
-      (variant == UNIMP_GEMM_DMA256 || variant == UNIMP_GEMM_DMA128 || variant == UNIMP_GEMM_W4 || variant == UNIMP_GEMM_SKINNY))
+      (variant == UNIMP_GEMM_DMA256 || variant == UNIMP_GEMM_DMA128 || variant == UNIMP_GEMM_W4 || variant == UNIMP_GEMM_SKINNY))   // (w4x has the kinds)
     return unimp_set_error(UNIMP_ERR_UNSUPPORTED, "gemm: the uint8 derivative is served by variants v1 / pp256 / pp128 / w8 / pp256p (kernels with the specialised epilogue kinds)");
   if (d->rope_rot) {
     if (d->rope_rot < 0 || (d->rope_rot & 7) || d->rope_hd <= 0 || (d->rope_hd & 7) || d->rope_rot > d->rope_hd || d->rope_L <= 0 ||
         d->rope_period <= 0 || d->rope_period % d->rope_hd || d->rope_span % d->rope_hd || d->rope_span > d->rope_period || !(d->rope_log2_base > 0.f))
       return unimp_set_error(UNIMP_ERR_ARG, "gemm: rotary epilogue needs rot % 8 == 0 <= hd, hd % 8 == 0, period / span multiples of hd, L > 0, base > 1");
     if (d->M >= (1 << 24)) return unimp_set_error(UNIMP_ERR_SHAPE, "gemm: rotary epilogue needs M < 2^24");
-    bool kern = (variant == UNIMP_GEMM_PP256 || variant == UNIMP_GEMM_PP256P || variant == UNIMP_GEMM_PP256X || variant == UNIMP_GEMM_PP256PX || variant == UNIMP_GEMM_PP256A) && !d->a_kstrided && d->b_kstrided != 2;
+    bool kern = (variant == UNIMP_GEMM_PP256 || variant == UNIMP_GEMM_PP256P || variant == UNIMP_GEMM_PP256X || variant == UNIMP_GEMM_PP256PX || variant == UNIMP_GEMM_PP256A || variant == UNIMP_GEMM_PP256B ||
+                 variant == UNIMP_GEMM_W4X || variant == UNIMP_GEMM_W4X_NT || variant == UNIMP_GEMM_W4X_SC1) && !d->a_kstrided && d->b_kstrided != 2;
     if (!kern || d->res || d->aux || d->pre || d->act || d->dact || d->accumulate || d->gate || d->out_f32 || (d->N & 7) || (d->ldc & 7) || d->M < 256 || d->N < 128)
       return unimp_set_error(UNIMP_ERR_UNSUPPORTED, "gemm: the rotary epilogue is served by variants pp256 / pp256p (and their one-set forms) with a k-contiguous A operand, an unpacked B operand and a plain (alpha, bias) bf16 epilogue, N % 8 == 0, ldc % 8 == 0");
   }
@@ -534,6 +539,12 @@ extern "C" int unimp_gemm_bf16_variant(const unimp_gemm_desc* d, int variant, vo
     case UNIMP_GEMM_PP256PX: unimp_gemm6x_launch(d, stream); break;
     case UNIMP_GEMM_PP256A: unimp_gemm3a_launch(d, 256, stream); break;
     case UNIMP_GEMM_PP128A: unimp_gemm3a_launch(d, 128, stream); break;
+    case UNIMP_GEMM_PP256B: unimp_gemm3b_launch(d, 256, stream); break;
+    case UNIMP_GEMM_PP128B: unimp_gemm3b_launch(d, 128, stream); break;
+    case UNIMP_GEMM_W4X: case UNIMP_GEMM_W4X_NT: case UNIMP_GEMM_W4X_SC1: {
+      int ok = variant == UNIMP_GEMM_W4X ? unimp_gemm7_launch(d, stream) : variant == UNIMP_GEMM_W4X_NT ? unimp_gemm7n_launch(d, stream) : unimp_gemm7s_launch(d, stream);
+      if (!ok) return unimp_set_error(UNIMP_ERR_UNSUPPORTED, "gemm: variant w4x serves a k-contiguous A operand, an unpacked B operand, K % 64 == 0, K >= 128, operands below 4 GiB");
+      break; }
     case UNIMP_GEMM_SKINNY:
       if (!skinny_ok(d)) return unimp_set_error(UNIMP_ERR_UNSUPPORTED, "gemm: the skinny kernel needs M <= 64, k-contiguous operands, K %% 64 == 0");
       launch_skinny(d, stream); break;

@@ -29,7 +29,15 @@
 #include <stdlib.h>
 #include "gemm_half.h"
 
-#if defined(G3X) && defined(G3_AFULL)   // third build (Makefile: gemm3a.o): the one-set schedule with the A operand staged in whole 128-byte rows
+#if defined(G3X) && defined(G3_AFULL) && defined(G3_PEEL)   // fourth build (Makefile: gemm3b.o): gemm3a with the K loop's tail peeled off (no branch in a steady-state half-step)
+#define gemm3_bf16_kernel gemm3b_bf16_kernel
+#define unimp_gemm3_launch unimp_gemm3b_launch
+#define unimp_gemm3_launch_splitk unimp_gemm3b_launch_splitk
+#define launch3 launch3b
+#define g3_stamps g3b_stamps
+#define unimp_debug_g3_stamps unimp_debug_g3b_stamps
+#define getenv_no_fixed getenv_no_fixed_b
+#elif defined(G3X) && defined(G3_AFULL)   // third build (Makefile: gemm3a.o): the one-set schedule with the A operand staged in whole 128-byte rows
 #define gemm3_bf16_kernel gemm3a_bf16_kernel
 #define unimp_gemm3_launch unimp_gemm3a_launch
 #define unimp_gemm3_launch_splitk unimp_gemm3a_launch_splitk
@@ -235,10 +243,34 @@ static_assert(G3_NST == 4, "the one-set schedule is written for a prefetch dista
     G3_BARRIER();
     G3_T(1);
     if (wm == 1) G3_BARRIER();
+#ifdef G3_PEEL
+    // Round 5: the same half-steps with the K tail PEELED: HALF_STEP_AF decides per half-step whether to issue the A / B DMA and which of
+    // four vmcnt counts applies -- eight scalar branches in every L phase (ISA of round 4), the phase that sets the pace of the ping-pong.
+    // Steady state (h <= nh - 6) has no decision left; the last four half-steps are written out with their constants.  dma_full: K % 64 == 0
+    // here, so the ragged-k path of dma_issue (and its branch) is not compiled in.  Same instructions otherwise: same bits.
+#undef DMA_B
+#define DMA_B(H) dma_full<BKS, BN>(p.B, p.ldb, (H), smem + A_RING + ((H) % 4) * B_SUB, wave, boff)
+#define HS_AF(H, DOA, DOB, VM) do {                                                                                \
+      LOADF_AF(H);                                                                                                 \
+      if (DOA) DMA_A(((H) >> 1) + 2);                                                                              \
+      if (DOB) DMA_B((H) + 3);                                                                                     \
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(VM) : "memory");                                                   \
+      G3_BARRIER();                                                                                                \
+      MFMAS(0);                                                                                                    \
+      G3_BARRIER(); } while (0)
+    {
+      int h = 0;
+#pragma unroll 1
+      for (; h + 6 <= nh; h += 2) { HS_AF(h, true, true, NFULL); HS_AF(h + 1, false, true, NFULL); }
+      HS_AF(h, false, true, 2 * NB); HS_AF(h + 1, false, false, NB); HS_AF(h + 2, false, false, 0); HS_AF(h + 3, false, false, 0);
+    }
+#undef HS_AF
+#else
     for (int h = 0; h < nh; h += 2) {
       HALF_STEP_AF(h, true);
       HALF_STEP_AF(h + 1, false);
     }
+#endif
     if (wm == 0) G3_BARRIER();
     G3_T(2);
 #undef DMA_A

@@ -104,6 +104,16 @@ __device__ __forceinline__ void dma_issue(const bf16* __restrict__ X, long ld, i
 }
 
 
+// dma_issue without its ragged-k branch: the caller guarantees a full 32-k half-stage (K % 32 == 0 up to and including half-step h)
+template <bool KS, int ROWS, int NW = 8>
+__device__ __forceinline__ void dma_full(const bf16* __restrict__ X, long ld, int h, char* img, int wave, const uint32_t (&off)[ROWS / (16 * NW)]) {
+  constexpr int NI = ROWS / (16 * NW);
+  const char* ub = (const char*)X + (KS ? (long)h * 32 * ld * 2 : (long)h * 64);       // wave-uniform
+  uint32_t dst = __builtin_amdgcn_readfirstlane(lds_addr(img) + wave * NI * 1024);
+#pragma unroll
+  for (int i = 0; i < NI; ++i) glds16_s(ub, off[i], dst + i * 1024);
+}
+
 // one wave-instruction of dma_issue's steady-state path (full 32-k half-stage), so a kernel can spread a half-stage's
 // DMA between its MFMAs
 template <bool KS, int ROWS, int NW>

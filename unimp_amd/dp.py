@@ -76,6 +76,9 @@ class GradBucketer:
         self.launch_log = []      # bucket indices in issue order, last step (tests)
         self.record_exposed = False   # bench.py: bracket the waits of finish() with HIP events on the compute stream
         self.exposed_events = []      # (start, end) per step: the part of the exchange that backward did not hide
+        self.record_ready = False     # bench.py: a HIP event on the compute stream at every bucket's issue point (when its gradients are complete)
+        self.ready_events = []        # per step: (step-start event, [(bucket index, bytes, event)], finish event)
+        self._step_ready = None
         if self.active:
             for n, p, o, k in optimizer.layout:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
@@ -112,11 +115,22 @@ class GradBucketer:
             self._launch(self._order[self._next])
             self._next += 1
 
+    def mark_step_start(self):
+        """bench.py (record_ready): the compute-stream time origin of this step's bucket-ready timeline"""
+        if self.record_ready and self.opt.flat_g.is_cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self._step_ready = (ev, [])
+
     def _launch(self, bi):
         s, e, _ = self.buckets[bi]
         self._issued.add(bi)
         self.launch_log.append(bi)
         g = self.opt.flat_g
+        if self.record_ready and self._step_ready is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self._step_ready[1].append((bi, (e - s) * g.element_size(), ev))
         if self.sharded and dist.get_backend(self.pg) == "nccl":
             # ZeRO-2: the rank only needs the sum over its own 1/world of the bucket (in place: output = its slice of the input)
             lo, hi, _ = self.opt.owned[bi]
@@ -139,6 +153,11 @@ class GradBucketer:
             if self.record_exposed and self.opt.flat_g.is_cuda:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record()
+            if self.record_ready and self._step_ready is not None:
+                fe = torch.cuda.Event(enable_timing=True)
+                fe.record()
+                self.ready_events.append(self._step_ready + (fe,))
+                self._step_ready = None
             for h in self._handles:
                 h.wait()
             if ev is not None:
@@ -154,6 +173,26 @@ class GradBucketer:
         """per-step exposed exchange time (ms) of the steps recorded so far; synchronises on the last event."""
         out = [a.elapsed_time(b) for a, b in self.exposed_events if (b.synchronize() or True)]
         return out
+
+    def ready_timeline(self):
+        """per recorded step: (ms from step start at which backward is over, [(bucket, bytes, ms from step start at which it could go out)])"""
+        out = []
+        for e0, lst, fe in self.ready_events:
+            fe.synchronize()
+            out.append((e0.elapsed_time(fe), [(bi, nb, e0.elapsed_time(ev)) for bi, nb, ev in lst]))
+        return out
+
+    @staticmethod
+    def model_exposed_ms(timeline, world, bus_gbps, latency_us=30.0):
+        """exchange model over a measured bucket-ready timeline: ring all-reduce of S bytes moves 2 (W - 1) / W x S per GPU, buckets go out in
+        issue order on one communication stream at `bus_gbps` (RCCL's 'bus bandwidth') + a fixed latency each; returns the ms the compute
+        stream would wait in finish() -- what backward does not hide."""
+        t_end, lst = timeline
+        free = 0.0
+        for bi, nb, t_ready in lst:
+            start = max(free, t_ready)
+            free = start + latency_us * 1e-3 + 2.0 * (world - 1) / world * nb / (bus_gbps * 1e9) * 1e3
+        return max(0.0, free - t_end)
 
     def remove(self):
         for h in self._hooks:

@@ -186,6 +186,7 @@ class Flamingo(nn.Module):
             "Must provide either vision_x or have precached media using cache_media()."
         if self.lang_encoder._use_cached_vision_x:
             assert vision_x is None and self.lang_encoder.is_conditioned()
+            self._params_barrier()
         else:
             self._encode_vision_x(vision_x=vision_x)
             self._condition_media_locations(input_ids=lang_x)
@@ -209,10 +210,19 @@ class Flamingo(nn.Module):
         with torch.no_grad():
             tok = ve(vision_x.reshape(b * T * Fr, *vision_x.shape[3:]))[1]
         ve.output_tokens = prev
+        self._params_barrier()            # everything above ran on frozen weights; from here on trainable parameters are read
         tok = tok.reshape(b, T, Fr, tok.shape[1], tok.shape[2])
         vis = self.perceiver(tok)
         for layer in self._layers():
             layer.condition_vis_x(vis)
+
+    def _params_barrier(self):
+        """train.Trainer(overlap_optimizer=True) runs clip + AdamW on a side stream and leaves its completion event here: the frozen
+        ViT forward above overlaps the update, every reader of a trainable parameter comes after this wait (stream-ordered, no host block)"""
+        ev = getattr(self, "_params_ready", None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+            self._params_ready = None
 
     def _condition_media_locations(self, input_ids):
         media_locations = input_ids == self.media_token_id

@@ -59,6 +59,8 @@ def save_checkpoint(path, model, trainer=None, epoch=0, barrier=False, group=Non
         call it**: the owned slices are gathered bucket by bucket, rank 0 keeps the host copy and writes, and a barrier
         closes the call so no rank runs ahead into the next step's collectives."""
     import torch.distributed as dist
+    if trainer is not None:
+        trainer.sync()                                 # an optimizer update on the side stream (overlap_optimizer) lands first
     if group is None and trainer is not None:
         group = trainer.dp.pg                          # the Trainer may run on a subgroup: WORLD would wait for ranks that never call
     rank0 = not dist.is_initialized() or dist.get_rank(group) == 0
@@ -181,7 +183,7 @@ class Trainer:
     def __init__(self, model, special_ids, lr=2e-4, weight_decay=0.1, gamma=2.0, use_reweight=True, max_grad_norm=1.0,
                  lr_scheduler="cosine", warmup_steps=0, total_steps=1000, bucket_bytes=256 << 20, process_group=None,
                  sparse_head=False, grad_accum=1, mask_lm_head=False, force_dp_hooks=False, dense_head_backward=False,
-                 shard_optimizer=False, direct_wgrad=True, graph=False, fuse_accum=None, packed=None):
+                 shard_optimizer=False, direct_wgrad=True, graph=False, fuse_accum=None, packed=None, overlap_optimizer=False):
         """packed (None: the UNIMP_PACKED environment default, off): packed token order in the language tower -- LayerNorm and the
         QKV / out / MLP / gated feed-forward projections run on the VALID tokens only ([1, M, H], M = the valid count rounded up to 2048
         rows), the attention kernels take the sequences as row ranges of the packed buffers (functional.Pack, include/unimp_hip.h
@@ -204,6 +206,13 @@ class Trainer:
         ``pending`` goes NaN instead of being silently skewed); the GA-th call runs the fused pass and returns its loss.  Micro-batches of
         different lengths are right-padded.  When the loader ends inside a group, call ``flush()`` (accelerate steps at the end of
         the dataloader: ``sync_with_dataloader``) -- otherwise the buffered micro-batches would join the next epoch's first group.
+        overlap_optimizer (off by default): clip + AdamW (HBM-bound: 28 B per trainable parameter, 7.3 ms at cfg2) run on a SECOND stream
+        and the next step's forward starts at once on the main stream -- the ViT is frozen and runs under no_grad, so nothing it reads or
+        writes is touched by the update; ``Flamingo._encode_vision_x`` makes the main stream wait for the update right before the
+        Perceiver, the first reader of a trainable parameter (``model._params_ready``).  Same kernels, same order per buffer: the
+        parameters equal the serial order's BIT FOR BIT (tests/test_model_gpu.py::test_overlapped_optimizer_equals_serial).  At the
+        reference's b = 3 x GA 2 the update is 8.6 % of the step, at b = 64 about 1 %.  Needs a frozen vision encoder and replicated
+        optimizer state; code that reads parameters or optimizer buffers between steps (checkpoints do it themselves) calls ``sync()``.
         graph (off by default): replay the forward + loss + backward of a micro-batch as ONE HIP graph.  At the reference's
         shipped shape (--batch 3 --grad-accum 2, unimp_task.sh:2-30) a micro-step is ~3 000 launches of kernels that run for
         10-40 us each: the host, not the GPU, sets the pace.  The first micro-step with a given set of batch shapes runs eagerly
@@ -266,9 +275,41 @@ class Trainer:
             self.dp.on_remove = lambda: setattr(ops, "AVOID_PERSISTENT", prev)
         self.sched, self.base_lr, self.warmup, self.total = lr_scheduler, lr, warmup_steps, total_steps
         self.sched_step = 0
+        self.overlap_optimizer, self._opt_stream, self._opt_event = bool(overlap_optimizer), None, None
+        if self.overlap_optimizer:
+            ve = getattr(model, "vision_encoder", None)
+            if ve is None or any(p.requires_grad for p in ve.parameters()):
+                raise ValueError("Trainer(overlap_optimizer=True) needs a frozen vision encoder (the forward that runs beside the update)")
+            if shard is not None or graph:
+                raise ValueError("Trainer(overlap_optimizer=True) is not combined with shard_optimizer (its step issues collectives) or graph")
         # the weight-gradient GEMMs add straight into the flat gradient buffer (functional.WGRAD_SINK); under data parallelism
         # the sink plays the post-accumulate hook for the bucketer
         self._sink = _WgradSink(self.opt, exclude=late, dp=self.dp if self.dp.active else None) if direct_wgrad else None
+
+    def _opt_step(self, gscale):
+        """clip + AdamW; with overlap_optimizer on a side stream behind everything queued so far (backward, the gradient exchange)"""
+        lr = self.current_lr()
+        if not (self.overlap_optimizer and self.opt.flat_g.is_cuda):
+            self.opt.step(lr=lr, grad_scale=gscale)
+            return
+        if self._opt_stream is None:
+            self._opt_stream = torch.cuda.Stream()
+        main = torch.cuda.current_stream()
+        self._opt_stream.wait_stream(main)
+        with torch.cuda.stream(self._opt_stream):
+            self.opt.step(lr=lr, grad_scale=gscale)
+            ev = torch.cuda.Event()
+            ev.record(self._opt_stream)
+        self._opt_event = ev
+        self.model._params_ready = ev          # consumed by Flamingo._params_barrier (before the first trainable parameter is read)
+
+    def sync(self):
+        """make the current stream wait for an optimizer update still running on the side stream (overlap_optimizer): call before reading
+        parameters, gradients or optimizer buffers outside ``step()``"""
+        if self._opt_event is not None:
+            torch.cuda.current_stream().wait_event(self._opt_event)
+            self._opt_event = None
+            self.model._params_ready = None
 
     def close(self):
         """detach from the process: gradient hooks removed, ops.AVOID_PERSISTENT restored (a later single-rank Trainer in the same
@@ -315,7 +356,7 @@ class Trainer:
         loss, stats = self._micro_step(self._fused_batch(batches))
         self._mask_lm_head_grads()
         gscale = self.dp.finish() * scale
-        self.opt.step(lr=self.current_lr(), grad_scale=gscale)
+        self._opt_step(gscale)
         self.sched_step += 1
         self._last = (loss, stats)
         return StepOut(loss, stats)
@@ -349,9 +390,10 @@ class Trainer:
         if k == 0:
             return None
         self._mask_lm_head_grads()
+        self.sync()
         gscale = self.dp.finish() / (self.grad_accum if mean_over == "ga" else k)
         self.dp.sync = True
-        self.opt.step(lr=self.current_lr(), grad_scale=gscale)
+        self._opt_step(gscale)
         self.sched_step += 1
         self._micro = 0
         return StepOut(*self._last) if self._last is not None else None
@@ -480,12 +522,12 @@ class Trainer:
                 self._mask_lm_head_grads()
                 gscale = self.dp.finish() / self.grad_accum
                 self.dp.sync = True
-                self.opt.step(lr=self.current_lr(), grad_scale=gscale)
+                self._opt_step(gscale)
                 self.sched_step += 1
             return StepOut(loss, stats)
         loss, stats = micro(batch)
         self._mask_lm_head_grads()
         gscale = self.dp.finish()
-        self.opt.step(lr=self.current_lr(), grad_scale=gscale)
+        self._opt_step(gscale)
         self.sched_step += 1
         return StepOut(loss, stats)
