@@ -141,7 +141,8 @@ def test_gemm_persistent_many_tiles_per_workgroup(ops, pv):
 
 @pytest.mark.parametrize("M,N,K", [(256 * 5 + 40, 256 * 3 + 136, 64 * 21), (1024, 2560, 2560), (2048, 768, 64 * 37), (512, 512, 128), (300, 264, 192)])
 @pytest.mark.parametrize("b_ks", [False, True])
-def test_gemm_w4x_equals_pingpong_bit_for_bit(ops, M, N, K, b_ks):
+@pytest.mark.parametrize("w4x", ["w4x", "w4x_s1"])
+def test_gemm_w4x_equals_pingpong_bit_for_bit(ops, M, N, K, b_ks, w4x):
     """gemm7.hip (variant w4x, round 5): one wave per SIMD, 128 x 128 per wave, 64-k stages, every instruction of the main loop placed by hand
     (two fragment register sets, LDS-DMA two stages ahead, two barriers per 128 MFMAs).  Same k grouping inside every MFMA and the same k
     order per accumulator as the ping-pong kernels, same epilogue code: the results must be the ping-pong kernel's BIT FOR BIT under every
@@ -160,21 +161,21 @@ def test_gemm_w4x_equals_pingpong_bit_for_bit(ops, M, N, K, b_ks):
     for kw in kws:
         want = ops.gemm(ad, bd, b_ks=b_ks, variant="pp256", **kw)
         for _ in range(3):
-            got = ops.gemm(ad, bd, b_ks=b_ks, variant="w4x", **kw)
-            assert torch.equal(got, want), f"w4x != pp256 for {sorted(kw)} ({int((got != want).sum())} elements)"
-    close(ops.gemm(ad, bd, b_ks=b_ks, variant="w4x"), a.float() @ b.float().t(), name="w4x vs fp32")
+            got = ops.gemm(ad, bd, b_ks=b_ks, variant=w4x, **kw)
+            assert torch.equal(got, want), f"{w4x} != pp256 for {sorted(kw)} ({int((got != want).sum())} elements)"
+    close(ops.gemm(ad, bd, b_ks=b_ks, variant=w4x), a.float() @ b.float().t(), name="w4x vs fp32")
     if N % 8 == 0:
         pre_w = torch.empty(M, N, dtype=torch.uint8, device="cuda"); pre_g = torch.empty_like(pre_w)
         want = ops.gemm(ad, bd, b_ks=b_ks, variant="pp256", bias=biasd, act="gelu", pre=pre_w, pre_deriv=True)
-        got = ops.gemm(ad, bd, b_ks=b_ks, variant="w4x", bias=biasd, act="gelu", pre=pre_g, pre_deriv=True)
+        got = ops.gemm(ad, bd, b_ks=b_ks, variant=w4x, bias=biasd, act="gelu", pre=pre_g, pre_deriv=True)
         assert torch.equal(got, want) and torch.equal(pre_g, pre_w)
         acc_w = ops.gemm(ad, bd, b_ks=b_ks, variant="pp256").clone(); acc_g = acc_w.clone()
         ops.gemm(ad, bd, b_ks=b_ks, variant="pp256", out=acc_w, accumulate=True)
-        ops.gemm(ad, bd, b_ks=b_ks, variant="w4x", out=acc_g, accumulate=True)
+        ops.gemm(ad, bd, b_ks=b_ks, variant=w4x, out=acc_g, accumulate=True)
         assert torch.equal(acc_g, acc_w)
     if M % 8 == 0:
         with pytest.raises(Exception):                                   # a k-strided A is refused (UNIMP_ERR_UNSUPPORTED), not mis-served
-            ops.gemm(ad.t().contiguous(), bd, a_ks=True, b_ks=b_ks, variant="w4x")
+            ops.gemm(ad.t().contiguous(), bd, a_ks=True, b_ks=b_ks, variant=w4x)
 
 
 def test_gemm_w4x_rotary_epilogue_equals_pingpong(ops):
@@ -816,7 +817,7 @@ def _adjacent_perm(hd, rot):
     return torch.where(p < rot, d, p)
 
 
-@pytest.mark.parametrize("variant", ["pp256", "pp256p", "pp256x", "pp256px", "pp256a"])
+@pytest.mark.parametrize("variant", ["pp256", "pp256p", "pp256x", "pp256px", "pp256a", "w4x"])
 @pytest.mark.parametrize("nh,hd,rot,interleaved,L", [(4, 80, 80, True, 200), (6, 64, 16, True, 128), (3, 128, 128, False, 300),
                                                      (4, 80, 80, True, 2304), (2, 128, 128, False, 4100)])      # positions >= 2048
 def test_gemm_rotary_epilogue(ops, variant, nh, hd, rot, interleaved, L):

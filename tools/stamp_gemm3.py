@@ -30,7 +30,7 @@ torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(); ops.gemm(x, w, **kw); e1.record(); torch.cuda.synchronize()
 buf = np.zeros(8192 * 12, dtype=np.uint64)
-fn = _lib.lib().unimp_debug_g3x_stamps if variant.endswith("x") else _lib.lib().unimp_debug_g3_stamps
+fn = getattr(_lib.lib(), {"x": "unimp_debug_g3x_stamps", "a": "unimp_debug_g3a_stamps", "b": "unimp_debug_g3b_stamps"}.get(variant[-1], "unimp_debug_g3_stamps"))
 rc = fn(ctypes.c_void_p(buf.ctypes.data))
 nb = min(8192, ((M + 255) // 256) * ((N + 255) // 256))
 t = buf.reshape(8192, 12)[:nb].astype(np.int64)

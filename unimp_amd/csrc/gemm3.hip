@@ -29,15 +29,7 @@
 #include <stdlib.h>
 #include "gemm_half.h"
 
-#if defined(G3X) && defined(G3_AFULL) && defined(G3_PEEL)   // fourth build (Makefile: gemm3b.o): gemm3a with the K loop's tail peeled off (no branch in a steady-state half-step)
-#define gemm3_bf16_kernel gemm3b_bf16_kernel
-#define unimp_gemm3_launch unimp_gemm3b_launch
-#define unimp_gemm3_launch_splitk unimp_gemm3b_launch_splitk
-#define launch3 launch3b
-#define g3_stamps g3b_stamps
-#define unimp_debug_g3_stamps unimp_debug_g3b_stamps
-#define getenv_no_fixed getenv_no_fixed_b
-#elif defined(G3X) && defined(G3_AFULL)   // third build (Makefile: gemm3a.o): the one-set schedule with the A operand staged in whole 128-byte rows
+#if defined(G3X) && defined(G3_AFULL)   // third build (Makefile: gemm3a.o): the one-set schedule with the A operand staged in whole 128-byte rows
 #define gemm3_bf16_kernel gemm3a_bf16_kernel
 #define unimp_gemm3_launch unimp_gemm3a_launch
 #define unimp_gemm3_launch_splitk unimp_gemm3a_launch_splitk
@@ -243,8 +235,9 @@ static_assert(G3_NST == 4, "the one-set schedule is written for a prefetch dista
     G3_BARRIER();
     G3_T(1);
     if (wm == 1) G3_BARRIER();
-#ifdef G3_PEEL
-    // Round 5: the same half-steps with the K tail PEELED: HALF_STEP_AF decides per half-step whether to issue the A / B DMA and which of
+#ifndef G3_NO_PEEL
+    // Round 5: the same half-steps with the K tail PEELED (-DG3_NO_PEEL restores round 4's loop for A/B; profiles/r05_gemm_ab_peel_w4x.txt:
+    // +5 ... 10 % with a k-strided B, +1 ... 3.5 % with a k-contiguous one, same bits): HALF_STEP_AF decides per half-step whether to issue the A / B DMA and which of
     // four vmcnt counts applies -- eight scalar branches in every L phase (ISA of round 4), the phase that sets the pace of the ping-pong.
     // Steady state (h <= nh - 6) has no decision left; the last four half-steps are written out with their constants.  dma_full: K % 64 == 0
     // here, so the ragged-k path of dma_issue (and its branch) is not compiled in.  Same instructions otherwise: same bits.
@@ -291,9 +284,29 @@ static_assert(G3_NST == 4, "the one-set schedule is written for a prefetch dista
 #endif
   G3_T(1);
   if (wm == 1) G3_BARRIER();                            // group B runs one phase behind group A
-  for (int h = 0; h < nh; h += 2) {
-    HALF_STEP(h, 0, 1);
-    if (h + 1 < nh) HALF_STEP(h + 1, 1, 0);
+  {
+    int h = 0;
+#if defined(G3_ONESET) && !defined(G3_NO_PEEL)
+    // Round 5, as in the whole-row-A path: the steady state without its per-half-step decisions.  While h + PD + 2 < nh both half-steps
+    // of a trip prefetch a half-step that is neither beyond K nor the (possibly ragged) last one: dma_full, one vmcnt constant, no branch.
+    // The weight-gradient GEMMs (both operands k-strided, K = all tokens) spend their whole K loop here.
+    if constexpr (!BPK) {
+#define DMA_F(H) do { char* b_ = smem + ((H) % G3_NST) * SUB;                                                        \
+      dma_full<AKS, G3_BM>(p.A, p.lda, (H), b_, wave, aoff); dma_full<BKS, BN>(p.B, p.ldb, (H), b_ + A_SUB, wave, boff); } while (0)
+#pragma unroll 1
+      for (; h + PD + 2 < nh; h += 2) {
+        LOADF(0, h); DMA_F(h + PD); asm volatile("s_waitcnt vmcnt(%0)" :: "n"((PD - 1) * NEW) : "memory");
+        G3_BARRIER(); MFMAS(0); G3_BARRIER();
+        LOADF(0, h + 1); DMA_F(h + 1 + PD); asm volatile("s_waitcnt vmcnt(%0)" :: "n"((PD - 1) * NEW) : "memory");
+        G3_BARRIER(); MFMAS(0); G3_BARRIER();
+      }
+#undef DMA_F
+    }
+#endif
+    for (; h < nh; h += 2) {
+      HALF_STEP(h, 0, 1);
+      if (h + 1 < nh) HALF_STEP(h + 1, 1, 0);
+    }
   }
   if (wm == 0) G3_BARRIER();                            // equalise the barrier count; all LDS reads are complete
   G3_T(2);

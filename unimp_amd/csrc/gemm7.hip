@@ -75,6 +75,20 @@ __device__ __forceinline__ void g7_dma(const void* sbase, uint32_t voff, uint32_
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
 #endif
 }
+// schedule 2: an MFMA and the LDS-DMA that rides in its gap as ONE statement -- M0 (the DMA's LDS destination = wave base + immediate) is
+// written before the MFMA, which then is the wait state the DMA needs after an M0 write: one SALU + one VMEM per DMA, like a ds_read gap
+template <int IMM>
+__device__ __forceinline__ void g7_mfma_dma(f32x4& c, bf16x8 b, bf16x8 a, uint32_t m0base, const void* sbase, uint32_t voff) {
+  asm volatile("s_add_u32 m0, %3, %4\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\tglobal_load_lds_dwordx4 %5, %6"
+               : "+a"(c) : "v"(b), "v"(a), "s"(m0base), "n"(IMM), "v"(voff), "s"(sbase) : "memory", "m0", "scc");
+}
+__device__ __forceinline__ void g7_xor_stage(uint32_t& x) { asm volatile("v_xor_b32 %0, 0x10000, %0" : "+v"(x)); }
+#ifndef G7_SCHED
+#define G7_SCHED 2
+#endif
+#ifndef G7_PF
+#define G7_PF 0
+#endif
 #define G7_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define G7_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory")
 #define G7_BAR() asm volatile("s_barrier" ::: "memory")
@@ -136,6 +150,33 @@ __global__ __launch_bounds__(256, 1) void gemm7_bf16_kernel(Gemm2Params p) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) vbs[j] = smem_lds + G7_ASUB + (lb ^ ((uint32_t)j << 5));
   }
+#if G7_PF > 0
+  // ---- L2 prefetch (measurement knob G7_PF = lead in stages beyond the DMA's two): the 8 workgroups that share an A panel (same tile row,
+  // consecutive in the XCD's raster) and the 4 that share a B panel run the same k at about the same time, so a line's first request is a
+  // fabric miss that all of them wait on.  Here each workgroup touches ITS SHARE of the two panels' lines G7_PF stages before anybody's
+  // DMA asks for them (one byte per 128-byte line, ONE instruction per wave and stage, result never read): 1/8 of the A stage (32 rows)
+  // and 1/4 of the B stage (64 lines), split over the 4 waves -- lanes 0..7 A rows, lanes 8..23 B lines, the rest repeat lane 0.
+  uint64_t pfaddr; uint32_t pfstride; uint32_t pfdummy = 0;
+  {
+    const int ga = tn & 7, gb = tm & 3;
+    // opaque scalar copies of everything uniform that goes into the per-lane address: the selects below must not become THE values the DMA
+    // statements' "s" operands are built from (hipcc then hands those a VGPR pair: "invalid operand for instruction")
+    uint64_t bA = (uint64_t)(uintptr_t)p.A, bB = (uint64_t)(uintptr_t)p.B;
+    uint32_t ldb2 = (uint32_t)(p.ldb * 2), lda2 = (uint32_t)(p.lda * 2);
+    asm volatile("" : "+s"(bA), "+s"(bB), "+s"(ldb2), "+s"(lda2));
+    const bool isB = lane >= 8 && lane < 24;
+    const int li = 64 * gb + 16 * wave + ((lane - 8) & 15);                      // B line of this lane (0 .. 255)
+    const int rowA = min(m0 + 32 * ga + 8 * wave + (lane & 7), p.M - 1);
+    const uint64_t offA = (uint64_t)rowA * lda2 + 256;                             // tile 2 is the first one nobody has requested yet
+    const uint64_t offB = BKS ? (uint64_t)(li >> 2) * ldb2 + (uint64_t)min(n0 + (li & 3) * 64, ((p.N + 7) & ~7) - 8) * 2 + (uint64_t)128 * ldb2
+                              : (uint64_t)min(n0 + li, p.N - 1) * ldb2 + 256;
+    pfaddr = isB ? bB + offB : bA + offA;
+    pfstride = isB ? (BKS ? 64u * ldb2 : 128u) : 128u;
+  }
+// the destination register stays RESERVED from the first prefetch to the vmcnt(0) of the second-to-last iteration ("+v" here, a use after
+// the loop): the byte lands a microsecond after the statement, in a register the compiler would otherwise hand to a fragment
+#define G7_PF_ISSUE() do { asm volatile("global_load_ubyte %0, %1, off" : "+v"(pfdummy) : "v"(pfaddr) : "memory"); } while (0)
+#endif
   // rider R of the 24 (k-strided B) / 16 (k-contiguous B) fragment reads of k-half KH into set F: B first (block KH needs all of B at once)
 #define G7_RD_A(F, KH, I) g7_read128<(I) * 2048>(fa##F[I], (KH) ? va1 : va0)
 #define G7_RD_BC(F, KH, J) g7_read128<(J) * 2048>(fb##F[J], (KH) ? vb1 : vb0)
@@ -151,7 +192,12 @@ __global__ __launch_bounds__(256, 1) void gemm7_bf16_kernel(Gemm2Params p) {
     G7_DMA(T, S_, 13); G7_DMA(T, S_, 14); G7_DMA(T, S_, 15); } while (0)
   G7_DMA_ALL(0, 0);
   G7_DMA_ALL(1, 1);
-  G7_WAIT_VM(16);
+#if G7_PF > 0
+  int pf_tile = 2;                                   // next tile to prefetch; never beyond the last one (the address stops advancing)
+#pragma unroll
+  for (int i = 0; i < G7_PF; ++i) { G7_PF_ISSUE(); if (pf_tile + 1 < nt) { pfaddr += pfstride; ++pf_tile; } }
+#endif
+  G7_WAIT_VM(16 + G7_PF);
   G7_BAR();
 #define G7_READ_ALL(F, KH) do {                                                                                             \
     if (BKS) { G7_RD_BSL(F, KH, 0); G7_RD_BSH(F, KH, 0); G7_RD_BSL(F, KH, 1); G7_RD_BSH(F, KH, 1); G7_RD_BSL(F, KH, 2); G7_RD_BSH(F, KH, 2);   \
@@ -177,6 +223,7 @@ __global__ __launch_bounds__(256, 1) void gemm7_bf16_kernel(Gemm2Params p) {
   // gap of read R: k-strided 2 R (0 .. 46); k-contiguous 3 R (0 .. 45)
 #define G7_RD_GAP(R) (BKS ? 2 * (R) : 3 * (R))
 
+#if G7_SCHED == 1
   auto iter = [&](auto mode_c, int t, int s) __attribute__((always_inline)) {
     constexpr int MODE = decltype(mode_c)::value;
     // ---------------- block 0: MFMAs on F0; reads of k-half 1 -> F1; release of stage s; first DMAs of tile t+2
@@ -214,6 +261,69 @@ __global__ __launch_bounds__(256, 1) void gemm7_bf16_kernel(Gemm2Params p) {
     G7_B1_ROW(0); G7_B1_ROW(1); G7_B1_ROW(2); G7_B1_ROW(3); G7_B1_ROW(4); G7_B1_ROW(5); G7_B1_ROW(6); G7_B1_ROW(7);
     if (MODE != 2) G7_WAIT_LGKM0();
   };
+#else
+  // Schedule 2 (the default).  Differences from schedule 1: (a) the A region of stage s is released as soon as the A fragments of k-half 1
+  // are in (barrier at gap 17), the B region at gap 53 -- the A half of tile t+2 is requested ~36 MFMAs earlier; (b) every DMA is fused
+  // with the MFMA it follows (g7_mfma_dma); (c) the stage toggles of the read addresses are riders too (no VALU cluster in one gap);
+  // (d) all 16 DMAs of tile t+2 are out before tile t+1 is waited for: vmcnt(16).
+  //   block 0: A reads (k-half 1) gaps 0,2..14 | gap 17 lgkmcnt(0)+barrier | B reads gaps 18.. | A DMA fused at MFMA 19,21..33 |
+  //            gap 53 lgkmcnt(0)+barrier | B DMA fused at MFMA 54,56..62 | address toggles in the free gaps 49..63
+  //   block 1: B DMA fused at MFMA 0,2,4 | gap 11 vmcnt(16)+barrier | reads of tile t+1 (B then A) from gap 12 | lgkmcnt(0) at the end
+  uint32_t dAs = dA, dBs = dB;                       // DMA destination bases of the stage being refilled (SGPR; toggled per iteration)
+  auto iter = [&](auto mode_c, int t, int s) __attribute__((always_inline)) {
+    constexpr int MODE = decltype(mode_c)::value;
+    const char* srcA = (const char*)p.A + (long)(t + 2) * 128;
+    const char* srcB0 = BKS ? (const char*)p.B + ((long)(2 * (t + 2)) * 32 * p.ldb) * 2 : (const char*)p.B + (long)(t + 2) * 128;
+    const char* srcB1 = BKS ? srcB0 + (long)32 * p.ldb * 2 : srcB0;
+    // MFMA number M of block F (row M / 8, column M % 8), alone or fused with DMA number D of tile t+2 (0..7 A, 8..15 B)
+#define G7_MFD(F, M, D) do { constexpr int D_ = (D) & 15, J_ = (D_ - 8) & 7;                                                         \
+      if (D_ < 8) g7_mfma_dma<D_ * 1024>(acc[(M) / 8][(M) % 8], G7_FB(F, (M) % 8), fa##F[(M) / 8], dAs, srcA, aoff[D_ & 7]);               \
+      else if (!BKS) g7_mfma_dma<J_ * 1024>(acc[(M) / 8][(M) % 8], G7_FB(F, (M) % 8), fa##F[(M) / 8], dBs, srcB0, boff[J_]);              \
+      else g7_mfma_dma<(J_ >> 2) * 16384 + (J_ & 3) * 1024>(acc[(M) / 8][(M) % 8], G7_FB(F, (M) % 8), fa##F[(M) / 8], dBs,                \
+                                                            (J_ >> 2) ? srcB1 : srcB0, boffs[J_ & 3]); } while (0)
+#define G7_XOR_RIDER(X) do { constexpr int X_ = (X);                                                                                 \
+      if (X_ == 0) g7_xor_stage(va0); else if (X_ == 1) g7_xor_stage(va1);                                                           \
+      else if (!BKS) { if (X_ == 2) g7_xor_stage(vb0); else if (X_ == 3) g7_xor_stage(vb1); }                                        \
+      else if (X_ < 10) g7_xor_stage(vbs[(X_ - 2) & 7]); } while (0)
+    // ---- block 0
+#define G7_S2_B0(M) do {                                                                                                             \
+      if (MODE == 0 && (M) >= 19 && (M) <= 33 && ((M) & 1)) G7_MFD(0, M, ((M) - 19) >> 1);                                           \
+      else if (MODE == 0 && (M) >= 54 && ((M) & 1) == 0) G7_MFD(0, M, 8 + (((M) - 54) >> 1));                                        \
+      else G7_MF(0, (M) / 8, (M) % 8);                                                                                               \
+      if ((M) <= 14 && ((M) & 1) == 0) G7_RD_A(1, 1, ((M) >> 1) & 7);                                                               \
+      if ((M) == 17) { G7_WAIT_LGKM0(); if (MODE == 0) G7_BAR(); }                                                                    \
+      if (BKS && (M) >= 18 && (M) <= 48 && ((M) & 1) == 0) { if ((((M) - 18) >> 1) & 1) G7_RD_BSH(1, 1, (((M) - 18) >> 2) & 7); else G7_RD_BSL(1, 1, (((M) - 18) >> 2) & 7); }   \
+      if (!BKS && (M) >= 18 && (M) <= 46 && (((M) - 18) & 3) == 0) G7_RD_BC(1, 1, (((M) - 18) >> 2) & 7);                            \
+      if ((M) == 53) { G7_WAIT_LGKM0(); if (MODE == 0) G7_BAR(); }                                                                    \
+      if (MODE != 2 && (M) >= 49 && (M) <= 52) G7_XOR_RIDER((M) - 49);                                                                \
+      if (MODE != 2 && (M) >= 55 && ((M) & 1)) G7_XOR_RIDER(4 + (((M) - 55) >> 1)); } while (0)
+#define G7_S2_ROW0(I) do { G7_S2_B0((I) * 8 + 0); G7_S2_B0((I) * 8 + 1); G7_S2_B0((I) * 8 + 2); G7_S2_B0((I) * 8 + 3);               \
+                           G7_S2_B0((I) * 8 + 4); G7_S2_B0((I) * 8 + 5); G7_S2_B0((I) * 8 + 6); G7_S2_B0((I) * 8 + 7); } while (0)
+    G7_S2_ROW0(0); G7_S2_ROW0(1); G7_S2_ROW0(2); G7_S2_ROW0(3); G7_S2_ROW0(4); G7_S2_ROW0(5); G7_S2_ROW0(6); G7_S2_ROW0(7);
+    // ---- block 1
+#if G7_PF > 0
+#define G7_PF_RIDER(M) do { if (MODE == 0 && (M) == 13) G7_PF_ISSUE(); } while (0)
+#else
+#define G7_PF_RIDER(M) do {} while (0)
+#endif
+#define G7_S2_B1(M) do {                                                                                                             \
+      if (MODE == 0 && (M) <= 4 && ((M) & 1) == 0) G7_MFD(1, M, 13 + ((M) >> 1));                                                    \
+      else G7_MF(1, (M) / 8, (M) % 8);                                                                                               \
+      if (MODE != 2 && (M) == 1) G7_XOR_RIDER(9);                                                                                     \
+      if ((M) == 11 && MODE != 2) { if (MODE == 0) G7_WAIT_VM(16 + (G7_PF > 0)); else G7_WAIT_VM(0); G7_BAR(); }                      \
+      G7_PF_RIDER(M);                                                                                                                \
+      if (MODE != 2 && BKS && (M) >= 12 && (M) <= 58 && ((M) & 1) == 0) G7_RIDER_RD(0, 0, ((M) - 12) >> 1);                           \
+      if (MODE != 2 && !BKS && (M) >= 12 && (M) <= 57 && ((M) - 12) % 3 == 0) G7_RIDER_RD(0, 0, ((M) - 12) / 3); } while (0)
+#define G7_S2_ROW1(I) do { G7_S2_B1((I) * 8 + 0); G7_S2_B1((I) * 8 + 1); G7_S2_B1((I) * 8 + 2); G7_S2_B1((I) * 8 + 3);               \
+                           G7_S2_B1((I) * 8 + 4); G7_S2_B1((I) * 8 + 5); G7_S2_B1((I) * 8 + 6); G7_S2_B1((I) * 8 + 7); } while (0)
+    G7_S2_ROW1(0); G7_S2_ROW1(1); G7_S2_ROW1(2); G7_S2_ROW1(3); G7_S2_ROW1(4); G7_S2_ROW1(5); G7_S2_ROW1(6); G7_S2_ROW1(7);
+    if (MODE != 2) G7_WAIT_LGKM0();
+    dAs ^= G7_STG; dBs ^= G7_STG;                    // the next iteration refills the other stage
+#if G7_PF > 0
+    if (MODE == 0 && pf_tile + 1 < nt) { pfaddr += pfstride; ++pf_tile; }
+#endif
+  };
+#endif
   // NOTE on the address toggle above: block 0's reads (k-half 1 of tile t) use the addresses of stage s, block 1's (k-half 0 of tile
   // t+1) those of stage s ^ 1 -- the XOR sits between the two blocks, after the last read of block 0 has been issued (gap <= 46).
   {
@@ -223,6 +333,9 @@ __global__ __launch_bounds__(256, 1) void gemm7_bf16_kernel(Gemm2Params p) {
     iter(std::integral_constant<int, 1>{}, t, t & 1);
     iter(std::integral_constant<int, 2>{}, t + 1, (t + 1) & 1);
   }
+#if G7_PF > 0
+  asm volatile("" :: "v"(pfdummy));                  // end of the prefetch register's reservation (every prefetch has landed: vmcnt(0) above)
+#endif
   // asm MFMAs are opaque to the hazard recogniser: wait out the last results before anything reads an accumulator
 #define G7_SETTLE(I) asm volatile("s_nop 7" : "+a"(acc[I][0]), "+a"(acc[I][1]), "+a"(acc[I][2]), "+a"(acc[I][3]),    \
                                               "+a"(acc[I][4]), "+a"(acc[I][5]), "+a"(acc[I][6]), "+a"(acc[I][7]))
