@@ -4,7 +4,7 @@ cd $GRAFT_REPO_ROOT
 O=gpurun_out/r5c; mkdir -p $O
 timeout 1200 python -m pytest tests/test_kernels_gpu.py -m gpu -q -x -k "gemm" > $O/pytest_gemm.log 2>&1; echo "pytest_gemm rc=$?" >> $O/rc.txt
 tail -4 $O/pytest_gemm.log
-timeout 1200 python tools/bench_gemm_ab.py 3 pp256a,pp256x,w4x,w4x_pf > $O/gemm_ab.log 2>&1; echo "gemm_ab rc=$?" >> $O/rc.txt
+timeout 1200 python tools/bench_gemm_ab.py 3 pp256a,pp256b,pp256x,w4x,w4x_pf > $O/gemm_ab.log 2>&1; echo "gemm_ab rc=$?" >> $O/rc.txt
 cat $O/gemm_ab.log
 ROUND=r05 bash tools/gpu/final.sh tune > $O/tune.log 2>&1; echo "tune rc=$?" >> $O/rc.txt
 tail -15 $O/tune.log

@@ -29,7 +29,15 @@
 #include <stdlib.h>
 #include "gemm_half.h"
 
-#if defined(G3X) && defined(G3_AFULL)   // third build (Makefile: gemm3a.o): the one-set schedule with the A operand staged in whole 128-byte rows
+#if defined(G3X) && defined(G3_AFULL) && defined(G3_FUSE)   // A/B build (Makefile: gemm3b.o): gemm3a with the steady-state L phase spelled in asm, M0 writes fused
+#define gemm3_bf16_kernel gemm3b_bf16_kernel
+#define unimp_gemm3_launch unimp_gemm3b_launch
+#define unimp_gemm3_launch_splitk unimp_gemm3b_launch_splitk
+#define launch3 launch3b
+#define g3_stamps g3b_stamps
+#define unimp_debug_g3_stamps unimp_debug_g3b_stamps
+#define getenv_no_fixed getenv_no_fixed_b
+#elif defined(G3X) && defined(G3_AFULL)   // third build (Makefile: gemm3a.o): the one-set schedule with the A operand staged in whole 128-byte rows
 #define gemm3_bf16_kernel gemm3a_bf16_kernel
 #define unimp_gemm3_launch unimp_gemm3a_launch
 #define unimp_gemm3_launch_splitk unimp_gemm3a_launch_splitk
@@ -251,10 +259,46 @@ static_assert(G3_NST == 4, "the one-set schedule is written for a prefetch dista
       G3_BARRIER();                                                                                                \
       MFMAS(0);                                                                                                    \
       G3_BARRIER(); } while (0)
+#ifdef G3_FUSE
+    // Steady-state L phase with every instruction placed: the fragment reads are asm statements too, and each LDS-DMA's destination goes
+    // into M0 with ONE scalar add whose wait state is the fragment read that follows it (glds16_s spends s_add + s_mov + s_nop per DMA):
+    //   even half-step: B reads | [M0, A read, DMA] x 4 (A stage) | [M0, A read, DMA] x NB (B half-stage) | remaining A reads
+    //   odd  half-step: B reads | [M0, A read, DMA] x NB | remaining A reads
+#define M0_SET(BASE, IMM) asm volatile("s_add_u32 m0, %0, %1" :: "s"(BASE), "n"(IMM) : "m0", "scc")
+#define DMA_M0(SB, VOFF) asm volatile("global_load_lds_dwordx4 %0, %1" :: "v"(VOFF), "s"(SB) : "memory")
+#define RD_A(I) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ra0[I]) : "v"(va_), "n"((I) * 2048) : "memory")
+#define RD_B_ALL(H) do { uint32_t ubb_ = smem_lds + A_RING + ((H) % 4) * B_SUB;                                     \
+      if (BKS) { _Pragma("unroll") for (int j = 0; j < NJ; ++j) frag_ks32_asm<BN>(lbB + ubb_, j, lb0[j], hb0[j]); }  \
+      else { uint32_t vb_ = ubb_ + kc32_off(wn * WN + (lane & 15), lane >> 4);                                       \
+        _Pragma("unroll") for (int j = 0; j < NJ; ++j) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(rb0[j]) : "v"(vb_), "n"(j * 1024) : "memory"); } } while (0)
+    static_assert(NJ <= 4 && NB <= 2, "rider slots below");
+#define HS_FUSE(H, DOA) do {                                                                                         \
+      const uint32_t va_ = smem_lds + (((H) >> 1) % 3) * A_STG + (a_lane ^ (((H) & 1) << 6));                        \
+      RD_B_ALL(H);                                                                                                   \
+      if (DOA) {                                                                                                     \
+        const char* ua_ = (const char*)p.A + (long)(((H) >> 1) + 2) * 128;                                           \
+        const uint32_t da_ = __builtin_amdgcn_readfirstlane(a_dst0 + ((((H) >> 1) + 2) % 3) * A_STG);                 \
+        M0_SET(da_, 0); RD_A(0); DMA_M0(ua_, aoffF[0]); M0_SET(da_, 1024); RD_A(1); DMA_M0(ua_, aoffF[1]);            \
+        M0_SET(da_, 2048); RD_A(2); DMA_M0(ua_, aoffF[2]); M0_SET(da_, 3072); RD_A(3); DMA_M0(ua_, aoffF[3]);         \
+      } else { RD_A(0); RD_A(1); RD_A(2); RD_A(3); }                                                                 \
+      { const char* ub_ = (const char*)p.B + (BKS ? (long)((H) + 3) * 32 * p.ldb * 2 : (long)((H) + 3) * 64);        \
+        const uint32_t db_ = __builtin_amdgcn_readfirstlane(smem_lds + A_RING + (((H) + 3) % 4) * B_SUB + wave * NB * 1024);   \
+        M0_SET(db_, 0); RD_A(4); DMA_M0(ub_, boff[0]);                                                               \
+        if (NB > 1) { M0_SET(db_, 1024); RD_A(5); DMA_M0(ub_, boff[NB > 1 ? 1 : 0]); } else RD_A(5); }                \
+      RD_A(6); RD_A(7);                                                                                              \
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NFULL) : "memory");                                                  \
+      G3_BARRIER();                                                                                                  \
+      MFMAS(0);                                                                                                      \
+      G3_BARRIER(); } while (0)
+#endif
     {
       int h = 0;
 #pragma unroll 1
+#ifdef G3_FUSE
+      for (; h + 6 <= nh; h += 2) { HS_FUSE(h, true); HS_FUSE(h + 1, false); }
+#else
       for (; h + 6 <= nh; h += 2) { HS_AF(h, true, true, NFULL); HS_AF(h + 1, false, true, NFULL); }
+#endif
       HS_AF(h, false, true, 2 * NB); HS_AF(h + 1, false, false, NB); HS_AF(h + 2, false, false, 0); HS_AF(h + 3, false, false, 0);
     }
 #undef HS_AF
