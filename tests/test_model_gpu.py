@@ -648,7 +648,7 @@ def test_fp8_loss_curve_tracks_bf16(P, monkeypatch):
     the gradients that flow back through them by a few per cent per step.  Asserted: both curves fall, the fp8 curve stays within
     10 % of the bf16 curve at every step (measured: <= 2.6 %), and the mean loss of the last 8 steps agrees within 5 % (measured 0.2 %).
     Round 4: the run stops at step 48.  At this learning rate the toy model's training goes unstable near step 58 in BOTH precisions
-    (bf16: 3.70 then 21.70 at steps 58 / 59, fp8: 29.97 / 22.29 -- tools/scratch/fp8curve.py); which step the spike lands on moves with
+    (bf16: 3.70 then 21.70 at steps 58 / 59, fp8: 29.97 / 22.29 -- tools/fp8curve.py); which step the spike lands on moves with
     any bit-level change, and a spike one step apart read as a 7 x "gap" under the old 60-step bound.  That is the optimizer's chaos,
     not the fp8 path; the cfg5-width run against a measured chaos floor is test_widths_gpu.py::test_cfg5_width_fp8_loss_curve_...."""
     from unimp_amd import functional as F_

@@ -284,7 +284,7 @@ def test_cfg5_width_fp8_loss_curve_against_the_chaos_floor(P, monkeypatch):
     """the fp8 loss-curve test at cfg5's WIDTH (MPT-7B dims, 2 of 32 blocks, one gated block, L = 1024) instead of
     the toy tower, with bounds read off a measured noise floor instead of a flat 25 %.  Three 16-step runs from identical weights, a FRESH
     batch every step (at this width the model memorises a b = 1 batch in one visit: a cycled pool's loss is 0.000 from the second pass on,
-    tools/scratch/fp8curve_cfg5.py): bf16 (A), bf16 with ONE trainable weight moved by one bf16 ulp (B: how far two bf16 runs part by
+    tools/fp8curve_cfg5.py): bf16 (A), bf16 with ONE trainable weight moved by one bf16 ulp (B: how far two bf16 runs part by
     themselves -- the chaos floor, measured 5e-4), fp8 frozen towers (C).  The fp8 effect is NOT chaos: it perturbs every step's forward
     by the e4m3 error (logits 1.1e-1 rel-L2 at this width, test_cfg5_fp8_vs_error_model), which moves a 74 k-way focal loss by 0.1-1.8 %
     per step (measured).  Asserted: step 0 (same weights) within 0.5 %; every step within 4 %; mean gap within 2 %; and the floor itself

@@ -1,7 +1,7 @@
 """A/B of the ViT attention forward forms (UNIMP_ATTN_VIT = 0 | 3 | 5 | 9, read once per process): time at the step's shape
 (512 images x 16 heads x 257 x 64) and error against an fp32 softmax on a small batch."""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from unimp_amd import ops
 torch.manual_seed(0)
 bf = torch.bfloat16

@@ -1,5 +1,5 @@
 import sys, os, torch
-R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import _parity as P
 from unimp_amd import functional as F_
 from unimp_amd.train import Trainer

@@ -1,6 +1,6 @@
 """scratch: bf16 / nudged bf16 / fp8 loss curves at cfg5's width (the data behind test_cfg5_width_fp8_loss_curve_against_the_chaos_floor)"""
 import sys, os, torch
-R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import _parity as P
 from unimp_amd import functional as F_
 from unimp_amd.train import Trainer

@@ -1,6 +1,6 @@
 """host time of one optimizer step at the reference's shape (b = 3 x GA 2, fused) vs its device time: is the step launch-bound?"""
 import os, sys, time, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from unimp_amd.synthetic import make_batch
 from unimp_amd.train import Trainer
