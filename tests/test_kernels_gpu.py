@@ -88,7 +88,7 @@ def test_gemm_layouts(ops, M, N, K, a_ks, b_ks):
     bd = (b.t().contiguous() if b_ks else b).cuda()
     got = ops.gemm(ad, bd, a_ks=a_ks, b_ks=b_ks)                  # autotuned choice
     close(got, want, name=f"gemm {M}x{N}x{K} {a_ks}{b_ks}")
-    w4x = ["w4x"] if (not a_ks and K % 64 == 0 and K >= 128) else []         # gemm7.hip: k-contiguous A, whole 64-k stages
+    w4x = ["w4x"] if ((not a_ks or b_ks) and K % 64 == 0 and K >= 128) else []         # gemm7.hip: whole 64-k stages; a k-strided A only with a k-strided B (dW form)
     for variant in (["v1"] if M < 256 else ["v1", "dma256", "dma128", "pp256", "pp128", "w4", "w8", "pp256p", "pp256x", "pp128x", "pp256px", "pp256a", "pp128a"] + w4x):   # every kernel, explicitly
         got = ops.gemm(ad, bd, a_ks=a_ks, b_ks=b_ks, variant=variant)
         close(got, want, name=f"gemm[{variant}] {M}x{N}x{K} {a_ks}{b_ks}")
@@ -141,7 +141,7 @@ def test_gemm_persistent_many_tiles_per_workgroup(ops, pv):
 
 @pytest.mark.parametrize("M,N,K", [(256 * 5 + 40, 256 * 3 + 136, 64 * 21), (1024, 2560, 2560), (2048, 768, 64 * 37), (512, 512, 128), (300, 264, 192)])
 @pytest.mark.parametrize("b_ks", [False, True])
-@pytest.mark.parametrize("w4x", ["w4x", "w4x_s1"])
+@pytest.mark.parametrize("w4x", ["w4x", "w4x_s1", "w4x_pf", "pp256b"])
 def test_gemm_w4x_equals_pingpong_bit_for_bit(ops, M, N, K, b_ks, w4x):
     """gemm7.hip (variant w4x, round 5): one wave per SIMD, 128 x 128 per wave, 64-k stages, every instruction of the main loop placed by hand
     (two fragment register sets, LDS-DMA two stages ahead, two barriers per 128 MFMAs).  Same k grouping inside every MFMA and the same k
@@ -173,9 +173,21 @@ def test_gemm_w4x_equals_pingpong_bit_for_bit(ops, M, N, K, b_ks, w4x):
         ops.gemm(ad, bd, b_ks=b_ks, variant="pp256", out=acc_w, accumulate=True)
         ops.gemm(ad, bd, b_ks=b_ks, variant=w4x, out=acc_g, accumulate=True)
         assert torch.equal(acc_g, acc_w)
-    if M % 8 == 0:
-        with pytest.raises(Exception):                                   # a k-strided A is refused (UNIMP_ERR_UNSUPPORTED), not mis-served
-            ops.gemm(ad.t().contiguous(), bd, a_ks=True, b_ks=b_ks, variant=w4x)
+    if M % 8 == 0 and not b_ks and w4x != "pp256b":
+        with pytest.raises(Exception):                                   # k-strided A with a k-contiguous B is refused (UNIMP_ERR_UNSUPPORTED), not mis-served
+            ops.gemm(ad.t().contiguous(), bd, a_ks=True, b_ks=False, variant=w4x)
+    if M % 8 == 0 and N % 8 == 0 and b_ks and w4x == "w4x":                # the weight-gradient form: both operands k-strided
+        at = ad.t().contiguous()
+        for kw in (dict(), dict(gate=gate), dict(alpha=0.125), dict(out_f32=True)):
+            want = ops.gemm(at, bd, a_ks=True, b_ks=True, variant="pp256", **kw)
+            for _ in range(3):
+                got = ops.gemm(at, bd, a_ks=True, b_ks=True, variant="w4x", **kw)
+                assert torch.equal(got, want), f"w4x (dW form) != pp256 for {sorted(kw)} ({int((got != want).sum())} elements)"
+        acc_w = torch.zeros(M, N, dtype=torch.float32, device="cuda"); acc_g = acc_w.clone()
+        for _ in range(2):
+            ops.gemm(at, bd, a_ks=True, b_ks=True, variant="pp256", out=acc_w, accumulate=True)
+            ops.gemm(at, bd, a_ks=True, b_ks=True, variant="w4x", out=acc_g, accumulate=True)
+        assert torch.equal(acc_g, acc_w)
 
 
 def test_gemm_w4x_rotary_epilogue_equals_pingpong(ops):

@@ -239,7 +239,39 @@ static_assert(G3_NST == 4, "the one-set schedule is written for a prefetch dista
       G3_BARRIER(); } while (0)
     // host-checked: K % 64 == 0, K >= 256 (nh >= 8, even)
     DMA_A(0); DMA_B(0); DMA_A(1); DMA_B(1); DMA_B(2);
-    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NFULL) : "memory");       // stage 0 / half-stage 0 have landed; A(1), B(1), B(2) stay in flight
+#if defined(G3_FUSE) && defined(G3_PF)
+    // L2 prefetch (gemm7.hip's G7_PF, measured there: +2.5 ... 5 % on the long-K and ViT up-projection shapes): the 8 workgroups that share
+    // this tile's A panel and the 4 that share its B panel each touch THEIR share of the two panels' lines ahead of everybody's DMA (stage
+    // 3 here, then one stage per even half-step: two stages ahead of the A stage's DMA) -- one byte per 128-byte line, one instruction per
+    // wave and 64-k stage, issued right BEHIND the counted wait of the even half-step so that it is the oldest operation of the next window
+    // and has three half-steps to land; every steady-state vmcnt allows one more operation in flight (G3_PFN).  The destination register
+    // is reserved for the whole loop ("+v", a use after it); lanes 0..3 carry A rows, the next BSH / 8 lanes B lines, the rest repeat lane 0.
+    uint64_t pfaddr; uint32_t pfstride, pfdummy = 0; int pf_stage = 3;
+    {
+      uint64_t bA = (uint64_t)(uintptr_t)p.A, bB = (uint64_t)(uintptr_t)p.B;
+      uint32_t ldb2 = (uint32_t)(p.ldb * 2), lda2 = (uint32_t)(p.lda * 2);
+      asm volatile("" : "+s"(bA), "+s"(bB), "+s"(ldb2), "+s"(lda2));
+      const int ga = tn & 7, gb = tm & 3;
+      constexpr int LPS = BN / 64;                         // 128-byte lines per k-row of a k-strided B stage (BN columns)
+      constexpr int BSH = BKS ? 64 * LPS / 4 : BN / 4;      // this workgroup's share of the B stage's lines (1/4); BSH / 8 lanes per wave
+      const bool isB = lane >= 4 && lane < 4 + BSH / 8;
+      const int li = BSH * gb + (BSH / 8) * wave + ((lane - 4) & (BSH / 8 - 1));
+      const int rowA = min(m0 + 32 * ga + 4 * wave + (lane & 3), p.M - 1);
+      const uint64_t offA = (uint64_t)rowA * lda2 + 3 * 128;
+      const uint64_t offB = BKS ? (uint64_t)(li / LPS) * ldb2 + (uint64_t)min(n0 + (li % LPS) * 64, ((p.N + 7) & ~7) - 8) * 2 + (uint64_t)(3 * 64) * ldb2
+                                : (uint64_t)min(n0 + li, p.N - 1) * ldb2 + 3 * 128;
+      pfaddr = isB ? bB + offB : bA + offA;
+      pfstride = isB ? (BKS ? 64u * ldb2 : 128u) : 128u;
+    }
+#define G3_PFN 1
+#define G3_PF_ISSUE() do { asm volatile("global_load_ubyte %0, %1, off" : "+v"(pfdummy) : "v"(pfaddr) : "memory");       \
+      if (pf_stage + 1 < (nh >> 1)) { pfaddr += pfstride; ++pf_stage; } } while (0)
+    G3_PF_ISSUE();
+#else
+#define G3_PFN 0
+#define G3_PF_ISSUE() do {} while (0)
+#endif
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NFULL + G3_PFN) : "memory");       // stage 0 / half-stage 0 have landed; A(1), B(1), B(2) (and the prefetch) stay in flight
     G3_BARRIER();
     G3_T(1);
     if (wm == 1) G3_BARRIER();
@@ -286,7 +318,8 @@ static_assert(G3_NST == 4, "the one-set schedule is written for a prefetch dista
         M0_SET(db_, 0); RD_A(4); DMA_M0(ub_, boff[0]);                                                               \
         if (NB > 1) { M0_SET(db_, 1024); RD_A(5); DMA_M0(ub_, boff[NB > 1 ? 1 : 0]); } else RD_A(5); }                \
       RD_A(6); RD_A(7);                                                                                              \
-      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NFULL) : "memory");                                                  \
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NFULL + G3_PFN) : "memory");                                         \
+      if (DOA) G3_PF_ISSUE();                                                                                        \
       G3_BARRIER();                                                                                                  \
       MFMAS(0);                                                                                                      \
       G3_BARRIER(); } while (0)
@@ -301,6 +334,9 @@ static_assert(G3_NST == 4, "the one-set schedule is written for a prefetch dista
 #endif
       HS_AF(h, false, true, 2 * NB); HS_AF(h + 1, false, false, NB); HS_AF(h + 2, false, false, 0); HS_AF(h + 3, false, false, 0);
     }
+#if defined(G3_FUSE) && defined(G3_PF)
+    asm volatile("" :: "v"(pfdummy));                  // every prefetch has landed (vmcnt(0) of the last half-steps): the register is free again
+#endif
 #undef HS_AF
 #else
     for (int h = 0; h < nh; h += 2) {

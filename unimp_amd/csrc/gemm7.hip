@@ -94,8 +94,11 @@ __device__ __forceinline__ void g7_xor_stage(uint32_t& x) { asm volatile("v_xor_
 #define G7_BAR() asm volatile("s_barrier" ::: "memory")
 
 // EPI: as gemm3.hip (-1 = kind chosen per tile at run time; EK_* = that kind only)
-template <bool BKS, int EPI>
+// AKS: the A operand k-strided too (X[k * lda + m]: the weight-gradient form dy^T . x, both operands [tokens][features]) -- staged and
+// read exactly like a k-strided B (two 32-k half-stage images per stage, ds_read_b64_tr_b16 fragments); served together with BKS only
+template <bool AKS, bool BKS, int EPI>
 __global__ __launch_bounds__(256, 1) void gemm7_bf16_kernel(Gemm2Params p) {
+  static_assert(!AKS || BKS, "a k-strided A comes with a k-strided B (the dW form)");
   constexpr bool ROPE = EPI == EK_ROPE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   G7_T(0);
@@ -120,30 +123,39 @@ __global__ __launch_bounds__(256, 1) void gemm7_bf16_kernel(Gemm2Params p) {
     for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   bf16x8 fa0[8], fa1[8], fb0[8], fb1[8];            // fragments of k-half 0 / 1; fb*: k-contiguous B
   s16x4 bl0[8], bh0[8], bl1[8], bh1[8];             // k-strided B: the two transposed halves of a fragment
+  s16x4 al0[8], ah0[8], al1[8], ah1[8];             // k-strided A likewise
 
   // ---- LDS-DMA source offsets (bytes, per lane; loop-invariant) and the wave's destination bases
   uint32_t aoff[8], boff[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int P = (wave * 8 + i) * 64 + lane, row = P >> 3, c = (P & 7) ^ ((row >> 1) & 7);
-    aoff[i] = (uint32_t)(((long)min(m0 + row, p.M - 1) * p.lda + c * 8) * 2);
+    if (!AKS) aoff[i] = (uint32_t)(((long)min(m0 + row, p.M - 1) * p.lda + c * 8) * 2);
     if (!BKS) boff[i] = (uint32_t)(((long)min(n0 + row, p.N - 1) * p.ldb + c * 8) * 2);
   }
-  uint32_t boffs[4];
+  uint32_t boffs[4], aoffs[4];
   if (BKS) dma_setup<true, G7_BN, 4>(p.ldb, n0, p.N, wave, boffs);
+  if (AKS) dma_setup<true, G7_BM, 4>(p.lda, m0, p.M, wave, aoffs);
   const uint32_t smem_lds = lds_addr(smem);
-  const uint32_t dA = __builtin_amdgcn_readfirstlane(smem_lds + wave * 8192);                       // + stage * G7_STG + i * 1024
+  const uint32_t dA = __builtin_amdgcn_readfirstlane(smem_lds + (AKS ? wave * 4096 : wave * 8192));  // + stage * G7_STG + i * 1024 (k-strided: + kh * 16384)
   const uint32_t dB = __builtin_amdgcn_readfirstlane(smem_lds + G7_ASUB + (BKS ? wave * 4096 : wave * 8192));   // k-strided: + kh * 16384 + i * 1024
   // one LDS-DMA instruction of tile T (stage S_): I = 0..7 A, 8..15 B
 #define G7_DMA(T, S_, I) do { constexpr int I_ = (I) & 15, J_ = (I_ - 8) & 7;      /* masked: dead branches may name any gap */           \
-    if (I_ < 8) g7_dma((const char*)p.A + (long)(T) * 128, aoff[I_ & 7], dA + (S_) * G7_STG + I_ * 1024);                      \
+    if (I_ < 8 && AKS) g7_dma((const char*)p.A + ((long)(2 * (T) + ((I_ & 7) >> 2)) * 32 * p.lda) * 2, aoffs[I_ & 3],             \
+                              dA + (S_) * G7_STG + ((I_ & 7) >> 2) * 16384 + (I_ & 3) * 1024);                                  \
+    else if (I_ < 8) g7_dma((const char*)p.A + (long)(T) * 128, aoff[I_ & 7], dA + (S_) * G7_STG + I_ * 1024);                 \
     else if (!BKS) g7_dma((const char*)p.B + (long)(T) * 128, boff[J_], dB + (S_) * G7_STG + J_ * 1024);                        \
     else g7_dma((const char*)p.B + ((long)(2 * (T) + (J_ >> 2)) * 32 * p.ldb) * 2, boffs[J_ & 3],                               \
                 dB + (S_) * G7_STG + (J_ >> 2) * 16384 + (J_ & 3) * 1024); } while (0)
 
   // ---- fragment read addresses (stage 0; the stage bit is toggled per iteration)
   uint32_t va0 = smem_lds + kc_off(wm * 128 + (lane & 15), lane >> 4), va1 = va0 ^ 64;
-  uint32_t vb0 = 0, vb1 = 0, vbs[8];
+  uint32_t vb0 = 0, vb1 = 0, vbs[8], vas[8];
+  if (AKS) {
+    const uint32_t la = ks32_lane_base<G7_BM>(wm * 128);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) vas[i] = smem_lds + (la ^ ((uint32_t)i << 5));
+  }
   if (!BKS) { vb0 = smem_lds + G7_ASUB + kc_off(wn * 128 + (lane & 15), lane >> 4); vb1 = vb0 ^ 64; }
   else {
     const uint32_t lb = ks32_lane_base<G7_BN>(wn * 128);
@@ -179,11 +191,14 @@ __global__ __launch_bounds__(256, 1) void gemm7_bf16_kernel(Gemm2Params p) {
 #endif
   // rider R of the 24 (k-strided B) / 16 (k-contiguous B) fragment reads of k-half KH into set F: B first (block KH needs all of B at once)
 #define G7_RD_A(F, KH, I) g7_read128<(I) * 2048>(fa##F[I], (KH) ? va1 : va0)
+#define G7_RD_ASL(F, KH, I) g7_read_tr<(KH) * 16384>(al##F[I], vas[I])
+#define G7_RD_ASH(F, KH, I) g7_read_tr<(KH) * 16384 + 2048>(ah##F[I], vas[I])
+#define G7_FA(F, I) (AKS ? join_halves(al##F[I], ah##F[I]) : fa##F[I])
 #define G7_RD_BC(F, KH, J) g7_read128<(J) * 2048>(fb##F[J], (KH) ? vb1 : vb0)
 #define G7_RD_BSL(F, KH, J) g7_read_tr<(KH) * 16384>(bl##F[J], vbs[J])
 #define G7_RD_BSH(F, KH, J) g7_read_tr<(KH) * 16384 + 2048>(bh##F[J], vbs[J])
 #define G7_FB(F, J) (BKS ? join_halves(bl##F[J], bh##F[J]) : fb##F[J])
-#define G7_MF(F, I, J) g7_mfma(acc[I][J], G7_FB(F, J), fa##F[I])
+#define G7_MF(F, I, J) g7_mfma(acc[I][J], G7_FB(F, J), G7_FA(F, I))
 
   const int nt = p.K >> 6;                         // host-checked: K % 64 == 0, nt >= 2
   // ---- prologue: tiles 0 and 1 on their way, k-half 0 of tile 0 in F0
@@ -205,8 +220,11 @@ __global__ __launch_bounds__(256, 1) void gemm7_bf16_kernel(Gemm2Params p) {
                G7_RD_BSL(F, KH, 6); G7_RD_BSH(F, KH, 6); G7_RD_BSL(F, KH, 7); G7_RD_BSH(F, KH, 7); }                                          \
     else { G7_RD_BC(F, KH, 0); G7_RD_BC(F, KH, 1); G7_RD_BC(F, KH, 2); G7_RD_BC(F, KH, 3); G7_RD_BC(F, KH, 4); G7_RD_BC(F, KH, 5);             \
            G7_RD_BC(F, KH, 6); G7_RD_BC(F, KH, 7); }                                                                                          \
-    G7_RD_A(F, KH, 0); G7_RD_A(F, KH, 1); G7_RD_A(F, KH, 2); G7_RD_A(F, KH, 3); G7_RD_A(F, KH, 4); G7_RD_A(F, KH, 5); G7_RD_A(F, KH, 6);       \
-    G7_RD_A(F, KH, 7); } while (0)
+    if (AKS) { G7_RD_ASL(F, KH, 0); G7_RD_ASH(F, KH, 0); G7_RD_ASL(F, KH, 1); G7_RD_ASH(F, KH, 1); G7_RD_ASL(F, KH, 2); G7_RD_ASH(F, KH, 2);   \
+               G7_RD_ASL(F, KH, 3); G7_RD_ASH(F, KH, 3); G7_RD_ASL(F, KH, 4); G7_RD_ASH(F, KH, 4); G7_RD_ASL(F, KH, 5); G7_RD_ASH(F, KH, 5);   \
+               G7_RD_ASL(F, KH, 6); G7_RD_ASH(F, KH, 6); G7_RD_ASL(F, KH, 7); G7_RD_ASH(F, KH, 7); }                                          \
+    else { G7_RD_A(F, KH, 0); G7_RD_A(F, KH, 1); G7_RD_A(F, KH, 2); G7_RD_A(F, KH, 3); G7_RD_A(F, KH, 4); G7_RD_A(F, KH, 5); G7_RD_A(F, KH, 6);  \
+           G7_RD_A(F, KH, 7); } } while (0)
   G7_READ_ALL(0, 0);
   G7_WAIT_LGKM0();
   G7_T(1);
@@ -217,6 +235,7 @@ __global__ __launch_bounds__(256, 1) void gemm7_bf16_kernel(Gemm2Params p) {
   // k-strided B: 24 reads per k-half (B lo/hi x 8, then A x 8) in the even gaps 0 .. 46; k-contiguous B: 16 reads in the gaps 0, 3, 6 .. 45.
 #define G7_RIDER_RD(F, KH, R) do {                                                                                          \
     if (BKS) { if ((R) < 16) { if ((R) & 1) G7_RD_BSH(F, KH, ((R) >> 1) & 7); else G7_RD_BSL(F, KH, ((R) >> 1) & 7); }             \
+               else if (AKS) { if ((R) & 1) G7_RD_ASH(F, KH, (((R) - 16) >> 1) & 7); else G7_RD_ASL(F, KH, (((R) - 16) >> 1) & 7); } \
                else G7_RD_A(F, KH, ((R) - 16) & 7); }                                                                       \
     else { if ((R) < 8) G7_RD_BC(F, KH, (R) & 7); else G7_RD_A(F, KH, ((R) - 8) & 7); } } while (0)
   constexpr int NRD = BKS ? 24 : 16;               // fragment reads per k-half
@@ -272,17 +291,21 @@ __global__ __launch_bounds__(256, 1) void gemm7_bf16_kernel(Gemm2Params p) {
   uint32_t dAs = dA, dBs = dB;                       // DMA destination bases of the stage being refilled (SGPR; toggled per iteration)
   auto iter = [&](auto mode_c, int t, int s) __attribute__((always_inline)) {
     constexpr int MODE = decltype(mode_c)::value;
-    const char* srcA = (const char*)p.A + (long)(t + 2) * 128;
+    const char* srcA = AKS ? (const char*)p.A + ((long)(2 * (t + 2)) * 32 * p.lda) * 2 : (const char*)p.A + (long)(t + 2) * 128;
+    const char* srcA1 = AKS ? srcA + (long)32 * p.lda * 2 : srcA;
     const char* srcB0 = BKS ? (const char*)p.B + ((long)(2 * (t + 2)) * 32 * p.ldb) * 2 : (const char*)p.B + (long)(t + 2) * 128;
     const char* srcB1 = BKS ? srcB0 + (long)32 * p.ldb * 2 : srcB0;
     // MFMA number M of block F (row M / 8, column M % 8), alone or fused with DMA number D of tile t+2 (0..7 A, 8..15 B)
 #define G7_MFD(F, M, D) do { constexpr int D_ = (D) & 15, J_ = (D_ - 8) & 7;                                                         \
-      if (D_ < 8) g7_mfma_dma<D_ * 1024>(acc[(M) / 8][(M) % 8], G7_FB(F, (M) % 8), fa##F[(M) / 8], dAs, srcA, aoff[D_ & 7]);               \
-      else if (!BKS) g7_mfma_dma<J_ * 1024>(acc[(M) / 8][(M) % 8], G7_FB(F, (M) % 8), fa##F[(M) / 8], dBs, srcB0, boff[J_]);              \
-      else g7_mfma_dma<(J_ >> 2) * 16384 + (J_ & 3) * 1024>(acc[(M) / 8][(M) % 8], G7_FB(F, (M) % 8), fa##F[(M) / 8], dBs,                \
+      if (D_ < 8 && AKS) g7_mfma_dma<((D_ & 7) >> 2) * 16384 + (D_ & 3) * 1024>(acc[(M) / 8][(M) % 8], G7_FB(F, (M) % 8), G7_FA(F, (M) / 8), dAs,   \
+                                                                               ((D_ & 7) >> 2) ? srcA1 : srcA, aoffs[D_ & 3]);               \
+      else if (D_ < 8) g7_mfma_dma<D_ * 1024>(acc[(M) / 8][(M) % 8], G7_FB(F, (M) % 8), G7_FA(F, (M) / 8), dAs, srcA, aoff[D_ & 7]);       \
+      else if (!BKS) g7_mfma_dma<J_ * 1024>(acc[(M) / 8][(M) % 8], G7_FB(F, (M) % 8), G7_FA(F, (M) / 8), dBs, srcB0, boff[J_]);            \
+      else g7_mfma_dma<(J_ >> 2) * 16384 + (J_ & 3) * 1024>(acc[(M) / 8][(M) % 8], G7_FB(F, (M) % 8), G7_FA(F, (M) / 8), dBs,              \
                                                             (J_ >> 2) ? srcB1 : srcB0, boffs[J_ & 3]); } while (0)
 #define G7_XOR_RIDER(X) do { constexpr int X_ = (X);                                                                                 \
-      if (X_ == 0) g7_xor_stage(va0); else if (X_ == 1) g7_xor_stage(va1);                                                           \
+      if (AKS) { if (X_ < 8) g7_xor_stage(vas[X_ & 7]); else if (X_ < 16) g7_xor_stage(vbs[(X_ - 8) & 7]); }                          \
+      else if (X_ == 0) g7_xor_stage(va0); else if (X_ == 1) g7_xor_stage(va1);                                                      \
       else if (!BKS) { if (X_ == 2) g7_xor_stage(vb0); else if (X_ == 3) g7_xor_stage(vb1); }                                        \
       else if (X_ < 10) g7_xor_stage(vbs[(X_ - 2) & 7]); } while (0)
     // ---- block 0
@@ -290,7 +313,8 @@ __global__ __launch_bounds__(256, 1) void gemm7_bf16_kernel(Gemm2Params p) {
       if (MODE == 0 && (M) >= 19 && (M) <= 33 && ((M) & 1)) G7_MFD(0, M, ((M) - 19) >> 1);                                           \
       else if (MODE == 0 && (M) >= 54 && ((M) & 1) == 0) G7_MFD(0, M, 8 + (((M) - 54) >> 1));                                        \
       else G7_MF(0, (M) / 8, (M) % 8);                                                                                               \
-      if ((M) <= 14 && ((M) & 1) == 0) G7_RD_A(1, 1, ((M) >> 1) & 7);                                                               \
+      if (!AKS && (M) <= 14 && ((M) & 1) == 0) G7_RD_A(1, 1, ((M) >> 1) & 7);                                                       \
+      if (AKS && (M) <= 15) { if ((M) & 1) G7_RD_ASH(1, 1, ((M) >> 1) & 7); else G7_RD_ASL(1, 1, ((M) >> 1) & 7); }                   \
       if ((M) == 17) { G7_WAIT_LGKM0(); if (MODE == 0) G7_BAR(); }                                                                    \
       if (BKS && (M) >= 18 && (M) <= 48 && ((M) & 1) == 0) { if ((((M) - 18) >> 1) & 1) G7_RD_BSH(1, 1, (((M) - 18) >> 2) & 7); else G7_RD_BSL(1, 1, (((M) - 18) >> 2) & 7); }   \
       if (!BKS && (M) >= 18 && (M) <= 46 && (((M) - 18) & 3) == 0) G7_RD_BC(1, 1, (((M) - 18) >> 2) & 7);                            \
@@ -310,9 +334,12 @@ __global__ __launch_bounds__(256, 1) void gemm7_bf16_kernel(Gemm2Params p) {
       if (MODE == 0 && (M) <= 4 && ((M) & 1) == 0) G7_MFD(1, M, 13 + ((M) >> 1));                                                    \
       else G7_MF(1, (M) / 8, (M) % 8);                                                                                               \
       if (MODE != 2 && (M) == 1) G7_XOR_RIDER(9);                                                                                     \
+      if (MODE != 2 && AKS && ((M) == 3 || ((M) >= 5 && (M) <= 9))) G7_XOR_RIDER((M) == 3 ? 10 : 6 + (M));                            \
       if ((M) == 11 && MODE != 2) { if (MODE == 0) G7_WAIT_VM(16 + (G7_PF > 0)); else G7_WAIT_VM(0); G7_BAR(); }                      \
       G7_PF_RIDER(M);                                                                                                                \
-      if (MODE != 2 && BKS && (M) >= 12 && (M) <= 58 && ((M) & 1) == 0) G7_RIDER_RD(0, 0, ((M) - 12) >> 1);                           \
+      if (MODE != 2 && BKS && !AKS && (M) >= 12 && (M) <= 58 && ((M) & 1) == 0) G7_RIDER_RD(0, 0, ((M) - 12) >> 1);                   \
+      if (MODE != 2 && AKS && (M) >= 12 && (M) <= 42 && ((M) & 1) == 0) G7_RIDER_RD(0, 0, ((M) - 12) >> 1);                           \
+      if (MODE != 2 && AKS && (M) >= 43 && (M) <= 58) G7_RIDER_RD(0, 0, 16 + (M) - 43);                                               \
       if (MODE != 2 && !BKS && (M) >= 12 && (M) <= 57 && ((M) - 12) % 3 == 0) G7_RIDER_RD(0, 0, ((M) - 12) / 3); } while (0)
 #define G7_S2_ROW1(I) do { G7_S2_B1((I) * 8 + 0); G7_S2_B1((I) * 8 + 1); G7_S2_B1((I) * 8 + 2); G7_S2_B1((I) * 8 + 3);               \
                            G7_S2_B1((I) * 8 + 4); G7_S2_B1((I) * 8 + 5); G7_S2_B1((I) * 8 + 6); G7_S2_B1((I) * 8 + 7); } while (0)
@@ -365,29 +392,34 @@ __global__ __launch_bounds__(256, 1) void gemm7_bf16_kernel(Gemm2Params p) {
   G7_EPI_STAGE(0);
   epi_fetch<WN>(p, lane, em + 64, en, kind, pre1);
   if (kind != EK_GENERIC) epi_inputs_ready();
-  if (EPI >= 0 && !ROPE) epi_pass_fixed<WN, EPI < 0 ? 0 : EPI>(p, er, lane, em, en, gate, pre0, biasv);
-  else epi_pass_kind<WN, 64, ROPE>(p, er, lane, em, en, gate, fast, kind, pre0, biasv);
+  // a wave is alone on its SIMD here: row groups in flight are its only cover for LDS and store latency (G7_EPI_UNR per kind)
+  constexpr int EUNR = EPI == EK_PLAIN ? 8 : (EPI == EK_ACT || EPI == EK_GELU2) ? 8 : 0, RUNR = 4;
+  if (EPI >= 0 && !ROPE) epi_pass_fixed<WN, EPI < 0 ? 0 : EPI, 64, EUNR>(p, er, lane, em, en, gate, pre0, biasv);
+  else epi_pass_kind<WN, 64, ROPE, RUNR>(p, er, lane, em, en, gate, fast, kind, pre0, biasv);
   __builtin_amdgcn_s_waitcnt(0xc07f);
   G7_EPI_STAGE(1);
-  if (EPI >= 0 && !ROPE) epi_pass_fixed<WN, EPI < 0 ? 0 : EPI>(p, er, lane, em + 64, en, gate, pre1, biasv);
-  else epi_pass_kind<WN, 64, ROPE>(p, er, lane, em + 64, en, gate, fast, kind, pre1, biasv);
+  if (EPI >= 0 && !ROPE) epi_pass_fixed<WN, EPI < 0 ? 0 : EPI, 64, EUNR>(p, er, lane, em + 64, en, gate, pre1, biasv);
+  else epi_pass_kind<WN, 64, ROPE, RUNR>(p, er, lane, em + 64, en, gate, fast, kind, pre1, biasv);
   G7_T(3);
 }
 
-template <bool BKS, int EPI>
+template <bool AKS, bool BKS, int EPI>
 static void launch7(const Gemm2Params& p, hipStream_t s) {
   static bool attr_set = false;
   constexpr size_t lds = 2 * G7_STG;               // the ring; the epilogue's 4 x 32 KiB staging regions reuse it
-  auto kern = gemm7_bf16_kernel<BKS, EPI>;
+  auto kern = gemm7_bf16_kernel<AKS, BKS, EPI>;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
   hipLaunchKernelGGL(kern, dim3(p.nbm * p.nbn), dim3(256), lds, s, p);
 }
 
 // returns 1 if launched, 0 if this form is not served (the caller falls back to another variant)
 extern "C" int unimp_gemm7_launch(const unimp_gemm_desc* d, void* stream) {
-  if (d->a_kstrided || d->b_kstrided == 2 || (d->K & 63) || d->K < 128) return 0;
+  if ((d->a_kstrided && d->b_kstrided != 1) || d->b_kstrided == 2 || (d->K & 63) || d->K < 128) return 0;
+#if G7_SCHED == 1 || G7_PF > 0
+  if (d->a_kstrided) return 0;                     // the measurement builds serve the k-contiguous A only
+#endif
   // the per-lane source offsets are 32-bit byte offsets from the operand's base
-  if ((long)d->M * d->lda * 2 >= (1L << 32) || (long)(d->b_kstrided ? 32 : d->N) * d->ldb * 2 >= (1L << 32)) return 0;
+  if ((long)(d->a_kstrided ? 32 : d->M) * d->lda * 2 >= (1L << 32) || (long)(d->b_kstrided ? 32 : d->N) * d->ldb * 2 >= (1L << 32)) return 0;
   Gemm2Params p;
   p.A = (const bf16*)d->A; p.B = (const bf16*)d->B; p.C = d->C;
   p.M = d->M; p.N = d->N; p.K = d->K; p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;
@@ -400,7 +432,13 @@ extern "C" int unimp_gemm7_launch(const unimp_gemm_desc* d, void* stream) {
   p.nbn = (d->N + G7_BN - 1) / G7_BN;
   hipStream_t s = (hipStream_t)stream;
   const int b = d->b_kstrided;
-#define L7(K_) do { if (b) launch7<true, K_>(p, s); else launch7<false, K_>(p, s); return 1; } while (0)
+#if G7_SCHED != 1 && G7_PF == 0
+  if (d->a_kstrided) {                             // weight gradients: plain (alpha / gate / accumulate) epilogues, chosen per tile at run time
+    if (epi_kind_host(p) == EK_PLAIN) launch7<true, true, EK_PLAIN>(p, s); else launch7<true, true, -1>(p, s);
+    return 1;
+  }
+#endif
+#define L7(K_) do { if (b) launch7<false, true, K_>(p, s); else launch7<false, false, K_>(p, s); return 1; } while (0)
   if (p.rope_rot) L7(EK_ROPE);
   switch (epi_kind_host(p)) {
     case EK_PLAIN: L7(EK_PLAIN);

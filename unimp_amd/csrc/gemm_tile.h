@@ -281,7 +281,9 @@ __device__ __forceinline__ void epi8k(const Gemm2Params& p, float (&v)[8], int m
 }
 // FIXED: called from a fixed-kind kernel (room to unroll); false = the run-time-dispatch kernels, which hold every kind and must stay
 // inside the instruction cache (tests/test_cabi_cpu.py): their activation kind runs as a rolled loop
-template <int WN, int KIND, int ROWS = 64, bool FIXED = false>
+// UNR > 0 (gemm7.hip: one wave per SIMD, nobody to overlap a wave's LDS / store latency but its own other row groups): row groups in flight
+// for the kinds without a per-row-group input; 0 = the depths chosen for the 8-wave kernels
+template <int WN, int KIND, int ROWS = 64, bool FIXED = false, int UNR = 0>
 __device__ __forceinline__ void epi_groups(const Gemm2Params& p, const char* er, int lane, int mbase, int nbase, float gate,
                                            const EpiPre<WN, ROWS>& e, bf16x8 biasv) {
   constexpr int ESTR = WN * 4, UNITS = WN / 4, LPR = EpiPre<WN, ROWS>::LPR, RPI = EpiPre<WN, ROWS>::RPI, NIT = EpiPre<WN, ROWS>::NIT;
@@ -299,6 +301,9 @@ __device__ __forceinline__ void epi_groups(const Gemm2Params& p, const char* er,
   if (KIND == EK_AUX || KIND == EK_RES) {
 #pragma unroll
     for (int u = 0; u < NIT; ++u) EPI_GROUP(u, e.xv[u]);
+  } else if (UNR > 0) {
+#pragma unroll (UNR > 0 ? UNR : 1)
+    for (int u = 0; u < NIT; ++u) EPI_GROUP(u, bf16x8{});
   } else if (KIND == EK_PLAIN) {          // small body: 4 row groups per trip so their LDS reads overlap
 #pragma unroll 4
     for (int u = 0; u < NIT; ++u) EPI_GROUP(u, bf16x8{});
@@ -320,10 +325,10 @@ __device__ __forceinline__ void epi_groups(const Gemm2Params& p, const char* er,
 // Kernel instantiations with the epilogue kind FIXED at compile time (gemm3.hip, template parameter EPI >= 0): the host has checked the
 // kind's conditions (epi_kind_host) plus N % 8 == 0, so neither the run-time kind dispatch nor the generic element-wise form is compiled
 // in -- 8-15 KiB of code instead of 62, which leaves room to unroll the activation kinds for instruction-level parallelism.
-template <int WN, int KIND, int ROWS = 64>
+template <int WN, int KIND, int ROWS = 64, int UNR = 0>
 __device__ __forceinline__ void epi_pass_fixed(const Gemm2Params& p, const char* er, int lane, int mbase, int nbase, float gate,
                                                const EpiPre<WN, ROWS>& e, bf16x8 biasv) {
-  epi_groups<WN, KIND, ROWS, true>(p, er, lane, mbase, nbase, gate, e, biasv);
+  epi_groups<WN, KIND, ROWS, true, UNR>(p, er, lane, mbase, nbase, gate, e, biasv);
 }
 // host-side twin of epi_kind() + the fixed kinds' extra conditions; returns the EPI template value to launch, -1 = the generic kernel
 static inline int epi_kind_host(const Gemm2Params& p) {
@@ -338,10 +343,10 @@ static inline int epi_kind_host(const Gemm2Params& p) {
 // one pass of the chosen kind
 // ROPE: the kernel instantiation that serves the rotary epilogue (and nothing else: the host validated a plain alpha / bias
 // epilogue, N % 8 == 0) -- a separate instantiation because the ordinary kernels sit within 1 KiB of the instruction cache.
-template <int WN, int ROWS = 64, bool ROPE = false>
+template <int WN, int ROWS = 64, bool ROPE = false, int ROPE_UNR = 0>
 __device__ __forceinline__ void epi_pass_kind(const Gemm2Params& p, const char* er, int lane, int mbase, int nbase, float gate, bool fast,
                                               int kind, const EpiPre<WN, ROWS>& e, bf16x8 biasv) {
-  if (ROPE) { epi_groups<WN, EK_ROPE, ROWS>(p, er, lane, mbase, nbase, gate, e, biasv); return; }
+  if (ROPE) { epi_groups<WN, EK_ROPE, ROWS, false, ROPE_UNR>(p, er, lane, mbase, nbase, gate, e, biasv); return; }
   // generic form: the whole wave for EK_GENERIC; otherwise only the lanes that own the partial last 8-column group of a ragged N
   // (the 74 053-column LM head) -- one copy of the general code serves both
   const int n_ = nbase + (lane % (WN / 8)) * 8;

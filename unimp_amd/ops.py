@@ -77,9 +77,10 @@ def _tune_gemm(M, N, K, a_ks, b_ks, device, reads_mn=False):
         return 0
     cands = [1] if (M < 512 or N < 128 or K < 128) else ([1, 4, 5, 8, 9, 10, 11] if reads_mn == "out2" else [1, 4, 5, 2, 3, 8, 9, 10, 11])   # "out2": the uint8 derivative
     if len(cands) > 1 and not a_ks and K % 64 == 0 and K >= 256:
-        cands += [13, 14]                       # whole-row A staging (k-contiguous A, 64-k stages); other forms would only re-run the X kernels
-    if len(cands) > 1 and not a_ks and K % 64 == 0 and K >= 128 and M >= 1024 and N >= 256:
-        cands += [15]                           # w4x (gemm7.hip): one wave per SIMD, hand-ordered two-set loop; same bits as the others
+        cands += [13, 14, 18, 19]               # whole-row A staging (k-contiguous A, 64-k stages); other forms would only re-run the X kernels.
+        #                                         18 / 19: the same with the L phase spelled in asm + the L2 prefetch of the panels' shares
+    if len(cands) > 1 and (not a_ks or b_ks) and K % 64 == 0 and K >= 128 and M >= 1024 and N >= 256 and reads_mn != "out2x":
+        cands += [15] if a_ks else [15, 17]     # w4x (gemm7.hip): one wave per SIMD, hand-ordered two-set loop; 17: with the L2 prefetch.  Same bits as the others
     if len(cands) == 1:
         _GEMM_CHOICE[key] = cands[0]
         return cands[0]
