@@ -153,9 +153,10 @@ def test_gemm_kernel_code_fits_the_instruction_cache():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = os.path.join(root, "unimp_amd", "csrc")
     with tempfile.TemporaryDirectory() as tmp:
-        for name in ("gemm3", "gemm5", "gemm6"):
+        for name in ("gemm3", "gemm5", "gemm6", "gemm7"):
             obj, hsaco = os.path.join(tmp, name + ".o"), os.path.join(tmp, name + ".hsaco")
-            r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form", f"-I{root}/include",
+            vgpr_form = [] if name == "gemm7" else ["-mllvm", "-amdgpu-mfma-vgpr-form"]       # gemm7 keeps its accumulators in AGPRs (Makefile)
+            r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", *vgpr_form, f"-I{root}/include",
                                 f"-I{src}", "-c", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-o", obj,
                                 os.path.join(src, name + ".hip")], capture_output=True, text=True, timeout=900)
             assert r.returncode == 0, r.stderr[-2000:]
@@ -168,7 +169,17 @@ def test_gemm_kernel_code_fits_the_instruction_cache():
             # gemm6 instantiates every epilogue kind for each of its four 32-row sub-passes; a tile executes one kind only
             limit = (112 if name == "gemm6" else 64) * 1024
             for k, v in kern.items():
+                if name == "gemm7" and k.endswith("ELin1EEv11Gemm2Params"):
+                    # gemm7's run-time-dispatch kernels (EPI = -1: accumulate / f32 / generic forms, i.e. the weight gradients with K = all tokens):
+                    # three copies of the hand-ordered loop body (steady state, second-to-last, last stage) + every epilogue kind = 94 KiB; the steady
+                    # loop is 3.5 KiB of it and the epilogue runs once per 512-stage tile
+                    assert v <= 100 * 1024, (k, v)
+                    continue
                 assert v <= limit, (k, v)
+            if name == "gemm7":
+                scr = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stderr)]
+                agpr = [int(x) for x in re.findall(r"AGPRs: (\d+)", r.stderr)]
+                assert scr and max(scr) == 0 and agpr and min(agpr) == 256, (scr, agpr)         # no spill; the 64 accumulator tiles live in AGPRs
             if name == "gemm6":
                 occ = [int(x) for x in re.findall(r"Occupancy \[waves/SIMD\]: (\d+)", r.stderr)]
                 scr = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stderr)]

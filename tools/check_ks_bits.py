@@ -13,7 +13,7 @@ for M, N, K in ((1024, 512, 2560), (1536, 2560, 2560), (2048, 1024, 4096), (1024
     res = torch.randn(M, N, device="cuda").to(bf)
     for name, kw in (("plain", {}), ("bias+gelu", dict(bias=bias, act="gelu")), ("bias+res", dict(bias=bias, res=res))):
         ref_kc = ops.gemm(a, w, variant="pp256", **kw)
-        outs = {v: ops.gemm(a, wt, b_ks=True, variant=v, **kw) for v in ("v1", "pp256", "pp128", "w8", "pp256p", "pp256x", "pp128x", "pp256a", "pp128a", "dma256", "dma128")}
+        outs = {v: ops.gemm(a, wt, b_ks=True, variant=v, **kw) for v in ("v1", "pp256", "pp128", "w8", "pp256p", "pp256x", "pp128x", "pp256a", "pp128a", "pp256b", "w4x", "w4x_pf", "dma256", "dma128")}
         base = outs["pp256"]
         diff = {v: int((o != base).sum()) for v, o in outs.items()}
         print(f"[{M},{N},{K}] {name:10s} elements differing from pp256(W^T): {diff};  W^T vs W (pp256): {int((base != ref_kc).sum())} of {base.numel()}", flush=True)

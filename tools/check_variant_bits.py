@@ -26,7 +26,7 @@ for M, N, K in shapes:
         kw = {"plain": {}, "res": dict(res=res), "gelu": dict(act="gelu"), "bias": dict(bias=bias), "bias+quick_gelu": dict(bias=bias, act="quick_gelu"),
               "bias+res": dict(bias=bias, res=res), "gate+res": dict(res=res, gate=gate), "bias+gate+res": dict(bias=bias, res=res, gate=gate)}[epi]
         outs = {}
-        for v in ("v1", "dma256", "dma128", "pp256", "pp128", "w8", "pp256p"):
+        for v in ("v1", "dma256", "dma128", "pp256", "pp128", "w8", "pp256p", "pp256x", "pp256a", "pp128a", "pp256b", "w4x", "w4x_pf"):
             try:
                 ldc = (N + 7) // 8 * 8
                 o = ops.gemm(a, b, variant=v, ldc=ldc, **kw)

@@ -46,6 +46,7 @@ if has bench; then
   leg bench_dphooks 900 $O/bench_dphooks.json python bench.py --no-cpu-baseline --dp-hooks
   leg bench_packed 900 $O/bench_packed.json python bench.py --no-cpu-baseline --packed
   leg bench_b3ga2 900 $O/bench_b3ga2.json python bench.py --no-cpu-baseline --batch 3 --grad-accum 2
+  leg bench_b3ga2_dphooks 900 $O/bench_b3ga2_dphooks.json python bench.py --no-cpu-baseline --batch 3 --grad-accum 2 --dp-hooks
   leg bench_b3ga2_seq 900 $O/bench_b3ga2_seq.json python bench.py --no-cpu-baseline --batch 3 --grad-accum 2 --no-fuse-accum
   leg bench_b48 900 $O/bench_b48.json python bench.py --no-cpu-baseline --batch 48
   leg bench_9b 900 $O/bench_9b.json python bench.py --no-cpu-baseline --model 9b
@@ -84,13 +85,15 @@ fi
 
 if has micro; then
   # 3b. micro-benchmarks: HBM-bound kernels, decode, the GEMM family (forms, power, bits)
+  leg stamps7 900 $O/stamps7.log bash -c 'for shp in "32768 2560 10240 plain 1" "32768 10240 2560 gelu2 1" "32768 2560 2560 res 1" "131584 1024 4096 res 1"; do python tools/stamp_gemm7.py $shp; set -- $shp; python tools/stamp_gemm3.py $1 $2 $3 pp256a $4 $5; done'
+  keep stamps7 $O/stamps7.log ${R}_gemm7_stamps_final.txt
   leg ln 300 $O/bench_ln.log python tools/bench_ln.py --rotate 3
   leg adamw 300 $O/bench_adamw.log python tools/bench_adamw.py
   cat $O/bench_ln.log $O/bench_adamw.log > $O/hbm_kernels.txt; RC[hbm]=$(( ${RC[ln]} + ${RC[adamw]} ))
   keep hbm $O/hbm_kernels.txt ${R}_hbm_kernels_microbench.txt
   leg decode 900 $O/bench_decode.log python tools/bench_decode.py
   keep decode $O/bench_decode.log ${R}_decode_timings.txt
-  leg gemm_ab 1500 $O/gemm_ab.log python tools/bench_gemm_ab.py 5 pp256,pp256x,pp256p,w8
+  leg gemm_ab 1800 $O/gemm_ab.log python tools/bench_gemm_ab.py 5 pp256a,pp256b,pp256x,pp256px,w4x,w4x_pf,w8
   keep gemm_ab $O/gemm_ab.log ${R}_gemm_ab_forms.txt
   leg ks_bits 600 $O/ks_bits.log python tools/check_ks_bits.py
   keep ks_bits $O/ks_bits.log ${R}_kstrided_weight_bit_identity.txt

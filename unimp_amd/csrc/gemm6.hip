@@ -117,9 +117,25 @@ __global__ __launch_bounds__(512, 2) void gemm6_bf16_kernel(Gemm2Params p) {
     LOADF(0, 0);
 #endif
     if (wm == 1) G3_BARRIER();                            // group B runs one phase behind group A
-    for (int h = 0; h < nh; h += 2) {
-      HALF_STEP(h, 0, 1);
-      if (h + 1 < nh) HALF_STEP(h + 1, 1, 0);
+    {
+      int h = 0;
+#if defined(G3_ONESET) && !defined(G3_NO_PEEL)
+      // round 5 (gemm3.hip): steady-state half-steps without their per-half-step decisions -- no scalar branch in the L phase; same bits
+#define DMA_F(H) do { char* b_ = smem + ((H) % G3_NST) * SUB;                                                        \
+        dma_full<AKS, G3_BM>(p.A, p.lda, (H), b_, wave, aoff); dma_full<BKS, BN>(p.B, p.ldb, (H), b_ + A_SUB, wave, boff); } while (0)
+#pragma unroll 1
+      for (; h + PD + 2 < nh; h += 2) {
+        LOADF(0, h); DMA_F(h + PD); asm volatile("s_waitcnt vmcnt(%0)" :: "n"((PD - 1) * NEW) : "memory");
+        G3_BARRIER(); MFMAS(0); G3_BARRIER();
+        LOADF(0, h + 1); DMA_F(h + 1 + PD); asm volatile("s_waitcnt vmcnt(%0)" :: "n"((PD - 1) * NEW) : "memory");
+        G3_BARRIER(); MFMAS(0); G3_BARRIER();
+      }
+#undef DMA_F
+#endif
+      for (; h < nh; h += 2) {
+        HALF_STEP(h, 0, 1);
+        if (h + 1 < nh) HALF_STEP(h + 1, 1, 0);
+      }
     }
     if (wm == 0) G3_BARRIER();                            // equalise the barrier count; all LDS reads are complete
 

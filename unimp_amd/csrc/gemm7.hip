@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256, 1) void gemm7_bf16_kernel(Gemm2Params p) {
   epi_fetch<WN>(p, lane, em + 64, en, kind, pre1);
   if (kind != EK_GENERIC) epi_inputs_ready();
   // a wave is alone on its SIMD here: row groups in flight are its only cover for LDS and store latency (G7_EPI_UNR per kind)
-  constexpr int EUNR = EPI == EK_PLAIN ? 8 : (EPI == EK_ACT || EPI == EK_GELU2) ? 8 : 0, RUNR = 4;
+  constexpr int EUNR = (EPI == EK_PLAIN || EPI == EK_GELU2) ? 8 : 0, RUNR = 4;      // EK_ACT keeps its run-time activation switch: unrolled 8 deep it is 65 KiB of code
   if (EPI >= 0 && !ROPE) epi_pass_fixed<WN, EPI < 0 ? 0 : EPI, 64, EUNR>(p, er, lane, em, en, gate, pre0, biasv);
   else epi_pass_kind<WN, 64, ROPE, RUNR>(p, er, lane, em, en, gate, fast, kind, pre0, biasv);
   __builtin_amdgcn_s_waitcnt(0xc07f);
