@@ -94,7 +94,9 @@ def test_kernel_register_budgets():
         gx = remarks("gemm3.hip", vg + flags)
         assert len(gx) == n, (flags, len(gx))            # no packed-B form in these builds
         for k, r in gx.items():
-            assert r["ScratchSize"] == 0 and r["VGPRs"] + r.get("AGPRs", 0) <= 232 and r["Occupancy"] >= 2, (flags, k, r)
+            # round 5: the K loop exists twice (steady state + the written-out tail), the residual kind's prefetched epilogue chunks live across both:
+            # 244 registers at most (230 before the peel) -- still two waves per SIMD, nothing in scratch, and the faster kernel (profiles/r05_gemm_ab_*)
+            assert r["ScratchSize"] == 0 and r["VGPRs"] + r.get("AGPRs", 0) <= 248 and r["Occupancy"] >= 2, (flags, k, r)
     vg_a = vg + ("-fno-slp-vectorize",)             # the Makefile's flags for the attention kernels
     at = remarks("attention.hip", vg_a)
     plain = {k: r for k, r in at.items() if "Li96ELi80ELb0" in k}

@@ -503,7 +503,8 @@ static int auto_variant(const unimp_gemm_desc* d) {
   long t256 = nbm * ((d->N + 255) / 256), t128 = nbm * ((d->N + 127) / 128);
   auto eff = [](long tiles) { long rounds = (tiles + 255) / 256; return (double)tiles / (double)(rounds * 256); };
   bool wide = d->N >= 256 && eff(t256) >= eff(t128) * 0.88;
-  return wide ? UNIMP_GEMM_PP256 : UNIMP_GEMM_PP128;
+  // round 5: the whole-row-A one-set builds with the peeled K loop (forms they do not serve fall through to the generic one-set kernel inside)
+  return wide ? UNIMP_GEMM_PP256A : UNIMP_GEMM_PP128A;
 }
 
 extern "C" int unimp_gemm_bf16_variant(const unimp_gemm_desc* d, int variant, void* stream) {

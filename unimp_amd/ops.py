@@ -75,7 +75,7 @@ def _tune_gemm(M, N, K, a_ks, b_ks, device, reads_mn=False):
         return v
     if not GEMM_AUTOTUNE or torch.cuda.is_current_stream_capturing():
         return 0
-    cands = [1] if (M < 512 or N < 128 or K < 128) else ([1, 4, 5, 8, 9, 10, 11] if reads_mn == "out2" else [1, 4, 5, 2, 3, 8, 9, 10, 11])   # "out2": the uint8 derivative
+    cands = [1] if (M < 512 or N < 128 or K < 128) else ([1, 4, 5, 8, 9, 10, 11, 12] if reads_mn == "out2" else [1, 4, 5, 2, 3, 8, 9, 10, 11, 12])   # "out2": the uint8 derivative
     if len(cands) > 1 and not a_ks and K % 64 == 0 and K >= 256:
         cands += [13, 14, 18, 19]               # whole-row A staging (k-contiguous A, 64-k stages); other forms would only re-run the X kernels.
         #                                         18 / 19: the same with the L phase spelled in asm + the L2 prefetch of the panels' shares
