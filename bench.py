@@ -792,6 +792,8 @@ def main():
                               if args.sparse_head else {})},
                 "roofline": roofline, "cpu_baseline": cpu, **({"parity": parity} if parity else {}), **({"rccl": rccl} if rccl else {}), **({"packed_token_order": packed_leg} if packed_leg else {}), **({"other_shapes": shape_legs} if shape_legs else {}), **({"cfg4_hm": cfg4_leg} if cfg4_leg else {}),
                 **({"cfg5_imggen_fp8": cfg5_leg} if cfg5_leg else {}), **({"cfg5_fp8": cfg5_rec_leg} if cfg5_rec_leg else {})}
+        if ops.TUNE_MISSES:       # shapes the committed table lacked (tuned live above): listed on stderr so that the table can be completed
+            print("gemm autotune: tuned live this run: " + "; ".join(str(k) for k in ops.TUNE_MISSES), file=sys.stderr)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if dist.is_initialized():

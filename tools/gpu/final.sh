@@ -49,6 +49,7 @@ if has bench; then
   leg bench_b3ga2_dphooks 900 $O/bench_b3ga2_dphooks.json python bench.py --no-cpu-baseline --batch 3 --grad-accum 2 --dp-hooks
   leg bench_b3ga2_seq 900 $O/bench_b3ga2_seq.json python bench.py --no-cpu-baseline --batch 3 --grad-accum 2 --no-fuse-accum
   leg bench_b48 900 $O/bench_b48.json python bench.py --no-cpu-baseline --batch 48
+  leg bench_overlap 900 $O/bench_overlap.json python bench.py --no-cpu-baseline --overlap-optimizer --no-shape-legs --no-cfg5-leg --no-packed-leg
   leg bench_9b 900 $O/bench_9b.json python bench.py --no-cpu-baseline --model 9b
   leg bench_9b_fp8 900 $O/bench_9b_fp8.json python bench.py --no-cpu-baseline --model 9b --fp8
   leg bench_9b_imggen 900 $O/bench_9b_imggen.json python bench.py --no-cpu-baseline --model 9b --task img_gen --batch 12
