@@ -40,7 +40,9 @@ fi
 
 if has bench; then
   # 2. bench lines with the committed table (no live tuning expected: config.gemm_autotune.tuned_live_this_run)
-  UNIMP_BENCH_SHAPES=1 leg bench_default 1500 $O/bench_default.json python bench.py
+  # the default command also completes the table (the parity leg's b = 1 shapes are not part of any tune run): written back and kept
+  UNIMP_GEMM_TUNE_WRITE=1 UNIMP_BENCH_SHAPES=1 leg bench_default 1500 $O/bench_default.json python bench.py
+  cp profiles/gemm_autotune_gfx950.json $O/gemm_autotune_gfx950.json; keep bench_default $O/gemm_autotune_gfx950.json gemm_autotune_gfx950.json
   grep "^  gemm M=" $O/bench_default.err > $O/gemm_shapes.txt
   keep bench_default $O/gemm_shapes.txt ${R}_gemm_shapes_b64.txt
   leg bench_dphooks 900 $O/bench_dphooks.json python bench.py --no-cpu-baseline --dp-hooks

@@ -398,7 +398,6 @@ extern "C" int unimp_gemm3x_launch(const unimp_gemm_desc* d, int bn, void* strea
 extern "C" int unimp_gemm6x_launch(const unimp_gemm_desc* d, void* stream);          // gemm6.hip built with G3_ONESET
 extern "C" int unimp_gemm3a_launch(const unimp_gemm_desc* d, int bn, void* stream);  // gemm3.hip built with G3_ONESET + G3_AFULL: A staged in whole 128-byte rows
 extern "C" int unimp_gemm3b_launch(const unimp_gemm_desc* d, int bn, void* stream);  // A/B build of gemm3a (G3_FUSE)
-extern "C" int unimp_gemm8_launch(const unimp_gemm_desc* d, void* stream);           // gemm8.hip: gemm7's loop at two waves per SIMD
 extern "C" int unimp_gemm7_launch(const unimp_gemm_desc* d, void* stream);           // gemm7.hip: one wave per SIMD, hand-ordered two-set main loop, 64-k stages
 extern "C" int unimp_gemm7o_launch(const unimp_gemm_desc* d, void* stream);          // ... its first schedule (A/B partner)
 extern "C" int unimp_gemm7p_launch(const unimp_gemm_desc* d, void* stream);          // ... with the L2 prefetch of the panels' shares
@@ -523,7 +522,7 @@ extern "C" int unimp_gemm_bf16_variant(const unimp_gemm_desc* d, int variant, vo
       return unimp_set_error(UNIMP_ERR_ARG, "gemm: rotary epilogue needs rot % 8 == 0 <= hd, hd % 8 == 0, period / span multiples of hd, L > 0, base > 1");
     if (d->M >= (1 << 24)) return unimp_set_error(UNIMP_ERR_SHAPE, "gemm: rotary epilogue needs M < 2^24");
     bool kern = (variant == UNIMP_GEMM_PP256 || variant == UNIMP_GEMM_PP256P || variant == UNIMP_GEMM_PP256X || variant == UNIMP_GEMM_PP256PX || variant == UNIMP_GEMM_PP256A || variant == UNIMP_GEMM_PP256B ||
-                 variant == UNIMP_GEMM_W4X || variant == UNIMP_GEMM_W4X_S1 || variant == UNIMP_GEMM_W4X_PF || variant == UNIMP_GEMM_W8X) && !d->a_kstrided && d->b_kstrided != 2;
+                 variant == UNIMP_GEMM_W4X || variant == UNIMP_GEMM_W4X_S1 || variant == UNIMP_GEMM_W4X_PF) && !d->a_kstrided && d->b_kstrided != 2;
     if (!kern || d->res || d->aux || d->pre || d->act || d->dact || d->accumulate || d->gate || d->out_f32 || (d->N & 7) || (d->ldc & 7) || d->M < 256 || d->N < 128)
       return unimp_set_error(UNIMP_ERR_UNSUPPORTED, "gemm: the rotary epilogue is served by variants pp256 / pp256p (and their one-set forms) with a k-contiguous A operand, an unpacked B operand and a plain (alpha, bias) bf16 epilogue, N % 8 == 0, ldc % 8 == 0");
   }
@@ -543,9 +542,6 @@ extern "C" int unimp_gemm_bf16_variant(const unimp_gemm_desc* d, int variant, vo
     case UNIMP_GEMM_PP128A: unimp_gemm3a_launch(d, 128, stream); break;
     case UNIMP_GEMM_PP256B: unimp_gemm3b_launch(d, 256, stream); break;
     case UNIMP_GEMM_PP128B: unimp_gemm3b_launch(d, 128, stream); break;
-    case UNIMP_GEMM_W8X:
-      if (!unimp_gemm8_launch(d, stream)) return unimp_set_error(UNIMP_ERR_UNSUPPORTED, "gemm: variant w8x serves a k-contiguous A operand, an unpacked B operand, K % 64 == 0, K >= 128");
-      break;
     case UNIMP_GEMM_W4X: case UNIMP_GEMM_W4X_S1: case UNIMP_GEMM_W4X_PF: {
       int ok = variant == UNIMP_GEMM_W4X ? unimp_gemm7_launch(d, stream) : variant == UNIMP_GEMM_W4X_S1 ? unimp_gemm7o_launch(d, stream) : unimp_gemm7p_launch(d, stream);
       if (!ok) return unimp_set_error(UNIMP_ERR_UNSUPPORTED, "gemm: variant w4x serves a k-contiguous A operand, an unpacked B operand, K % 64 == 0, K >= 128, operands below 4 GiB");

@@ -20,7 +20,7 @@ bf16 = torch.bfloat16
 GEMM_PROFILE = None      # bench.py sets this to a list: (start_event, end_event, flops) per GEMM launch
 GEMM_AUTOTUNE = True     # time the kernel variants once per (M, N, K, layout) on scratch operands and keep the fastest
 GEMM_VARIANTS = {"auto": 0, "v1": 1, "dma256": 2, "dma128": 3, "pp256": 4, "pp128": 5, "skinny": 6, "w4": 7, "w8": 8, "pp256p": 9,
-                 "pp256x": 10, "pp128x": 11, "pp256px": 12, "pp256a": 13, "pp128a": 14, "w4x": 15, "w4x_s1": 16, "w4x_pf": 17, "pp256b": 18, "pp128b": 19, "w8x": 20}
+                 "pp256x": 10, "pp128x": 11, "pp256px": 12, "pp256a": 13, "pp128a": 14, "w4x": 15, "w4x_s1": 16, "w4x_pf": 17, "pp256b": 18, "pp128b": 19}
 _GEMM_CHOICE = {}
 # The autotune table is DATA: the one the published numbers were measured with is committed (profiles/gemm_autotune_gfx950.json,
 # keyed by (M, N, K, a k-strided, b k-strided, epilogue reads an [M, N] input)) and loaded by default, so the variant per shape --
@@ -237,7 +237,7 @@ def _tune_packed(M, N, K, a_ks, device, reads_mn, unpacked_variant, b_ks):
 TAIL_SPLIT = os.environ.get("UNIMP_GEMM_TAIL_SPLIT", "1") != "0"
 
 
-ROPE_VARIANTS = (4, 9, 10, 12, 13, 15, 18, 20)  # pp256 / pp256p, their one-set forms and the whole-row-A form: the kernels with a rotary-epilogue instantiation (gemm3.hip, gemm6.hip)
+ROPE_VARIANTS = (4, 9, 10, 12, 13, 15, 18)  # pp256 / pp256p, their one-set forms and the whole-row-A form: the kernels with a rotary-epilogue instantiation (gemm3.hip, gemm6.hip)
 
 
 ROPE_MIN_M = 256                # rows (one tile row) from which the QKV projection takes the rotary epilogue: low enough that a training
