@@ -22,7 +22,7 @@ extern "C" {
 
 /* bumped whenever a signature, a descriptor layout or a buffer-size requirement changes incompatibly (2: round-2 additions --
  * layernorm_bwd(wgrad_accumulate), dot_bf16's fp32[1+1024] scratch, grown gemm / attention descriptors; 3: round 3) */
-#define UNIMP_ABI_VERSION 6
+#define UNIMP_ABI_VERSION 7
 enum { UNIMP_OK = 0, UNIMP_ERR_ARG = 1, UNIMP_ERR_SHAPE = 2, UNIMP_ERR_ALIGN = 3, UNIMP_ERR_LAUNCH = 4,
        UNIMP_ERR_UNSUPPORTED = 5 };
 enum { UNIMP_ACT_NONE = 0, UNIMP_ACT_GELU = 1, UNIMP_ACT_QUICKGELU = 2, UNIMP_ACT_RELU = 3, UNIMP_ACT_SILU = 4,
@@ -207,14 +207,20 @@ int unimp_attn_decode(const unimp_attn_desc* d, float* workspace, int splits, vo
 int unimp_attn_decode_grouped(const unimp_attn_desc* d, float* workspace, int splits, int group, const int* shared_len, void* stream);
 int unimp_attn_decode_splits(int B, int H, int Sk);
 /* tuning / test knob: which generation of attention kernels serves the calls above.  2 (default; env UNIMP_ATTN_GEN):
- * the 32x32x16-MFMA / LDS-DMA kernels of attention2.hip; 1: the first-generation kernels (kept for A/B measurements and
- * run by the tests as a second implementation of the same contract).  Returns the previous value. */
+ * the 32x32x16-MFMA / LDS-DMA kernels of attention2.hip for the forward and dQ; dK/dV by attention3.hip (64 keys per wave, one
+ * wave per SIMD) where it serves the form -- head dim 80, causal / no mask, Sq and Sk multiples of 32, padded rows -- else by
+ * the first generation; 1: the first-generation kernels (kept for A/B measurements and run by the tests as a second
+ * implementation of the same contract); 3: attention2.hip throughout; 4 (ABI 7): generation 2 without attention3.hip.
+ * Returns the previous value. */
 int unimp_attn_set_generation(int generation);
 int unimp_attn_get_generation(void);
 /* measurement knob (ABI 6; env UNIMP_ATTN_VIT): 1 (default) = the ViT forward (S = 257, no mask) seeds its online softmax with the 257th
  * key and walks four full key tiles; 0 = the general five-tile path.  Same contract, different rounding of one key's contribution
  * (bench.py's parity leg reports both).  Returns the previous value. */
 int unimp_attn_set_vit_tail(int on);
+/* measurement knob (ABI 7; env UNIMP_DKV3): 0 = generation 2 keeps the first-generation dK/dV kernel everywhere (what generation 4
+ * selects), 1 (default) = attention3.hip where eligible.  Returns the previous value. */
+int unimp_attn_set_dkv3(int on);
 
 /* ---- token embedding (gpt_neox.embed_in / OPT embed_tokens+embed_positions) -------------------------------
  * fwd: out[r] = W[ids[r]] (+ P[pos[r]]);  bwd: dW[ids[r]] += dout[r]  (fp32 atomics into dW32, then cast)

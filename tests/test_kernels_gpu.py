@@ -21,10 +21,11 @@ def ops():
     return o
 
 
-@pytest.fixture(params=[1, 2, 3], ids=["gen1", "gen2", "gen3"])
+@pytest.fixture(params=[1, 2, 3, 4], ids=["gen1", "gen2", "gen3", "gen4"])
 def attn_gen(request):
-    """run an attention test on every kernel generation (1: attention.hip; 2: attention2.hip forward + dQ with the
-    first-generation dK/dV kernel -- the default; 3: attention2.hip throughout): independent implementations of one
+    """run an attention test on every kernel generation (1: attention.hip; 2 -- the default: attention2.hip forward + dQ, dK/dV by
+    attention3.hip where it serves the form (head dim 80, causal / no mask, 32-row multiples) and by the first generation
+    elsewhere; 3: attention2.hip throughout; 4: generation 2 without attention3.hip): independent implementations of one
     contract, each checked against the fp32 reference."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
@@ -612,6 +613,8 @@ ATTN_CASES = [
     (2, 2, 1024, 1024, 128, 1),      # cfg5's workload: MPT head dim 128 over an image-generation sequence (L = 1024)
     (1, 4, 1000, 1000, 80, 1), (1, 2, 257, 257, 80, 0), (1, 8, 512, 1024, 64, 2),     # cfg4: 16 images x 64 latents
     (1, 3, 257, 257, 64, 0),         # the ViT-L/14 form (B = 1: no kv_len): last key seeds the softmax state, 9 waves per block
+    # forms attention3.hip's dK/dV kernel serves (generation 2): 1, 2 and 3 key super-blocks of 256, kv_len inside a block, a ragged last super-block
+    (2, 2, 512, 512, 80, 1), (2, 3, 256, 256, 80, 0), (1, 2, 96, 96, 80, 1), (2, 2, 640, 640, 80, 1), (1, 2, 64, 320, 80, 0), (2, 1, 32, 32, 80, 1),
 ]
 
 

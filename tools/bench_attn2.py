@@ -1,10 +1,12 @@
-"""A/B of the attention kernel generations at the step's shapes (b = 48): ms and TFLOP/s (4 S_q S_k D per (b, h), full count)."""
+"""A/B of the attention kernel generations at the step's shapes (b = 48; lm64: b = 64): ms and TFLOP/s (4 S_q S_k D per (b, h), full
+count).  Generation 2 = the default (second-generation forward / dQ; dK/dV: attention3.hip where it serves the form, else first
+generation), 3 = second generation throughout, 4 = generation 2 without attention3.hip (the round-4 default)."""
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from unimp_amd import ops, _lib
 torch.manual_seed(0)
 bf = torch.bfloat16
-SHAPES = {"lm": (48, 32, 512, 512, 80, 1), "vit": (384, 16, 257, 257, 64, 0), "xattn": (48, 8, 512, 512, 64, 2),
+SHAPES = {"lm": (48, 32, 512, 512, 80, 1), "lm64": (64, 32, 512, 512, 80, 1), "vit": (384, 16, 257, 257, 64, 0), "xattn": (48, 8, 512, 512, 64, 2),
           "perc": (384, 8, 64, 320, 64, 0), "mpt": (8, 32, 1024, 1024, 128, 1), "lm2k": (4, 32, 2048, 2048, 80, 1)}
 
 
@@ -45,12 +47,13 @@ for name in (sys.argv[1:] or SHAPES):
     q, k, v, dq, dk, dv, do, kv_len, seg, seg_len = setup(B, H, Sq, Sk, D, mode)
     fl = 4.0 * B * H * Sq * Sk * D
     res = {}
-    for gen in (1, 2, 3):
+    for gen in (1, 2, 3, 4):
         _lib.lib().unimp_attn_set_generation(gen)
         o, lse = ops.attn_fwd(q, k, v, D ** -0.5, mode, kv_len, seg, seg_len)
         tf = timeit(lambda: ops.attn_fwd(q, k, v, D ** -0.5, mode, kv_len, seg, seg_len))
         tb = timeit(lambda: ops.attn_bwd(q, k, v, o, lse, do, dq, dk, dv, D ** -0.5, mode, kv_len, seg, seg_len))
         res[gen] = (tf, tb, o.float().clone(), dq.float().clone(), dk.float().clone(), dv.float().clone())
     d = [float((res[1][i] - res[2][i]).abs().max()) for i in range(2, 6)]
+    d4 = [float((res[4][i] - res[2][i]).abs().max()) for i in range(4, 6)]
     print(f"{name:6s} B{B} H{H} {Sq}x{Sk} D{D} mode{mode}: fwd gen1 {res[1][0]:.3f} ms ({fl / res[1][0] / 1e9:.0f} TF) gen2 {res[2][0]:.3f} ms ({fl / res[2][0] / 1e9:.0f} TF) | "
-          f"bwd gen1 {res[1][1]:.3f} ms ({2.5 * fl / res[1][1] / 1e9:.0f} TF) gen2 {res[2][1]:.3f} ms gen3 {res[3][1]:.3f} ms | max|gen1-gen2| o {d[0]:.2e} dq {d[1]:.2e} dk {d[2]:.2e} dv {d[3]:.2e}", flush=True)
+          f"bwd gen1 {res[1][1]:.3f} ms ({2.5 * fl / res[1][1] / 1e9:.0f} TF) gen2 {res[2][1]:.3f} ms gen3 {res[3][1]:.3f} ms gen4 {res[4][1]:.3f} ms | max|gen4-gen2| dk {d4[0]:.2e} dv {d4[1]:.2e} | max|gen1-gen2| o {d[0]:.2e} dq {d[1]:.2e} dk {d[2]:.2e} dv {d[3]:.2e}", flush=True)

@@ -33,9 +33,15 @@ CASES = [
     ("gated FF dW up (KS,KS)", 10240, 2560, M, 1, 1, "plain", "pp256a", "gemm3x_bf16_kernel<true, true, 256, false"),
     ("ViT MLP up W^T + QuickGELU (KC,KS)", MV, 4096, 1024, 0, 1, "act_q", "pp256a", "gemm3a_bf16_kernel<false, true, 256, false, 1>"),
     ("ViT attention-out W^T + residual (KC,KS)", MV, 1024, 1024, 0, 1, "res", "pp256a", "gemm3a_bf16_kernel<false, true, 256, false, 3>"),
+    # round 5: gemm7 (w4x; 256-thread workgroups) on the shapes the table gives it, and its L2-prefetch build next to the plain one on a long-K shape
+    ("gated FF up-projection + GELU + stored GELU' (KC,KC) on w4x", M, 10240, 2560, 0, 0, "out2", "w4x", "gemm7_bf16_kernel<false, false, 6>", 256),
+    ("gated FF down-projection + residual (KC,KC) on w4x", M, 2560, 10240, 0, 0, "res", "w4x", "gemm7_bf16_kernel<false, false, 3>", 256),
+    ("gated FF down-projection + residual (KC,KC) on w4x + L2 prefetch", M, 2560, 10240, 0, 0, "res", "w4x_pf", "gemm7p_bf16_kernel<false, false, 3>", 256),
 ]
 manifest = []
-for label, m, n, k, aks, bks, epi, variant, inst in CASES:
+for case in CASES:
+    label, m, n, k, aks, bks, epi, variant, inst = case[:9]
+    threads = case[9] if len(case) > 9 else 512
     a = torch.randn((k, m) if aks else (m, k), device=dev).to(bf)
     b = torch.randn((k, n) if bks else (n, k), device=dev).to(bf)
     out = torch.empty((m, n), dtype=bf, device=dev)
@@ -58,7 +64,7 @@ for label, m, n, k, aks, bks, epi, variant, inst in CASES:
     torch.cuda.synchronize()
     tiles = ((m + 255) // 256) * ((n + 255) // 256)
     wgs = min(tiles, 256) if variant in ("pp256p", "pp256px") else tiles
-    manifest.append(dict(label=label, kernel=inst, grid_size=wgs * 512, shape=[m, n, k], a_kstrided=aks, b_kstrided=bks, epilogue=epi,
+    manifest.append(dict(label=label, kernel=inst, grid_size=wgs * threads, shape=[m, n, k], a_kstrided=aks, b_kstrided=bks, epilogue=epi,
                          variant=variant, flop=2 * m * n * k, algorithmic_bytes=(m * k + n * k + m * n) * 2 + extra))
     del a, b, out, kw
 keys = [(c["kernel"], c["grid_size"]) for c in manifest]

@@ -74,6 +74,7 @@ _SIGS = {
     "unimp_attn_set_generation": [c_i],
     "unimp_attn_get_generation": [],
     "unimp_attn_set_vit_tail": [c_i],
+    "unimp_attn_set_dkv3": [c_i],
     "unimp_pack_b_bf16": [c_p, c_l, c_i, c_i, c_i, c_p, c_p],
     "unimp_mx_quantize": [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_p],
     "unimp_gemm_mxfp8": [C.POINTER(MxGemmDesc), c_p],
@@ -85,7 +86,7 @@ _SIGS = {
     "unimp_image_resize_normalize": [c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_p],
 }
 
-ABI_VERSION = 6          # must equal UNIMP_ABI_VERSION of include/unimp_hip.h the library was built from
+ABI_VERSION = 7          # must equal UNIMP_ABI_VERSION of include/unimp_hip.h the library was built from
 
 _lib = None
 
