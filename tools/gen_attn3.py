@@ -66,8 +66,11 @@ class Stmt:
             for e, i in index.items():
                 ln = ln.replace("{" + e + "}", "%" + str(i))
             body.append(ln)
+        # every output of a multi-instruction statement is early-clobber: hipcc may otherwise give it the register of an input whose
+        # last use is this statement -- and an instruction further down the string still reads that input
+        multi = len(self.lines) > 1
         def cons(m, c):
-            return {"out": "=" + c, "early": "=&" + c, "inout": "+" + c, "in": c}[m]
+            return {"out": ("=&" if multi else "=") + c, "early": "=&" + c, "inout": "+" + c, "in": c}[m]
         o = ", ".join('"%s"(%s)' % (cons(m, c), e) for e, m, c in outs)
         i_ = ", ".join('"%s"(%s)' % (cons(m, c), e) for e, m, c in ins)
         text = "\\n\\t".join(body)
@@ -165,9 +168,9 @@ class Sched:
         for kb in kbs:
             for ks in range(KS):
                 mf.append(("S", ks, kb))
-        for kb in kbs:
-            for ks in range(KS):
-                mf.append(("D", ks, kb))
+        for ks in range(KS):
+            for kb in kbs:
+                mf.append(("D", ks, kb))          # dP: k-step by k-step (a dO fragment serves both blocks and dies; 12 registers less at the peak)
         order = [(nd, kk) for kk in range(2) for nd in range(ND)]          # both accumulate chains of a block start on P / dS dwords 0-3
         # dV of both blocks, then dK of both: the dO^T fragments (24 registers) are dead before the Q^T fragments arrive
         for kb in kbs:
@@ -213,6 +216,9 @@ class Sched:
         # dO fragments are needed from the first D slot on, the transposed ones from the first A / B slot: one unit per slot, late
         # enough that no fragment waits in a register for longer than it must
         rd_start = max(0, slot_of[("D", 0, kbs[0])] - 6)
+        # the Q^T fragments (dK, the last phase) are read as late as their first use allows: they take over the registers of the dO^T
+        # fragments as those die (both sets live at once cost 48 registers at the kernel's peak)
+        uq_start = max(0, first_b[kbs[0]] - 6)
         need = {}
         for m, i in slot_of.items():
             if m[0] == "S":
@@ -246,7 +252,7 @@ class Sched:
                 self.m_acc(st, "dv", m[1], m[2], m[3], "ud", "pf")
             else:
                 self.m_acc(st, "dk", m[1], m[2], m[3], "uq", "dsf")
-            if rd_queue and i >= rd_start:
+            if rd_queue and i >= (uq_start if rd_queue[0][0] == "uq" else rd_start):
                 kind, k = rd_queue.pop(0)
                 if kind == "dof":
                     self.rd_row(st, "dof", k, OFF_DO)

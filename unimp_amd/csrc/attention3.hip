@@ -30,96 +30,36 @@ __device__ __forceinline__ s16x8 a3_join(s16x4 lo, s16x4 hi) { return __builtin_
 // the value lives in the accumulator half of the register file from here on (its only readers are MFMA operands)
 template <typename T> __device__ __forceinline__ void a3_pin_acc(T& v) { asm volatile("" : "+a"(v)); }
 
-template <int D>
-__global__ __launch_bounds__(256, 1) void attn_dkv3_kernel(AttnP p, int nx) {
+// LDS of a workgroup of NW waves: four tile stages (Q image + dO image each, row pitch 12 chunks), then per wave the staging of
+// its two key blocks' K (then V) rows -- two 32-row images at the odd pitch of 11 chunks, 11 DMA pieces -- which is also the wave's
+// epilogue staging.
+constexpr int A3_PT = 12, A3_IMG = 32 * A3_PT * 16, A3_STAGE = 2 * A3_IMG, A3_KV0 = 4 * A3_STAGE;
+constexpr int A3_KPT = 11, A3_KIMG = 32 * A3_KPT * 16, A3_KVW = 2 * A3_KIMG;
+constexpr size_t a3_lds(int nw) { return A3_KV0 + (size_t)nw * A3_KVW; }
+
+// Workgroup = NW waves, each alone on its SIMD (512 registers) with two 32-key blocks: 64 NW keys per workgroup.  NW = 2 (default):
+// TWO workgroups share a CU, and one's start-up (K / V rows in, first tiles) and drain (dK / dV out) -- pure memory time, 40 % of
+// the first version's run time with nothing co-resident to hide it -- runs beside the other's tile loop.  Workgroups are
+// persistent: workgroup g walks the (batch, head) pairs g, g + G, ... and inside a pair the key super-blocks, even workgroups first
+// to last, odd ones last to first (the CU's two workgroups, and the chip's, leave lock-step: under the causal mask the super-blocks
+// differ in length); a later super-block re-reads Q / dO tiles an earlier one pulled through the XCD's L2.  With fewer pairs than
+// workgroups (item_mode) the (pair, super-block) items are dealt out one by one instead.
+template <int D, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void attn_dkv3_kernel(AttnP p, int nx, int item_mode, int dbg) {
   static_assert(D == 80, "image layout below: 10 chunks per row in a pitch of 12");
-  constexpr int CPR = D / 8, PT = 12, KS = D / 16, ND = (D + 31) / 32;
-  constexpr int IMG = 32 * PT * 16, NJ = IMG / 1024, OFF_DO = IMG, STAGE = 2 * IMG, NST = 4;
-  constexpr int NT = (2 * NJ) / 4;                            // DMA instructions per wave and tile
-  static_assert((2 * NJ) % 4 == 0, "image pieces divide over the four waves");
+  constexpr int CPR = D / 8, PT = A3_PT, KS = D / 16, ND = (D + 31) / 32;
+  constexpr int IMG = A3_IMG, NJ = IMG / 1024, OFF_DO = IMG, STAGE = A3_STAGE;
+  constexpr int NT = (2 * NJ) / NW;                           // DMA instructions per wave and tile
+  constexpr int KPT = A3_KPT, KIMG = A3_KIMG, NKJ = A3_KVW / 1024;      // K (or V) staging of a wave: 2 images = NKJ whole pieces
+  static_assert((2 * NJ) % NW == 0 && A3_KVW % 1024 == 0, "pieces divide over the waves; the staging is whole pieces");
+  constexpr int WKEYS = 64 * NW;                              // keys per workgroup
   extern __shared__ __attribute__((aligned(1024))) char smem[];
-  int kblk, h, b;
-  a2_decode(nx, p.H, p.B, kblk, h, b);
-  kblk = nx - 1 - kblk;                                      // causal: the FIRST key block sees the most query tiles
-  const int kbase = kblk * 256;
-  if (kbase >= p.Sk) return;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = lane_id(), hi5 = l >> 5, kl = l & 31;
   const bool causal = p.mask_mode == UNIMP_MASK_CAUSAL;
-  const int kvl = p.kv_len ? min(p.kv_len[b], p.Sk) : p.Sk;
-  const int key0a = kbase + 32 * wave, key0b = key0a + 128;  // the wave's two 32-key blocks
-  const char* qb = (const char*)(p.q + b * p.q_bs + h * p.q_hs);
-  const char* dob = (const char*)(p.d_o + b * p.do_bs + h * p.do_hs);
-  const bf16* kbp = p.k + b * p.k_bs + h * p.k_hs;
-  const bf16* vbp = p.v + b * p.v_bs + h * p.v_hs;
-  const char* lse_b = (const char*)(p.lse + ((long)b * p.H + h) * p.SqS);
-  const char* dl_b = (const char*)(p.delta + ((long)b * p.H + h) * p.SqS);
   const uint32_t q_sb = (uint32_t)(p.q_ss * 2), do_sb = (uint32_t)(p.do_ss * 2);
-
-  const int nqt = p.Sq >> 5;
-  int qt_a = causal ? kbase >> 5 : 0;
-  const int qt_b = nqt;
-  if (kbase >= kvl) qt_a = qt_b;                              // every key of the workgroup is padding: dk = dv = 0
-
-  // DMA plan: instruction i = wave + 4 t (t < NT) moves piece i % NJ of image i / NJ (0: Q, 1: dO).  Slot s = 64 piece + lane of
-  // an image holds row s / PT, chunk (s % PT) ^ ((row >> 2) & 3).  Chunks 10, 11 of a row are padding -- and chunk 10 of the Q
-  // image's rows 0-7 / 8-15 carries the tile's lse / delta (four rows of 4 bytes per chunk): no separate row-block instruction,
-  // every wave issues exactly NT per tile.  Per lane and t: a 64-bit source pointer for tile qt_a and its step per tile.
-  const char* src0[NT];
-  uint32_t step[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    int i = wave + 4 * t;
-    int img = i >= NJ, j = i - img * NJ;
-    int s_ = 64 * j + l;
-    int r = s_ / PT, cp = s_ - r * PT;
-    int c = cp ^ ((r >> 2) & 3);
-    const uint32_t sb_ = img ? do_sb : q_sb;
-    const char* base = (img ? dob : qb) + (long)qt_a * 32 * sb_ + (long)r * sb_ + min(c, CPR - 1) * 16;
-    uint32_t st_ = 32 * sb_;
-    if (!img && c == CPR && r < 16) { base = (r < 8 ? lse_b : dl_b) + ((long)qt_a * 32 + 4 * (r & 7)) * 4; st_ = 128; }
-    src0[t] = base; step[t] = st_;
-  }
   const uint32_t smem_lds = (uint32_t)(uintptr_t)LDS_PTR(char, smem);
-  auto dma_tile = [&](int qt, int stage) {
-    const uint32_t n = (uint32_t)(min(qt, qt_b - 1) - qt_a);   // past the last tile: fetch it again (uniform counts; the stage is never read)
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      int i = wave + 4 * t;                                   // wave-uniform
-      int img = i >= NJ, j = i - img * NJ;
-      uint32_t dst = smem_lds + stage * STAGE + img * IMG + j * 1024;
-      a2_glds_v(src0[t] + (unsigned long)n * step[t], __builtin_amdgcn_readfirstlane(dst));
-    }
-  };
-
-  bf16x8 kf[2][KS], vf[2][KS];
-#pragma unroll
-  for (int kb = 0; kb < 2; ++kb) {
-    int key = min((kb ? key0b : key0a) + kl, p.Sk - 1);
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      kf[kb][ks] = *(const bf16x8*)(kbp + (long)key * p.k_ss + ks * 16 + hi5 * 8);
-      vf[kb][ks] = *(const bf16x8*)(vbp + (long)key * p.v_ss + ks * 16 + hi5 * 8);
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-  for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) { a2_pin(kf[kb][ks]); a3_pin_acc(vf[kb][ks]); }
-  f32x16 dk[2][ND], dv[2][ND];
-#pragma unroll
-  for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-    for (int nd = 0; nd < ND; ++nd)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { dk[kb][nd][r] = 0.f; dv[kb][nd][r] = 0.f; }
-#pragma unroll
-  for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-    for (int nd = 0; nd < ND; ++nd) { a3_pin_acc(dk[kb][nd]); a3_pin_acc(dv[kb][nd]); }
   const float sc2 = p.scale * LOG2E;
-
-  // fragment addresses inside a stage.  Row fragments (ds_read_b128, lane: query row kl, chunk 2 ks + hi5): chunks hi5, 4 + hi5,
+  // fragment addresses inside a tile image.  Row fragments (ds_read_b128, lane: row kl, chunk 2 ks + hi5): chunks hi5, 4 + hi5,
   // 8 + hi5 (ks 0, 2, 4) share the swizzled low bits, chunks 2 + hi5, 6 + hi5 (ks 1, 3) the other pair.
   const int kq = (kl >> 2) & 3;
   const int r_a = (kl * PT + (hi5 ^ kq)) * 16, r_b = (kl * PT + ((hi5 ^ kq) ^ 2)) * 16;
@@ -129,94 +69,205 @@ __global__ __launch_bounds__(256, 1) void attn_dkv3_kernel(AttnP p, int nx) {
   const int trow = 4 * hi5 + (i16 >> 2), tc = 2 * g16 + ((i16 & 3) >> 1);
   const int t_0 = (trow * PT + (tc ^ hi5)) * 16 + 8 * (i16 & 1);
   const int t_1 = ((trow + 8) * PT + (tc ^ (2 + hi5))) * 16 + 8 * (i16 & 1);
-  const int mykey_a = key0a + kl, mykey_b = key0b + kl;
+  char* const kvw = smem + A3_KV0 + wave * A3_KVW;            // this wave's K / V staging (and epilogue staging)
+  const int kv_rd = (kl * KPT + hi5) * 16;                    // K / V fragment of k-step ks: + 32 ks (odd pitch: no swizzle needed)
 
-  // one query tile for the wave's two key blocks; V = 0: the block sees no row of the tile, 1: every element is visible,
-  // 2: per-element mask (the diagonal, or keys beyond kv_len).  The instruction stream is attention3_sched.inc (generated and
-  // checked by tools/gen_attn3.py); this side prepares the per-row constants: nl = -lse log2(e) (the exponent offset; -1e30 for a
-  // masked element of this lane's key: p = 0, dS = 0) and ndl = -delta, the value the dP accumulators START from.
-  auto tile = [&](auto v0c, auto v1c, int stage, int q0) {
-    constexpr int V0 = decltype(v0c)::value, V1 = decltype(v1c)::value;
-    const uint32_t sbo = smem_lds + stage * STAGE;
-    const uint32_t a_ra = sbo + r_a, a_rb = sbo + r_b, a_t0 = sbo + t_0, a_t1 = sbo + t_1;
-    // lse / delta of rows 8 g + 4 hi5 .. + 3: chunk 10 of the Q image's row 2 g + hi5 (lse) and row 8 + 2 g + hi5 (delta)
-    const char* ax = smem + stage * STAGE + hi5 * (PT * 16);
-    f32x16 nl, ndl;
+  // Tile DMA plan: instruction i = wave + NW t (t < NT) moves piece i % NJ of image i / NJ (0: Q, 1: dO).  Slot s = 64 piece + lane
+  // of an image holds row s / PT, chunk (s % PT) ^ ((row >> 2) & 3).  Chunks 10, 11 of a row are padding -- and chunk 10 of the Q
+  // image's rows 0-7 / 8-15 carries the tile's lse / delta (four rows of 4 bytes per chunk): no separate row-block instruction,
+  // every wave issues exactly NT per tile.  Per lane and t one 32-bit byte offset from the tile's first row (a lane of the lse /
+  // delta chunks: from the tile's first lse / delta entry) -- the same for every tile of every item.
+  uint32_t voff[NT];
+  bool is_lse[NT], is_dl[NT];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      f32x4 a = *(const f32x4*)(ax + (2 * g * PT + (CPR ^ (g >> 1))) * 16);
-      f32x4 d = *(const f32x4*)(ax + ((8 + 2 * g) * PT + (CPR ^ ((2 + (g >> 1)) & 3))) * 16);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { nl[4 * g + e] = a[e] * -LOG2E; ndl[4 * g + e] = -d[e]; }
-    }
-    // lane holds key = mykey and query rows q0 + 8 g + 4 hi5 + e (r = 4 g + e); element visible <=> qmin <= row (and the key is real)
-    auto masked = [&](int mykey) {
-      const int qmin = causal ? mykey : 0;
-      const int a0 = q0 + 4 * hi5 - qmin;
-      const unsigned rng = mykey < kvl ? (unsigned)(p.Sq - qmin) : 0u;
-      f32x16 m;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) m[r] = (unsigned)(a0 + 8 * (r >> 2) + (r & 3)) < rng ? nl[r] : -1e30f;
-      return m;
-    };
-    f32x16 nl0 = nl, nl1 = nl;
-    if (V0 == 2) nl0 = masked(mykey_a);
-    if (V1 == 2) nl1 = masked(mykey_b);
-    f32x16 s0, s1, dp0, dp1;
-    bf16x8 qf[KS], dof[KS];
-    s16x4 udl[2 * ND], udh[2 * ND], uql[2 * ND], uqh[2 * ND];
-    u32x4 pf[2][2], dsf[2][2];
-#include "attention3_sched.inc"
-  };
-  // visibility of a 32-key block for the 32 rows from q0: 0 none, 1 all, 2 mixed
-  auto vis = [&](int k0, int q0) {
-    if (k0 >= kvl || (causal && k0 > q0 + 31)) return 0;
-    return (k0 + 32 <= kvl && (!causal || k0 + 31 <= q0)) ? 1 : 2;
-  };
-
-  // prologue: tiles qt_a, +1, +2 in flight, the first one waited for
-  if (qt_a < qt_b) {
-    dma_tile(qt_a, 0); dma_tile(qt_a + 1, 1); dma_tile(qt_a + 2, 2);
-    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NT) : "memory");
+  for (int t = 0; t < NT; ++t) {
+    int i = wave + NW * t;
+    int img = i >= NJ, j = i - img * NJ;
+    int s_ = 64 * j + l;
+    int r = s_ / PT, cp = s_ - r * PT;
+    int c = cp ^ ((r >> 2) & 3);
+    const bool aux = !img && c == CPR && r < 16;
+    is_lse[t] = aux && r < 8; is_dl[t] = aux && r >= 8;
+    voff[t] = aux ? (uint32_t)(16 * (r & 7)) : (uint32_t)r * (img ? do_sb : q_sb) + (uint32_t)min(c, CPR - 1) * 16;
   }
-  __syncthreads();
 
-  // The tile loop, one straight-line loop per visibility state of the wave's two blocks.  A block's state over the tiles of a
-  // sequence only moves none -> mixed -> all (causal: the diagonal passes once; keys beyond kv_len stay invisible), so the pairs
-  // are visited in an order that is a chain of the product order and every loop below runs at most once.  (One loop with a
-  // switch over the states made the structurizer merge the 192 accumulator registers through copies after every tile.)
-  int stage = 0, qt = qt_a;
-  auto run = [&](auto v0c, auto v1c) {
-    constexpr int V0 = decltype(v0c)::value, V1 = decltype(v1c)::value;
-    while (qt < qt_b && vis(key0a, qt * 32) == V0 && vis(key0b, qt * 32) == V1) {
-      dma_tile(qt + 3, (stage + 3) & 3);
-      if (V0 || V1) tile(v0c, v1c, stage, qt * 32);
-      // tile qt + 1 must have landed before the barrier: the two newest (qt + 2, qt + 3) may stay in flight
-      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NT) : "memory");
-      __syncthreads();
-      stage = (stage + 1) & 3;
-      ++qt;
-    }
-  };
-  run(A3V<0>{}, A3V<0>{});
-  run(A3V<2>{}, A3V<0>{}); run(A3V<0>{}, A3V<2>{});
-  run(A3V<1>{}, A3V<0>{}); run(A3V<2>{}, A3V<2>{}); run(A3V<0>{}, A3V<1>{});
-  run(A3V<1>{}, A3V<2>{}); run(A3V<2>{}, A3V<1>{});
-  run(A3V<1>{}, A3V<1>{});
+  const int npair = p.H * p.B, G = gridDim.x;
+  for (int rnd = 0;; ++rnd) {
+    int pair, kblk;
+    if (item_mode) { const int it = blockIdx.x + rnd * G; kblk = it / npair; pair = it - kblk * npair; if (kblk >= nx) break; }
+    else { pair = (rnd / nx) * G + blockIdx.x; kblk = rnd % nx; if (blockIdx.x & 1) kblk = nx - 1 - kblk; if (pair >= npair) break; }
+    const int h = pair % p.H, b = pair / p.H;
+    const int kbase = kblk * WKEYS;
+    const int kvl = p.kv_len ? min(p.kv_len[b], p.Sk) : p.Sk;
+    const int key0a = kbase + 32 * wave, key0b = key0a + 32 * NW;  // the wave's two 32-key blocks
+    const char* qb = (const char*)(p.q + b * p.q_bs + h * p.q_hs);
+    const char* dob = (const char*)(p.d_o + b * p.do_bs + h * p.do_hs);
+    const char* kbp = (const char*)(p.k + b * p.k_bs + h * p.k_hs);
+    const char* vbp = (const char*)(p.v + b * p.v_bs + h * p.v_hs);
+    const char* lse_b = (const char*)(p.lse + ((long)b * p.H + h) * p.SqS);
+    const char* dl_b = (const char*)(p.delta + ((long)b * p.H + h) * p.SqS);
+    const int qt_b = p.Sq >> 5;
+    int qt_a = causal ? kbase >> 5 : 0;
+    if (kbase >= kvl) qt_a = qt_b;                            // every key of the super-block is padding: dk = dv = 0
 
-  // epilogue through a wave-private LDS region, once the tiles fetched past the end have landed
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  char* ew = smem + wave * (32 * (D * 2 + 16));
+    // K (then V) rows of the wave's two blocks -> its staging: slot s = 64 piece + lane holds block s / 352, row (s % 352) / 11,
+    // chunk (s % 352) % 11 (chunk 10: padding).  Whole 160-byte row segments per group of ten lanes (the per-lane 16-byte gathers
+    // of the first version took 7 us of a workgroup's 11 us start-up).  Rows clamped to Sk.
+    auto dma_kv = [&](const char* base, long row_bytes) {
 #pragma unroll
-  for (int kb = 0; kb < 2; ++kb) {
-    const int key0 = kb ? key0b : key0a;
-    if (key0 < p.Sk) {
-      a2_store_rows<D, ND>(ew, dk[kb], p.scale, p.dk + b * p.dk_bs + h * p.dk_hs, p.dk_ss, key0, p.Sk, p.rope_cos, p.rope_sin, p.rope_half, p.rope_step);
-      __builtin_amdgcn_wave_barrier();
-      a2_store_rows<D, ND>(ew, dv[kb], 1.f, p.dv + b * p.dv_bs + h * p.dv_hs, p.dv_ss, key0, p.Sk);
-      __builtin_amdgcn_wave_barrier();
+      for (int j = 0; j < NKJ; ++j) {
+        const int s_ = 64 * j + l;
+        const int kb = s_ >= 32 * KPT, w_ = s_ - kb * 32 * KPT;
+        const int r = w_ / KPT, c16 = min(w_ - r * KPT, CPR - 1) * 16;
+        const long row = min((kb ? key0b : key0a) + r, p.Sk - 1);
+        a2_glds_v(base + row * row_bytes + c16, __builtin_amdgcn_readfirstlane(smem_lds + A3_KV0 + wave * A3_KVW + j * 1024));
+      }
+    };
+    if (!(dbg & 4)) dma_kv(kbp, p.k_ss * 2);                  // (measurement switch UNIMP_A3_DBG: 4 = no K / V loads)
+
+    auto dma_tile = [&](int qt, int stage) {
+      const int qc = min(qt, qt_b - 1);                       // past the last tile: fetch it again (uniform counts; the stage is never read)
+      const char* q_t = qb + (long)qc * 32 * q_sb;
+      const char* do_t = dob + (long)qc * 32 * do_sb;
+      const char* lse_t = lse_b + (long)qc * 128;
+      const char* dl_t = dl_b + (long)qc * 128;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        int i = wave + NW * t;                                // wave-uniform
+        int img = i >= NJ, j = i - img * NJ;
+        uint32_t dst = smem_lds + stage * STAGE + img * IMG + j * 1024;
+        if (dbg & 8) continue;                                // (8 = no tile fetches)
+        if (!img && j < 3) {                                  // a piece with lse / delta lanes: per-lane base
+          const char* base = is_lse[t] ? lse_t : (is_dl[t] ? dl_t : q_t);
+          a2_glds_v(base + voff[t], __builtin_amdgcn_readfirstlane(dst));
+        } else a2_glds(img ? do_t : q_t, voff[t], __builtin_amdgcn_readfirstlane(dst));
+      }
+    };
+    // the first three tiles go out behind the K rows
+    if (qt_a < qt_b) { dma_tile(qt_a, 0); dma_tile(qt_a + 1, 1); dma_tile(qt_a + 2, 2); }
+
+    f32x16 dk[2][ND], dv[2][ND];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int nd = 0; nd < ND; ++nd)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[kb][nd][r] = 0.f; dv[kb][nd][r] = 0.f; }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int nd = 0; nd < ND; ++nd) { a3_pin_acc(dk[kb][nd]); a3_pin_acc(dv[kb][nd]); }
+
+    // K fragments (B operands, all k-steps) out of the staging; then the V rows take its place.  In flight behind the K rows are at
+    // most the three tiles.
+    bf16x8 kf[2][KS], vf[2][KS];
+    if (qt_a < qt_b && !(dbg & 8)) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * NT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        if (!(dbg & 4)) kf[kb][ks] = *(const bf16x8*)(kvw + kb * KIMG + kv_rd + ks * 32);
+        else kf[kb][ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (!(dbg & 4)) dma_kv(vbp, p.v_ss * 2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        if (!(dbg & 4)) vf[kb][ks] = *(const bf16x8*)(kvw + kb * KIMG + kv_rd + ks * 32);
+        else vf[kb][ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) { a2_pin(kf[kb][ks]); a3_pin_acc(vf[kb][ks]); }
+    const int mykey_a = key0a + kl, mykey_b = key0b + kl;
+
+    // one query tile for the wave's two key blocks; V = 0: the block sees no row of the tile, 1: every element is visible,
+    // 2: per-element mask (the diagonal, or keys beyond kv_len).  The instruction stream is attention3_sched.inc (generated and
+    // checked by tools/gen_attn3.py); this side prepares the per-row constants: nl = -lse log2(e) (the exponent offset; -1e30 for a
+    // masked element of this lane's key: p = 0, dS = 0) and ndl = -delta, the value the dP accumulators START from.
+    auto tile = [&](auto v0c, auto v1c, int stage, int q0) {
+      constexpr int V0 = decltype(v0c)::value, V1 = decltype(v1c)::value;
+      const uint32_t sbo = smem_lds + stage * STAGE;
+      const uint32_t a_ra = sbo + r_a, a_rb = sbo + r_b, a_t0 = sbo + t_0, a_t1 = sbo + t_1;
+      // lse / delta of rows 8 g + 4 hi5 .. + 3: chunk 10 of the Q image's row 2 g + hi5 (lse) and row 8 + 2 g + hi5 (delta)
+      const char* ax = smem + stage * STAGE + hi5 * (PT * 16);
+      f32x16 nl, ndl;
+  #pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 a = *(const f32x4*)(ax + (2 * g * PT + (CPR ^ (g >> 1))) * 16);
+        f32x4 d = *(const f32x4*)(ax + ((8 + 2 * g) * PT + (CPR ^ ((2 + (g >> 1)) & 3))) * 16);
+  #pragma unroll
+        for (int e = 0; e < 4; ++e) { nl[4 * g + e] = a[e] * -LOG2E; ndl[4 * g + e] = -d[e]; }
+      }
+      // lane holds key = mykey and query rows q0 + 8 g + 4 hi5 + e (r = 4 g + e); element visible <=> qmin <= row (and the key is real)
+      auto masked = [&](int mykey) {
+        const int qmin = causal ? mykey : 0;
+        const int a0 = q0 + 4 * hi5 - qmin;
+        const unsigned rng = mykey < kvl ? (unsigned)(p.Sq - qmin) : 0u;
+        f32x16 m;
+  #pragma unroll
+        for (int r = 0; r < 16; ++r) m[r] = (unsigned)(a0 + 8 * (r >> 2) + (r & 3)) < rng ? nl[r] : -1e30f;
+        return m;
+      };
+      f32x16 nl0 = nl, nl1 = nl;
+      if (V0 == 2) nl0 = masked(mykey_a);
+      if (V1 == 2) nl1 = masked(mykey_b);
+      f32x16 s0, s1, dp0, dp1;
+      bf16x8 qf[KS], dof[KS];
+      s16x4 udl[2 * ND], udh[2 * ND], uql[2 * ND], uqh[2 * ND];
+      u32x4 pf[2][2], dsf[2][2];
+  #include "attention3_sched.inc"
+    };
+    // visibility of a 32-key block for the 32 rows from q0: 0 none, 1 all, 2 mixed
+    auto vis = [&](int k0, int q0) {
+      if (k0 >= kvl || (causal && k0 > q0 + 31)) return 0;
+      return (k0 + 32 <= kvl && (!causal || k0 + 31 <= q0)) ? 1 : 2;
+    };
+
+    __syncthreads();                                          // every wave's first three tiles have landed (the V rows came in behind them)
+
+    // The tile loop, one straight-line loop per visibility state of the wave's two blocks.  A block's state over the tiles of a
+    // sequence only moves none -> mixed -> all (causal: the diagonal passes once; keys beyond kv_len stay invisible), so the pairs
+    // are visited in an order that is a chain of the product order and every loop below runs at most once.  (One loop with a
+    // switch over the states made the structurizer merge the 192 accumulator registers through copies after every tile.)
+    int stage = 0, qt = qt_a;
+    auto run = [&](auto v0c, auto v1c) {
+      constexpr int V0 = decltype(v0c)::value, V1 = decltype(v1c)::value;
+      while (qt < qt_b && vis(key0a, qt * 32) == V0 && vis(key0b, qt * 32) == V1) {
+        dma_tile(qt + 3, (stage + 3) & 3);
+        if ((V0 || V1) && !(dbg & 1)) tile(v0c, v1c, stage, qt * 32);                       // (1 = no tile arithmetic)
+        // tile qt + 1 must have landed before the barrier: the two newest (qt + 2, qt + 3) may stay in flight
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NT) : "memory");
+        __syncthreads();
+        stage = (stage + 1) & 3;
+        ++qt;
+      }
+    };
+    run(A3V<0>{}, A3V<0>{});
+    run(A3V<2>{}, A3V<0>{}); run(A3V<0>{}, A3V<2>{});
+    run(A3V<1>{}, A3V<0>{}); run(A3V<2>{}, A3V<2>{}); run(A3V<0>{}, A3V<1>{});
+    run(A3V<1>{}, A3V<2>{}); run(A3V<2>{}, A3V<1>{});
+    run(A3V<1>{}, A3V<1>{});
+
+    // epilogue through the wave's own staging area (nobody else's; the tile stages stay untouched, so the tiles fetched past the end
+    // may still be landing: the next item's tile fetches are ordered behind them)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const int key0 = kb ? key0b : key0a;
+      if (key0 < p.Sk && !(dbg & 2)) {                        // (2 = no result stores)
+        a2_store_rows<D, ND>(kvw, dk[kb], p.scale, p.dk + b * p.dk_bs + h * p.dk_hs, p.dk_ss, key0, p.Sk, p.rope_cos, p.rope_sin, p.rope_half, p.rope_step);
+        __builtin_amdgcn_wave_barrier();
+        a2_store_rows<D, ND>(kvw, dv[kb], 1.f, p.dv + b * p.dv_bs + h * p.dv_hs, p.dv_ss, key0, p.Sk);
+        __builtin_amdgcn_wave_barrier();
+      }
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the staging area is about to be the next item's K / V images
   }
 }
 
@@ -231,15 +282,30 @@ extern "C" int unimp_attn_dkv3_eligible(const AttnP* p) {
   return 1;
 }
 
-int unimp_attn_dkv3_launch(const AttnP& p, void* stream) {
+template <int NW>
+static int a3_launch(const AttnP& p, hipStream_t s, int ncu, int dbg) {
   constexpr int D = 80;
-  constexpr int STAGE = 2 * (32 * 12 * 16);
-  constexpr size_t lds = 4 * STAGE;
-  static_assert(4 * 32 * (D * 2 + 16) <= lds, "epilogue staging fits");
+  static_assert(32 * (D * 2 + 16) <= A3_KVW, "epilogue staging fits a wave's K / V staging");
+  static_assert((4 / NW) * a3_lds(NW) <= 160 * 1024, "4 / NW workgroups per CU: 160 KiB of LDS");
   static bool attr_set = false;
-  auto kern = attn_dkv3_kernel<D>;
-  if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
-  const int nk = (p.Sk + 255) / 256;
-  hipLaunchKernelGGL(kern, dim3(nk * p.H * p.B), dim3(256), lds, (hipStream_t)stream, p, nk);
+  auto kern = attn_dkv3_kernel<D, NW>;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)a3_lds(NW)); attr_set = true; }
+  const int nk = (p.Sk + 64 * NW - 1) / (64 * NW), npair = p.H * p.B, nwg = ncu * (4 / NW);
+  const int item_mode = npair < nwg;
+  const int grid = item_mode ? (npair * nk < nwg ? npair * nk : nwg) : nwg;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), a3_lds(NW), s, p, nk, item_mode, dbg);
   return unimp_check_launch("attn_dkv3");
+}
+
+int unimp_attn_dkv3_launch(const AttnP& p, void* stream) {
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return unimp_set_error(UNIMP_ERR_LAUNCH, "attn_dkv3: no device properties");
+    ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  // measurement switches: UNIMP_A3_DBG (kernel comments), UNIMP_A3_NW = 4: one 4-wave workgroup per CU instead of two 2-wave ones
+  static const int dbg = [] { const char* e = getenv("UNIMP_A3_DBG"); return e ? atoi(e) : 0; }();
+  static const int nw = [] { const char* e = getenv("UNIMP_A3_NW"); return e && atoi(e) == 4 ? 4 : 2; }();
+  return nw == 4 ? a3_launch<4>(p, (hipStream_t)stream, ncu, dbg) : a3_launch<2>(p, (hipStream_t)stream, ncu, dbg);
 }
