@@ -208,7 +208,8 @@ int unimp_attn_decode_grouped(const unimp_attn_desc* d, float* workspace, int sp
 int unimp_attn_decode_splits(int B, int H, int Sk);
 /* tuning / test knob: which generation of attention kernels serves the calls above.  2 (default; env UNIMP_ATTN_GEN):
  * the 32x32x16-MFMA / LDS-DMA kernels of attention2.hip for the forward and dQ; dK/dV by attention3.hip (64 keys per wave, one
- * wave per SIMD) where it serves the form -- head dim 80, causal / no mask, Sq and Sk multiples of 32, padded rows -- else by
+ * wave per SIMD) where it serves the form -- head dim 80, causal / no mask, Sq and Sk multiples of 32, padded rows, a (batch,
+ * head) pair per CU -- else by
  * the first generation; 1: the first-generation kernels (kept for A/B measurements and run by the tests as a second
  * implementation of the same contract); 3: attention2.hip throughout; 4 (ABI 7): generation 2 without attention3.hip.
  * Returns the previous value. */
@@ -218,9 +219,11 @@ int unimp_attn_get_generation(void);
  * key and walks four full key tiles; 0 = the general five-tile path.  Same contract, different rounding of one key's contribution
  * (bench.py's parity leg reports both).  Returns the previous value. */
 int unimp_attn_set_vit_tail(int on);
-/* measurement knob (ABI 7; env UNIMP_DKV3): 0 = generation 2 keeps the first-generation dK/dV kernel everywhere (what generation 4
- * selects), 1 (default) = attention3.hip where eligible.  Returns the previous value. */
-int unimp_attn_set_dkv3(int on);
+/* measurement / test knob (ABI 7; env UNIMP_DKV3): 0 = generation 2 keeps the first-generation dK/dV kernel everywhere (what
+ * generation 4 selects); 1 (default) = attention3.hip where it serves the form AND the launch has a (batch, head) pair per CU
+ * (one persistent workgroup per CU: below that the first generation's many small workgroups are faster); 2 = wherever it serves
+ * the form (the tests' small cases).  Returns the previous value. */
+int unimp_attn_set_dkv3(int mode);
 
 /* ---- token embedding (gpt_neox.embed_in / OPT embed_tokens+embed_positions) -------------------------------
  * fwd: out[r] = W[ids[r]] (+ P[pos[r]]);  bwd: dW[ids[r]] += dout[r]  (fp32 atomics into dW32, then cast)

@@ -31,7 +31,9 @@ def attn_gen(request):
         pytest.skip("needs a GPU")
     from unimp_amd import _lib
     old = _lib.lib().unimp_attn_set_generation(request.param)
+    old3 = _lib.lib().unimp_attn_set_dkv3(2)          # generation 2 takes attention3.hip for every form it serves, also below its size threshold
     yield request.param
+    _lib.lib().unimp_attn_set_dkv3(old3)
     _lib.lib().unimp_attn_set_generation(old)
 
 
@@ -616,6 +618,50 @@ ATTN_CASES = [
     # forms attention3.hip's dK/dV kernel serves (generation 2): 1, 2 and 3 key super-blocks of 256, kv_len inside a block, a ragged last super-block
     (2, 2, 512, 512, 80, 1), (2, 3, 256, 256, 80, 0), (1, 2, 96, 96, 80, 1), (2, 2, 640, 640, 80, 1), (1, 2, 64, 320, 80, 0), (2, 1, 32, 32, 80, 1),
 ]
+
+
+@pytest.mark.parametrize("B,H,S,mode", [(40, 8, 64, 1), (35, 8, 320, 1), (33, 8, 288, 0), (48, 6, 512, 1)])
+def test_attention3_many_items_per_workgroup(ops, B, H, S, mode):
+    """attention3.hip's persistent workgroups with MORE (batch, head) pairs than CUs: every workgroup walks several items, the next
+    item's K / V rows and first tiles ride in the current item's loop.  Short sequences (fewer tiles than the pipeline is deep: the
+    after-loop fetches), two super-blocks with a short second one, key lengths that leave a whole super-block without a visible key
+    (an item of zero tiles), against the first-generation kernel and the fp32 reference."""
+    from unimp_amd import _lib
+    D = 80
+    g = torch.Generator().manual_seed(S + B)
+    qkv = torch.randn(B, S, H, 3 * D, generator=g).to(bf16).cuda()
+    q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+    do = torch.randn(B, S, H, D, generator=g).to(bf16).cuda()
+    kv_len = torch.randint(1, S + 1, (B,), generator=g).to(torch.int32)
+    kv_len[0] = S
+    kv_len[1] = min(S, 37)
+    kv_len = kv_len.cuda()
+    res = {}
+    old3 = _lib.lib().unimp_attn_set_dkv3(2)
+    try:
+        for gen in (4, 2):
+            old = _lib.lib().unimp_attn_set_generation(gen)
+            try:
+                o, lse = ops.attn_fwd(q, k, v, D ** -0.5, mode, kv_len)
+                dqkv = torch.full_like(qkv, float("nan"))
+                dq, dk, dv = dqkv[..., :D], dqkv[..., D:2 * D], dqkv[..., 2 * D:]
+                ops.attn_bwd(q, k, v, o, lse, do, dq, dk, dv, D ** -0.5, mode, kv_len)
+                torch.cuda.synchronize()
+                res[gen] = (dk.float().cpu(), dv.float().cpu())
+            finally:
+                _lib.lib().unimp_attn_set_generation(old)
+    finally:
+        _lib.lib().unimp_attn_set_dkv3(old3)
+    # two implementations of one contract: same values up to the bf16 rounding of P / dS and of the results
+    close(res[2][1], res[4][1], rel=2 ** -6, name="attention3 dv vs first generation")
+    close(res[2][0], res[4][0], rel=2 ** -5, name="attention3 dk vs first generation")
+    # and the first batch rows against the fp32 reference
+    nb = 2
+    qr, kr, vr = (t[:nb].float().cpu().requires_grad_(True) for t in (q, k, v))
+    want = attn_ref(qr, kr, vr, D ** -0.5, mode, kv_len[:nb].long().cpu(), None, 0)
+    want.backward(do[:nb].float().cpu())
+    close(res[2][0][:nb], kr.grad, rel=2 ** -5, name="attention3 dk")
+    close(res[2][1][:nb], vr.grad, rel=2 ** -5, name="attention3 dv")
 
 
 @pytest.mark.parametrize("B,H,Sq,Sk,D,mode", ATTN_CASES)

@@ -6,7 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from unimp_amd import ops, _lib
 torch.manual_seed(0)
 bf = torch.bfloat16
-SHAPES = {"lm": (48, 32, 512, 512, 80, 1), "lm64": (64, 32, 512, 512, 80, 1), "vit": (384, 16, 257, 257, 64, 0), "xattn": (48, 8, 512, 512, 64, 2),
+SHAPES = {"lm": (48, 32, 512, 512, 80, 1), "lm64": (64, 32, 512, 512, 80, 1), "lm3": (3, 32, 512, 512, 80, 1), "lm6": (6, 32, 512, 512, 80, 1), "lm8": (8, 32, 512, 512, 80, 1),
+          "lm16": (16, 32, 512, 512, 80, 1), "lm32": (32, 32, 512, 512, 80, 1), "lm1k": (16, 32, 1024, 1024, 80, 1), "vit": (384, 16, 257, 257, 64, 0), "xattn": (48, 8, 512, 512, 64, 2),
           "perc": (384, 8, 64, 320, 64, 0), "mpt": (8, 32, 1024, 1024, 128, 1), "lm2k": (4, 32, 2048, 2048, 80, 1)}
 
 

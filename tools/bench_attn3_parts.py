@@ -28,9 +28,7 @@ e1.record(); e1.synchronize()
 print("%%.1f" %% (e0.elapsed_time(e1) / 20 * 1000))
 ''' % ROOT
 names = {0: "everything", 1: "no tile arithmetic", 2: "no result stores", 4: "no K / V loads", 8: "no tile fetches", 3: "no arithmetic, no stores", 15: "nothing but the loop skeleton"}
-NW = os.environ.get("UNIMP_A3_NW", "2")
-print(f"waves per workgroup {NW} (UNIMP_A3_NW)")
-for gen, dbg in [(4, 0), (2, 0), (2, 1), (2, 2), (2, 4), (2, 8), (2, 3), (2, 15)]:
+for gen, dbg in [(4, 0), (2, 0), (2, 2)]:
     env = dict(os.environ, UNIMP_A3_DBG=str(dbg))
     out = subprocess.run([sys.executable, "-c", CHILD, str(gen)], env=env, capture_output=True, text=True)
     us = out.stdout.strip().split("\n")[-1] if out.returncode == 0 else "failed: " + out.stderr[-300:]

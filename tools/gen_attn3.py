@@ -219,25 +219,26 @@ class Sched:
         # the Q^T fragments (dK, the last phase) are read as late as their first use allows: they take over the registers of the dO^T
         # fragments as those die (both sets live at once cost 48 registers at the kernel's peak)
         uq_start = max(0, first_b[kbs[0]] - 6)
+        # one counted wait per GROUP of fragments (every wait statement is an issue slot, and hipcc pads the statement after it): all
+        # Q fragments before the first S, all dO fragments before the first dP; the transposed fragments in two halves (before the
+        # first and before the fourth MFMA of their phase: in the one-block variants the second half is still being read at the first)
         need = {}
-        for m, i in slot_of.items():
-            if m[0] == "S":
-                need[i] = ("qf%d" % m[1], ["qf[%d]" % m[1]])
-            elif m[0] == "D":
-                need[i] = ("dof%d" % m[1], ["dof[%d]" % m[1]])
-            elif m[0] == "A":
-                fi = 2 * m[2] + m[3]
-                need[i] = ("udh%d" % fi, ["udl[%d]" % fi, "udh[%d]" % fi])
-            else:
-                fi = 2 * m[2] + m[3]
-                need[i] = ("uqh%d" % fi, ["uql[%d]" % fi, "uqh[%d]" % fi])
+        first_s, first_d = slot_of[("S", 0, kbs[0])], slot_of[("D", 0, kbs[0])]
+        fa, fb = first_a[kbs[0]], first_b[kbs[0]]
+        need[first_s] = ("qf%d" % (KS - 1), ["qf[%d]" % k for k in range(KS)])
+        need[first_d] = ("dof%d" % (KS - 1), ["dof[%d]" % k for k in range(KS)])
+        fr = [2 * nd + kk for nd, kk in order]
+        need[fa] = ("udh%d" % fr[2], ["ud%s[%d]" % (hl, f) for f in fr[:3] for hl in "lh"])
+        need[fa + 3] = ("udh%d" % fr[-1], ["ud%s[%d]" % (hl, f) for f in fr[3:] for hl in "lh"])
+        need[fb] = ("uqh%d" % fr[2], ["uq%s[%d]" % (hl, f) for f in fr[:3] for hl in "lh"])
+        need[fb + 3] = ("uqh%d" % fr[-1], ["uq%s[%d]" % (hl, f) for f in fr[3:] for hl in "lh"])
         released = set()
         placed = {}
         self.waits = {}
         for i, m in enumerate(mf):
             st = Stmt()
-            nm, exprs = need[i]
-            if nm not in released:
+            nm, exprs = need.get(i, (None, None))
+            if nm is not None and nm not in released:
                 assert nm in self.reads, "read %s not issued before slot %d" % (nm, i)
                 w = Stmt()
                 self.wait_for(w, nm, exprs)

@@ -802,10 +802,10 @@ extern "C" int unimp_attn_set_generation(int gen) { int old = attn_generation();
 extern "C" int unimp_attn_get_generation(void) { return attn_generation(); }
 static int g_attn_dkv3 = -1;
 static int attn_dkv3_on() {
-  if (g_attn_dkv3 < 0) { const char* e = getenv("UNIMP_DKV3"); g_attn_dkv3 = (!e || atoi(e) != 0) ? 1 : 0; }
+  if (g_attn_dkv3 < 0) { const char* e = getenv("UNIMP_DKV3"); int v = e ? atoi(e) : 1; g_attn_dkv3 = v < 0 ? 0 : (v > 2 ? 2 : v); }
   return g_attn_dkv3;
 }
-extern "C" int unimp_attn_set_dkv3(int on) { int old = attn_dkv3_on(); g_attn_dkv3 = on ? 1 : 0; return old; }
+extern "C" int unimp_attn_set_dkv3(int mode) { int old = attn_dkv3_on(); g_attn_dkv3 = mode < 0 ? 0 : (mode > 2 ? 2 : mode); return old; }
 
 extern "C" int unimp_attn_fwd(const unimp_attn_desc* d, void* stream) {
   AttnP p;
@@ -836,7 +836,8 @@ extern "C" int unimp_attn_bwd(const unimp_attn_desc* d, void* stream) {
   int gen = attn_generation();
   // generation 2 (default) hands the forms attention3.hip serves (head dim 80, causal / no mask, 32-row multiples: the language
   // model's self-attention) to its 64-keys-per-wave dK/dV kernel; generation 4 = 2 without it (the round-4 default; A/B and tests);
-  // UNIMP_DKV3=0 / unimp_attn_set_dkv3(0): the same switch without changing the generation
+  // UNIMP_DKV3 / unimp_attn_set_dkv3: 0 = never (what generation 4 selects), 1 (default) = where it serves the form AND the launch has a
+  // (batch, head) pair per CU (below that the first generation's many small workgroups win), 2 = wherever it serves the form (tests)
   bool al16 = !(((p.dq_bs | p.dq_ss | p.dq_hs | p.dk_bs | p.dk_ss | p.dk_hs | p.dv_bs | p.dv_ss | p.dv_hs) & 7) ||
                 (((uintptr_t)p.dq | (uintptr_t)p.dk | (uintptr_t)p.dv) & 15)) && p.Sq >= 4;
   int which2 = (gen >= 2 && al16) ? (gen == 3 ? 3 : 1) : 0;
@@ -847,7 +848,8 @@ extern "C" int unimp_attn_bwd(const unimp_attn_desc* d, void* stream) {
   // delta = rowsum(dO * O): the second-generation dQ kernel computes and publishes it itself
   if (!(which2 & 1)) hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((n * 16 + 255) / 256)), dim3(256), 0, s, p);
   if (which2) { int e2 = unimp_attn_bwd2_dispatch(p, which2, stream); if (e2) return e2; }
-  if (gen == 2 && which2 == 1 && attn_dkv3_on() && unimp_attn_dkv3_eligible(&p)) return unimp_attn_dkv3_launch(p, stream);
+  if (gen == 2 && which2 == 1 && attn_dkv3_on() && unimp_attn_dkv3_eligible(&p) && (attn_dkv3_on() == 2 || unimp_attn_dkv3_preferred(&p)))
+    return unimp_attn_dkv3_launch(p, stream);
   // dK/dV: 16 keys per wave (KU = 1, 64-key workgroups; default) or 32 (KU = 2, 128-key workgroups; UNIMP_DKV_KU=2).  With 32 the
   // kernel held 248 registers at head dim 80 (dK^T, dV^T accumulators and the K / V fragments of two 16-key blocks): two waves
   // per SIMD, 55 % of wave time in waits.  With 16 it holds 166: a third wave per SIMD (hd 64: four; hd 128: two instead of one

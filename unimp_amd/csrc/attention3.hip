@@ -27,31 +27,42 @@ extern "C" int unimp_attn_dkv3_eligible(const AttnP* p);
 template <int V> struct A3V { static constexpr int value = V; };
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 __device__ __forceinline__ s16x8 a3_join(s16x4 lo, s16x4 hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); }
+// LDS-DMA with the lanes chosen by a scalar mask (the compiler sees no control flow): a piece that only has to be COUNTED moves 16 bytes
+__device__ __forceinline__ void a3_glds_v_masked(const void* vaddr, uint32_t lds_dst, unsigned long long mask) {
+  unsigned long long save;
+  asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %3\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b64 exec, %0"
+               : "=&s"(save) : "v"(vaddr), "s"(lds_dst), "s"(mask) : "memory", "m0");
+}
 // the value lives in the accumulator half of the register file from here on (its only readers are MFMA operands)
 template <typename T> __device__ __forceinline__ void a3_pin_acc(T& v) { asm volatile("" : "+a"(v)); }
 
-// LDS of a workgroup of NW waves: four tile stages (Q image + dO image each, row pitch 12 chunks), then per wave the staging of
-// its two key blocks' K (then V) rows -- two 32-row images at the odd pitch of 11 chunks, 11 DMA pieces -- which is also the wave's
-// epilogue staging.
+// LDS of the workgroup (4 waves): four tile stages (Q image + dO image each, row pitch 12 chunks); per wave the staging of its two
+// key blocks' K and V rows -- four 32-row images at the odd pitch of 11 chunks = 22 DMA pieces; per wave the epilogue staging.
 constexpr int A3_PT = 12, A3_IMG = 32 * A3_PT * 16, A3_STAGE = 2 * A3_IMG, A3_KV0 = 4 * A3_STAGE;
-constexpr int A3_KPT = 11, A3_KIMG = 32 * A3_KPT * 16, A3_KVW = 2 * A3_KIMG;
-constexpr size_t a3_lds(int nw) { return A3_KV0 + (size_t)nw * A3_KVW; }
+constexpr int A3_KPT = 11, A3_KIMG = 32 * A3_KPT * 16, A3_KVW = 4 * A3_KIMG, A3_EP0 = A3_KV0 + 4 * A3_KVW, A3_EPW = 6144;
+constexpr size_t A3_LDS = A3_EP0 + 4 * A3_EPW;
 
-// Workgroup = NW waves, each alone on its SIMD (512 registers) with two 32-key blocks: 64 NW keys per workgroup.  NW = 2 (default):
-// TWO workgroups share a CU, and one's start-up (K / V rows in, first tiles) and drain (dK / dV out) -- pure memory time, 40 % of
-// the first version's run time with nothing co-resident to hide it -- runs beside the other's tile loop.  Workgroups are
-// persistent: workgroup g walks the (batch, head) pairs g, g + G, ... and inside a pair the key super-blocks, even workgroups first
-// to last, odd ones last to first (the CU's two workgroups, and the chip's, leave lock-step: under the causal mask the super-blocks
-// differ in length); a later super-block re-reads Q / dO tiles an earlier one pulled through the XCD's L2.  With fewer pairs than
-// workgroups (item_mode) the (pair, super-block) items are dealt out one by one instead.
-template <int D, int NW>
-__global__ __launch_bounds__(64 * NW, 1) void attn_dkv3_kernel(AttnP p, int nx, int item_mode, int dbg) {
+// One workgroup per CU, each wave alone on its SIMD (512 registers): nothing is co-resident to hide an item's start-up (K / V rows
+// in, first tiles) or drain (dK / dV out) -- 55 % of the first version's run time (tools/bench_attn3_parts.py).  So the workgroups
+// are persistent and an item's memory phases ride inside its neighbours' tile loops:
+//   * workgroup g walks the (batch, head) pairs g, g + G, ... and inside a pair the key super-blocks first to last (a later
+//     super-block re-reads Q / dO tiles the earlier one pulled through the XCD's L2); with fewer pairs than workgroups (item_mode)
+//     the (pair, super-block) items are dealt out one by one instead;
+//   * the NEXT item's K / V rows go into the wave's staging during the first eight iterations of the current item's loop (three
+//     pieces per iteration), its first three tiles take the place of the fetches "past the end" of the current item's last three
+//     iterations: when an item starts, its operands are in LDS;
+//   * all of that is confirmed landed BEFORE the epilogue issues its stores (stores count in vmcnt and complete out of order with
+//     loads: a counted wait behind them would wait for their acknowledgements) and the next item's first two iterations need no
+//     wait at all -- by its third the stores have drained.
+template <int D>
+__global__ __launch_bounds__(256, 1) void attn_dkv3_kernel(AttnP p, int nx, int item_mode, int dbg) {
   static_assert(D == 80, "image layout below: 10 chunks per row in a pitch of 12");
-  constexpr int CPR = D / 8, PT = A3_PT, KS = D / 16, ND = (D + 31) / 32;
+  constexpr int CPR = D / 8, PT = A3_PT, KS = D / 16, ND = (D + 31) / 32, NW = 4;
   constexpr int IMG = A3_IMG, NJ = IMG / 1024, OFF_DO = IMG, STAGE = A3_STAGE;
-  constexpr int NT = (2 * NJ) / NW;                           // DMA instructions per wave and tile
-  constexpr int KPT = A3_KPT, KIMG = A3_KIMG, NKJ = A3_KVW / 1024;      // K (or V) staging of a wave: 2 images = NKJ whole pieces
-  static_assert((2 * NJ) % NW == 0 && A3_KVW % 1024 == 0, "pieces divide over the waves; the staging is whole pieces");
+  constexpr int NT = (2 * NJ) / NW;                           // tile DMA instructions per wave and tile
+  constexpr int KPT = A3_KPT, KIMG = A3_KIMG, NKJ = A3_KVW / 1024;      // K / V staging of a wave: 4 images = NKJ whole pieces
+  constexpr int KVI = 3, KVN = 8;                             // K / V pieces per iteration, iterations that carry them
+  static_assert((2 * NJ) % NW == 0 && A3_KVW % 1024 == 0 && KVI * KVN >= NKJ, "pieces divide over the waves; the staging is whole pieces");
   constexpr int WKEYS = 64 * NW;                              // keys per workgroup
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = lane_id(), hi5 = l >> 5, kl = l & 31;
@@ -69,7 +80,8 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_dkv3_kernel(AttnP p, int nx, 
   const int trow = 4 * hi5 + (i16 >> 2), tc = 2 * g16 + ((i16 & 3) >> 1);
   const int t_0 = (trow * PT + (tc ^ hi5)) * 16 + 8 * (i16 & 1);
   const int t_1 = ((trow + 8) * PT + (tc ^ (2 + hi5))) * 16 + 8 * (i16 & 1);
-  char* const kvw = smem + A3_KV0 + wave * A3_KVW;            // this wave's K / V staging (and epilogue staging)
+  char* const kvw = smem + A3_KV0 + wave * A3_KVW;            // this wave's K / V staging: K blocks a, b, V blocks a, b
+  char* const epw = smem + A3_EP0 + wave * A3_EPW;            // this wave's epilogue staging
   const int kv_rd = (kl * KPT + hi5) * 16;                    // K / V fragment of k-step ks: + 32 ks (odd pitch: no swizzle needed)
 
   // Tile DMA plan: instruction i = wave + NW t (t < NT) moves piece i % NJ of image i / NJ (0: Q, 1: dO).  Slot s = 64 piece + lane
@@ -91,61 +103,95 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_dkv3_kernel(AttnP p, int nx, 
     voff[t] = aux ? (uint32_t)(16 * (r & 7)) : (uint32_t)r * (img ? do_sb : q_sb) + (uint32_t)min(c, CPR - 1) * 16;
   }
 
-  const int npair = p.H * p.B, G = gridDim.x;
-  for (int rnd = 0;; ++rnd) {
+  // an item = (pair, key super-block); round rnd of this workgroup
+  struct Item { bool valid; int h, b, kbase, kvl, qt_a; const char *qb, *dob, *kbp, *vbp, *lse_b, *dl_b; };
+  const int npair = p.H * p.B, G = gridDim.x, qt_b = p.Sq >> 5;
+  auto item_of = [&](int rnd) {
+    Item it;
     int pair, kblk;
-    if (item_mode) { const int it = blockIdx.x + rnd * G; kblk = it / npair; pair = it - kblk * npair; if (kblk >= nx) break; }
-    else { pair = (rnd / nx) * G + blockIdx.x; kblk = rnd % nx; if (blockIdx.x & 1) kblk = nx - 1 - kblk; if (pair >= npair) break; }
-    const int h = pair % p.H, b = pair / p.H;
-    const int kbase = kblk * WKEYS;
-    const int kvl = p.kv_len ? min(p.kv_len[b], p.Sk) : p.Sk;
-    const int key0a = kbase + 32 * wave, key0b = key0a + 32 * NW;  // the wave's two 32-key blocks
-    const char* qb = (const char*)(p.q + b * p.q_bs + h * p.q_hs);
-    const char* dob = (const char*)(p.d_o + b * p.do_bs + h * p.do_hs);
-    const char* kbp = (const char*)(p.k + b * p.k_bs + h * p.k_hs);
-    const char* vbp = (const char*)(p.v + b * p.v_bs + h * p.v_hs);
-    const char* lse_b = (const char*)(p.lse + ((long)b * p.H + h) * p.SqS);
-    const char* dl_b = (const char*)(p.delta + ((long)b * p.H + h) * p.SqS);
-    const int qt_b = p.Sq >> 5;
-    int qt_a = causal ? kbase >> 5 : 0;
-    if (kbase >= kvl) qt_a = qt_b;                            // every key of the super-block is padding: dk = dv = 0
-
-    // K (then V) rows of the wave's two blocks -> its staging: slot s = 64 piece + lane holds block s / 352, row (s % 352) / 11,
-    // chunk (s % 352) % 11 (chunk 10: padding).  Whole 160-byte row segments per group of ten lanes (the per-lane 16-byte gathers
-    // of the first version took 7 us of a workgroup's 11 us start-up).  Rows clamped to Sk.
-    auto dma_kv = [&](const char* base, long row_bytes) {
+    if (item_mode) { const int id = blockIdx.x + rnd * G; kblk = id / npair; pair = id - kblk * npair; it.valid = kblk < nx; }
+    else { pair = (rnd / nx) * G + blockIdx.x; kblk = rnd % nx; it.valid = pair < npair; }
+    if (!it.valid) { pair = 0; kblk = 0; }                    // pointers stay inside the tensors: fetches past the last item are harmless
+    it.h = pair % p.H; it.b = pair / p.H;
+    it.kbase = kblk * WKEYS;
+    it.kvl = p.kv_len ? min(p.kv_len[it.b], p.Sk) : p.Sk;
+    it.qt_a = causal ? it.kbase >> 5 : 0;
+    if (it.kbase >= it.kvl) it.qt_a = qt_b;                   // every key of the super-block is padding: no tiles, dk = dv = 0
+    it.qb = (const char*)(p.q + it.b * p.q_bs + it.h * p.q_hs);
+    it.dob = (const char*)(p.d_o + it.b * p.do_bs + it.h * p.do_hs);
+    it.kbp = (const char*)(p.k + it.b * p.k_bs + it.h * p.k_hs);
+    it.vbp = (const char*)(p.v + it.b * p.v_bs + it.h * p.v_hs);
+    it.lse_b = (const char*)(p.lse + ((long)it.b * p.H + it.h) * p.SqS);
+    it.dl_b = (const char*)(p.delta + ((long)it.b * p.H + it.h) * p.SqS);
+    return it;
+  };
+  // K / V rows of an item's two blocks of this wave -> staging pieces [j0, j0 + n): slot s = 64 piece + lane holds image s / 352
+  // (K block a, K block b, V block a, V block b), row (s % 352) / 11, chunk (s % 352) % 11 (chunk 10: padding).  Whole 160-byte row
+  // segments per group of ten lanes (the per-lane 16-byte gathers of the first version took 7 us per item).  Rows clamped to Sk;
+  // pieces past the last repeat it (uniform instruction counts).
+  auto dma_kv = [&](const Item& it, int j0, int n) {
+#pragma unroll 3
+    for (int jj = 0; jj < n; ++jj) {
+      const unsigned long long live = j0 + jj < NKJ ? ~0ull : 1ull;       // past the last piece: one lane of it again
+      const int j = min(j0 + jj, NKJ - 1);
+      const int s_ = 64 * j + l;
+      const int im = s_ / (32 * KPT), w_ = s_ - im * 32 * KPT;
+      const int r = w_ / KPT, c16 = min(w_ - r * KPT, CPR - 1) * 16;
+      const long row = min(it.kbase + 32 * wave + ((im & 1) ? 32 * NW : 0) + r, p.Sk - 1);
+      const char* base = im >= 2 ? it.vbp : it.kbp;
+      const long rb = (im >= 2 ? p.v_ss : p.k_ss) * 2;
+      a3_glds_v_masked(base + row * rb + c16, __builtin_amdgcn_readfirstlane(smem_lds + A3_KV0 + wave * A3_KVW + j * 1024), live);
+    }
+  };
+  // tile qt of item a -- past its last tile: the next tiles of item b from its first on -- -> a stage (branch-free: the selects are
+  // scalar; tile indices clamped into the tensor: an item without tiles fetches harmlessly)
+  auto dma_tile = [&](const Item& a, const Item& b_, int qt, int stage) {
+    const bool own = qt < qt_b;
+    const int qc = max(min(own ? qt : b_.qt_a + (qt - qt_b), qt_b - 1), 0);
+    const char* q_t = (own ? a.qb : b_.qb) + (long)qc * 32 * q_sb;
+    const char* do_t = (own ? a.dob : b_.dob) + (long)qc * 32 * do_sb;
+    const char* lse_t = (own ? a.lse_b : b_.lse_b) + (long)qc * 128;
+    const char* dl_t = (own ? a.dl_b : b_.dl_b) + (long)qc * 128;
 #pragma unroll
-      for (int j = 0; j < NKJ; ++j) {
-        const int s_ = 64 * j + l;
-        const int kb = s_ >= 32 * KPT, w_ = s_ - kb * 32 * KPT;
-        const int r = w_ / KPT, c16 = min(w_ - r * KPT, CPR - 1) * 16;
-        const long row = min((kb ? key0b : key0a) + r, p.Sk - 1);
-        a2_glds_v(base + row * row_bytes + c16, __builtin_amdgcn_readfirstlane(smem_lds + A3_KV0 + wave * A3_KVW + j * 1024));
-      }
-    };
-    if (!(dbg & 4)) dma_kv(kbp, p.k_ss * 2);                  // (measurement switch UNIMP_A3_DBG: 4 = no K / V loads)
+    for (int t = 0; t < NT; ++t) {
+      int i = wave + NW * t;                                  // wave-uniform
+      int img = i >= NJ, j = i - img * NJ;
+      uint32_t dst = smem_lds + stage * STAGE + img * IMG + j * 1024;
+      if (!img && j < 3) {                                    // a piece with lse / delta lanes: per-lane base
+        const char* base = is_lse[t] ? lse_t : (is_dl[t] ? dl_t : q_t);
+        a2_glds_v(base + voff[t], __builtin_amdgcn_readfirstlane(dst));
+      } else a2_glds(img ? do_t : q_t, voff[t], __builtin_amdgcn_readfirstlane(dst));
+    }
+  };
 
-    auto dma_tile = [&](int qt, int stage) {
-      const int qc = min(qt, qt_b - 1);                       // past the last tile: fetch it again (uniform counts; the stage is never read)
-      const char* q_t = qb + (long)qc * 32 * q_sb;
-      const char* do_t = dob + (long)qc * 32 * do_sb;
-      const char* lse_t = lse_b + (long)qc * 128;
-      const char* dl_t = dl_b + (long)qc * 128;
+  // first item of this workgroup: everything it needs, confirmed
+  Item cur = item_of(0);
+  if (!cur.valid) return;
+  int stage = 0;
+  dma_kv(cur, 0, NKJ);
+  dma_tile(cur, cur, cur.qt_a, 0); dma_tile(cur, cur, cur.qt_a + 1, 1); dma_tile(cur, cur, cur.qt_a + 2, 2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int rnd = 0; cur.valid; ++rnd) {
+    const Item nxt = item_of(rnd + 1);
+    const int h = cur.h, b = cur.b, kvl = cur.kvl, qt_a = cur.qt_a;
+    const int key0a = cur.kbase + 32 * wave, key0b = key0a + 32 * NW;  // the wave's two 32-key blocks
+
+    // K / V fragments (B operands, all k-steps) out of the staging, which is then free for the next item's rows
+    bf16x8 kf[2][KS], vf[2][KS];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        int i = wave + NW * t;                                // wave-uniform
-        int img = i >= NJ, j = i - img * NJ;
-        uint32_t dst = smem_lds + stage * STAGE + img * IMG + j * 1024;
-        if (dbg & 8) continue;                                // (8 = no tile fetches)
-        if (!img && j < 3) {                                  // a piece with lse / delta lanes: per-lane base
-          const char* base = is_lse[t] ? lse_t : (is_dl[t] ? dl_t : q_t);
-          a2_glds_v(base + voff[t], __builtin_amdgcn_readfirstlane(dst));
-        } else a2_glds(img ? do_t : q_t, voff[t], __builtin_amdgcn_readfirstlane(dst));
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        kf[kb][ks] = *(const bf16x8*)(kvw + kb * KIMG + kv_rd + ks * 32);
+        vf[kb][ks] = *(const bf16x8*)(kvw + (2 + kb) * KIMG + kv_rd + ks * 32);
       }
-    };
-    // the first three tiles go out behind the K rows
-    if (qt_a < qt_b) { dma_tile(qt_a, 0); dma_tile(qt_a + 1, 1); dma_tile(qt_a + 2, 2); }
-
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) { a2_pin(kf[kb][ks]); a3_pin_acc(vf[kb][ks]); }
     f32x16 dk[2][ND], dv[2][ND];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -157,34 +203,6 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_dkv3_kernel(AttnP p, int nx, 
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int nd = 0; nd < ND; ++nd) { a3_pin_acc(dk[kb][nd]); a3_pin_acc(dv[kb][nd]); }
-
-    // K fragments (B operands, all k-steps) out of the staging; then the V rows take its place.  In flight behind the K rows are at
-    // most the three tiles.
-    bf16x8 kf[2][KS], vf[2][KS];
-    if (qt_a < qt_b && !(dbg & 8)) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * NT) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        if (!(dbg & 4)) kf[kb][ks] = *(const bf16x8*)(kvw + kb * KIMG + kv_rd + ks * 32);
-        else kf[kb][ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-      }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (!(dbg & 4)) dma_kv(vbp, p.v_ss * 2);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        if (!(dbg & 4)) vf[kb][ks] = *(const bf16x8*)(kvw + kb * KIMG + kv_rd + ks * 32);
-        else vf[kb][ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-      }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) { a2_pin(kf[kb][ks]); a3_pin_acc(vf[kb][ks]); }
     const int mykey_a = key0a + kl, mykey_b = key0b + kl;
 
     // one query tile for the wave's two key blocks; V = 0: the block sees no row of the tile, 1: every element is visible,
@@ -197,7 +215,8 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_dkv3_kernel(AttnP p, int nx, 
       const uint32_t a_ra = sbo + r_a, a_rb = sbo + r_b, a_t0 = sbo + t_0, a_t1 = sbo + t_1;
       // lse / delta of rows 8 g + 4 hi5 .. + 3: chunk 10 of the Q image's row 2 g + hi5 (lse) and row 8 + 2 g + hi5 (delta)
       const char* ax = smem + stage * STAGE + hi5 * (PT * 16);
-      f32x16 nl, ndl;
+      float nl[16];                                           // scalars, not a register tuple: only the MFMA's C operand (ndl) must be contiguous
+      f32x16 ndl;
   #pragma unroll
       for (int g = 0; g < 4; ++g) {
         f32x4 a = *(const f32x4*)(ax + (2 * g * PT + (CPR ^ (g >> 1))) * 16);
@@ -206,18 +225,18 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_dkv3_kernel(AttnP p, int nx, 
         for (int e = 0; e < 4; ++e) { nl[4 * g + e] = a[e] * -LOG2E; ndl[4 * g + e] = -d[e]; }
       }
       // lane holds key = mykey and query rows q0 + 8 g + 4 hi5 + e (r = 4 g + e); element visible <=> qmin <= row (and the key is real)
-      auto masked = [&](int mykey) {
+      float nlm0[16], nlm1[16];
+      auto masked = [&](int mykey, float (&m)[16]) {
         const int qmin = causal ? mykey : 0;
         const int a0 = q0 + 4 * hi5 - qmin;
         const unsigned rng = mykey < kvl ? (unsigned)(p.Sq - qmin) : 0u;
-        f32x16 m;
   #pragma unroll
         for (int r = 0; r < 16; ++r) m[r] = (unsigned)(a0 + 8 * (r >> 2) + (r & 3)) < rng ? nl[r] : -1e30f;
-        return m;
       };
-      f32x16 nl0 = nl, nl1 = nl;
-      if (V0 == 2) nl0 = masked(mykey_a);
-      if (V1 == 2) nl1 = masked(mykey_b);
+      if (V0 == 2) masked(mykey_a, nlm0);
+      if (V1 == 2) masked(mykey_b, nlm1);
+      const float* nl0 = V0 == 2 ? nlm0 : nl;
+      const float* nl1 = V1 == 2 ? nlm1 : nl;
       f32x16 s0, s1, dp0, dp1;
       bf16x8 qf[KS], dof[KS];
       s16x4 udl[2 * ND], udh[2 * ND], uql[2 * ND], uqh[2 * ND];
@@ -230,20 +249,23 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_dkv3_kernel(AttnP p, int nx, 
       return (k0 + 32 <= kvl && (!causal || k0 + 31 <= q0)) ? 1 : 2;
     };
 
-    __syncthreads();                                          // every wave's first three tiles have landed (the V rows came in behind them)
-
     // The tile loop, one straight-line loop per visibility state of the wave's two blocks.  A block's state over the tiles of a
     // sequence only moves none -> mixed -> all (causal: the diagonal passes once; keys beyond kv_len stay invisible), so the pairs
     // are visited in an order that is a chain of the product order and every loop below runs at most once.  (One loop with a
     // switch over the states made the structurizer merge the 192 accumulator registers through copies after every tile.)
-    int stage = 0, qt = qt_a;
+    // Iteration it of the item: the next item's K / V pieces 3 it .. 3 it + 2 (from the eighth iteration on: one lane of the last piece again --
+    // every iteration issues the same count), then the tile three ahead -- past this item's last
+    // tile: the next item's first tiles -- then the arithmetic, then the wait for tile + 1: newer than its pieces are the pieces of
+    // the last two iterations.  The first two iterations wait for nothing (tiles 1 and 2 were confirmed before the item began).
+    int qt = qt_a;
     auto run = [&](auto v0c, auto v1c) {
       constexpr int V0 = decltype(v0c)::value, V1 = decltype(v1c)::value;
       while (qt < qt_b && vis(key0a, qt * 32) == V0 && vis(key0b, qt * 32) == V1) {
-        dma_tile(qt + 3, (stage + 3) & 3);
-        if ((V0 || V1) && !(dbg & 1)) tile(v0c, v1c, stage, qt * 32);                       // (1 = no tile arithmetic)
-        // tile qt + 1 must have landed before the barrier: the two newest (qt + 2, qt + 3) may stay in flight
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NT) : "memory");
+        const int it = qt - qt_a;
+        dma_kv(nxt, KVI * it, KVI);
+        dma_tile(cur, nxt, qt + 3, (stage + 3) & 3);
+        if ((V0 || V1) && !(dbg & 1)) tile(v0c, v1c, stage, qt * 32);                       // (measurement switch UNIMP_A3_DBG: 1 = no tile arithmetic)
+        if (it >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NT + 2 * KVI) : "memory");
         __syncthreads();
         stage = (stage + 1) & 3;
         ++qt;
@@ -255,19 +277,26 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_dkv3_kernel(AttnP p, int nx, 
     run(A3V<1>{}, A3V<2>{}); run(A3V<2>{}, A3V<1>{});
     run(A3V<1>{}, A3V<1>{});
 
-    // epilogue through the wave's own staging area (nobody else's; the tile stages stay untouched, so the tiles fetched past the end
-    // may still be landing: the next item's tile fetches are ordered behind them)
+    // what the loop did not get to (an item of fewer than eight / three tiles): the rest of the next item's K / V rows and first tiles
+    const int n_it = qt_b - qt_a;
+    if (n_it < KVN) dma_kv(nxt, KVI * n_it, NKJ - KVI * n_it);
+    for (int j = 0; j < 3 - n_it; ++j) dma_tile(nxt, nxt, nxt.qt_a + j, (stage + j) & 3);       // iteration i fetched the next item's tile 3 - n_it + i
+    // ... all of it landed before the first store goes out; the barrier publishes every wave's tile pieces
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // epilogue through the wave's own staging area
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       const int key0 = kb ? key0b : key0a;
       if (key0 < p.Sk && !(dbg & 2)) {                        // (2 = no result stores)
-        a2_store_rows<D, ND>(kvw, dk[kb], p.scale, p.dk + b * p.dk_bs + h * p.dk_hs, p.dk_ss, key0, p.Sk, p.rope_cos, p.rope_sin, p.rope_half, p.rope_step);
+        a2_store_rows<D, ND>(epw, dk[kb], p.scale, p.dk + b * p.dk_bs + h * p.dk_hs, p.dk_ss, key0, p.Sk, p.rope_cos, p.rope_sin, p.rope_half, p.rope_step);
         __builtin_amdgcn_wave_barrier();
-        a2_store_rows<D, ND>(kvw, dv[kb], 1.f, p.dv + b * p.dv_bs + h * p.dv_hs, p.dv_ss, key0, p.Sk);
+        a2_store_rows<D, ND>(epw, dv[kb], 1.f, p.dv + b * p.dv_bs + h * p.dv_hs, p.dv_ss, key0, p.Sk);
         __builtin_amdgcn_wave_barrier();
       }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the staging area is about to be the next item's K / V images
+    cur = nxt;
   }
 }
 
@@ -282,30 +311,32 @@ extern "C" int unimp_attn_dkv3_eligible(const AttnP* p) {
   return 1;
 }
 
-template <int NW>
-static int a3_launch(const AttnP& p, hipStream_t s, int ncu, int dbg) {
-  constexpr int D = 80;
-  static_assert(32 * (D * 2 + 16) <= A3_KVW, "epilogue staging fits a wave's K / V staging");
-  static_assert((4 / NW) * a3_lds(NW) <= 160 * 1024, "4 / NW workgroups per CU: 160 KiB of LDS");
-  static bool attr_set = false;
-  auto kern = attn_dkv3_kernel<D, NW>;
-  if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)a3_lds(NW)); attr_set = true; }
-  const int nk = (p.Sk + 64 * NW - 1) / (64 * NW), npair = p.H * p.B, nwg = ncu * (4 / NW);
-  const int item_mode = npair < nwg;
-  const int grid = item_mode ? (npair * nk < nwg ? npair * nk : nwg) : nwg;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), a3_lds(NW), s, p, nk, item_mode, dbg);
-  return unimp_check_launch("attn_dkv3");
-}
-
-int unimp_attn_dkv3_launch(const AttnP& p, void* stream) {
+static int a3_ncu() {
   static int ncu = 0;
   if (!ncu) {
     int dev = 0; hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return unimp_set_error(UNIMP_ERR_LAUNCH, "attn_dkv3: no device properties");
-    ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
   }
-  // measurement switches: UNIMP_A3_DBG (kernel comments), UNIMP_A3_NW = 4: one 4-wave workgroup per CU instead of two 2-wave ones
-  static const int dbg = [] { const char* e = getenv("UNIMP_A3_DBG"); return e ? atoi(e) : 0; }();
-  static const int nw = [] { const char* e = getenv("UNIMP_A3_NW"); return e && atoi(e) == 4 ? 4 : 2; }();
-  return nw == 4 ? a3_launch<4>(p, (hipStream_t)stream, ncu, dbg) : a3_launch<2>(p, (hipStream_t)stream, ncu, dbg);
+  return ncu;
+}
+
+// ... and where it is the faster choice: one persistent workgroup per CU needs a (batch, head) pair per CU to keep the chip busy and
+// to carry an item's memory phases inside its neighbour's loop.  Measured at the LM's shape (profiles/r05_attention3_ab.txt, backward
+// = dQ + dK/dV, this kernel vs the first generation): 3 x 32 pairs 69 vs 58 us, 6 x 32: 96 vs 94, 8 x 32: 106 vs 117, 64 x 32: 723 vs 840.
+extern "C" int unimp_attn_dkv3_preferred(const AttnP* p) { return p->H * p->B >= a3_ncu(); }
+
+int unimp_attn_dkv3_launch(const AttnP& p, void* stream) {
+  constexpr int D = 80;
+  static_assert(32 * (D * 2 + 16) <= A3_EPW, "epilogue staging fits");
+  static_assert(A3_LDS <= 160 * 1024, "one workgroup per CU: 160 KiB of LDS");
+  static bool attr_set = false;
+  auto kern = attn_dkv3_kernel<D>;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)A3_LDS); attr_set = true; }
+  const int ncu = a3_ncu();
+  const int nk = (p.Sk + 255) / 256, npair = p.H * p.B;
+  const int item_mode = npair < ncu;
+  const int grid = item_mode ? (npair * nk < ncu ? npair * nk : ncu) : ncu;
+  static const int dbg = [] { const char* e = getenv("UNIMP_A3_DBG"); return e ? atoi(e) : 0; }();       // measurement switches (kernel comments)
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), A3_LDS, (hipStream_t)stream, p, nk, item_mode, dbg);
+  return unimp_check_launch("attn_dkv3");
 }

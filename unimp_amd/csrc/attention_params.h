@@ -104,4 +104,5 @@ __device__ __forceinline__ u32x4 attn_rope_inv_apply(const AttnRopeChunk& k) {
 int unimp_attn_fwd2_dispatch(const AttnP& p, void* stream);      // attention2.hip
 int unimp_attn_bwd2_dispatch(const AttnP& p, int which, void* stream);      // attention2.hip (after the delta kernel): 1 dQ, 2 dK/dV
 extern "C" int unimp_attn_dkv3_eligible(const AttnP* p);         // attention3.hip: forms its dK/dV kernel serves
+extern "C" int unimp_attn_dkv3_preferred(const AttnP* p);        // ... and sizes at which it is the faster choice (a pair per CU)
 int unimp_attn_dkv3_launch(const AttnP& p, void* stream);        // attention3.hip (after the dQ kernel, which publishes delta)
