@@ -224,6 +224,9 @@ int unimp_attn_set_vit_tail(int on);
  * (one persistent workgroup per CU: below that the first generation's many small workgroups are faster); 2 = wherever it serves
  * the form (the tests' small cases).  Returns the previous value. */
 int unimp_attn_set_dkv3(int mode);
+/* which dK/dV kernel the last unimp_attn_bwd of this process launched: 1 = first generation (attention.hip), 2 = attention2.hip,
+ * 3 = attention3.hip; 0 = none yet (tests: the size threshold, and that a data-parallel group keeps the persistent kernel out) */
+int unimp_attn_last_dkv(void);
 
 /* ---- token embedding (gpt_neox.embed_in / OPT embed_tokens+embed_positions) -------------------------------
  * fwd: out[r] = W[ids[r]] (+ P[pos[r]]);  bwd: dW[ids[r]] += dout[r]  (fp32 atomics into dW32, then cast)

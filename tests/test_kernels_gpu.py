@@ -620,6 +620,39 @@ ATTN_CASES = [
 ]
 
 
+def test_attention3_dispatch_threshold_and_data_parallel_switch(ops):
+    """which dK/dV kernel serves the LM's form: attention3.hip from one (batch, head) pair per CU on, the first generation below it, and
+    the first generation as well while ops.AVOID_PERSISTENT is set (a data-parallel group's collectives share the CUs: no persistent
+    kernels) -- with the same gradients either way."""
+    from unimp_amd import _lib
+    L = _lib.lib()
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    D, S, H = 80, 64, 8
+    assert L.unimp_attn_get_generation() == 2
+    def run(B):
+        g = torch.Generator().manual_seed(B)
+        qkv = torch.randn(B, S, H, 3 * D, generator=g).to(bf16).cuda()
+        q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+        do = torch.randn(B, S, H, D, generator=g).to(bf16).cuda()
+        o, lse = ops.attn_fwd(q, k, v, D ** -0.5, ops.MASK_CAUSAL)
+        dqkv = torch.zeros_like(qkv)
+        ops.attn_bwd(q, k, v, o, lse, do, dqkv[..., :D], dqkv[..., D:2 * D], dqkv[..., 2 * D:], D ** -0.5, ops.MASK_CAUSAL)
+        torch.cuda.synchronize()
+        return dqkv.float().cpu()
+    big, small = (ncu + H - 1) // H, max(1, (ncu - 1) // H)
+    a = run(big)
+    assert L.unimp_attn_last_dkv() == 3
+    run(small)
+    assert L.unimp_attn_last_dkv() == 1
+    was, ops.AVOID_PERSISTENT = ops.AVOID_PERSISTENT, True
+    try:
+        b = run(big)
+        assert L.unimp_attn_last_dkv() == 1
+    finally:
+        ops.AVOID_PERSISTENT = was
+    close(a[..., D:], b[..., D:], rel=2 ** -5, name="dk / dv: attention3 vs first generation")
+
+
 @pytest.mark.parametrize("B,H,S,mode", [(40, 8, 64, 1), (35, 8, 320, 1), (33, 8, 288, 0), (48, 6, 512, 1)])
 def test_attention3_many_items_per_workgroup(ops, B, H, S, mode):
     """attention3.hip's persistent workgroups with MORE (batch, head) pairs than CUs: every workgroup walks several items, the next

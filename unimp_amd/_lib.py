@@ -75,6 +75,7 @@ _SIGS = {
     "unimp_attn_get_generation": [],
     "unimp_attn_set_vit_tail": [c_i],
     "unimp_attn_set_dkv3": [c_i],
+    "unimp_attn_last_dkv": [],
     "unimp_pack_b_bf16": [c_p, c_l, c_i, c_i, c_i, c_p, c_p],
     "unimp_mx_quantize": [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_p],
     "unimp_gemm_mxfp8": [C.POINTER(MxGemmDesc), c_p],

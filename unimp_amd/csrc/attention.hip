@@ -805,6 +805,8 @@ static int attn_dkv3_on() {
   if (g_attn_dkv3 < 0) { const char* e = getenv("UNIMP_DKV3"); int v = e ? atoi(e) : 1; g_attn_dkv3 = v < 0 ? 0 : (v > 2 ? 2 : v); }
   return g_attn_dkv3;
 }
+static int g_attn_last_dkv = 0;
+extern "C" int unimp_attn_last_dkv(void) { return g_attn_last_dkv; }
 extern "C" int unimp_attn_set_dkv3(int mode) { int old = attn_dkv3_on(); g_attn_dkv3 = mode < 0 ? 0 : (mode > 2 ? 2 : mode); return old; }
 
 extern "C" int unimp_attn_fwd(const unimp_attn_desc* d, void* stream) {
@@ -848,8 +850,11 @@ extern "C" int unimp_attn_bwd(const unimp_attn_desc* d, void* stream) {
   // delta = rowsum(dO * O): the second-generation dQ kernel computes and publishes it itself
   if (!(which2 & 1)) hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((n * 16 + 255) / 256)), dim3(256), 0, s, p);
   if (which2) { int e2 = unimp_attn_bwd2_dispatch(p, which2, stream); if (e2) return e2; }
-  if (gen == 2 && which2 == 1 && attn_dkv3_on() && unimp_attn_dkv3_eligible(&p) && (attn_dkv3_on() == 2 || unimp_attn_dkv3_preferred(&p)))
+  if (gen == 2 && which2 == 1 && attn_dkv3_on() && unimp_attn_dkv3_eligible(&p) && (attn_dkv3_on() == 2 || unimp_attn_dkv3_preferred(&p))) {
+    g_attn_last_dkv = 3;
     return unimp_attn_dkv3_launch(p, stream);
+  }
+  g_attn_last_dkv = (which2 & 2) ? 2 : 1;
   // dK/dV: 16 keys per wave (KU = 1, 64-key workgroups; default) or 32 (KU = 2, 128-key workgroups; UNIMP_DKV_KU=2).  With 32 the
   // kernel held 248 registers at head dim 80 (dK^T, dV^T accumulators and the K / V fragments of two 16-key blocks): two waves
   // per SIMD, 55 % of wave time in waits.  With 16 it holds 166: a third wave per SIMD (hd 64: four; hd 128: two instead of one

@@ -659,7 +659,18 @@ def attn_bwd(q, k, v, o, lse, do, dq, dk, dv, scale, mask_mode=MASK_NONE, kv_len
         assert cos.dtype == torch.float32 and sin.dtype == torch.float32 and cos.is_contiguous() and sin.is_contiguous()
         assert cos.shape == sin.shape and cos.shape[0] >= max(Sq, Sk), (cos.shape, Sq, Sk)
         d.rope_cos, d.rope_sin, d.rope_half = cos.data_ptr(), sin.data_ptr(), cos.shape[1]
-    check(_lib.lib().unimp_attn_bwd(C.byref(d), _stream()), "attn_bwd")
+    L = _lib.lib()
+    if AVOID_PERSISTENT:
+        # a data-parallel group's collectives share the CUs with backward: attention3.hip's dK/dV kernel is one persistent workgroup per CU
+        # (a CU held by a collective would leave its workgroup waiting for a free one: the kernel runs twice as long) -- like the persistent
+        # GEMM variants it stays out while the flag is set
+        old = L.unimp_attn_set_dkv3(0)
+        try:
+            check(L.unimp_attn_bwd(C.byref(d), _stream()), "attn_bwd")
+        finally:
+            L.unimp_attn_set_dkv3(old)
+        return
+    check(L.unimp_attn_bwd(C.byref(d), _stream()), "attn_bwd")
 
 
 def embedding_fwd(ids, W, pos=None, P=None):
