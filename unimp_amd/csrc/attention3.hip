@@ -39,7 +39,7 @@ template <typename T> __device__ __forceinline__ void a3_pin_acc(T& v) { asm vol
 // LDS of the workgroup (4 waves): four tile stages (Q image + dO image each, row pitch 12 chunks); per wave the staging of its two
 // key blocks' K and V rows -- four 32-row images at the odd pitch of 11 chunks = 22 DMA pieces; per wave the epilogue staging.
 constexpr int A3_PT = 12, A3_IMG = 32 * A3_PT * 16, A3_STAGE = 2 * A3_IMG, A3_KV0 = 4 * A3_STAGE;
-constexpr int A3_KPT = 11, A3_KIMG = 32 * A3_KPT * 16, A3_KVW = 4 * A3_KIMG, A3_EP0 = A3_KV0 + 4 * A3_KVW, A3_EPW = 6144;
+constexpr int A3_KVW = 22 * 1024, A3_EP0 = A3_KV0 + 4 * A3_KVW, A3_EPW = 6144;      // 128 rows of a wave, six per 1-KiB piece
 constexpr size_t A3_LDS = A3_EP0 + 4 * A3_EPW;
 
 // One workgroup per CU, each wave alone on its SIMD (512 registers): nothing is co-resident to hide an item's start-up (K / V rows
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256, 1) void attn_dkv3_kernel(AttnP p, int nx, int 
   constexpr int CPR = D / 8, PT = A3_PT, KS = D / 16, ND = (D + 31) / 32, NW = 4;
   constexpr int IMG = A3_IMG, NJ = IMG / 1024, OFF_DO = IMG, STAGE = A3_STAGE;
   constexpr int NT = (2 * NJ) / NW;                           // tile DMA instructions per wave and tile
-  constexpr int KPT = A3_KPT, KIMG = A3_KIMG, NKJ = A3_KVW / 1024;      // K / V staging of a wave: 4 images = NKJ whole pieces
+  constexpr int NKJ = A3_KVW / 1024;                          // K / V staging of a wave: 128 rows in NKJ pieces of six
   constexpr int KVI = 3, KVN = 8;                             // K / V pieces per iteration, iterations that carry them
   static_assert((2 * NJ) % NW == 0 && A3_KVW % 1024 == 0 && KVI * KVN >= NKJ, "pieces divide over the waves; the staging is whole pieces");
   constexpr int WKEYS = 64 * NW;                              // keys per workgroup
@@ -82,7 +82,6 @@ __global__ __launch_bounds__(256, 1) void attn_dkv3_kernel(AttnP p, int nx, int 
   const int t_1 = ((trow + 8) * PT + (tc ^ (2 + hi5))) * 16 + 8 * (i16 & 1);
   char* const kvw = smem + A3_KV0 + wave * A3_KVW;            // this wave's K / V staging: K blocks a, b, V blocks a, b
   char* const epw = smem + A3_EP0 + wave * A3_EPW;            // this wave's epilogue staging
-  const int kv_rd = (kl * KPT + hi5) * 16;                    // K / V fragment of k-step ks: + 32 ks (odd pitch: no swizzle needed)
 
   // Tile DMA plan: instruction i = wave + NW t (t < NT) moves piece i % NJ of image i / NJ (0: Q, 1: dO).  Slot s = 64 piece + lane
   // of an image holds row s / PT, chunk (s % PT) ^ ((row >> 2) & 3).  Chunks 10, 11 of a row are padding -- and chunk 10 of the Q
@@ -90,7 +89,8 @@ __global__ __launch_bounds__(256, 1) void attn_dkv3_kernel(AttnP p, int nx, int 
   // every wave issues exactly NT per tile.  Per lane and t one 32-bit byte offset from the tile's first row (a lane of the lse /
   // delta chunks: from the tile's first lse / delta entry) -- the same for every tile of every item.
   uint32_t voff[NT];
-  bool is_lse[NT], is_dl[NT];
+  int lane_arr0 = 0;                                          // this lane in the wave's first piece: 0 = a Q chunk, 1 = an lse chunk, 2 = a delta chunk
+  static_assert(NW <= NJ && 3 <= NW, "instruction t = 0 of every wave is a Q piece, and Q pieces 0 - 2 are t = 0 pieces");
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     int i = wave + NW * t;
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256, 1) void attn_dkv3_kernel(AttnP p, int nx, int 
     int r = s_ / PT, cp = s_ - r * PT;
     int c = cp ^ ((r >> 2) & 3);
     const bool aux = !img && c == CPR && r < 16;
-    is_lse[t] = aux && r < 8; is_dl[t] = aux && r >= 8;
+    if (t == 0 && aux) lane_arr0 = r < 8 ? 1 : 2;
     voff[t] = aux ? (uint32_t)(16 * (r & 7)) : (uint32_t)r * (img ? do_sb : q_sb) + (uint32_t)min(c, CPR - 1) * 16;
   }
 
@@ -125,22 +125,26 @@ __global__ __launch_bounds__(256, 1) void attn_dkv3_kernel(AttnP p, int nx, int 
     it.dl_b = (const char*)(p.delta + ((long)it.b * p.H + it.h) * p.SqS);
     return it;
   };
-  // K / V rows of an item's two blocks of this wave -> staging pieces [j0, j0 + n): slot s = 64 piece + lane holds image s / 352
-  // (K block a, K block b, V block a, V block b), row (s % 352) / 11, chunk (s % 352) % 11 (chunk 10: padding).  Whole 160-byte row
-  // segments per group of ten lanes (the per-lane 16-byte gathers of the first version took 7 us per item).  Rows clamped to Sk;
-  // pieces past the last repeat it (uniform instruction counts).
+  // K / V rows of an item's two blocks of this wave -> staging pieces [j0, j0 + n).  The wave stages 128 rows R = 32 image + row (images:
+  // K block a, K block b, V block a, V block b); piece j holds rows 6 j .. 6 j + 5, lane l the chunk l % 10 of row 6 j + l / 10 (lanes 60-63:
+  // the next row's first chunks again, never read): whole 160-byte row segments per ten lanes (the per-lane 16-byte gathers of the
+  // first version took 7 us per item) and an address a lane forms from two constants of its own.  Rows clamped to Sk; pieces past the
+  // last: one lane of it again (uniform instruction counts without the traffic).
+  const int kv_ri = l / 10, kv_c16 = (l - 10 * kv_ri) * 16;
+  const uint32_t k_rb = (uint32_t)(p.k_ss * 2), v_rb = (uint32_t)(p.v_ss * 2);
   auto dma_kv = [&](const Item& it, int j0, int n) {
+    const unsigned long long dv_ = (unsigned long long)(it.vbp - it.kbp);
 #pragma unroll 3
     for (int jj = 0; jj < n; ++jj) {
-      const unsigned long long live = j0 + jj < NKJ ? ~0ull : 1ull;       // past the last piece: one lane of it again
+      const unsigned long long live = j0 + jj < NKJ ? ~0ull : 1ull;
       const int j = min(j0 + jj, NKJ - 1);
-      const int s_ = 64 * j + l;
-      const int im = s_ / (32 * KPT), w_ = s_ - im * 32 * KPT;
-      const int r = w_ / KPT, c16 = min(w_ - r * KPT, CPR - 1) * 16;
-      const long row = min(it.kbase + 32 * wave + ((im & 1) ? 32 * NW : 0) + r, p.Sk - 1);
-      const char* base = im >= 2 ? it.vbp : it.kbp;
-      const long rb = (im >= 2 ? p.v_ss : p.k_ss) * 2;
-      a3_glds_v_masked(base + row * rb + c16, __builtin_amdgcn_readfirstlane(smem_lds + A3_KV0 + wave * A3_KVW + j * 1024), live);
+      const int R = min(6 * j + kv_ri, 127);
+      const uint32_t row = (uint32_t)min(it.kbase + 32 * wave + ((R & 32) << 2) + (R & 31), p.Sk - 1);
+      const uint32_t mv = 0u - (uint32_t)(R >= 64);           // V rows: bitwise selection of the (scalar) distance, no select of pointers
+      const unsigned long long sel = (((unsigned long long)(mv & (uint32_t)(dv_ >> 32))) << 32) | (mv & (uint32_t)dv_);
+      const uint32_t rb = R >= 64 ? v_rb : k_rb;
+      // row and row pitch are below 2^24, a (batch, head) slice below 4 GiB (unimp_attn_dkv3_eligible): one 24-bit multiply
+      a3_glds_v_masked(it.kbp + sel + (__umul24(row, rb) + (uint32_t)kv_c16), __builtin_amdgcn_readfirstlane(smem_lds + A3_KV0 + wave * A3_KVW + j * 1024), live);
     }
   };
   // tile qt of item a -- past its last tile: the next tiles of item b from its first on -- -> a stage (branch-free: the selects are
@@ -157,9 +161,14 @@ __global__ __launch_bounds__(256, 1) void attn_dkv3_kernel(AttnP p, int nx, int 
       int i = wave + NW * t;                                  // wave-uniform
       int img = i >= NJ, j = i - img * NJ;
       uint32_t dst = smem_lds + stage * STAGE + img * IMG + j * 1024;
-      if (!img && j < 3) {                                    // a piece with lse / delta lanes: per-lane base
-        const char* base = is_lse[t] ? lse_t : (is_dl[t] ? dl_t : q_t);
-        a2_glds_v(base + voff[t], __builtin_amdgcn_readfirstlane(dst));
+      if (t == 0) {
+        // the wave's first piece is a Q piece (i = wave < NJ), and only Q pieces 0 - 2 carry lse / delta lanes: this one takes the per-lane
+        // base -- bitwise selection of the (scalar) distances, no select of pointers (hipcc turns that into divergent branches) -- the
+        // others the scalar base + 32-bit lane offset form.  No run-time choice of form anywhere.
+        const unsigned long long dL = (unsigned long long)(lse_t - q_t), dD = (unsigned long long)(dl_t - q_t);
+        const uint32_t mL = 0u - (uint32_t)(lane_arr0 == 1), mD = 0u - (uint32_t)(lane_arr0 == 2);
+        const uint32_t lo = (mL & (uint32_t)dL) | (mD & (uint32_t)dD), hi = (mL & (uint32_t)(dL >> 32)) | (mD & (uint32_t)(dD >> 32));
+        a2_glds_v(q_t + ((((unsigned long long)hi) << 32) | lo) + voff[t], __builtin_amdgcn_readfirstlane(dst));
       } else a2_glds(img ? do_t : q_t, voff[t], __builtin_amdgcn_readfirstlane(dst));
     }
   };
@@ -184,8 +193,10 @@ __global__ __launch_bounds__(256, 1) void attn_dkv3_kernel(AttnP p, int nx, int 
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        kf[kb][ks] = *(const bf16x8*)(kvw + kb * KIMG + kv_rd + ks * 32);
-        vf[kb][ks] = *(const bf16x8*)(kvw + (2 + kb) * KIMG + kv_rd + ks * 32);
+        // staged row R = 32 image + kl sits in piece R / 6 at row R % 6 (a 2-way bank conflict on these twenty reads per item)
+        const int Rk = 32 * kb + kl, Rv = 64 + 32 * kb + kl;
+        kf[kb][ks] = *(const bf16x8*)(kvw + (Rk / 6) * 1024 + (Rk % 6) * 160 + hi5 * 16 + ks * 32);
+        vf[kb][ks] = *(const bf16x8*)(kvw + (Rv / 6) * 1024 + (Rv % 6) * 160 + hi5 * 16 + ks * 32);
       }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -260,7 +271,15 @@ __global__ __launch_bounds__(256, 1) void attn_dkv3_kernel(AttnP p, int nx, int 
     int qt = qt_a;
     auto run = [&](auto v0c, auto v1c) {
       constexpr int V0 = decltype(v0c)::value, V1 = decltype(v1c)::value;
+      // the state can only change at the tiles where a block's diagonal starts and ends (causal) -- between them it is not re-evaluated
+      // (the kernel is issue-bound: two visibility tests per iteration were 5 % of its scalar instructions)
       while (qt < qt_b && vis(key0a, qt * 32) == V0 && vis(key0b, qt * 32) == V1) {
+        int qe = qt_b;
+        if (causal) {
+          const int ta = key0a >> 5, tb = key0b >> 5;
+          for (int c : {ta, ta + 1, tb, tb + 1}) if (c > qt && c < qe) qe = c;
+        }
+        for (; qt < qe; ++qt) {
         const int it = qt - qt_a;
         dma_kv(nxt, KVI * it, KVI);
         dma_tile(cur, nxt, qt + 3, (stage + 3) & 3);
@@ -268,7 +287,7 @@ __global__ __launch_bounds__(256, 1) void attn_dkv3_kernel(AttnP p, int nx, int 
         if (it >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NT + 2 * KVI) : "memory");
         __syncthreads();
         stage = (stage + 1) & 3;
-        ++qt;
+        }
       }
     };
     run(A3V<0>{}, A3V<0>{});
@@ -308,6 +327,8 @@ extern "C" int unimp_attn_dkv3_eligible(const AttnP* p) {
   if ((p->q_ss | p->do_ss) & 7) return 0;
   if ((p->q_ss * 2 * 32) >> 31 || (p->do_ss * 2 * 32) >> 31) return 0;      // 32-bit per-lane source offsets inside a tile
   if (((uintptr_t)p->lse | (uintptr_t)p->delta) & 15) return 0;
+  if (p->Sk >= (1 << 24) || p->k_ss * 2 >= (1 << 24) || p->v_ss * 2 >= (1 << 24) || p->k_ss < 0 || p->v_ss < 0) return 0;      // 24-bit row x pitch products
+  if ((long)p->Sk * p->k_ss * 2 >= (1ll << 32) || (long)p->Sk * p->v_ss * 2 >= (1ll << 32)) return 0;
   return 1;
 }
 
