@@ -120,6 +120,13 @@ def test_kernel_register_budgets():
     for k, r in a2.items():
         if "dkv2" not in k or "Li128" not in k:                  # the experimental dK/dV kernel at head dim 128 runs one wave per SIMD
             assert r["ScratchSize"] == 0, (k, r)
+    # third-generation dK/dV (attention3.hip; no VGPR-form flag: its accumulators live in the AGPRs): one wave per SIMD by design, and NOTHING in
+    # scratch -- with nothing co-resident a scratch reload is an exposed memory round trip (round 5: the epilogue's hoisted per-lane constants
+    # reloaded from scratch cost 97 us of a 570 us launch until the lane id was made opaque per item)
+    a3 = remarks("attention3.hip", ("-fno-slp-vectorize",))
+    assert len(a3) == 1, sorted(a3)
+    for k, r in a3.items():
+        assert r["ScratchSize"] == 0 and r["VGPRs"] <= 256 and r.get("AGPRs", 0) <= 256, (k, r)
     # LayerNorm: HBM-bound, lives on waves in flight.  The forward and the plain backward at the LM width (5 chunks of 512) keep
     # three waves per SIMD (the scheduler widens gamma / beta or both passes' operands to fp32 if allowed to: 180-255 registers),
     # the weight-gradient form two (its partial sums are in LDS, not in 80 more registers); nothing spills at the widths in use

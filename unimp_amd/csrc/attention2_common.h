@@ -66,9 +66,11 @@ template <int D> struct A2Cfg {
 template <int D, int ND>
 __device__ __forceinline__ void a2_store_rows(char* lds_wave, const f32x16 (&acc)[ND], float mul, bf16* __restrict__ gbase, long row_stride,
                                               int row0, int nrows, const float* rope_cos = nullptr, const float* rope_sin = nullptr,
-                                              int rope_half = 0, float rope_step = 0.f) {
+                                              int rope_half = 0, float rope_step = 0.f, int lane = -1) {
   constexpr int PITCH = D * 2 + 16, CPR = D / 8;
-  const int l = lane_id(), hi5 = l >> 5, rl = l & 31;
+  // lane: the caller's (possibly opaque) copy of the lane id -- a persistent kernel passes one it re-made opaque inside its item loop, so
+  // that hipcc does not hoist this function's per-lane constants out of that loop and spill them (attention3.hip)
+  const int l = lane >= 0 ? lane : lane_id(), hi5 = l >> 5, rl = l & 31;
 #pragma unroll
   for (int nd = 0; nd < ND; ++nd)
 #pragma unroll

@@ -304,14 +304,19 @@ __global__ __launch_bounds__(256, 1) void attn_dkv3_kernel(AttnP p, int nx, int 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    // epilogue through the wave's own staging area
+    // epilogue through the wave's own staging area.  The lane id is made opaque per item: hipcc otherwise hoists the epilogue's per-lane
+    // constants (row / chunk indices, store addresses, the twenty rotary frequencies of the dk rotation) out of the item loop, has no
+    // registers to keep them across the tile loops and reloads each from scratch behind its own vmcnt(0) -- with one wave per SIMD that
+    // was 2.8 us per dk block, 97 us per launch with the rotation (profiles/r05_attention3_parts.txt); recomputing them is ~100 instructions
+    int lz = l;
+    asm volatile("" : "+v"(lz));
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       const int key0 = kb ? key0b : key0a;
       if (key0 < p.Sk && !(dbg & 2)) {                        // (2 = no result stores)
-        a2_store_rows<D, ND>(epw, dk[kb], p.scale, p.dk + b * p.dk_bs + h * p.dk_hs, p.dk_ss, key0, p.Sk, p.rope_cos, p.rope_sin, p.rope_half, p.rope_step);
+        a2_store_rows<D, ND>(epw, dk[kb], p.scale, p.dk + b * p.dk_bs + h * p.dk_hs, p.dk_ss, key0, p.Sk, p.rope_cos, p.rope_sin, p.rope_half, p.rope_step, lz);
         __builtin_amdgcn_wave_barrier();
-        a2_store_rows<D, ND>(epw, dv[kb], 1.f, p.dv + b * p.dv_bs + h * p.dv_hs, p.dv_ss, key0, p.Sk);
+        a2_store_rows<D, ND>(epw, dv[kb], 1.f, p.dv + b * p.dv_bs + h * p.dv_hs, p.dv_ss, key0, p.Sk, nullptr, nullptr, 0, 0.f, lz);
         __builtin_amdgcn_wave_barrier();
       }
     }
