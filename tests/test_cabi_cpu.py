@@ -124,7 +124,7 @@ def test_kernel_register_budgets():
     # scratch -- with nothing co-resident a scratch reload is an exposed memory round trip (round 5: the epilogue's hoisted per-lane constants
     # reloaded from scratch cost 97 us of a 570 us launch until the lane id was made opaque per item)
     a3 = remarks("attention3.hip", ("-fno-slp-vectorize",))
-    assert len(a3) == 1, sorted(a3)
+    assert len(a3) == 3, sorted(a3)                          # one instantiation per rotation form of the dk epilogue (none / part of the row / the whole row)
     for k, r in a3.items():
         assert r["ScratchSize"] == 0 and r["VGPRs"] <= 256 and r.get("AGPRs", 0) <= 256, (k, r)
     # LayerNorm: HBM-bound, lives on waves in flight.  The forward and the plain backward at the LM width (5 chunks of 512) keep

@@ -780,7 +780,14 @@ def test_attention_bwd_fused_inverse_rope(ops, attn_gen, B, H, S, D, rot, interl
             dq, dk, dv = dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2]
         ops.attn_bwd(q, k, v, out, lse, do, dq, dk, dv, scale, 1, rope=rope)
         return dqkv, (dq, dk, dv)
-    two, (dq, dk, dv) = grads(None)
+    # the table form of the fused rotation lives in the first / second generation kernels (attention3.hip serves the computed adjacent-pair
+    # form only): the unrotated reference must come from the same dK/dV kernel for the bitwise comparison below
+    from unimp_amd import _lib
+    was3 = _lib.lib().unimp_attn_set_dkv3(0)
+    try:
+        two, (dq, dk, dv) = grads(None)
+    finally:
+        _lib.lib().unimp_attn_set_dkv3(was3)
     ops.rope_(two.view(B * S, -1), S, H, hs, rot, offs, ct, st, inverse=True)
     if attn_gen == 1:
         assert not ops.attn_rope_fusable(dq, dk, dv, half, D)
@@ -945,7 +952,8 @@ def test_gemm_rotary_epilogue(ops, variant, nh, hd, rot, interleaved, L):
         ops.gemm(x.cuda(), w.cuda(), rope=rope, variant="w8")
 
 
-@pytest.mark.parametrize("B,H,S,D,rot", [(2, 4, 200, 80, 80), (1, 2, 512, 80, 80), (2, 3, 130, 128, 128), (2, 3, 96, 64, 16)])
+@pytest.mark.parametrize("B,H,S,D,rot", [(2, 4, 200, 80, 80), (1, 2, 512, 80, 80), (2, 3, 130, 128, 128), (2, 3, 96, 64, 16),
+                                        (2, 2, 96, 80, 32)])       # head dim 80 rotated in part: attention3.hip's second rotation form (generation 2)
 def test_attention_bwd_adjacent_inverse_rope(ops, attn_gen, B, H, S, D, rot):
     """adjacent-pair form of the fused inverse rotation (the layout of the GEMM's rotary epilogue): dq / dk of the plain
     backward, rotated back in fp32 with table cos / sin, against the kernels' on-the-fly version; dv untouched."""

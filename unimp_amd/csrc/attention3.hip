@@ -36,6 +36,58 @@ __device__ __forceinline__ void a3_glds_v_masked(const void* vaddr, uint32_t lds
 // the value lives in the accumulator half of the register file from here on (its only readers are MFMA operands)
 template <typename T> __device__ __forceinline__ void a3_pin_acc(T& v) { asm volatile("" : "+a"(v)); }
 
+// Epilogue of this kernel: a wave's transposed accumulator tile X^T[d][row] (lane: row = l & 31, d = 32 nd + 8 g + 4 hi5 + e) -> 32 global rows of D bf16
+// through the wave's staging area, as whole 16-byte chunks (a2_store_rows' scheme), specialised to what this kernel can meet: all 32 rows exist
+// (Sk is a multiple of 32), the 320 chunks are exactly five per lane, the rotation is none (ROT 0), the adjacent-pair form over part of the row (1) or
+// over the whole row (2: rotary_pct = 1, the LM's) -- fixed at compile time.  With one wave per SIMD every instruction of an item's drain is exposed:
+// the general function's three run-time rotation forms, bounds branches and 64-bit row products were ~3 000 instructions per item.
+// Same arithmetic as attn_rope_inv_adjacent (attention_params.h) on the same staged bf16 values: no bit changes.
+template <int D, int ND, int ROT>
+__device__ __forceinline__ void a3_store_rows(char* lds_wave, const f32x16 (&acc)[ND], float mul, bf16* __restrict__ gbase, uint32_t row_stride, int row0,
+                                              int rope_half, float rope_step, int l) {
+  constexpr int PITCH = D * 2 + 16, CPR = D / 8, NCH = 32 * CPR / 64;
+  static_assert(32 * CPR % 64 == 0, "whole chunks per lane");
+  const int hi5 = l >> 5, rl = l & 31;
+#pragma unroll
+  for (int nd = 0; nd < ND; ++nd)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      if (32 * nd + 8 * g + 4 < D) {                          // d0 = 32 nd + 8 g + 4 hi5 < D for both halves (D is a multiple of 8)
+        const int d0 = 32 * nd + 8 * g + 4 * hi5;
+        bf16x4 w = {f2bf(acc[nd][4 * g] * mul), f2bf(acc[nd][4 * g + 1] * mul), f2bf(acc[nd][4 * g + 2] * mul), f2bf(acc[nd][4 * g + 3] * mul)};
+        *(bf16x4*)(lds_wave + rl * PITCH + d0 * 2) = w;
+      }
+  __builtin_amdgcn_s_waitcnt(0xc07f);                         // lgkmcnt(0): the wave's own LDS writes have landed (wave-private region)
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int id = l + 64 * i;
+    const int r = id / CPR, c = id - r * CPR;
+    bf16x8 x = *(const bf16x8*)(lds_wave + r * PITCH + c * 16);
+    if (ROT != 0) {
+      const float pos = (float)(row0 + r);
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float turns = __builtin_amdgcn_fractf(pos * (__builtin_amdgcn_exp2f(-(float)(4 * c + j) * rope_step) * 0.15915494309189535f));
+        float co = __builtin_amdgcn_cosf(turns), si = __builtin_amdgcn_sinf(turns);
+        float x1 = bf2f(x[j]), x2 = bf2f(x[j + 4]);
+        o[j] = f2bf(x1 * co + x2 * si);
+        o[j + 4] = f2bf(x2 * co - x1 * si);
+      }
+      if (ROT == 2) x = o;
+      else {                                                  // chunks beyond the rotated part pass through: a select, not a branch
+        const bool rot = c * 4 < rope_half;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = rot ? o[j] : x[j];
+      }
+    }
+    union { bf16x8 b; u32x4 u; } cv; cv.b = x;
+    // row and row pitch below 2^24 elements, the slice below 4 GiB (unimp_attn_dkv3_eligible): one 24-bit multiply per chunk
+    *(u32x4*)((char*)gbase + (size_t)(__umul24((uint32_t)(row0 + r), row_stride) + (uint32_t)c * 8u) * 2u) = cv.u;
+  }
+}
+
 // LDS of the workgroup (4 waves): four tile stages (Q image + dO image each, row pitch 12 chunks); per wave the staging of its two
 // key blocks' K and V rows -- four 32-row images at the odd pitch of 11 chunks = 22 DMA pieces; per wave the epilogue staging.
 constexpr int A3_PT = 12, A3_IMG = 32 * A3_PT * 16, A3_STAGE = 2 * A3_IMG, A3_KV0 = 4 * A3_STAGE;
@@ -54,7 +106,7 @@ constexpr size_t A3_LDS = A3_EP0 + 4 * A3_EPW;
 //   * all of that is confirmed landed BEFORE the epilogue issues its stores (stores count in vmcnt and complete out of order with
 //     loads: a counted wait behind them would wait for their acknowledgements) and the next item's first two iterations need no
 //     wait at all -- by its third the stores have drained.
-template <int D>
+template <int D, int ROT>
 __global__ __launch_bounds__(256, 1) void attn_dkv3_kernel(AttnP p, int nx, int item_mode, int dbg) {
   static_assert(D == 80, "image layout below: 10 chunks per row in a pitch of 12");
   constexpr int CPR = D / 8, PT = A3_PT, KS = D / 16, ND = (D + 31) / 32, NW = 4;
@@ -314,9 +366,9 @@ __global__ __launch_bounds__(256, 1) void attn_dkv3_kernel(AttnP p, int nx, int 
     for (int kb = 0; kb < 2; ++kb) {
       const int key0 = kb ? key0b : key0a;
       if (key0 < p.Sk && !(dbg & 2)) {                        // (2 = no result stores)
-        a2_store_rows<D, ND>(epw, dk[kb], p.scale, p.dk + b * p.dk_bs + h * p.dk_hs, p.dk_ss, key0, p.Sk, p.rope_cos, p.rope_sin, p.rope_half, p.rope_step, lz);
+        a3_store_rows<D, ND, ROT>(epw, dk[kb], p.scale, p.dk + b * p.dk_bs + h * p.dk_hs, (uint32_t)p.dk_ss, key0, p.rope_half, p.rope_step, lz);
         __builtin_amdgcn_wave_barrier();
-        a2_store_rows<D, ND>(epw, dv[kb], 1.f, p.dv + b * p.dv_bs + h * p.dv_hs, p.dv_ss, key0, p.Sk, nullptr, nullptr, 0, 0.f, lz);
+        a3_store_rows<D, ND, 0>(epw, dv[kb], 1.f, p.dv + b * p.dv_bs + h * p.dv_hs, (uint32_t)p.dv_ss, key0, 0, 0.f, lz);
         __builtin_amdgcn_wave_barrier();
       }
     }
@@ -332,6 +384,8 @@ extern "C" int unimp_attn_dkv3_eligible(const AttnP* p) {
   if ((p->q_ss | p->do_ss) & 7) return 0;
   if ((p->q_ss * 2 * 32) >> 31 || (p->do_ss * 2 * 32) >> 31) return 0;      // 32-bit per-lane source offsets inside a tile
   if (((uintptr_t)p->lse | (uintptr_t)p->delta) & 15) return 0;
+  if (p->rope_cos || p->rope_sin) return 0;                   // the table form of the fused rotation stays on the earlier kernels
+  if (p->dk_ss < 0 || p->dv_ss < 0 || p->dk_ss >= (1 << 24) || p->dv_ss >= (1 << 24) || (long)p->Sk * p->dk_ss * 2 >= (1ll << 32) || (long)p->Sk * p->dv_ss * 2 >= (1ll << 32)) return 0;
   if (p->Sk >= (1 << 24) || p->k_ss * 2 >= (1 << 24) || p->v_ss * 2 >= (1 << 24) || p->k_ss < 0 || p->v_ss < 0) return 0;      // 24-bit row x pitch products
   if ((long)p->Sk * p->k_ss * 2 >= (1ll << 32) || (long)p->Sk * p->v_ss * 2 >= (1ll << 32)) return 0;
   return 1;
@@ -355,9 +409,11 @@ int unimp_attn_dkv3_launch(const AttnP& p, void* stream) {
   constexpr int D = 80;
   static_assert(32 * (D * 2 + 16) <= A3_EPW, "epilogue staging fits");
   static_assert(A3_LDS <= 160 * 1024, "one workgroup per CU: 160 KiB of LDS");
-  static bool attr_set = false;
-  auto kern = attn_dkv3_kernel<D>;
-  if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)A3_LDS); attr_set = true; }
+  // rotation form of the dk epilogue, fixed per instantiation: 0 none, 1 adjacent pairs over part of the row, 2 over the whole row
+  const int rot = p.rope_step == 0.f ? 0 : (2 * p.rope_half == D ? 2 : 1);
+  auto kern = rot == 0 ? attn_dkv3_kernel<D, 0> : (rot == 1 ? attn_dkv3_kernel<D, 1> : attn_dkv3_kernel<D, 2>);
+  static bool attr_set[3] = {false, false, false};
+  if (!attr_set[rot]) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)A3_LDS); attr_set[rot] = true; }
   const int ncu = a3_ncu();
   const int nk = (p.Sk + 255) / 256, npair = p.H * p.B;
   const int item_mode = npair < ncu;
