@@ -193,3 +193,14 @@ def test_gemm_kernel_code_fits_the_instruction_cache():
                 occ = [int(x) for x in re.findall(r"Occupancy \[waves/SIMD\]: (\d+)", r.stderr)]
                 scr = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stderr)]
                 assert occ and min(occ) >= 2 and max(scr) <= 512, (occ, scr)
+
+
+def test_attention3_schedule_is_the_generators_output():
+    """unimp_amd/csrc/attention3_sched.inc is generated (and its hazard / wait / early-clobber rules checked) by tools/gen_attn3.py: the
+    committed file must be exactly what the script produces -- a hand edit would bypass every check the schedule relies on."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_attn3.py"), "--check"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr

@@ -17,6 +17,7 @@ in the per-row exponent offsets the C++ side passes (a masked element's offset i
 
     python tools/gen_attn3.py            # rewrites the .inc
     python tools/gen_attn3.py --report   # per-slot cost table on stdout
+    python tools/gen_attn3.py --check    # the committed .inc is what this script generates (tests/test_cabi_cpu.py)
 """
 import argparse
 import os
@@ -319,6 +320,7 @@ HEADER = """// GENERATED by tools/gen_attn3.py -- do not edit; the schedule and 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--report", action="store_true")
+    ap.add_argument("--check", action="store_true", help="do not write: exit 1 if the committed .inc differs from what this script generates")
     args = ap.parse_args()
     variants = [((True, True), "V0 && V1"), ((True, False), "V0"), ((False, True), "true")]
     text = [HEADER]
@@ -333,6 +335,10 @@ def main():
             for i, st in enumerate(s.slots):
                 print("  %2d %-12s cost %3d  %s" % (i, " ".join(str(x) for x in s.mf[i]), st.cost, " ".join(k for k, v in s.placed.items() if v == i)))
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "unimp_amd", "csrc", "attention3_sched.inc")
+    if args.check:
+        same = os.path.exists(path) and open(path).read() == "\n".join(text) + "\n"
+        print("attention3_sched.inc is", "up to date" if same else "STALE: run tools/gen_attn3.py")
+        raise SystemExit(0 if same else 1)
     with open(path, "w") as f:
         f.write("\n".join(text) + "\n")
 
