@@ -22,7 +22,7 @@ extern "C" {
 
 /* bumped whenever a signature, a descriptor layout or a buffer-size requirement changes incompatibly (2: round-2 additions --
  * layernorm_bwd(wgrad_accumulate), dot_bf16's fp32[1+1024] scratch, grown gemm / attention descriptors; 3: round 3) */
-#define UNIMP_ABI_VERSION 7
+#define UNIMP_ABI_VERSION 8
 enum { UNIMP_OK = 0, UNIMP_ERR_ARG = 1, UNIMP_ERR_SHAPE = 2, UNIMP_ERR_ALIGN = 3, UNIMP_ERR_LAUNCH = 4,
        UNIMP_ERR_UNSUPPORTED = 5 };
 enum { UNIMP_ACT_NONE = 0, UNIMP_ACT_GELU = 1, UNIMP_ACT_QUICKGELU = 2, UNIMP_ACT_RELU = 3, UNIMP_ACT_SILU = 4,
@@ -188,7 +188,12 @@ typedef struct {
    * longest of the batch; this is the layout in which the language tower never computes the <PAD> rows.  Needs kernel
    * generation >= 2 in the backward (UNIMP_ERR_UNSUPPORTED otherwise); the decode entry points refuse it. */
   const int32_t* q_row_off; const int32_t* q_len; const int32_t* k_row_off;
+  /* per-call switches (ABI 8).  UNIMP_ATTN_NO_PERSISTENT: unimp_attn_bwd keeps this launch off the persistent dK/dV kernel
+   * (attention3.hip: one workgroup per CU) whatever unimp_attn_set_dkv3 says -- the caller runs beside collectives that hold CUs
+   * (mmrec.py:215's gradient exchange overlapped with backward); same gradients from the first-generation kernel. */
+  int flags;
 } unimp_attn_desc;
+#define UNIMP_ATTN_NO_PERSISTENT 1
 int unimp_attn_fwd(const unimp_attn_desc* d, void* stream);
 int unimp_attn_bwd(const unimp_attn_desc* d, void* stream);
 /* Decode step of Flamingo.generate with a KV cache (eval_rec.py:100-110; eval_exp.py:103-113 and eval_img_gen.py:102-111 at

@@ -22,7 +22,7 @@ def test_library_exports_every_header_symbol():
     for s in syms:
         assert hasattr(L, s), s
     assert set(_lib.declared_symbols()) == set(syms)
-    assert L.unimp_abi_version() == _lib.ABI_VERSION == 7
+    assert L.unimp_abi_version() == _lib.ABI_VERSION == 8
 
 
 def test_no_cpu_fallback():

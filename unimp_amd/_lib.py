@@ -31,7 +31,7 @@ class AttnDesc(C.Structure):
                 ("d_o", c_p), ("dq", c_p), ("dk", c_p), ("dv", c_p), ("delta", c_p)] + \
                [(n, c_l) for n in ("do_bs", "do_ss", "do_hs", "dq_bs", "dq_ss", "dq_hs", "dk_bs", "dk_ss", "dk_hs",
                                    "dv_bs", "dv_ss", "dv_hs")] + [("alibi_slopes", c_p), ("rope_cos", c_p), ("rope_sin", c_p), ("rope_half", c_i), ("rope_log2_base", c_f),
-                                                    ("q_row_off", c_p), ("q_len", c_p), ("k_row_off", c_p)]
+                                                    ("q_row_off", c_p), ("q_len", c_p), ("k_row_off", c_p), ("flags", c_i)]
 
 
 class MxGemmDesc(C.Structure):
@@ -87,7 +87,7 @@ _SIGS = {
     "unimp_image_resize_normalize": [c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_p],
 }
 
-ABI_VERSION = 7          # must equal UNIMP_ABI_VERSION of include/unimp_hip.h the library was built from
+ABI_VERSION = 8          # must equal UNIMP_ABI_VERSION of include/unimp_hip.h the library was built from
 
 _lib = None
 

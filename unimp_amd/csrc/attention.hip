@@ -850,7 +850,7 @@ extern "C" int unimp_attn_bwd(const unimp_attn_desc* d, void* stream) {
   // delta = rowsum(dO * O): the second-generation dQ kernel computes and publishes it itself
   if (!(which2 & 1)) hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((n * 16 + 255) / 256)), dim3(256), 0, s, p);
   if (which2) { int e2 = unimp_attn_bwd2_dispatch(p, which2, stream); if (e2) return e2; }
-  if (gen == 2 && which2 == 1 && attn_dkv3_on() && unimp_attn_dkv3_eligible(&p) && (attn_dkv3_on() == 2 || unimp_attn_dkv3_preferred(&p))) {
+  if (gen == 2 && which2 == 1 && !(d->flags & UNIMP_ATTN_NO_PERSISTENT) && attn_dkv3_on() && unimp_attn_dkv3_eligible(&p) && (attn_dkv3_on() == 2 || unimp_attn_dkv3_preferred(&p))) {
     g_attn_last_dkv = 3;
     return unimp_attn_dkv3_launch(p, stream);
   }

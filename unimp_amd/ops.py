@@ -22,12 +22,13 @@ GEMM_AUTOTUNE = True     # time the kernel variants once per (M, N, K, layout) o
 GEMM_VARIANTS = {"auto": 0, "v1": 1, "dma256": 2, "dma128": 3, "pp256": 4, "pp128": 5, "skinny": 6, "w4": 7, "w8": 8, "pp256p": 9,
                  "pp256x": 10, "pp128x": 11, "pp256px": 12, "pp256a": 13, "pp128a": 14, "w4x": 15, "w4x_s1": 16, "w4x_pf": 17, "pp256b": 18, "pp128b": 19}
 _GEMM_CHOICE = {}
-# The autotune table is DATA: the one the published numbers were measured with is committed (profiles/gemm_autotune_gfx950.json,
-# keyed by (M, N, K, a k-strided, b k-strided, epilogue reads an [M, N] input)) and loaded by default, so the variant per shape --
+# The autotune table is DATA: the one the published numbers were measured with ships INSIDE the package (unimp_amd/gemm_autotune_gfx950.json;
+# profiles/gemm_autotune_gfx950.json is the measured copy the profiles cite -- tests/test_cabi_cpu.py keeps the two identical),
+# keyed by (M, N, K, a k-strided, b k-strided, epilogue reads an [M, N] input), and is loaded by default, so the variant per shape --
 # hence the fp32 summation order, hence the bits, and +-2 % of throughput -- does not depend on timing noise of the box; only a
 # shape that is not in the table is tuned live.  UNIMP_GEMM_TUNE_FILE names another table; UNIMP_GEMM_TUNE_WRITE=1 writes newly
 # tuned entries back to it (rank 0 only, tmp file + rename); UNIMP_GEMM_TUNE_FILE="" starts from an empty table.
-_TUNE_DEFAULT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "gemm_autotune_gfx950.json")
+_TUNE_DEFAULT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_autotune_gfx950.json")
 _TUNE_FILE = os.environ.get("UNIMP_GEMM_TUNE_FILE", _TUNE_DEFAULT)
 _TUNE_WRITE = os.environ.get("UNIMP_GEMM_TUNE_WRITE", "0") == "1"
 TUNE_MISSES = []         # keys tuned live in this process (bench.py reports the count)
@@ -79,7 +80,7 @@ def _tune_gemm(M, N, K, a_ks, b_ks, device, reads_mn=False):
     if len(cands) > 1 and not a_ks and K % 64 == 0 and K >= 256:
         cands += [13, 14, 18, 19]               # whole-row A staging (k-contiguous A, 64-k stages); other forms would only re-run the X kernels.
         #                                         18 / 19: the same with the L phase spelled in asm + the L2 prefetch of the panels' shares
-    if len(cands) > 1 and (not a_ks or b_ks) and K % 64 == 0 and K >= 128 and M >= 1024 and N >= 256 and reads_mn != "out2x":
+    if len(cands) > 1 and (not a_ks or b_ks) and K % 64 == 0 and K >= 128 and M >= 1024 and N >= 256:
         cands += [15] if a_ks else [15, 17]     # w4x (gemm7.hip): one wave per SIMD, hand-ordered two-set loop; 17: with the L2 prefetch.  Same bits as the others
     if len(cands) == 1:
         _GEMM_CHOICE[key] = cands[0]
@@ -102,9 +103,15 @@ def _tune_gemm(M, N, K, a_ks, b_ks, device, reads_mn=False):
     # two interleaved rounds over the candidates (a candidate's two bursts are not back to back: clock and cache state drift during a
     # tuning pass), the better burst of each counts.  Round 5: with a dozen candidates within a few per cent of each other one burst of
     # three launches picked by noise as often as by speed.
-    times = {v: float("inf") for v in cands}
+    ok = []
     for v in cands:
-        _launch_gemm(d, v)                       # warm: code, attribute calls
+        try:
+            _launch_gemm(d, v)                   # warm: code, attribute calls
+            ok.append(v)
+        except _lib.UnimpHipError:               # a candidate the library refuses for this problem (operand size limits, ...) is not a candidate
+            pass
+    cands = ok or [1]
+    times = {v: float("inf") for v in cands}
     for _ in range(2):
         for v in cands:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -116,10 +123,20 @@ def _tune_gemm(M, N, K, a_ks, b_ks, device, reads_mn=False):
             times[v] = min(times[v], e0.elapsed_time(e1))
     best = min(cands, key=lambda v: times[v])
     _GEMM_CHOICE[key] = best
-    TUNE_MISSES.append(key)
+    _note_live_tune(key)
     if _TUNE_FILE and _TUNE_WRITE:
         _save_tune_table(_TUNE_FILE)
     return best
+
+
+def _note_live_tune(key):
+    """a shape the shipped table lacks was timed on this box: said ONCE per process (the pick -- hence the fp32 summation order of that
+    shape and a few per cent of its speed -- then depends on this run's timing; UNIMP_GEMM_TUNE_WRITE=1 keeps the picks)"""
+    if not TUNE_MISSES and not _TUNE_WRITE:
+        import warnings
+        warnings.warn(f"unimp_amd: GEMM shape {key} is not in the autotune table {_TUNE_FILE!r}: tuning live (this and any further such "
+                      "shape; set UNIMP_GEMM_TUNE_WRITE=1 to record the picks, UNIMP_GEMM_TUNE_FILE to name another table)", stacklevel=3)
+    TUNE_MISSES.append(key)
 
 
 # Data parallelism with more than one rank (set by train.Trainer): RCCL's all-reduce kernels take a handful of CUs for the whole backward
@@ -129,6 +146,22 @@ def _tune_gemm(M, N, K, a_ks, b_ks, device, reads_mn=False):
 # autotuned choice is mapped to the non-persistent twin with the same main loop; every variant produces the same bits.
 AVOID_PERSISTENT = False
 _PERSISTENT_TWIN = {9: 4, 12: 10}
+_avoid_persistent_holders = 0
+
+
+def avoid_persistent_acquire():
+    """a data-parallel Trainer with more than one rank comes up: AVOID_PERSISTENT holds while at least one such trainer lives"""
+    global AVOID_PERSISTENT, _avoid_persistent_holders
+    _avoid_persistent_holders += 1
+    AVOID_PERSISTENT = True
+
+
+def avoid_persistent_release():
+    """... and lets go (Trainer.close / dp.remove): the flag clears with the LAST holder, whatever the order trainers are closed in"""
+    global AVOID_PERSISTENT, _avoid_persistent_holders
+    _avoid_persistent_holders = max(0, _avoid_persistent_holders - 1)
+    if _avoid_persistent_holders == 0:
+        AVOID_PERSISTENT = False
 
 _IN_BACKWARD = 0
 
@@ -232,7 +265,7 @@ def _tune_packed(M, N, K, a_ks, device, reads_mn, unpacked_variant, b_ks):
         if t < best_t * 0.99:
             best, best_t = v, t
     _GEMM_CHOICE[key] = best
-    TUNE_MISSES.append(key)
+    _note_live_tune(key)
     if _TUNE_FILE and _TUNE_WRITE:
         _save_tune_table(_TUNE_FILE)
     return best
@@ -421,6 +454,10 @@ def gemm(a, b, *, a_ks=False, b_ks=False, bias=None, act=None, res=None, aux=Non
                                                                                  ("out2" if pre is not None else False)))
     if AVOID_PERSISTENT and (variant is None or tuned_rope) and v in _PERSISTENT_TWIN:
         v = _PERSISTENT_TWIN[v]
+    if v in (15, 16, 17) and variant is None and ((32 if a_ks else M) * lda * 2 >= 1 << 32 or (32 if b_ks else N) * ldb * 2 >= 1 << 32):
+        # gemm7 (w4x) addresses its operands with 32-bit offsets: below 4 GiB each.  The table key carries no lda, so a tuned w4x entry
+        # can be reached through a wide-ld view: the whole-row-A / one-set ping-pong kernel serves it instead (same bits)
+        v = 13 if (not a_ks and K % 64 == 0 and K >= 256) else 10
     if (d.pre_deriv == 2 or d.dact == ACT["deriv_u8"]) and variant is None and v in (0, 2, 3, 6, 7):
         # the uint8 derivative lives in the kernels with the specialised epilogue kinds; 0 = the library's own choice, which may be a DMA variant
         v = 1 if (M < 256 or N < 128) else (4 if N >= 256 else 5)
@@ -659,18 +696,11 @@ def attn_bwd(q, k, v, o, lse, do, dq, dk, dv, scale, mask_mode=MASK_NONE, kv_len
         assert cos.dtype == torch.float32 and sin.dtype == torch.float32 and cos.is_contiguous() and sin.is_contiguous()
         assert cos.shape == sin.shape and cos.shape[0] >= max(Sq, Sk), (cos.shape, Sq, Sk)
         d.rope_cos, d.rope_sin, d.rope_half = cos.data_ptr(), sin.data_ptr(), cos.shape[1]
-    L = _lib.lib()
-    if AVOID_PERSISTENT:
-        # a data-parallel group's collectives share the CUs with backward: attention3.hip's dK/dV kernel is one persistent workgroup per CU
-        # (a CU held by a collective would leave its workgroup waiting for a free one: the kernel runs twice as long) -- like the persistent
-        # GEMM variants it stays out while the flag is set
-        old = L.unimp_attn_set_dkv3(0)
-        try:
-            check(L.unimp_attn_bwd(C.byref(d), _stream()), "attn_bwd")
-        finally:
-            L.unimp_attn_set_dkv3(old)
-        return
-    check(L.unimp_attn_bwd(C.byref(d), _stream()), "attn_bwd")
+    # a data-parallel group's collectives share the CUs with backward: attention3.hip's dK/dV kernel is one persistent workgroup per CU
+    # (a CU held by a collective would leave its workgroup waiting for a free one: the kernel runs twice as long) -- like the persistent
+    # GEMM variants it stays out while the flag is set.  Per call, in the descriptor (ABI 8): no process-wide library state is flipped.
+    d.flags = 1 if AVOID_PERSISTENT else 0           # UNIMP_ATTN_NO_PERSISTENT
+    check(_lib.lib().unimp_attn_bwd(C.byref(d), _stream()), "attn_bwd")
 
 
 def embedding_fwd(ids, W, pos=None, P=None):

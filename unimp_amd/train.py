@@ -35,8 +35,17 @@ class AverageMeter:
         self.avg = self.sum / self.count
 
 
+def _wait_params(model):
+    """an optimizer update still running on a Trainer's side stream (overlap_optimizer) lands before the current stream reads or
+    writes a parameter: the model carries the update's event (``Flamingo._params_barrier``; a model without one has nothing pending)"""
+    pb = getattr(model, "_params_barrier", None)
+    if pb is not None:
+        pb()
+
+
 def get_checkpoint(model):
     """trainable-only state dict (train_utils.py:258-265)."""
+    _wait_params(model)
     sd = model.state_dict()
     for name, p in model.named_parameters():
         if not p.requires_grad:
@@ -61,6 +70,8 @@ def save_checkpoint(path, model, trainer=None, epoch=0, barrier=False, group=Non
     import torch.distributed as dist
     if trainer is not None:
         trainer.sync()                                 # an optimizer update on the side stream (overlap_optimizer) lands first
+    else:
+        _wait_params(model)                            # ... also when the caller did not pass its trainer
     if group is None and trainer is not None:
         group = trainer.dp.pg                          # the Trainer may run on a subgroup: WORLD would wait for ranks that never call
     rank0 = not dist.is_initialized() or dist.get_rank(group) == 0
@@ -93,6 +104,11 @@ def load_checkpoint(path, model, trainer=None):
     """inverse of save_checkpoint; also accepts OpenFlamingo ``checkpoint.pt`` / UniMP ``weights_epoch_*.pt`` files
     (same parameter names).  Returns the epoch to resume from (0 without a .resume side file)."""
     import os
+    # the side-stream update (overlap_optimizer) may still be writing flat_p / master: it lands before load_state_dict and
+    # refresh_master touch them on the current stream (ADVICE r5)
+    if trainer is not None:
+        trainer.sync()
+    _wait_params(model)
     sd = torch.load(path, map_location="cpu")
     if "model_state_dict" in sd:
         sd = sd["model_state_dict"]
@@ -269,10 +285,10 @@ class Trainer:
                                force_hooks=force_dp_hooks)
         if self.dp.active and self.dp.world > 1:
             # collectives share the CUs with backward: no persistent GEMM variant (ops.AVOID_PERSISTENT).  The flag is process-wide (the GEMM
-            # call sites do not know their trainer); close() / dp.remove() puts back what this trainer found
-            prev = ops.AVOID_PERSISTENT
-            ops.AVOID_PERSISTENT = True
-            self.dp.on_remove = lambda: setattr(ops, "AVOID_PERSISTENT", prev)
+            # call sites do not know their trainer): reference-counted, cleared when the LAST data-parallel trainer lets go (ADVICE r5:
+            # restoring the value found at construction was only right for LIFO close order)
+            ops.avoid_persistent_acquire()
+            self.dp.on_remove = ops.avoid_persistent_release
         self.sched, self.base_lr, self.warmup, self.total = lr_scheduler, lr, warmup_steps, total_steps
         self.sched_step = 0
         self.overlap_optimizer, self._opt_stream, self._opt_event = bool(overlap_optimizer), None, None
@@ -347,9 +363,21 @@ class Trainer:
                     attention_mask=torch.cat([padded(b["attention_mask"], 0) for b in batches]), weights=w * norm)
 
     def _fuse_decide(self, batch):
-        """automatic fuse_accum: take the fused pass only while its activations (GA x B x L tokens) stay inside FUSE_TOKEN_BUDGET"""
+        """automatic fuse_accum: take the fused pass only while its activations (GA x B x L tokens) stay inside FUSE_TOKEN_BUDGET.
+        Decided ONCE, at the first micro-batch, and -- under data parallelism -- by ALL ranks together (MIN over the trainer's group:
+        ranks that pad to different L near the budget would otherwise pick different paths).  Limitation, by design: later,
+        longer batches are not re-checked (a path switch inside a run would change the StepOut.pending contract mid-epoch); a loader
+        whose sequence lengths grow past the budget should pass fuse_accum=False or size UNIMP_FUSE_TOKENS for its longest batch."""
         B, L = batch["lang_x"].shape
-        self.fuse_accum = self.grad_accum * B * L <= FUSE_TOKEN_BUDGET
+        ok = self.grad_accum * B * L <= FUSE_TOKEN_BUDGET
+        if self.dp.active and self.dp.world > 1:
+            import torch.distributed as dist
+            # a host tensor on gloo, a device tensor on RCCL (the backend's own device)
+            dev = batch["lang_x"].device if dist.get_backend(self.dp.pg) == "nccl" else "cpu"
+            t = torch.tensor([1 if ok else 0], device=dev, dtype=torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.dp.pg)
+            ok = bool(int(t.item()))
+        self.fuse_accum = ok
         self._fuse_auto = False
 
     def _fused_pass(self, batches, scale=1.0):
