@@ -73,6 +73,12 @@ typedef struct {
   float rope_log2_base;
   /* ABI 4: NULL, or int32 [M]: the position of row m (instead of m % rope_L) -- packed rows, where a sequence starts at any row */
   const int32_t* rope_pos;
+  /* ABI 8, decode rows only (variant SKINNY with M <= 16, K % 512 == 0, K <= 4096: unimp_gemm_skinny_ln_ok): ln_gamma != NULL -- the rows of A
+   * are LAYER-NORMALISED on their way into the product, y = (a - mean) * rstd * ln_gamma + ln_beta (ln_beta may be NULL) in fp32, rounded to
+   * bf16: what unimp_layernorm_fwd would have stored, without that launch.  Replaces the nn.LayerNorm in front of a projection in a
+   * cached decode step (GPTNeoXLayer.input_layernorm / post_attention_layernorm, open_flamingo MaskedCrossAttention.norm, FeedForward[0],
+   * final_layer_norm in front of embed_out).  Other variants refuse it. */
+  const void* ln_gamma; const void* ln_beta; float ln_eps;
 } unimp_gemm_desc;
 /* Pre-packed B operand for FROZEN weights (b_kstrided = 2 in the descriptor; ping-pong variants only): every MFMA B fragment
  * of the 16x16x32 instruction -- (n-tile of 16, 32-k step) -- stored as one contiguous 1-KiB block in lane order, so a wave
@@ -104,6 +110,11 @@ enum { UNIMP_GEMM_AUTO = 0, UNIMP_GEMM_V1 = 1, UNIMP_GEMM_DMA256 = 2, UNIMP_GEMM
        /* PP256 / PP128 / PP256P with ONE fragment register set: the L phase of a half-step reads that half-step's own fragments
           (before its LDS-DMA issue) and leaves two half-stages in flight instead of one -- 48 registers fewer, same bits */ };
 int unimp_gemm_bf16_variant(const unimp_gemm_desc* d, int variant, void* stream);
+/* decode rows (ABI 8): M <= 16 rows run a persistent weight-streaming kernel (one workgroup per CU walks its 16-row weight tiles with a ring of
+ * loads in flight across tile boundaries; gemm.hip skinny2) instead of round 3's one-workgroup-per-tile kernel.  set_skinny2(0) restores the
+ * latter (A/B, tests; env UNIMP_SKINNY2); returns the previous setting.  skinny_ln_ok: may a decode GEMM of M rows, depth K take ln_gamma? */
+int unimp_gemm_set_skinny2(int on);
+int unimp_gemm_skinny_ln_ok(int M, int K);
 /* split-K form for outputs much smaller than the chip (weight gradients of narrow projections): `splits` K slices into
  * f32 slabs [splits][M][N] (caller-provided workspace), then an ordered reduction applying alpha*tanh(gate).  Only the
  * alpha / gate epilogue is allowed. */
@@ -143,6 +154,16 @@ int unimp_rope_halfsplit(void* x, int64_t row_stride, int64_t head_stride, int r
 int unimp_rope_halfsplit_pos(void* x, int64_t row_stride, int64_t head_stride, int rows, const int32_t* pos, int heads, int rot,
                              int nvec, int vec_off0, int vec_off1, const float* cos_t, const float* sin_t, int inverse,
                              void* stream);
+
+/* decode step (ABI 8; F1: eval_rec.py:100-110 / eval_img_gen.py:102-111 through Flamingo.generate with a KV cache -- transformers'
+ * GPTNeoXAttention with layer_past: apply_rotary_pos_emb on the new token's q / k, then torch.cat of k / v onto the cache): ONE launch
+ * rotates q and k of every row in place (row r at its own position: cos_rows / sin_rows fp32 [rows][rot / 2] hold that position's table
+ * row; rot = 0: no rotation) and writes the rotated k and v into slot pos_idx[r] of the caches
+ * (element strides: row, slot, head).  Same per-element arithmetic as unimp_rope_halfsplit.  q / k / v at element offsets
+ * q_off / k_off / v_off inside each head slot of qkv [rows][heads][head_stride]. */
+int unimp_decode_rope_append(void* qkv, int64_t row_stride, int64_t head_stride, int rows, int heads, int hd, int q_off, int k_off,
+                             int v_off, int rot, const float* cos_rows, const float* sin_rows, void* kcache, void* vcache,
+                             int64_t c_row_stride, int64_t c_slot_stride, int64_t c_head_stride, const int64_t* pos_idx, void* stream);
 
 /* ---- attention (flash-style, MFMA) -------------------------------------------------------------------------
  * replaces xformers.ops.memory_efficient_attention (clip.py:130-136; llama.py:287-301), the GPT-NeoX causal

@@ -13,24 +13,45 @@ bf16 and widened again (straight-through for autograd).  Tags:
   vis      ViT tokens / Perceiver output handed to the language tower
   logits   the LM head's output
 
+  grad     (round 6; not part of ALL) the BACKWARD side of every tag that is on: the gradient flowing back through a storage point is
+           rounded to bf16 as well -- the product keeps dX tensors (d residual, d LayerNorm output, dqkv, d act ...) in bf16 between its
+           backward kernels exactly where it keeps the activations in bf16 on the way forward.  ``ALL_BWD = ALL + ("grad",)`` is the
+           yardstick of the full-depth GRADIENT parity (bench.full_depth_parity: parity.gradients); parameter gradients themselves are
+           rounded to bf16 by the caller (the product's flat gradient buffer is bf16).
+
 ``with storage("res", "ln", ...):`` switches tags on for a block; ``ALL`` lists them.  Used by tests/error_budget.py (which
 storage point contributes how much of the logits error) and by the parity tests' "same storage precision" reference."""
 import contextlib
 import torch
 
 ALL = ("res", "ln", "gemm", "act", "attn_p", "attn_o", "vis", "logits")
+ALL_BWD = ALL + ("grad",)
 _ON = set()
+
+
+class _StoreBoth(torch.autograd.Function):
+    """bf16 storage point in both directions: the value on the way forward, its gradient on the way back"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(torch.float32)
 
 
 def st(tag, x):
     if tag in _ON and x.dtype == torch.float32:
+        if "grad" in _ON and x.requires_grad:
+            return _StoreBoth.apply(x)
         return x + (x.to(torch.bfloat16).to(torch.float32) - x).detach()
     return x
 
 
 @contextlib.contextmanager
 def storage(*tags):
-    bad = [t for t in tags if t not in ALL]
+    bad = [t for t in tags if t not in ALL_BWD]
     if bad:
         raise ValueError(f"unknown storage tags {bad}; known: {ALL}")
     old = set(_ON)

@@ -330,3 +330,20 @@ def test_save_checkpoint_barrier_then_load_on_every_rank_world2(tmp_path):
         p.join(120)
         assert p.exitcode == 0
     assert sorted(q.get(timeout=5) for _ in range(world)) == [(0, "ok"), (1, "ok")]
+
+
+def test_exchange_model_replicated_and_sharded():
+    """dp.GradBucketer.model_exposed_ms (bench.py's rccl.exchange_model): hand-computed ring times over a two-bucket timeline, for the
+    all-reduce and for the ZeRO-2 layout (reduce-scatter = half the bytes during backward + the parameter all-gather afterwards)."""
+    from unimp_amd.dp import GradBucketer
+    GB = 10 ** 9
+    tl = (100.0, [(0, 1 * GB, 50.0), (1, 2 * GB, 99.0)])            # backward ends at 100 ms; buckets ready at 50 and 99 ms
+    W, bus = 8, 100.0                                                # 100 GB/s: 1 GB of wire bytes = 10 ms
+    f = 2 * (W - 1) / W
+    # bucket 0: 50 -> 50 + 0.03 + 17.5 = 67.53; bucket 1 starts at 99: 99 + 0.03 + 35 = 134.03 -> exposed 34.03
+    assert abs(GradBucketer.model_exposed_ms(tl, W, bus) - (99 + 0.03 + f * 2 * 10 - 100)) < 1e-9
+    rs, ag = GradBucketer.model_exposed_ms(tl, W, bus, sharded=True)
+    assert abs(rs - (99 + 0.03 + (f / 2) * 2 * 10 - 100)) < 1e-9
+    assert abs(ag - (2 * 0.03 + (f / 2) * 3 * 10)) < 1e-9
+    # everything hidden when the buckets are ready early
+    assert GradBucketer.model_exposed_ms((100.0, [(0, GB, 10.0)]), 2, 100.0) == 0.0

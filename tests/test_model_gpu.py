@@ -42,7 +42,7 @@ def test_forward_backward_parity(P, cfgname):
     assert got_logits.shape == want_logits.shape
     e = P.rel_l2(got_logits, want_logits)
     assert e <= 1e-2, f"logits rel L2 {e}"
-    assert abs(loss.item() - want_loss.item()) <= 2e-3 * abs(want_loss.item()), (loss.item(), want_loss.item())
+    assert abs(loss.item() - want_loss.item()) <= 1e-3 * abs(want_loss.item()), (loss.item(), want_loss.item())     # north_star's bound (measured 1e-5 ... 3e-4)
     top2 = want_logits.topk(2, -1).values
     sure = (top2[..., 0] - top2[..., 1]) > 0.02 * want_logits.abs().max()
     assert sure.any()

@@ -19,7 +19,7 @@ class GemmDesc(C.Structure):
                 ("pre", c_p), ("ldpre", c_l), ("gate", c_p), ("alpha", c_f), ("act", c_i), ("dact", c_i),
                 ("out_f32", c_i), ("accumulate", c_i), ("pre_deriv", c_i),
                 ("rope_rot", c_i), ("rope_hd", c_i), ("rope_period", c_i), ("rope_span", c_i), ("rope_L", c_i), ("rope_log2_base", c_f),
-                ("rope_pos", c_p)]
+                ("rope_pos", c_p), ("ln_gamma", c_p), ("ln_beta", c_p), ("ln_eps", c_f)]
 
 
 class AttnDesc(C.Structure):
@@ -46,12 +46,15 @@ _SIGS = {
     "unimp_gemm_bf16": [C.POINTER(GemmDesc), c_p],
     "unimp_gemm_bf16_variant": [C.POINTER(GemmDesc), c_i, c_p],
     "unimp_gemm_bf16_splitk": [C.POINTER(GemmDesc), c_i, c_p, c_p],
+    "unimp_gemm_set_skinny2": [c_i],
+    "unimp_gemm_skinny_ln_ok": [c_i, c_i],
     "unimp_layernorm_fwd": [c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_p, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_p],
     "unimp_layernorm_fwd_mx": [c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_p, c_i, c_i, c_f, c_i, c_p],
     "unimp_layernorm_bwd": [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_i,
                             c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "unimp_rope_halfsplit": [c_p, c_l, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p],
     "unimp_rope_halfsplit_pos": [c_p, c_l, c_l, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p],
+    "unimp_decode_rope_append": [c_p, c_l, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_p, c_p],
     "unimp_attn_fwd": [C.POINTER(AttnDesc), c_p],
     "unimp_attn_bwd": [C.POINTER(AttnDesc), c_p],
     "unimp_attn_decode": [C.POINTER(AttnDesc), c_p, c_i, c_p],

@@ -178,6 +178,67 @@ extern "C" int unimp_rope_halfsplit_pos(void* x, int64_t row_stride, int64_t hea
   return rope_launch(x, row_stride, head_stride, rows, 1, heads, rot, nvec, vec_off0, vec_off1, cos_t, sin_t, inverse, pos, stream);
 }
 
+// ------------------------------------------------------------------------------------------- decode step: rotate q / k, append k / v
+// One launch per layer and decode step instead of three (rope_rows_kernel + two index_put_ of torch): item = (row, head, 8-element chunk).
+// Chunks [0, P) rotate the q pair (c, c + P) in place; [P, 2P) rotate the k pair and write it to qkv AND to the cache slot pos_idx[row];
+// [2P, 2P + T) copy the un-rotated tail chunks of k to the cache; the last hd / 8 chunks copy v.  P = rot / 16, T = (hd - rot) / 8.
+// Same arithmetic per element as rope_rows_kernel (x1 * cos - x2 * sin, x2 * cos + x1 * sin in fp32, rounded to bf16): same bits.
+__global__ __launch_bounds__(256) void decode_rope_append_kernel(bf16* __restrict__ qkv, long row_stride, long head_stride, int rows, int heads, int hd,
+                                                                 int q_off, int k_off, int v_off, int half, const float* __restrict__ cs,
+                                                                 const float* __restrict__ sn, bf16* __restrict__ kc, bf16* __restrict__ vc,
+                                                                 long c_row, long c_slot, long c_head, const int64_t* __restrict__ pos_idx) {
+  const int P = half >> 3, T = (hd - 2 * half) >> 3, V = hd >> 3, per = 2 * P + T + V;
+  const long total = (long)rows * heads * per;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % per); long rh = i / per;
+    int h = (int)(rh % heads); int r = (int)(rh / heads);
+    bf16* base = qkv + (long)r * row_stride + (long)h * head_stride;
+    const long slot = (long)r * c_row + (long)pos_idx[r] * c_slot + (long)h * c_head;
+    if (c < 2 * P) {
+      const bool isk = c >= P;
+      const int cc = isk ? c - P : c;
+      bf16* p = base + (isk ? k_off : q_off) + cc * 8;
+      bf16x8 a = *(const bf16x8*)p, b = *(const bf16x8*)(p + half);
+      const float* cr = cs + (long)r * half + cc * 8;
+      const float* sr = sn + (long)r * half + cc * 8;
+      f32x4 c0 = *(const f32x4*)cr, c1 = *(const f32x4*)(cr + 4), s0 = *(const f32x4*)sr, s1 = *(const f32x4*)(sr + 4);
+      bf16x8 oa, ob;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float co = j < 4 ? c0[j & 3] : c1[j & 3], si = j < 4 ? s0[j & 3] : s1[j & 3];
+        float x1 = bf2f(a[j]), x2 = bf2f(b[j]);
+        oa[j] = f2bf(x1 * co - x2 * si);
+        ob[j] = f2bf(x2 * co + x1 * si);
+      }
+      *(bf16x8*)p = oa; *(bf16x8*)(p + half) = ob;
+      if (isk) { *(bf16x8*)(kc + slot + cc * 8) = oa; *(bf16x8*)(kc + slot + half + cc * 8) = ob; }
+    } else if (c < 2 * P + T) {
+      const int cc = c - 2 * P;
+      *(bf16x8*)(kc + slot + 2 * half + cc * 8) = *(const bf16x8*)(base + k_off + 2 * half + cc * 8);
+    } else {
+      const int cc = c - 2 * P - T;
+      *(bf16x8*)(vc + slot + cc * 8) = *(const bf16x8*)(base + v_off + cc * 8);
+    }
+  }
+}
+
+extern "C" int unimp_decode_rope_append(void* qkv, int64_t row_stride, int64_t head_stride, int rows, int heads, int hd, int q_off, int k_off,
+                                        int v_off, int rot, const float* cos_rows, const float* sin_rows, void* kcache, void* vcache,
+                                        int64_t c_row_stride, int64_t c_slot_stride, int64_t c_head_stride, const int64_t* pos_idx, void* stream) {
+  if (!qkv || !kcache || !vcache || !pos_idx || (rot > 0 && (!cos_rows || !sin_rows))) return unimp_set_error(UNIMP_ERR_ARG, "decode_rope_append: null pointer");
+  if (rows <= 0 || heads <= 0) return UNIMP_OK;
+  const int half = rot / 2;
+  if (rot < 0 || rot > hd || (hd & 7) || (half & 7) || ((row_stride | head_stride | c_row_stride | c_slot_stride | c_head_stride) & 7) ||
+      ((q_off | k_off | v_off) & 7) || (((uintptr_t)qkv | (uintptr_t)kcache | (uintptr_t)vcache) & 15) ||
+      (rot > 0 && (((uintptr_t)cos_rows | (uintptr_t)sin_rows) & 15)))
+    return unimp_set_error(UNIMP_ERR_ALIGN, "decode_rope_append: hd, rot / 2, strides and offsets must be multiples of 8 elements, pointers 16-byte aligned");
+  long total = (long)rows * heads * (2 * (half >> 3) + ((hd - rot) >> 3) + (hd >> 3));
+  hipLaunchKernelGGL(decode_rope_append_kernel, GRID1D(total, 256), dim3(256), 0, (hipStream_t)stream, (bf16*)qkv, (long)row_stride, (long)head_stride,
+                     rows, heads, hd, q_off, k_off, v_off, half, cos_rows, sin_rows, (bf16*)kcache, (bf16*)vcache, (long)c_row_stride,
+                     (long)c_slot_stride, (long)c_head_stride, pos_idx);
+  return unimp_check_launch("decode_rope_append");
+}
+
 // ------------------------------------------------------------------------------------------- embedding
 __global__ void embedding_fwd_kernel(const int64_t* __restrict__ ids, const bf16* __restrict__ W, long ldw,
                                      const int64_t* __restrict__ pos, const bf16* __restrict__ P, long ldp,

@@ -34,6 +34,7 @@ struct GemmParams {
   int act, dact, out_f32, accumulate, pre_deriv;
   int nbm, nbn;
   int ksplit;                       // > 0: blockIdx.y handles k in [y*ksplit, (y+1)*ksplit) and writes f32 slab y of C
+  const bf16* ln_gamma; const bf16* ln_beta; float ln_eps;   // skinny2 only: A rows are layer-normalised on the fly (ln_gamma != null)
 };
 
 #define BM 128
@@ -339,8 +340,150 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(GemmParams p) {
   }
 }
 
+// ---- skinny2 (round 6): decode rows M <= 16 -- one token per row of K <= 16 beams (eval_rec.py:100-110) or one greedy row
+// (eval_img_gen.py:102-111) -- as a PERSISTENT weight stream.  The round-3 kernel above starts one 16-wave workgroup per 16 weight rows:
+// 80 KB of weights per workgroup at K = 2560, of which every wave fetches two or three 2-KB chunks, waits, multiplies, and the workgroup
+// retires behind an LDS reduction -- launch, first-byte latency and drain are paid per 80 KB (measured 2.3-3.3 TB/s on the step's shapes).
+// Here ONE workgroup per CU (8 waves) walks its weight tiles (16 rows x K each; tile t of workgroup b is row block b + t * grid):
+//   * each wave owns the 64-k chunks c = w (mod 8) of every tile and keeps a RING of D chunks (2 KB each) in flight ACROSS tile boundaries:
+//     the loads of the next tile are on their way while this tile's partial sums meet in LDS (one barrier per tile; the wave t mod 8 sums the
+//     eight partials in a fixed order and runs the epilogue while the others go on);
+//   * the M activation rows are staged ONCE per workgroup in LDS (row pitch = K * 2 + 16 bytes: the 16 rows of a fragment read hit 16
+//     different bank groups) -- and may be LAYER-NORMALISED on the way (ln_gamma / ln_beta / ln_eps: the LayerNorm in front of the QKV, the
+//     up-projection, the gated blocks' to_q / feed-forward and the head is no launch of its own in a decode step; the W ring is issued
+//     BEFORE the prologue, so the statistics run under the first weights' flight).  (x - mean) * rstd * gamma + beta in fp32, rounded to
+//     bf16: the values unimp_layernorm_fwd stores (up to the summation order of the statistics).
+// Lane (r, g) of a wave holds k = 16 g .. 16 g + 15 of weight row r of the chunk (32 contiguous bytes, two MFMAs) -- the round-3 operand
+// map; accumulator lane (r, g) = activation row r, weight rows 4 g .. 4 g + 3.  Deterministic: a tile's sum order is fixed.
+template <int D>
+__global__ __launch_bounds__(512) void gemm_skinny2_kernel(GemmParams p, int ntiles, int xpitch) {
+  constexpr int NW = 8;
+  extern __shared__ __attribute__((aligned(16))) char sk2_smem[];
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, r = lane & 15;
+  char* xs = sk2_smem;
+  f32x4* red = (f32x4*)(sk2_smem + (((long)p.M * xpitch + 15) & ~15L));          // [2][NW][64]
+  const int nchunk = p.K >> 6, cpw = nchunk / NW;
+  const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const long Q = (long)my_tiles * cpw;                                             // (tile, chunk) items of this wave
+  // ---- the ring: items 0 .. D - 1 go out before anything else
+  u32x4 buf[D][2];
+  int li = 0, lj = 0;                                                              // load cursor: tile index (of this workgroup), chunk index (of this wave)
+  auto issue = [&](u32x4 (&b)[2]) {
+    const int tile = blockIdx.x + li * gridDim.x;
+    const bf16* q = p.B + (long)min(tile * 16 + r, p.N - 1) * p.ldb + (long)(w + NW * lj) * 64 + g * 16;
+    b[0] = __builtin_nontemporal_load((const u32x4*)q);
+    b[1] = __builtin_nontemporal_load((const u32x4*)(q + 8));
+    if (++lj == cpw) { lj = 0; ++li; }
+  };
+#pragma unroll
+  for (int u = 0; u < D; ++u) if (u < Q) issue(buf[u]);
+  // ---- activation rows -> LDS (rows w, w + 8 of the M <= 16), layer-normalised if asked
+  const int pieces = p.K >> 3;
+  for (int m = w; m < p.M; m += NW) {
+    const bf16* xr = p.A + (long)m * p.lda;
+    char* xd = xs + (long)m * xpitch;
+    if (p.ln_gamma) {
+      bf16x8 raw[8];
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int pc = lane + 64 * c;
+        raw[c] = pc < pieces ? *(const bf16x8*)(xr + pc * 8) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += bf2f(raw[c][j]);
+      }
+      const float inv_d = 1.f / (float)p.K;
+      const float mu = wave_sum(s) * inv_d;
+      float qq = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { float d = (lane + 64 * c) < pieces ? bf2f(raw[c][j]) - mu : 0.f; qq += d * d; }
+      const float rs = rsqrtf(wave_sum(qq) * inv_d + p.ln_eps);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int pc = lane + 64 * c;
+        if (pc < pieces) {
+          bf16x8 gm = *(const bf16x8*)(p.ln_gamma + pc * 8), bt = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}, o;
+          if (p.ln_beta) bt = *(const bf16x8*)(p.ln_beta + pc * 8);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = f2bf((bf2f(raw[c][j]) - mu) * rs * bf2f(gm[j]) + bf2f(bt[j]));
+          *(bf16x8*)(xd + pc * 16) = o;
+        }
+      }
+    } else {
+      for (int pc = lane; pc < pieces; pc += 64) *(u32x4*)(xd + pc * 16) = *(const u32x4*)(xr + pc * 8);
+    }
+  }
+  __syncthreads();
+  const char* xl = xs + (long)min(r, p.M - 1) * xpitch + g * 32;                  // this lane's fragment base inside a chunk (chunk c: + 128 c)
+  float gate = 1.f;
+  if (p.gate) gate = tanhf(bf2f(*p.gate));
+  const bool fast = ((p.N & 3) == 0) && (((p.ldc | p.ldres | p.ldaux | p.ldpre) & 3) == 0);
+  for (int i = 0; i < my_tiles; ++i) {
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int jb = 0; jb < cpw; jb += D) {
+#pragma unroll
+      for (int u = 0; u < D; ++u) {
+        const char* xq = xl + (long)(w + NW * (jb + u)) * 128;
+        u32x4 x0 = *(const u32x4*)xq, x1 = *(const u32x4*)(xq + 16);
+        acc = MFMA16(buf[u][0], x0, acc);
+        acc = MFMA16(buf[u][1], x1, acc);
+        if (li < my_tiles) issue(buf[u]);                                          // the item D ahead (uniform: li is wave-uniform)
+      }
+    }
+    red[((i & 1) * NW + w) * 64 + lane] = acc;
+    __syncthreads();
+    if (w == (i & (NW - 1))) {
+      f32x4 a = red[((i & 1) * NW) * 64 + lane];
+#pragma unroll
+      for (int ww = 1; ww < NW; ++ww) a += red[((i & 1) * NW + ww) * 64 + lane];
+      const int n = (blockIdx.x + i * gridDim.x) * 16 + g * 4;
+      if (fast) epi_tile<true>(p, a, r, n, gate);
+      else epi_tile<false>(p, a, r, n, gate);
+    }
+  }
+}
+
+static int g_ncu = 0;
+static bool skinny2_ok(const unimp_gemm_desc* d) {
+  // M <= 16 decode rows, k-contiguous operands, K a multiple of 8 chunks of 64, the M staged rows + the partial sums inside the LDS
+  if (d->M > 16 || d->a_kstrided || d->b_kstrided || (d->K & 511) || d->K > 16384) return false;
+  if (d->ln_gamma && d->K > 4096) return false;
+  long lds = (long)d->M * (2L * d->K + 16) + 16 + 2 * 8 * 64 * 16;
+  return lds <= 160 * 1024 - 4096;
+}
+
+static void launch_skinny2(const unimp_gemm_desc* d, GemmParams& p, void* stream) {
+  if (!g_ncu) { int dev = 0; hipDeviceProp_t pr; (void)hipGetDevice(&dev); (void)hipGetDeviceProperties(&pr, dev); g_ncu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
+  const int ntiles = (d->N + 15) / 16, cpw = (d->K >> 6) / 8;
+  const int xpitch = 2 * d->K + 16;
+  const int grid = ntiles < g_ncu ? ntiles : g_ncu;
+  size_t lds = (((size_t)d->M * xpitch + 15) & ~(size_t)15) + 2 * 8 * 64 * sizeof(f32x4);
+  hipStream_t s = (hipStream_t)stream;
+#define SK2_GO(D_) do { auto kern = gemm_skinny2_kernel<D_>;                                                                      \
+    static size_t cur = 0;                                                                                                        \
+    if (lds > cur) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)); cur = 160 * 1024; } \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, p, ntiles, xpitch); } while (0)
+  if (cpw % 5 == 0) SK2_GO(5); else if (cpw % 4 == 0) SK2_GO(4); else if (cpw % 2 == 0) SK2_GO(2); else SK2_GO(1);
+#undef SK2_GO
+}
+
 static bool skinny_ok(const unimp_gemm_desc* d) {
   return d->M <= 64 && !d->a_kstrided && !d->b_kstrided && (d->K & 63) == 0;
+}
+
+static int g_skinny2 = -1;
+static int skinny2_on() {
+  if (g_skinny2 < 0) { const char* e = getenv("UNIMP_SKINNY2"); g_skinny2 = e ? (atoi(e) != 0) : 1; }
+  return g_skinny2;
+}
+extern "C" int unimp_gemm_set_skinny2(int on) { int old = skinny2_on(); g_skinny2 = on != 0; return old; }
+extern "C" int unimp_gemm_skinny_ln_ok(int M, int K) {      // may a decode GEMM of M rows and depth K take its LayerNorm fused (unimp_gemm_desc.ln_gamma)?
+  unimp_gemm_desc d = {};
+  d.M = M; d.K = K; d.ln_gamma = (const void*)1;
+  return skinny2_on() && skinny2_ok(&d);
 }
 
 static void launch_skinny(const unimp_gemm_desc* d, void* stream) {
@@ -352,6 +495,8 @@ static void launch_skinny(const unimp_gemm_desc* d, void* stream) {
   p.gate = (const bf16*)d->gate; p.alpha = d->alpha; p.act = d->act; p.dact = d->dact;
   p.out_f32 = d->out_f32; p.accumulate = d->accumulate; p.pre_deriv = d->pre_deriv;
   p.nbm = 1; p.nbn = (d->N + 15) / 16; p.ksplit = 0;
+  p.ln_gamma = (const bf16*)d->ln_gamma; p.ln_beta = (const bf16*)d->ln_beta; p.ln_eps = d->ln_eps;
+  if (skinny2_on() && skinny2_ok(d)) { launch_skinny2(d, p, stream); return; }
   hipStream_t s = (hipStream_t)stream;
   // Configuration by shape, from tools/bench_skinny.py on MI355X (profiles/r03_skinny_gemm_configs.txt; UNIMP_SKINNY_CFG = "nw,nr"
   // overrides for A/B):
@@ -511,6 +656,8 @@ extern "C" int unimp_gemm_bf16_variant(const unimp_gemm_desc* d, int variant, vo
   int e = validate(d);
   if (e) return e;
   if (variant == UNIMP_GEMM_AUTO) variant = auto_variant(d);
+  if (d->ln_gamma && variant != UNIMP_GEMM_SKINNY)
+    return unimp_set_error(UNIMP_ERR_UNSUPPORTED, "gemm: a fused LayerNorm of the A rows (ln_gamma) is served by the decode-row kernel only (variant skinny, M <= 16)");
   if (d->b_kstrided == 2 && variant != UNIMP_GEMM_PP256 && variant != UNIMP_GEMM_PP128)
     return unimp_set_error(UNIMP_ERR_UNSUPPORTED, "gemm: a pre-packed B operand is served by the ping-pong kernels only (variants pp256 / pp128)");
   if (((d->pre && d->pre_deriv == 2) || d->dact == ACT_DERIV_U8) &&
@@ -548,6 +695,8 @@ extern "C" int unimp_gemm_bf16_variant(const unimp_gemm_desc* d, int variant, vo
       break; }
     case UNIMP_GEMM_SKINNY:
       if (!skinny_ok(d)) return unimp_set_error(UNIMP_ERR_UNSUPPORTED, "gemm: the skinny kernel needs M <= 64, k-contiguous operands, K %% 64 == 0");
+      if (d->ln_gamma && !(skinny2_on() && skinny2_ok(d)))
+        return unimp_set_error(UNIMP_ERR_UNSUPPORTED, "gemm: a fused LayerNorm (ln_gamma) needs M <= 16, K %% 512 == 0, K <= 4096 (unimp_gemm_skinny_ln_ok)");
       launch_skinny(d, stream); break;
     default: return unimp_set_error(UNIMP_ERR_ARG, "gemm: unknown variant");
   }

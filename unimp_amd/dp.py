@@ -183,16 +183,24 @@ class GradBucketer:
         return out
 
     @staticmethod
-    def model_exposed_ms(timeline, world, bus_gbps, latency_us=30.0):
+    def model_exposed_ms(timeline, world, bus_gbps, latency_us=30.0, sharded=False):
         """exchange model over a measured bucket-ready timeline: ring all-reduce of S bytes moves 2 (W - 1) / W x S per GPU, buckets go out in
         issue order on one communication stream at `bus_gbps` (RCCL's 'bus bandwidth') + a fixed latency each; returns the ms the compute
-        stream would wait in finish() -- what backward does not hide."""
+        stream would wait in finish() -- what backward does not hide.  sharded (ZeRO-2 layout, Trainer(shard_optimizer=True)): the buckets
+        go out as reduce-scatters ((W - 1) / W x S per GPU: half the all-reduce's bytes) and the function returns a pair: (exposed
+        reduce-scatter ms, ms of the parameter all-gather that follows the sharded update -- (W - 1) / W x S per GPU per bucket, nothing of
+        the step left to hide it behind: the next forward's first trainable read waits for it)."""
         t_end, lst = timeline
         free = 0.0
+        f = (1.0 if sharded else 2.0) * (world - 1) / world
         for bi, nb, t_ready in lst:
             start = max(free, t_ready)
-            free = start + latency_us * 1e-3 + 2.0 * (world - 1) / world * nb / (bus_gbps * 1e9) * 1e3
-        return max(0.0, free - t_end)
+            free = start + latency_us * 1e-3 + f * nb / (bus_gbps * 1e9) * 1e3
+        exposed = max(0.0, free - t_end)
+        if not sharded:
+            return exposed
+        gather = sum(latency_us * 1e-3 + (world - 1) / world * nb / (bus_gbps * 1e9) * 1e3 for _, nb, _ in lst)
+        return exposed, gather
 
     def remove(self):
         for h in self._hooks:

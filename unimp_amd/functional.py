@@ -672,6 +672,9 @@ def self_attn_block(x, ln_w, ln_b, wqkv, bqkv, wd, bd, nh, *, rope=None, kv_len=
 
 
 # ----------------------------------------------------------------------------------------------- KV-cache decode (F1)
+DECODE_FUSED = _os.environ.get("UNIMP_DECODE_FUSED", "1") != "0"      # round 6: fused decode-step kernels (rope + cache append; LN inside the skinny GEMM); 0 = the round-5 launches (A/B, tests)
+
+
 class LayerKV:
     """decode state of one decoder layer: views ``k``, ``v`` [rows, capacity, nh, hd] into the cache's single K/V tensor
     (keys after RoPE) and the gated cross-attention's projected media ``xkv`` [rows, T*n, 2*inner] (constant over a decode)."""
@@ -786,10 +789,16 @@ def self_attn_block_cached(x, ln_w, ln_b, wqkv, bqkv, wd, bd, nh, lc, pos0, *, r
     if step is not None:
         if Ln != 1:
             raise NotImplementedError("a static decode step feeds one new token per row")
-        if rope is not None:                   # rope = the table rows of the R positions: "sequence" of R rows, row r at its own position
-            ops.rope_(qkv, R, nh, hs, rope[2], offs, rope[0], rope[1])
-        lc.k.index_put_((step.rows, step.pos_idx), k[:, 0])
-        lc.v.index_put_((step.rows, step.pos_idx), v[:, 0])
+        rot = rope[2] if rope is not None else 0
+        o3 = (offs[0], offs[1], (2 * hd) if interleaved else 2 * H)       # q, k, v element offsets inside a head slot (_split_qkv)
+        if DECODE_FUSED and qk_ln is None and ops.decode_rope_append_ok(hd, rot, hs, o3, qkv, lc.k):
+            # one launch: rotate q / k (row r at its own position) and write the rotated k and v into their cache slots
+            ops.decode_rope_append(qkv, nh, hs, hd, o3, rot, rope[0] if rot else None, rope[1] if rot else None, lc.k, lc.v, step.pos_idx)
+        else:
+            if rope is not None:               # rope = the table rows of the R positions: "sequence" of R rows, row r at its own position
+                ops.rope_(qkv, R, nh, hs, rope[2], offs, rope[0], rope[1])
+            lc.k.index_put_((step.rows, step.pos_idx), k[:, 0])
+            lc.v.index_put_((step.rows, step.pos_idx), v[:, 0])
         o = _decode_attn(q, lc.k, lc.v, scale, step.kv_len, alibi, lc.owner.group, lc.owner.shared_len)
         return ops.gemm(o.view(R, H), wd, bias=bd, res=r2).view(R, 1, H)
     if rope is not None:

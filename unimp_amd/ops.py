@@ -342,9 +342,10 @@ def _tail_split_plan(M, N, K):
 
 def gemm(a, b, *, a_ks=False, b_ks=False, bias=None, act=None, res=None, aux=None, dact=None, pre=None,
          gate=None, alpha=1.0, out=None, out_f32=False, accumulate=False, ldc=None, variant=None, pre_deriv=False, b_pk=None,
-         _splits=None, rope=None):
+         _splits=None, rope=None, ln=None):
     """C[M,N] = epi(alpha * A B^T).  a: [M,K] (or [K,M] if a_ks); b: [N,K] (or [K,N] if b_ks).
-    b_pk: optional PackedB image of the same b (frozen weights): used when the packed ping-pong kernel measured faster."""
+    b_pk: optional PackedB image of the same b (frozen weights): used when the packed ping-pong kernel measured faster.
+    ln = (gamma, beta or None, eps): decode rows only (skinny_ln_ok(M, K)) -- the rows of a are layer-normalised inside the kernel."""
     a, lda = _mat(a)
     b, ldb = _mat(b)
     if a_ks:
@@ -413,6 +414,9 @@ def gemm(a, b, *, a_ks=False, b_ks=False, bias=None, act=None, res=None, aux=Non
     plain = bias is None and res is None and aux is None and pre is None and act is None and dact is None   # alpha / gate / accumulate only
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     tiles256 = ((M + 255) // 256) * ((N + 255) // 256)
+    if ln is not None:
+        assert not a_ks and not b_ks and variant is None and skinny_ln_ok(M, K), "gemm(ln=...): decode rows only (ops.skinny_ln_ok)"
+        d.ln_gamma, d.ln_beta, d.ln_eps = ln[0].data_ptr(), _p(ln[1]), float(ln[2])
     if variant is None and M <= 64 and not a_ks and not b_ks and K % 64 == 0:
         variant = 6                      # decode rows: the weight-streaming kernel, any epilogue
     # dX form (dy [M, K] x W [K, N], k-strided weight) INSIDE a backward pass with few 256 x 256 tiles and a deep K: at the
@@ -475,6 +479,11 @@ def gemm(a, b, *, a_ks=False, b_ks=False, bias=None, act=None, res=None, aux=Non
         return out
     _launch_gemm(d, v)
     return out
+
+
+def skinny_ln_ok(M, K):
+    """may a decode GEMM of M rows and contraction depth K take its LayerNorm fused (gemm(ln=...))?"""
+    return bool(_lib.lib().unimp_gemm_skinny_ln_ok(int(M), int(K)))
 
 
 def layernorm_fwd(x, gamma, beta, eps, *, rms=False, out=None, grp=0, grp_stride=0, grp_off=0):
@@ -550,6 +559,24 @@ def rope_(x2d, L, heads, head_stride, rot, offs, cos, sin, inverse=False, pos=No
     check(_lib.lib().unimp_rope_halfsplit(_dev(x2d).data_ptr(), x2d.stride(0), head_stride, rows, L, heads, rot, len(offs),
                                            o0, o1, cos.data_ptr(), sin.data_ptr(), int(inverse), _stream()), "rope")
     return x2d
+
+
+def decode_rope_append(qkv2d, heads, head_stride, hd, offs, rot, cos_rows, sin_rows, kcache, vcache, pos_idx):
+    """decode step: rotate q / k of every row in place (row r with ITS table row) and append the rotated k and v to slot pos_idx[r] of
+    the caches [rows, capacity, heads, hd] -- one launch instead of rope_ + two index_put_.  offs = (q_off, k_off, v_off) element
+    offsets inside a head slot; rot = 0 appends only."""
+    rows = qkv2d.shape[0]
+    assert kcache.stride(3) == 1 and vcache.stride() == kcache.stride() and pos_idx.dtype == torch.int64 and pos_idx.is_contiguous()
+    if rot:
+        assert cos_rows.dtype == torch.float32 and cos_rows.is_contiguous() and sin_rows.is_contiguous() and cos_rows.shape == (rows, rot // 2)
+    check(_lib.lib().unimp_decode_rope_append(_dev(qkv2d).data_ptr(), qkv2d.stride(0), head_stride, rows, heads, hd, offs[0], offs[1], offs[2], rot,
+                                               _p(cos_rows) if rot else 0, _p(sin_rows) if rot else 0, kcache.data_ptr(), vcache.data_ptr(),
+                                               kcache.stride(0), kcache.stride(1), kcache.stride(2), pos_idx.data_ptr(), _stream()), "decode_rope_append")
+
+
+def decode_rope_append_ok(hd, rot, head_stride, offs, qkv2d, kcache):
+    return (hd % 8 == 0 and rot % 16 == 0 and rot <= hd and head_stride % 8 == 0 and all(o % 8 == 0 for o in offs) and qkv2d.stride(0) % 8 == 0
+            and qkv2d.data_ptr() % 16 == 0 and kcache.data_ptr() % 16 == 0 and all(s_ % 8 == 0 for s_ in kcache.stride()[:3]))
 
 
 def _fill_attn(d, q, k, v, o, lse, B, H, Sq, Sk, D, scale, mask_mode, kv_len, seg, seg_len, qs, ks, vs, os_, alibi=None):

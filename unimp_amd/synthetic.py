@@ -55,6 +55,40 @@ def make_batch(layout, batch, T, L, image_size=224, seed=1234, weight=2.0, min_f
     return out
 
 
+def make_exp_batch(layout, batch, T, L, image_size=224, seed=1234, weight=1.0, exp_len=28, device=None, vision_dtype=torch.float32):
+    """rating + explanation samples (BASELINE config 3's "explain" task; rec_dataset.py:1100-1134): T - 1 history chunks
+    ``<image> meta... <answer> rate_r explanation... <|endofchunk|>`` and the query chunk ``<image> meta... question... <answer> rate_r
+    explanation... [EOS]`` -- the label mask (mmrec.py:143-168) keeps every token between an ``<answer>`` and the chunk's end, so a sample
+    carries T x (1 + exp_len) + 1 labeled positions (233 at T = 8, exp_len = 28) where the rec template carries T + 2; loss weight 1.0
+    (rec_dataset.py:452: 2.0 is the rec task's).  Same return layout as make_batch."""
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.full((batch, L), layout.pad, dtype=torch.int64)
+    mask = torch.zeros((batch, L), dtype=torch.int64)
+    rate0 = layout.answer + 1                           # rate_1 .. rate_5 follow <answer> in the vocabulary (TokenLayout)
+    q_len = 10
+    fixed = 1 + T * (3 + 1 + exp_len) + q_len           # BOS + per chunk (<image>, <answer>, rate, explanation, <eoc> / EOS) + the question
+    for b in range(batch):
+        n_meta = max(T, L - fixed - int(torch.randint(0, max(1, L // 16), (1,), generator=g)))
+        per = [n_meta // T + (1 if i < n_meta % T else 0) for i in range(T)]
+        text = lambda n: torch.randint(1, layout.base_vocab, (n,), generator=g).tolist()
+        s = [layout.bos]
+        for t in range(T):
+            s += [layout.media] + text(per[t])
+            if t == T - 1:
+                s += text(q_len)
+            s += [layout.answer, rate0 + int(torch.randint(0, 5, (1,), generator=g))] + text(exp_len)
+            s += [layout.eoc if t < T - 1 else layout.eos]
+        if len(s) > L:
+            raise ValueError(f"explain sample of {len(s)} tokens does not fit L = {L}")
+        ids[b, :len(s)] = torch.tensor(s)
+        mask[b, :len(s)] = 1
+    vis = torch.randn((batch, T, 1, 3, image_size, image_size), generator=g).to(vision_dtype)
+    out = dict(vision_x=vis, lang_x=ids, attention_mask=mask, weights=torch.full((batch,), float(weight)))
+    if device is not None:
+        out = {k: v.to(device) for k, v in out.items()}
+    return out
+
+
 def make_imggen_batch(layout, batch, T=2, L=1024, image_size=224, seed=5, device=None, vision_dtype=torch.float32):
     """image-token generation samples (BASELINE config 5's task; rec_dataset.py:613-664, eval_img_gen.py:102-111): T history chunks
     ``<image> title... ID img_a,img_b,...(256 VQGAN code tokens) <|endofchunk|>``, then the query and ``<answer>`` + the target item's
