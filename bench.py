@@ -384,6 +384,85 @@ def full_depth_parity(om, model, trainer, layout, T, L, dev, n_batches=8, plante
         model.lang_encoder.packed = was
 
 
+HBM_PEAK_TBPS = 8.0            # MI355X_MICROARCH.md: HBM3E ~ 8 TB/s
+
+
+def decode_leg(model, layout, dev, T=8, L=512):
+    """F1: the reference's three cached-decode calls on the 4b-instruct model with the roofline that bounds them.  A token-step
+    is HBM-bound: it streams every weight the step multiplies with once (the decoder layers, the gated blocks' to_q / to_out / feed-forward,
+    the head) and reads the cached keys / values -- `bytes_per_step` -- against the ~8 TB/s of the part.  Three calls, one user each, a
+    ~470-token prompt with 8 history images: eval_rec.py:100-110 (K = 10 beams, 50 new tokens), eval_exp.py:103-113 (K = 5, 256 new),
+    eval_img_gen.py:102-111 (greedy, 600 new).  `ms_per_token_step` = the whole generate() call (vision encoder, prefill, beam bookkeeping on
+    the host included) / new tokens -- the figure rounds 4-5 quoted; `ms_per_step_decode_only` = the HIP-graph replay of the step + the
+    host's argmax, driven through DecodeSession after the prefill; `frac` = bytes_per_step / ms_per_step_decode_only / 8 TB/s."""
+    from unimp_amd.decode import DecodeSession
+    from unimp_amd.synthetic import make_batch
+    bt = make_batch(layout, 1, T, L, seed=7, device=dev, vision_dtype=torch.bfloat16)
+    n = int(bt["attention_mask"][0].sum())
+    ids, vx = bt["lang_x"][:1, :n - 2], bt["vision_x"][:1]
+    le = model.lang_encoder
+    layers = le._get_decoder_layers()
+    numel = lambda ps: sum(p.numel() for p in ps)
+    w_lm = sum(numel(l.decoder_layer.parameters()) for l in layers)
+    w_x = sum(numel(p for n_, p in l.gated_cross_attn_layer.named_parameters() if "to_kv" not in n_) for l in layers if l.gated_cross_attn_layer is not None)
+    w_head = le.get_output_embeddings().weight.numel()
+    wbytes = 2 * (w_lm + w_x + w_head)
+    H = le.get_input_embeddings().weight.shape[1]
+    n_x = sum(1 for l in layers if l.gated_cross_attn_layer is not None)
+    was_training = model.training
+    out = {"prompt_tokens": int(ids.shape[1]), "weights_streamed_bytes": int(wbytes),
+           "weights_note": f"bf16: decoder layers {w_lm / 1e9:.3f} B + gated blocks without to_kv {w_x / 1e9:.3f} B + head {w_head / 1e9:.3f} B parameters"}
+    try:
+        for name, K, new, ref in (("eval_rec_k10_50new", 10, 50, "eval_rec.py:100-110"), ("eval_exp_k5_256new", 5, 256, "eval_exp.py:103-113"),
+                                  ("eval_img_gen_greedy_600new", 1, 600, "eval_img_gen.py:102-111")):
+            kw = dict(num_beams=K, num_return_sequences=K, early_stopping=False, max_new_tokens=new, eos_token_id=-1, pad_token_id=layout.eos)
+            model.generate(vx, ids, **{**kw, "max_new_tokens": 3})
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            o = model.generate(vx, ids, **kw)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            got_new = int(o.shape[1] - ids.shape[1])
+            # the step alone: prefill, then `m` graph replays with the host's argmax between them
+            m = min(new, 64)
+            model.eval()
+            with torch.no_grad():
+                le._use_cached_vision_x = True
+                model._encode_vision_x(vision_x=vx)
+                try:
+                    sess = DecodeSession(model, m + 8, reorder=K > 1, graph=True, beams=K)
+                    tok = sess.prefill(ids, None).float().argmax(-1)
+                    src = torch.arange(K, device=dev)
+                    for _ in range(4):
+                        tok = sess.step(tok, src if K > 1 else None).float().argmax(-1)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(m):
+                        tok = sess.step(tok, src if K > 1 else None).float().argmax(-1)
+                    torch.cuda.synchronize()
+                    dstep = (time.perf_counter() - t1) / m
+                finally:
+                    model.clear_conditioned_layers()
+                    le._use_cached_vision_x = False
+            # K / V read per step at the middle of the decode: the prompt's keys once per prompt (the beams share them: decode_attn.hip), the generated tail
+            # per beam; the gated blocks' projected media per row
+            mid = new // 2
+            kv = len(layers) * 2 * H * 2 * (ids.shape[1] + K * mid)
+            xkv = n_x * K * (T * 64) * 2 * 512 * 2
+            bps = wbytes + kv + xkv
+            out[name] = {"reference": ref, "beams": K, "new_tokens": got_new, "s_per_user": round(dt, 4), "ms_per_token_step": round(dt / max(1, got_new) * 1e3, 3),
+                         "ms_per_step_decode_only": round(dstep * 1e3, 3), "bytes_per_step": int(bps), "kv_bytes_per_step": int(kv + xkv),
+                         "achieved_TBps": round(bps / dstep / 1e12, 3), "peak_TBps": HBM_PEAK_TBPS, "frac": round(bps / dstep / 1e12 / HBM_PEAK_TBPS, 4),
+                         "frac_whole_call": round(bps / (dt / max(1, got_new)) / 1e12 / HBM_PEAK_TBPS, 4)}
+    finally:
+        model.train(was_training)
+    out["frac"] = out["eval_img_gen_greedy_600new"]["frac"]
+    out["note"] = ("bound = hbm: a token-step multiplies M <= 10 rows with every weight once; bytes_per_step = weights streamed + cached K / V read (mid-decode) -- algorithmic bytes, "
+                   "not a counter; frac = bytes_per_step / ms_per_step_decode_only / 8 TB/s (frac_whole_call: against ms_per_token_step, which also pays the vision encoder, the "
+                   "prefill and the host's beam bookkeeping).  Kernels: gemm.hip skinny2 (persistent weight stream, LayerNorm fused), decode_attn.hip, one HIP graph per step")
+    return out
+
+
 def cpu_baseline(T, L, layout, fps, full_steps=2, before_full_steps=None):
     """The CPU oracle (a port of the reference's op sequence, fp32: unfused CE + softmax, the label-mask loop) timed on the
     host cores, b = 1, cfg2's real dimensions.
@@ -524,6 +603,7 @@ def main():
     ap.add_argument("--no-packed-leg", action="store_true", help="skip the short opt-in measurement (packed token order) that follows the timed steps")
     ap.add_argument("--no-cfg5-leg", action="store_true", help="skip the short legs on BASELINE config 4's shapes (H&M: T = 16, V = 66 216) and config 5's own "
                     "workload (9b model, image-token generation, frozen towers on the MX-fp8 GEMM)")
+    ap.add_argument("--no-decode-leg", action="store_true", help="skip the cached-decode leg (F1: eval_rec / eval_exp / eval_img_gen calls with their HBM roofline fraction)")
     ap.add_argument("--parity-batches", type=int, default=8, help="distinct b = 1 batches of the full-depth HIP-vs-oracle parity statistic")
     ap.add_argument("--no-shape-legs", action="store_true", help="skip the short legs at the reference's shipped shape (b = 3, GA 2) and b = 16 / 32")
     ap.add_argument("--fuse-accum", action="store_true", help="(the default since round 4 whenever --grad-accum > 1; kept for old command lines) the "
@@ -808,6 +888,7 @@ def main():
                         "gemm_flop_per_step": tot_fl / prof_steps, **({"mx_gemms": mx_roof} if mx_roof else {})}
         cpu = None
         parity = None
+        decode = None
         if not args.no_cpu_baseline and world == 1:
             def _parity_leg(om):             # after every timed leg: the bench model takes the oracle's weights for ONE checked forward
                 nonlocal parity
@@ -817,6 +898,11 @@ def main():
                     parity = full_depth_parity(om, model, trainer, layout, T, L, dev, n_batches=args.parity_batches)
                 except Exception as e:       # noqa: BLE001  (the headline must not depend on the checker leg)
                     parity = {"error": f"{type(e).__name__}: {e}"}
+            if not (args.no_decode_leg or nine or args.fp8 or args.task != "rec" or args.packed or args.graph or args.sparse_head or GA > 1 or TEST_DEPTH):
+                try:
+                    decode = decode_leg(model, layout, dev, T, L)
+                except Exception as e:       # noqa: BLE001  (the headline must not depend on the extra leg)
+                    decode = {"error": f"{type(e).__name__}: {e}"}
             cpu = cpu_baseline(T, L, layout, fps, args.cpu_full_steps, before_full_steps=_parity_leg)
             if parity is None and not (args.no_parity or nine or args.fp8 or args.task != "rec"):
                 parity = {"skipped": "the full-depth oracle was not built (--cpu-full-steps 0, or less than 56 GB of host memory available)"}
@@ -939,7 +1025,7 @@ def main():
                            "mfma_frac_whole_step": round(value / world * fps["total"] / 1e12 / PEAK_BF16_TFLOPS, 4),
                            **({"note": "--sparse-head: the utilisation fields above still count the dense head's FLOPs"}
                               if args.sparse_head else {})},
-                "roofline": roofline, "cpu_baseline": cpu, **({"parity": parity} if parity else {}), **({"rccl": rccl} if rccl else {}), **({"packed_token_order": packed_leg} if packed_leg else {}), **({"other_shapes": shape_legs} if shape_legs else {}), **({"cfg4_hm": cfg4_leg} if cfg4_leg else {}),
+                "roofline": roofline, "cpu_baseline": cpu, **({"parity": parity} if parity else {}), **({"decode": decode} if decode else {}), **({"rccl": rccl} if rccl else {}), **({"packed_token_order": packed_leg} if packed_leg else {}), **({"other_shapes": shape_legs} if shape_legs else {}), **({"cfg4_hm": cfg4_leg} if cfg4_leg else {}),
                 **({"cfg5_imggen_fp8": cfg5_leg} if cfg5_leg else {}), **({"cfg5_fp8": cfg5_rec_leg} if cfg5_rec_leg else {})}
         if ops.TUNE_MISSES:       # shapes the committed table lacked (tuned live above): listed on stderr so that the table can be completed
             print("gemm autotune: tuned live this run: " + "; ".join(str(k) for k in ops.TUNE_MISSES), file=sys.stderr)

@@ -73,7 +73,7 @@ typedef struct {
   float rope_log2_base;
   /* ABI 4: NULL, or int32 [M]: the position of row m (instead of m % rope_L) -- packed rows, where a sequence starts at any row */
   const int32_t* rope_pos;
-  /* ABI 8, decode rows only (variant SKINNY with M <= 16, K % 512 == 0, K <= 4096: unimp_gemm_skinny_ln_ok): ln_gamma != NULL -- the rows of A
+  /* ABI 8, decode rows only (variant SKINNY with M <= 16, K % 64 == 0, K <= 4096: unimp_gemm_skinny_ln_ok): ln_gamma != NULL -- the rows of A
    * are LAYER-NORMALISED on their way into the product, y = (a - mean) * rstd * ln_gamma + ln_beta (ln_beta may be NULL) in fp32, rounded to
    * bf16: what unimp_layernorm_fwd would have stored, without that launch.  Replaces the nn.LayerNorm in front of a projection in a
    * cached decode step (GPTNeoXLayer.input_layernorm / post_attention_layernorm, open_flamingo MaskedCrossAttention.norm, FeedForward[0],
@@ -110,9 +110,9 @@ enum { UNIMP_GEMM_AUTO = 0, UNIMP_GEMM_V1 = 1, UNIMP_GEMM_DMA256 = 2, UNIMP_GEMM
        /* PP256 / PP128 / PP256P with ONE fragment register set: the L phase of a half-step reads that half-step's own fragments
           (before its LDS-DMA issue) and leaves two half-stages in flight instead of one -- 48 registers fewer, same bits */ };
 int unimp_gemm_bf16_variant(const unimp_gemm_desc* d, int variant, void* stream);
-/* decode rows (ABI 8): M <= 16 rows run a persistent weight-streaming kernel (one workgroup per CU walks its 16-row weight tiles with a ring of
- * loads in flight across tile boundaries; gemm.hip skinny2) instead of round 3's one-workgroup-per-tile kernel.  set_skinny2(0) restores the
- * latter (A/B, tests; env UNIMP_SKINNY2); returns the previous setting.  skinny_ln_ok: may a decode GEMM of M rows, depth K take ln_gamma? */
+/* decode rows (ABI 8): M <= 16 rows with K <= 4096 run the second-generation weight-streaming kernel (gemm.hip skinny2: every load of a wave
+ * issued before the first wait, optional fused LayerNorm) instead of round 3's.  set_skinny2(0) restores the latter (A/B, tests; env
+ * UNIMP_SKINNY2); returns the previous setting.  skinny_ln_ok: may a decode GEMM of M rows, depth K take ln_gamma? */
 int unimp_gemm_set_skinny2(int on);
 int unimp_gemm_skinny_ln_ok(int M, int K);
 /* split-K form for outputs much smaller than the chip (weight gradients of narrow projections): `splits` K slices into

@@ -143,6 +143,15 @@ def test_kernel_register_budgets():
     # the lockstep 256 x 256 kernel + the ping-pong kernel with the general epilogue, its four fixed kinds (PLAIN, GELU2, AUX, RES) and the two with
     # the fused MX output (GELU2 -> MX, AUX -> MX)
     assert len(big) == 8 and all(b["ScratchSize"] == 0 and b["VGPRs"] + b.get("AGPRs", 0) <= 256 for b in big), big
+    # round 6: the decode-row GEMM (gemm.hip skinny2).  Nothing in scratch (the CW = 4 LayerNorm form spilled 84 bytes per lane until the fragments were
+    # kept packed across the statistics' barriers), and the cfg2 forms -- 8 waves x 5 chunks -- keep two workgroups per CU (4 waves per SIMD)
+    g1 = remarks("gemm.hip", vg)
+    sk = {k: r for k, r in g1.items() if "gemm_skinny2_kernel" in k or "gemm_skinny2_long_kernel" in k}
+    assert len(sk) == 30, sorted(sk)              # x 2: default-policy and nontemporal weight loads (A/B switch UNIMP_SKINNY_NT)
+    for k, r in sk.items():
+        assert r["ScratchSize"] == 0, (k, r)
+        if "ILi8E" in k:
+            assert r["Occupancy"] >= 4, (k, r)
 
 
 def test_gemm_kernel_code_fits_the_instruction_cache():

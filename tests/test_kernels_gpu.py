@@ -448,6 +448,108 @@ def test_gemm_skinny_decode_rows(ops, M, N, K):
     close(got, z, rel=1e-5, name="skinny f32")
 
 
+@pytest.mark.parametrize("M", [1, 5, 10, 16])
+@pytest.mark.parametrize("N,K", [(2560, 2560), (7680, 2560), (10240, 2560), (2560, 10240), (2560, 512), (512, 2560), (74053, 2560), (4096, 4096),
+                                 (1005, 1024), (24, 512), (5133, 1536), (777, 3072), (640, 64), (512, 2624), (1024, 16384), (520, 4160), (40, 7744)])
+def test_gemm_skinny2_persistent_decode_rows(ops, M, N, K):
+    """round 6: the second-generation weight-streaming kernel (gemm.hip skinny2: every load of a wave issued before its first wait, 8 waves x
+    up to five 64-k chunks or 16 x up to four) that serves M <= 16 decode rows with K <= 4096 -- the cfg2 / cfg5 decode shapes, the head's
+    4 629 tiles, N = 24, ragged N with a padded ldc, every chunk count per wave incl. a ragged last one (K = 1536: 24 chunks on 8 waves) -- and its
+    long-K form (K > 4096: rounds of three chunks per wave, the next round's loads issued before this round's MFMAs; K = 10 240, 16 384, a
+    ragged 4 160 and 7 744) -- against fp32 and against the round-3 kernel on the same operands (different partial-sum
+    grouping: bf16-level agreement), all epilogue flavours of the decode step; launching twice gives the same bits (fixed summation order)."""
+    from unimp_amd import _lib
+    L = _lib.lib()
+    a, b = rnd(M, K, seed=31), rnd(N, K, seed=32, scale=0.2)
+    bias, res = rnd(N, seed=33), rnd(M, N, seed=34)
+    gate = torch.tensor([0.4]).to(bf16)
+    z = a.float() @ b.float().t()
+    ad, bd = a.cuda(), b.cuda()
+    ldc = (N + 7) // 8 * 8
+    assert L.unimp_gemm_set_skinny2(1) in (0, 1)
+    try:
+        got = ops.gemm(ad, bd, ldc=ldc)
+        close(got, z, name="skinny2 plain")
+        again = ops.gemm(ad, bd, ldc=ldc)
+        assert torch.equal(got, again), "skinny2: two launches differ"
+        L.unimp_gemm_set_skinny2(0)
+        old = ops.gemm(ad, bd, ldc=ldc)
+        L.unimp_gemm_set_skinny2(1)
+        close(got, old.float(), rel=1e-2, name="skinny2 vs the round-3 kernel")
+        got = ops.gemm(ad, bd, variant="skinny", bias=bias.cuda(), act="gelu")
+        close(got, torch.nn.functional.gelu(z + bias.float()), name="skinny2 bias+gelu")
+        got = ops.gemm(ad, bd, variant="skinny", bias=bias.cuda(), res=res.cuda())
+        close(got, z + bias.float() + res.float(), name="skinny2 bias+res")
+        got = ops.gemm(ad, bd, variant="skinny", gate=gate.cuda(), res=res.cuda())
+        close(got, z * math.tanh(float(gate.float())) + res.float(), name="skinny2 gate+res")
+        got = ops.gemm(ad, bd, variant="skinny", out_f32=True)
+        close(got, z, rel=1e-5, name="skinny2 f32")
+    finally:
+        L.unimp_gemm_set_skinny2(1)
+
+
+@pytest.mark.parametrize("M", [1, 3, 10, 16])
+@pytest.mark.parametrize("N,K,beta", [(7680, 2560, True), (10240, 2560, True), (512, 2560, True), (74053, 2560, True), (12288, 4096, False),
+                                      (4096, 1024, True), (1005, 512, False), (333, 1536, True), (256, 3072, False), (128, 768, True)])
+def test_gemm_skinny2_fused_layernorm(ops, M, N, K, beta):
+    """ops.gemm(ln=...): the LayerNorm in front of a decode-step projection runs inside the weight-streaming GEMM.  Against the two-launch
+    form on the same operands (unimp_layernorm_fwd then the same kernel: the normalised rows differ at most by the statistics' summation
+    order, i.e. a bf16 ulp on a few elements) and against fp32 math; with and without beta (MPT's LayerNorm has none); bias + GELU on top
+    (the up-projection); refusals: RMS-free contract, K beyond 4096, more than 16 rows."""
+    x, w = rnd(M, K, seed=41, scale=2.0) + 0.5, rnd(N, K, seed=42, scale=0.05)
+    g, b_, bias = (rnd(K, seed=43, scale=0.2) + 1.0).to(bf16), rnd(K, seed=44, scale=0.3), rnd(N, seed=45)
+    eps = 1e-5
+    xd, wd, gd, bd = x.cuda(), w.cuda(), g.cuda(), (b_.cuda() if beta else None)
+    assert ops.skinny_ln_ok(M, K)
+    h, _, _ = ops.layernorm_fwd(xd, gd, bd, eps)
+    want2 = ops.gemm(h, wd)
+    got = ops.gemm(xd, wd, ln=(gd, bd, eps))
+    hf = torch.nn.functional.layer_norm(x.float(), (K,), g.float(), b_.float() if beta else None, eps).to(bf16).float()
+    close(got, hf @ w.float().t(), name="fused LN vs fp32")
+    close(got, want2.float(), rel=2 ** -8, name="fused LN vs layernorm_fwd + gemm")
+    got = ops.gemm(xd, wd, bias=bias.cuda(), act="gelu", ln=(gd, bd, eps))
+    close(got, torch.nn.functional.gelu(hf @ w.float().t() + bias.float()), name="fused LN + bias + gelu")
+    assert not ops.skinny_ln_ok(17, K) and not ops.skinny_ln_ok(M, 8192) and not ops.skinny_ln_ok(M, 2560 + 32)
+    with pytest.raises(Exception):
+        ops.gemm(rnd(32, K, seed=1).cuda(), wd, ln=(gd, bd, eps))
+
+
+@pytest.mark.parametrize("R,nh,hd,rot,interleaved", [(1, 32, 80, 80, True), (10, 32, 80, 80, True), (5, 8, 64, 32, True), (3, 32, 128, 0, False),
+                                                     (16, 12, 64, 64, False)])
+def test_decode_rope_append(ops, R, nh, hd, rot, interleaved):
+    """unimp_decode_rope_append: one launch = rope_ on the step's q / k rows (row r at its own position) + the two index_put_ of the rotated k
+    and of v into slot pos_idx[r] of the caches -- bit-identical with that three-launch sequence (GPT-NeoX interleaved [nh, 3 hd] and the
+    [3, nh, hd] layout; partial rotation; rot = 0 = append only: MPT / OPT); nothing else in the caches moves."""
+    H, cap = nh * hd, 40
+    g = torch.Generator().manual_seed(R * 7 + hd)
+    qkv = torch.randn(R, 3 * H, generator=g).to(bf16).cuda()
+    pos = torch.randint(0, cap, (R,), generator=g).cuda()
+    kc = torch.randn(R, cap, nh, hd, generator=g).to(bf16).cuda()
+    vc = torch.randn(R, cap, nh, hd, generator=g).to(bf16).cuda()
+    half = rot // 2
+    cos = torch.rand(R, max(half, 1), generator=g).cuda() if rot else None
+    sin = torch.rand(R, max(half, 1), generator=g).cuda() if rot else None
+    if interleaved:
+        hs, offs = 3 * hd, (0, hd, 2 * hd)
+        view = lambda t: t.view(R, 1, nh, 3 * hd)
+        kv = lambda t: (view(t)[..., hd:2 * hd], view(t)[..., 2 * hd:])
+    else:
+        hs, offs = hd, (0, H, 2 * H)
+        kv = lambda t: (t.view(R, 1, 3, nh, hd)[:, :, 1], t.view(R, 1, 3, nh, hd)[:, :, 2])
+    want_qkv, want_k, want_v = qkv.clone(), kc.clone(), vc.clone()
+    if rot:
+        ops.rope_(want_qkv, R, nh, hs, rot, offs[:2], cos, sin)
+    k_, v_ = kv(want_qkv)
+    rows = torch.arange(R, device="cuda")
+    want_k.index_put_((rows, pos), k_[:, 0])
+    want_v.index_put_((rows, pos), v_[:, 0])
+    assert ops.decode_rope_append_ok(hd, rot, hs, offs, qkv, kc)
+    ops.decode_rope_append(qkv, nh, hs, hd, offs, rot, cos, sin, kc, vc, pos)
+    torch.cuda.synchronize()
+    assert torch.equal(qkv, want_qkv), "q / k rows"
+    assert torch.equal(kc, want_k) and torch.equal(vc, want_v), "cache slots"
+
+
 def test_gemm_skinny_rejects_unsupported(ops):
     a, b = rnd(8, 72, seed=1).cuda(), rnd(16, 72, seed=2).cuda()
     with pytest.raises(Exception):

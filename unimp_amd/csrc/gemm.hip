@@ -341,133 +341,222 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(GemmParams p) {
 }
 
 // ---- skinny2 (round 6): decode rows M <= 16 -- one token per row of K <= 16 beams (eval_rec.py:100-110) or one greedy row
-// (eval_img_gen.py:102-111) -- as a PERSISTENT weight stream.  The round-3 kernel above starts one 16-wave workgroup per 16 weight rows:
-// 80 KB of weights per workgroup at K = 2560, of which every wave fetches two or three 2-KB chunks, waits, multiplies, and the workgroup
-// retires behind an LDS reduction -- launch, first-byte latency and drain are paid per 80 KB (measured 2.3-3.3 TB/s on the step's shapes).
-// Here ONE workgroup per CU (8 waves) walks its weight tiles (16 rows x K each; tile t of workgroup b is row block b + t * grid):
-//   * each wave owns the 64-k chunks c = w (mod 8) of every tile and keeps a RING of D chunks (2 KB each) in flight ACROSS tile boundaries:
-//     the loads of the next tile are on their way while this tile's partial sums meet in LDS (one barrier per tile; the wave t mod 8 sums the
-//     eight partials in a fixed order and runs the epilogue while the others go on);
-//   * the M activation rows are staged ONCE per workgroup in LDS (row pitch = K * 2 + 16 bytes: the 16 rows of a fragment read hit 16
-//     different bank groups) -- and may be LAYER-NORMALISED on the way (ln_gamma / ln_beta / ln_eps: the LayerNorm in front of the QKV, the
-//     up-projection, the gated blocks' to_q / feed-forward and the head is no launch of its own in a decode step; the W ring is issued
-//     BEFORE the prologue, so the statistics run under the first weights' flight).  (x - mean) * rstd * gamma + beta in fp32, rounded to
-//     bf16: the values unimp_layernorm_fwd stores (up to the summation order of the statistics).
-// Lane (r, g) of a wave holds k = 16 g .. 16 g + 15 of weight row r of the chunk (32 contiguous bytes, two MFMAs) -- the round-3 operand
-// map; accumulator lane (r, g) = activation row r, weight rows 4 g .. 4 g + 3.  Deterministic: a tile's sum order is fixed.
-template <int D>
-__global__ __launch_bounds__(512) void gemm_skinny2_kernel(GemmParams p, int ntiles, int xpitch) {
-  constexpr int NW = 8;
-  extern __shared__ __attribute__((aligned(16))) char sk2_smem[];
+// (eval_img_gen.py:102-111) -- with K <= 4096.  Round 3's blocking (one workgroup per 16 weight rows, its waves split K in 64-k chunks,
+// partial sums meet in LDS) with two changes that the decode step's trace asked for (profiles/r06_decode_step_k1_round5_launches.csv: 506 launches
+// of >= 4.5 us each -- the floor of a graph node -- of which 97 are LayerNorms on one row):
+//   * EVERYTHING a wave needs goes out before anything is waited for: its CW <= 4 chunks of the weight rows (32 contiguous bytes per lane and
+//     chunk) and the matching activation fragments -- one memory round trip per workgroup where the round-3 loop (not unrolled at K = 2560:
+//     2.5 chunks per wave) made two or three dependent ones;
+//   * the LayerNorm in front of the projection is computed HERE (ln_gamma / ln_beta / ln_eps): a wave sums its own chunks of the M rows, the
+//     16 waves' partial sums meet in LDS (fixed order; mean first, then the centred squares: two barriers under the weights' flight), every
+//     lane normalises the fragments it holds -- (x - mean) * rstd * gamma + beta in fp32, rounded to bf16: the values unimp_layernorm_fwd stores
+//     up to the summation order of the statistics -- and the LayerNorm is no launch of its own.
+// Lane (r, g) holds k = 16 g .. 16 g + 15 of weight row r (operand map of the round-3 kernel); accumulator lane (r, g) = activation row r,
+// weight rows 4 g .. 4 g + 3.  Deterministic: fixed summation order over chunks and waves.
+// (A PERSISTENT form -- one workgroup per CU walking its tiles with a ring of loads in flight -- was built first and measured slower:
+// profiles/r06_negative_results_decode_and_mx.txt.)
+template <bool NT> __device__ __forceinline__ u32x4 sk2_ldw(const bf16* q) {
+  if (NT) return __builtin_nontemporal_load((const u32x4*)q);
+  return *(const u32x4*)q;
+}
+
+template <int NW, int CW, bool LN, bool NT>
+__global__ __launch_bounds__(64 * NW) void gemm_skinny2_kernel(GemmParams p) {
+  __shared__ f32x4 red[NW * 64];
+  __shared__ float stat[2][NW][16];
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, r = lane & 15;
-  char* xs = sk2_smem;
-  f32x4* red = (f32x4*)(sk2_smem + (((long)p.M * xpitch + 15) & ~15L));          // [2][NW][64]
-  const int nchunk = p.K >> 6, cpw = nchunk / NW;
-  const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-  const long Q = (long)my_tiles * cpw;                                             // (tile, chunk) items of this wave
-  // ---- the ring: items 0 .. D - 1 go out before anything else
-  u32x4 buf[D][2];
-  int li = 0, lj = 0;                                                              // load cursor: tile index (of this workgroup), chunk index (of this wave)
-  auto issue = [&](u32x4 (&b)[2]) {
-    const int tile = blockIdx.x + li * gridDim.x;
-    const bf16* q = p.B + (long)min(tile * 16 + r, p.N - 1) * p.ldb + (long)(w + NW * lj) * 64 + g * 16;
-    b[0] = __builtin_nontemporal_load((const u32x4*)q);
-    b[1] = __builtin_nontemporal_load((const u32x4*)(q + 8));
-    if (++lj == cpw) { lj = 0; ++li; }
-  };
+  const int n0 = blockIdx.x * 16, nchunk = p.K >> 6;
+  // lane (r, g) holds k = 8 g .. 8 g + 7 of each 32-k half of the chunk: one load instruction of the wave covers a contiguous 64-byte half line of each
+  // of its 16 rows (the round-3 map -- 16 consecutive k per lane -- made every instruction touch both halves of every line; with streaming (nt) loads
+  // that measured as twice the requests: profiles/r06_negative_results_decode_and_mx.txt)
+  const bf16* wp = p.B + (long)min(n0 + r, p.N - 1) * p.ldb + g * 8;
+  const bf16* xp = p.A + (long)min(r, p.M - 1) * p.lda + g * 8;
+  u32x4 wv[CW][2];
+  bf16x8 xv[CW][2];
+  // ISSUE ORDER matters: a wave's loads return in order.  With the LayerNorm the activation fragments and gamma / beta go out FIRST (L2 hits), the
+  // weights behind them: the statistics, their two barriers and the normalisation then run under the weights' flight instead of behind it (with the
+  // weights first every later load -- the gamma / beta pieces of the normalisation most of all -- queued behind 10 KB of HBM reads per wave:
+  // 19 us per launch in the step where the plain form took 14).  gamma / beta reach the lanes through LDS (one 16-byte piece per thread).
+  __shared__ __attribute__((aligned(16))) bf16 gbs[LN ? 2 * 4096 : 8];
+  bf16x8 gmr = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}, btr = gmr;
+  const bool gb_mine = LN && (int)threadIdx.x < (p.K >> 3);       // K / 8 pieces <= the workgroup's threads (launch_skinny2: 8 waves up to K = 2560, 16 up to 4096)
+  if (gb_mine) {
+    gmr = *(const bf16x8*)(p.ln_gamma + threadIdx.x * 8);
+    if (p.ln_beta) btr = *(const bf16x8*)(p.ln_beta + threadIdx.x * 8);
+  }
 #pragma unroll
-  for (int u = 0; u < D; ++u) if (u < Q) issue(buf[u]);
-  // ---- activation rows -> LDS (rows w, w + 8 of the M <= 16), layer-normalised if asked
-  const int pieces = p.K >> 3;
-  for (int m = w; m < p.M; m += NW) {
-    const bf16* xr = p.A + (long)m * p.lda;
-    char* xd = xs + (long)m * xpitch;
-    if (p.ln_gamma) {
-      bf16x8 raw[8];
-      float s = 0.f;
+  for (int u = 0; u < CW; ++u) {
+    const int c = w + NW * u;
+    if (c < nchunk) { xv[u][0] = *(const bf16x8*)(xp + (long)c * 64); xv[u][1] = *(const bf16x8*)(xp + (long)c * 64 + 32); }
+    else { xv[u][0] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; xv[u][1] = xv[u][0]; }
+  }
+  if (LN) __builtin_amdgcn_sched_barrier(0);          // the loads above stay above the weight loads
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const int pc = lane + 64 * c;
-        raw[c] = pc < pieces ? *(const bf16x8*)(xr + pc * 8) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  for (int u = 0; u < CW; ++u) {
+    const int c = w + NW * u;
+    if (c < nchunk) {                      // wave-uniform
+      wv[u][0] = sk2_ldw<NT>(wp + (long)c * 64);
+      wv[u][1] = sk2_ldw<NT>(wp + (long)c * 64 + 32);
+    } else { wv[u][0] = u32x4{0, 0, 0, 0}; wv[u][1] = u32x4{0, 0, 0, 0}; }
+  }
+  if (LN) __builtin_amdgcn_sched_barrier(0);
+  if (gb_mine) { *(bf16x8*)(gbs + threadIdx.x * 8) = gmr; *(bf16x8*)(gbs + 4096 + threadIdx.x * 8) = btr; }      // waits for the two oldest loads only
+  if (LN) {
+    const float inv_d = 1.f / (float)p.K;
+    float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s += bf2f(raw[c][j]);
+    for (int u = 0; u < CW; ++u)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += bf2f(xv[u][0][j]) + bf2f(xv[u][1][j]);          // chunks beyond K hold zeros
+    s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);                          // over the four lane groups of row r
+    if (g == 0) stat[0][w][r] = s;
+#pragma unroll
+    for (int u = 0; u < CW; ++u) { asm volatile("" : "+v"(xv[u][0])); asm volatile("" : "+v"(xv[u][1])); }   // the fragments stay bf16 across the barrier (their fp32 widenings would be 32 registers per chunk)
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) tot += stat[0][ww][r];
+    const float mu = tot * inv_d;
+    float q = 0.f;
+#pragma unroll
+    for (int u = 0; u < CW; ++u) {
+      if (w + NW * u < nchunk) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { float d0 = bf2f(xv[u][0][j]) - mu, d1 = bf2f(xv[u][1][j]) - mu; q += d0 * d0 + d1 * d1; }
       }
-      const float inv_d = 1.f / (float)p.K;
-      const float mu = wave_sum(s) * inv_d;
-      float qq = 0.f;
+    }
+    q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+    if (g == 0) stat[1][w][r] = q;
 #pragma unroll
-      for (int c = 0; c < 8; ++c)
+    for (int u = 0; u < CW; ++u) { asm volatile("" : "+v"(xv[u][0])); asm volatile("" : "+v"(xv[u][1])); }
+    __syncthreads();
+    float qt = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { float d = (lane + 64 * c) < pieces ? bf2f(raw[c][j]) - mu : 0.f; qq += d * d; }
-      const float rs = rsqrtf(wave_sum(qq) * inv_d + p.ln_eps);
+    for (int ww = 0; ww < NW; ++ww) qt += stat[1][ww][r];
+    const float rs = rsqrtf(qt * inv_d + p.ln_eps);
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const int pc = lane + 64 * c;
-        if (pc < pieces) {
-          bf16x8 gm = *(const bf16x8*)(p.ln_gamma + pc * 8), bt = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}, o;
-          if (p.ln_beta) bt = *(const bf16x8*)(p.ln_beta + pc * 8);
+    for (int u = 0; u < CW; ++u) {
+      const int c = w + NW * u;
+      if (c < nchunk) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) o[j] = f2bf((bf2f(raw[c][j]) - mu) * rs * bf2f(gm[j]) + bf2f(bt[j]));
-          *(bf16x8*)(xd + pc * 16) = o;
+        for (int h = 0; h < 2; ++h) {
+          const int ko = c * 64 + h * 32 + g * 8;
+          bf16x8 gm = *(const bf16x8*)(gbs + ko), bt = *(const bf16x8*)(gbs + 4096 + ko), o;      // written before the statistics' first barrier
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = f2bf((bf2f(xv[u][h][j]) - mu) * rs * bf2f(gm[j]) + bf2f(bt[j]));
+          xv[u][h] = o;
+          __builtin_amdgcn_sched_barrier(0);          // one 8-element piece at a time: left alone the scheduler widens every gamma / beta piece to fp32 at once
         }
       }
-    } else {
-      for (int pc = lane; pc < pieces; pc += 64) *(u32x4*)(xd + pc * 16) = *(const u32x4*)(xr + pc * 8);
     }
   }
-  __syncthreads();
-  const char* xl = xs + (long)min(r, p.M - 1) * xpitch + g * 32;                  // this lane's fragment base inside a chunk (chunk c: + 128 c)
-  float gate = 1.f;
-  if (p.gate) gate = tanhf(bf2f(*p.gate));
-  const bool fast = ((p.N & 3) == 0) && (((p.ldc | p.ldres | p.ldaux | p.ldpre) & 3) == 0);
-  for (int i = 0; i < my_tiles; ++i) {
-    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int jb = 0; jb < cpw; jb += D) {
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int u = 0; u < D; ++u) {
-        const char* xq = xl + (long)(w + NW * (jb + u)) * 128;
-        u32x4 x0 = *(const u32x4*)xq, x1 = *(const u32x4*)(xq + 16);
-        acc = MFMA16(buf[u][0], x0, acc);
-        acc = MFMA16(buf[u][1], x1, acc);
-        if (li < my_tiles) issue(buf[u]);                                          // the item D ahead (uniform: li is wave-uniform)
-      }
+  for (int u = 0; u < CW; ++u) {
+    if (w + NW * u < nchunk) {
+      acc = MFMA16(wv[u][0], xv[u][0], acc);
+      acc = MFMA16(wv[u][1], xv[u][1], acc);
     }
-    red[((i & 1) * NW + w) * 64 + lane] = acc;
-    __syncthreads();
-    if (w == (i & (NW - 1))) {
-      f32x4 a = red[((i & 1) * NW) * 64 + lane];
+  }
+  red[w * 64 + lane] = acc;
+  __syncthreads();
+  if (w == 0) {
+    f32x4 a = red[lane];
 #pragma unroll
-      for (int ww = 1; ww < NW; ++ww) a += red[((i & 1) * NW + ww) * 64 + lane];
-      const int n = (blockIdx.x + i * gridDim.x) * 16 + g * 4;
-      if (fast) epi_tile<true>(p, a, r, n, gate);
-      else epi_tile<false>(p, a, r, n, gate);
+    for (int ww = 1; ww < NW; ++ww) a += red[ww * 64 + lane];
+    if (n0 < p.N) {
+      float gate = 1.f;
+      if (p.gate) gate = tanhf(bf2f(*p.gate));
+      const bool fast = ((p.N & 3) == 0) && (((p.ldc | p.ldres | p.ldaux | p.ldpre) & 3) == 0);
+      if (fast) epi_tile<true>(p, a, r, n0 + g * 4, gate);
+      else epi_tile<false>(p, a, r, n0 + g * 4, gate);
     }
   }
 }
 
-static int g_ncu = 0;
+// the same for a LONG contraction (K > 4096, no LayerNorm: the down-projections, K = 10 240 / 16 384): 16 waves, rounds of CW chunks per wave with the
+// NEXT round's weights and activation fragments issued before the current round's MFMAs (two register sets, no barrier inside the loop) -- the
+// round-3 loop drained its loads between iterations (four dependent memory round trips per workgroup at K = 10 240: 20 us for 52 MB).
+template <int CW, bool NT>
+__global__ __launch_bounds__(1024) void gemm_skinny2_long_kernel(GemmParams p) {
+  constexpr int NW = 16;
+  __shared__ f32x4 red[NW * 64];
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, r = lane & 15;
+  const int n0 = blockIdx.x * 16, nchunk = p.K >> 6;
+  const bf16* wp = p.B + (long)min(n0 + r, p.N - 1) * p.ldb + g * 8;
+  const bf16* xp = p.A + (long)min(r, p.M - 1) * p.lda + g * 8;
+  const int nrounds = ((nchunk + NW - 1) / NW + CW - 1) / CW;
+  u32x4 wb[2][CW][2];
+  bf16x8 xb[2][CW][2];
+  auto load = [&](u32x4 (&wv)[CW][2], bf16x8 (&xv)[CW][2], int rd) {
+#pragma unroll
+    for (int u = 0; u < CW; ++u) {
+      const int c = w + NW * (rd * CW + u);
+      if (c < nchunk) {                    // wave-uniform
+        wv[u][0] = sk2_ldw<NT>(wp + (long)c * 64);
+        wv[u][1] = sk2_ldw<NT>(wp + (long)c * 64 + 32);
+        xv[u][0] = *(const bf16x8*)(xp + (long)c * 64); xv[u][1] = *(const bf16x8*)(xp + (long)c * 64 + 32);
+      } else {
+        wv[u][0] = u32x4{0, 0, 0, 0}; wv[u][1] = u32x4{0, 0, 0, 0};
+        xv[u][0] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; xv[u][1] = xv[u][0];
+      }
+    }
+  };
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto mm = [&](const u32x4 (&wv)[CW][2], const bf16x8 (&xv)[CW][2]) {
+#pragma unroll
+    for (int u = 0; u < CW; ++u) { acc = MFMA16(wv[u][0], xv[u][0], acc); acc = MFMA16(wv[u][1], xv[u][1], acc); }
+  };
+  load(wb[0], xb[0], 0);
+  for (int rd = 0; rd < nrounds; rd += 2) {
+    if (rd + 1 < nrounds) load(wb[1], xb[1], rd + 1);
+    mm(wb[0], xb[0]);
+    if (rd + 2 < nrounds) load(wb[0], xb[0], rd + 2);
+    if (rd + 1 < nrounds) mm(wb[1], xb[1]);
+  }
+  red[w * 64 + lane] = acc;
+  __syncthreads();
+  if (w == 0) {
+    f32x4 a = red[lane];
+#pragma unroll
+    for (int ww = 1; ww < NW; ++ww) a += red[ww * 64 + lane];
+    if (n0 < p.N) {
+      float gate = 1.f;
+      if (p.gate) gate = tanhf(bf2f(*p.gate));
+      const bool fast = ((p.N & 3) == 0) && (((p.ldc | p.ldres | p.ldaux | p.ldpre) & 3) == 0);
+      if (fast) epi_tile<true>(p, a, r, n0 + g * 4, gate);
+      else epi_tile<false>(p, a, r, n0 + g * 4, gate);
+    }
+  }
+}
+
 static bool skinny2_ok(const unimp_gemm_desc* d) {
-  // M <= 16 decode rows, k-contiguous operands, K a multiple of 8 chunks of 64, the M staged rows + the partial sums inside the LDS
-  if (d->M > 16 || d->a_kstrided || d->b_kstrided || (d->K & 511) || d->K > 16384) return false;
-  if (d->ln_gamma && d->K > 4096) return false;
-  long lds = (long)d->M * (2L * d->K + 16) + 16 + 2 * 8 * 64 * 16;
-  return lds <= 160 * 1024 - 4096;
+  // M <= 16 decode rows, k-contiguous operands, whole 64-k chunks; a fused LayerNorm needs the row inside one round (K <= 4096)
+  return d->M <= 16 && !d->a_kstrided && !d->b_kstrided && !(d->K & 63) && d->K >= 64 && (d->K <= 4096 || !d->ln_gamma);
 }
 
 static void launch_skinny2(const unimp_gemm_desc* d, GemmParams& p, void* stream) {
-  if (!g_ncu) { int dev = 0; hipDeviceProp_t pr; (void)hipGetDevice(&dev); (void)hipGetDeviceProperties(&pr, dev); g_ncu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
-  const int ntiles = (d->N + 15) / 16, cpw = (d->K >> 6) / 8;
-  const int xpitch = 2 * d->K + 16;
-  const int grid = ntiles < g_ncu ? ntiles : g_ncu;
-  size_t lds = (((size_t)d->M * xpitch + 15) & ~(size_t)15) + 2 * 8 * 64 * sizeof(f32x4);
+  const int nchunk = d->K >> 6;
+  static const int nt = [] { const char* e = getenv("UNIMP_SKINNY_NT"); return e ? atoi(e) : 0; }();     // weight loads: 0 = default cache policy, 1 = nontemporal (A/B)
   hipStream_t s = (hipStream_t)stream;
-#define SK2_GO(D_) do { auto kern = gemm_skinny2_kernel<D_>;                                                                      \
-    static size_t cur = 0;                                                                                                        \
-    if (lds > cur) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)); cur = 160 * 1024; } \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, p, ntiles, xpitch); } while (0)
-  if (cpw % 5 == 0) SK2_GO(5); else if (cpw % 4 == 0) SK2_GO(4); else if (cpw % 2 == 0) SK2_GO(2); else SK2_GO(1);
+  dim3 grid((d->N + 15) / 16);
+  if (d->K > 4096) {
+    if (nt) hipLaunchKernelGGL((gemm_skinny2_long_kernel<3, true>), grid, dim3(1024), 0, s, p);
+    else hipLaunchKernelGGL((gemm_skinny2_long_kernel<3, false>), grid, dim3(1024), 0, s, p);
+    return;
+  }
+  // K <= 2560: 8 waves with up to five chunks each (two workgroups per CU at <= 128 registers: 640 tiles of the up-projection meet 512 slots, not 256);
+  // beyond: 16 waves with three or four
+  const int nw = nchunk <= 40 ? 8 : 16, cw = (nchunk + nw - 1) / nw;
+#define SK2_GO_(NW_, CW_, LN_) do { if (nt) hipLaunchKernelGGL((gemm_skinny2_kernel<NW_, CW_, LN_, true>), grid, dim3(64 * NW_), 0, s, p);  \
+                                    else hipLaunchKernelGGL((gemm_skinny2_kernel<NW_, CW_, LN_, false>), grid, dim3(64 * NW_), 0, s, p); } while (0)
+#define SK2_GO(NW_, CW_) do { if (d->ln_gamma) SK2_GO_(NW_, CW_, true); else SK2_GO_(NW_, CW_, false); } while (0)
+  if (nw == 8) { switch (cw) { case 1: SK2_GO(8, 1); break; case 2: SK2_GO(8, 2); break; case 3: SK2_GO(8, 3); break; case 4: SK2_GO(8, 4); break; default: SK2_GO(8, 5); break; } }
+  else if (cw <= 3) SK2_GO(16, 3); else SK2_GO(16, 4);
 #undef SK2_GO
+#undef SK2_GO_
 }
 
 static bool skinny_ok(const unimp_gemm_desc* d) {
@@ -696,7 +785,7 @@ extern "C" int unimp_gemm_bf16_variant(const unimp_gemm_desc* d, int variant, vo
     case UNIMP_GEMM_SKINNY:
       if (!skinny_ok(d)) return unimp_set_error(UNIMP_ERR_UNSUPPORTED, "gemm: the skinny kernel needs M <= 64, k-contiguous operands, K %% 64 == 0");
       if (d->ln_gamma && !(skinny2_on() && skinny2_ok(d)))
-        return unimp_set_error(UNIMP_ERR_UNSUPPORTED, "gemm: a fused LayerNorm (ln_gamma) needs M <= 16, K %% 512 == 0, K <= 4096 (unimp_gemm_skinny_ln_ok)");
+        return unimp_set_error(UNIMP_ERR_UNSUPPORTED, "gemm: a fused LayerNorm (ln_gamma) needs M <= 16, K %% 64 == 0, K <= 4096 (unimp_gemm_skinny_ln_ok)");
       launch_skinny(d, stream); break;
     default: return unimp_set_error(UNIMP_ERR_ARG, "gemm: unknown variant");
   }

@@ -422,36 +422,27 @@ __global__ __launch_bounds__(512, 2) void gemm_mx_pp_kernel(MxP p) {
   if (nk > 1) { dma_step(1, 1); asm volatile("s_waitcnt vmcnt(%0)" :: "n"(ND + NS) : "memory"); }      // step 0 has landed, step 1 stays in flight
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   MXP_BARRIER();
-  // Round 6: the K loop without decisions (the bf16 family's round-5 lever): stage index and "is there a step left to fetch" are compile-time
-  // constants of each written-out iteration -- steady state two K-steps per trip, the first / last steps peeled.  Same instruction order per
-  // output as the rolled loop: same bits.
-#define MXP_A_ITER(S, ST, DMA) do { MXP_LOADF(ST);                                                                       \
-    if (DMA) dma_step((S) + 1, (ST) ^ 1);          /* the other stage: both groups read step S - 1 out of it two and one intervals ago */ \
-    MXP_BARRIER(); MXP_MFMAS();                                                                                        \
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   /* this wave's share of step S + 1 (issued one phase ago) has landed */ \
-    MXP_BARRIER(); } while (0)
-#define MXP_B_ITER(S, ST, DMA) do { MXP_LOADF(ST);                                                                       \
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   /* the share of step S + 1 issued at the head of C(S - 1) (the prologue for S = 0) */ \
-    MXP_BARRIER();                                                                                                     \
-    if (DMA) dma_step((S) + 2, ST);                /* both groups have read step S out of this stage (intervals 2 S, 2 S + 1) */ \
-    MXP_MFMAS(); MXP_BARRIER(); } while (0)
-  if (wm == 0) {                                           // group A: L(s) at interval 2 s, C(s) at 2 s + 1
-    MXP_A_ITER(0, 0, false);                               // step 1 went out in the prologue
-    int s = 1;
-    for (; s + 2 < nk; s += 2) { MXP_A_ITER(s, 1, true); MXP_A_ITER(s + 1, 0, true); }
-    if (s + 1 < nk) { MXP_A_ITER(s, 1, true); MXP_A_ITER(s + 1, 0, false); }
-    else if (s < nk) MXP_A_ITER(s, 1, false);
+  if (wm == 0) {
+    for (int s = 0; s < nk; ++s) {                         // group A: L(s) at interval 2 s, C(s) at 2 s + 1
+      MXP_LOADF(s & 1);
+      if (s >= 1 && s + 1 < nk) dma_step(s + 1, (s + 1) & 1);       // the other stage: both groups read step s - 1 out of it two and one intervals ago
+      MXP_BARRIER();
+      MXP_MFMAS();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of step s + 1 (issued one phase ago) has landed
+      MXP_BARRIER();
+    }
     MXP_BARRIER();
   } else {
-    MXP_BARRIER();                                         // group B runs one interval behind: L(s) at interval 2 s + 1, C(s) at 2 s + 2
-    int s = 0;
-    for (; s + 3 < nk; s += 2) { MXP_B_ITER(s, 0, true); MXP_B_ITER(s + 1, 1, true); }
-    if (s + 2 < nk) { MXP_B_ITER(s, 0, true); MXP_B_ITER(s + 1, 1, false); MXP_B_ITER(s + 2, 0, false); }
-    else if (s + 1 < nk) { MXP_B_ITER(s, 0, false); MXP_B_ITER(s + 1, 1, false); }
-    else if (s < nk) MXP_B_ITER(s, 0, false);
+    MXP_BARRIER();                                         // group B runs one interval behind
+    for (int s = 0; s < nk; ++s) {                         // L(s) at interval 2 s + 1, C(s) at 2 s + 2
+      MXP_LOADF(s & 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the share of step s + 1 issued at the head of C(s - 1) (the prologue for s = 0)
+      MXP_BARRIER();
+      if (s + 2 < nk) dma_step(s + 2, s & 1);              // both groups have read step s out of this stage (intervals 2 s, 2 s + 1)
+      MXP_MFMAS();
+      MXP_BARRIER();
+    }
   }
-#undef MXP_A_ITER
-#undef MXP_B_ITER
 #undef MXP_LOADF
 #undef MXP_MFMAS
 

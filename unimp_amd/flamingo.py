@@ -243,8 +243,9 @@ class Flamingo(nn.Module):
         """decode steps (FlamingoLMMixin.forward with ``use_cached_media_locations``, MaskedCrossAttention with
         ``use_cached_media``): every new token attends with text_time = #<image> in the prompt."""
         media_time = cache.media_count.expand(-1, n_new).contiguous()
+        loc = media_time > 0                   # once per step, not once per layer (32 launches of a 4.5 us graph node each)
         for layer in self._layers():
-            layer.condition_media_locations(media_time > 0)
+            layer.condition_media_locations(loc)
             layer.condition_media_time(media_time)
             layer.condition_use_cached_media(True)
 

@@ -425,6 +425,15 @@ class MLPBlockFn(Function):
 
 
 def mlp_block(x, ln_w, ln_b, w1, b1, w2, b2, act, gate=None, res=None, eps=1e-5):
+    if not torch.is_grad_enabled() and x.numel() // x.shape[-1] <= 16 and _ln_fusable(x.numel() // x.shape[-1], x.shape[-1], False):
+        # a cached decode step (M <= 16 rows, autograd off -- decided HERE: inside a Function.forward grad mode is always off and
+        # needs_input_grad follows requires_grad, so the trainable gated blocks would look like training): two launches, the LayerNorm
+        # inside the up-projection's weight-streaming GEMM, no act'(z) output, nothing saved
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        r2 = x2 if res is None else res.reshape(-1, shp[-1])
+        a = ops.gemm(x2, w1, bias=b1, act=act, ln=(ln_w, ln_b, eps))
+        return ops.gemm(a, w2, bias=b2, gate=gate, res=r2).view(shp)
     return MLPBlockFn.apply(x, res, ln_w, ln_b, w1, b1, w2, b2, gate, act, eps)
 
 
@@ -675,6 +684,20 @@ def self_attn_block(x, ln_w, ln_b, wqkv, bqkv, wd, bd, nh, *, rope=None, kv_len=
 DECODE_FUSED = _os.environ.get("UNIMP_DECODE_FUSED", "1") != "0"      # round 6: fused decode-step kernels (rope + cache append; LN inside the skinny GEMM); 0 = the round-5 launches (A/B, tests)
 
 
+def _ln_fusable(rows, D, rms):
+    """decode rows whose LayerNorm the weight-streaming GEMM can take (ops.gemm(ln=...)): M <= 16, D % 512 == 0, D <= 4096, LayerNorm (not RMSNorm)"""
+    return DECODE_FUSED and not rms and rows <= 16 and ops.skinny_ln_ok(rows, D)
+
+
+def linear_ln(x, ln_w, ln_b, eps, w, ldc=None):
+    """linear(layer_norm(x), w) for decode rows (no autograd): one launch.  Returns what ``linear`` returns."""
+    shp = x.shape
+    x2 = x.reshape(-1, shp[-1])
+    y = ops.gemm(x2, w, ldc=ldc, ln=(ln_w, ln_b, eps))
+    return y.view(*shp[:-1], w.shape[0]) if ldc in (None, w.shape[0]) else \
+        y.as_strided((*shp[:-1], w.shape[0]), _lead_strides(shp[:-1], ldc) + (1,), y.storage_offset())
+
+
 class LayerKV:
     """decode state of one decoder layer: views ``k``, ``v`` [rows, capacity, nh, hd] into the cache's single K/V tensor
     (keys after RoPE) and the gated cross-attention's projected media ``xkv`` [rows, T*n, 2*inner] (constant over a decode)."""
@@ -777,8 +800,11 @@ def self_attn_block_cached(x, ln_w, ln_b, wqkv, bqkv, wd, bd, nh, lc, pos0, *, r
     step = lc.owner.step
     x2 = x.reshape(R * Ln, H)
     r2 = x2 if res is None else res.reshape(R * Ln, H)
-    h, _, _ = ops.layernorm_fwd(x2, ln_w, ln_b, eps, rms=rms)
-    qkv = ops.gemm(h, wqkv, bias=bqkv)
+    if _ln_fusable(R * Ln, H, rms) and lc.owner.step is not None:
+        qkv = ops.gemm(x2, wqkv, bias=bqkv, ln=(ln_w, ln_b, eps))       # decode rows: the LayerNorm runs inside the weight-streaming GEMM
+    else:
+        h, _, _ = ops.layernorm_fwd(x2, ln_w, ln_b, eps, rms=rms)
+        qkv = ops.gemm(h, wqkv, bias=bqkv)
     q, k, v, hs, offs = _split_qkv(qkv, R, Ln, nh, hd, interleaved)
     if qk_ln is not None:                      # LayerNorm over the whole d_model vector of q and of k, in place (one wave holds a row)
         qn, _, _ = ops.layernorm_fwd(qkv[:, :H], qk_ln[0], None, qk_ln[2])
@@ -822,8 +848,11 @@ def gated_xattn_cached(x, media, seg, ln_w, ln_b, wq, wkv, wo, gate, heads, n_la
     inner = wq.shape[0]
     dh = inner // heads
     x2 = x.reshape(R * Ln, D)
-    h, _, _ = ops.layernorm_fwd(x2, ln_w, ln_b, eps)
-    q = ops.gemm(h, wq)
+    if _ln_fusable(R * Ln, D, False) and lc.xkv is not None:
+        q = ops.gemm(x2, wq, ln=(ln_w, ln_b, eps))
+    else:
+        h, _, _ = ops.layernorm_fwd(x2, ln_w, ln_b, eps)
+        q = ops.gemm(h, wq)
     if lc.xkv is None:
         lc.xkv = ops.gemm(media.reshape(R * Sk, -1), wkv)
     kv5 = lc.xkv.view(R, Sk, 2, heads, dh)

@@ -281,8 +281,15 @@ class GPTNeoXForCausalLM(_TowerBase):
             for i, layer in enumerate(self.gpt_neox.layers):
                 x = layer(x, attention_mask=kv_len, rope=rope, cache=cache.layers[i] if cache else None, pos0=pos0)
         f = self.gpt_neox.final_layer_norm
-        h = F_.layer_norm(x, f.weight, f.bias, f.eps)
-        out = self._head(h, labels, kw.get("logits_last_only", False), kw.get("head_rows"), kw.get("last_index"))
+        if (cache is not None and cache.step is not None and labels is None and kw.get("head_rows") is None and kw.get("last_index") is None
+                and not torch.is_grad_enabled() and F_._ln_fusable(B * L, x.shape[-1], False)):
+            # a cached decode step: the final LayerNorm runs inside the head's weight-streaming GEMM (one launch for 379 MB of weights)
+            w = self.get_output_embeddings().weight
+            V = w.shape[0]
+            out = LMOutput(None, F_.linear_ln(x, f.weight, f.bias, f.eps, w, _pad8(V) if V % 8 else None))
+        else:
+            h = F_.layer_norm(x, f.weight, f.bias, f.eps)
+            out = self._head(h, labels, kw.get("logits_last_only", False), kw.get("head_rows"), kw.get("last_index"))
         if cache is not None:
             if cache.step is None:
                 cache.len = pos0 + L
