@@ -23,7 +23,14 @@ DERIVED = {"clock_ghz": lambda c, ns: c["GRBM_GUI_ACTIVE"] / 8 / ns,
            "mfma_util": lambda c, ns: c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8 * 1024),
            "lds_conflict_share": lambda c, ns: c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"],
            "wait_share": lambda c, ns: c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
-           "issue_stall_share": lambda c, ns: c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"]}
+           "issue_stall_share": lambda c, ns: c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"],
+           # L2 / fabric side (round 6): hit rate of the L2's tag lookups; share of the L2's fabric read requests whose ADDRESS belongs to local DRAM (the other
+           # destinations are GMI = another GPU and IO; an Infinity-Cache hit is still "destined for DRAM": the MALL sits behind this counter, its hits are
+           # not exposed by any TCC counter of this stack -- rocprofv3 -L, profiles/r06_tcc_counters_available.txt); share of 128-byte read requests
+           "l2_hit_rate": lambda c, ns: c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]),
+           "fabric_rd_dram_share": lambda c, ns: c["TCC_EA0_RDREQ_DRAM_sum"] / c["TCC_EA0_RDREQ_sum"],
+           "fabric_rd_128B_share": lambda c, ns: c["TCC_EA0_RDREQ_128B_sum"] / c["TCC_EA0_RDREQ_sum"],
+           "fabric_rd_GBps": lambda c, ns: (c["TCC_EA0_RDREQ_sum"] - c["TCC_EA0_RDREQ_128B_sum"] - c["TCC_EA0_RDREQ_32B_sum"]) * 64 / ns + c["TCC_EA0_RDREQ_128B_sum"] * 128 / ns + c["TCC_EA0_RDREQ_32B_sum"] * 32 / ns}
 for d in dirs:
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         disp = {}
