@@ -165,6 +165,13 @@ int unimp_decode_rope_append(void* qkv, int64_t row_stride, int64_t head_stride,
                              int v_off, int rot, const float* cos_rows, const float* sin_rows, void* kcache, void* vcache,
                              int64_t c_row_stride, int64_t c_slot_stride, int64_t c_head_stride, const int64_t* pos_idx, void* stream);
 
+/* beam search (ABI 8): transformers' GenerationMixin._reorder_cache (index_select of past_key_values per step; eval_rec.py:100-110, K = 10) on the
+ * generated tail of the cache, in place, one launch: kv = [n_planes = layers x 2][rows = n_groups x K][capacity][row_elems] (element strides s_plane,
+ * s_row, s_slot); row j of group g takes what row src_local[g K + j] (index INSIDE the group) held, for the slots slot0[g] .. pos_idx[g K] - 1 (the
+ * tokens generated so far; max_new bounds the launch).  K <= 16. */
+int unimp_kv_reorder_beams(void* kv, int64_t s_plane, int n_planes, int64_t s_row, int64_t s_slot, int row_elems, int K, int n_groups,
+                           const int64_t* src_local, const int32_t* slot0, const int64_t* pos_idx, int max_new, void* stream);
+
 /* ---- attention (flash-style, MFMA) -------------------------------------------------------------------------
  * replaces xformers.ops.memory_efficient_attention (clip.py:130-136; llama.py:287-301), the GPT-NeoX causal
  * SDPA, open_flamingo PerceiverAttention and MaskedCrossAttention softmax(QK^T)V.

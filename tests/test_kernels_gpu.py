@@ -550,6 +550,29 @@ def test_decode_rope_append(ops, R, nh, hd, rot, interleaved):
     assert torch.equal(kc, want_k) and torch.equal(vc, want_v), "cache slots"
 
 
+@pytest.mark.parametrize("K,groups,nh,hd", [(10, 1, 32, 80), (5, 3, 8, 64), (3, 2, 12, 64), (16, 1, 4, 128)])
+def test_kv_reorder_beams(ops, K, groups, nh, hd):
+    """unimp_kv_reorder_beams against transformers' _reorder_cache as decode.py ran it before (tail.copy_(tail.index_select(2, local)) per
+    group): the generated slots [slot0, pos) of every layer / K / V plane follow their hypotheses, bit for bit; the prompt's slots, the slots
+    the decode has not reached and the other groups' rows are untouched; groups sit at different lengths."""
+    layers, cap, max_new = 3, 48, 12
+    g = torch.Generator().manual_seed(K * 100 + groups)
+    R = K * groups
+    kv = torch.randn(layers, 2, R, cap, nh, hd, generator=g).to(bf16).cuda()
+    slot0 = torch.tensor([20 + 3 * i for i in range(groups)], dtype=torch.int32)
+    done = torch.tensor([7, 0, 12][:groups] if groups <= 3 else [5] * groups)             # generated so far per group (0: nothing to move; 12: the whole tail)
+    pos = (slot0.long() + done).repeat_interleave(K).cuda()
+    local = torch.stack([torch.randint(0, K, (K,), generator=g) for _ in range(groups)]).view(-1).cuda()
+    want = kv.clone()
+    for b in range(groups):
+        L0, n = int(slot0[b]), int(done[b])
+        tail = want[:, :, b * K:(b + 1) * K, L0:L0 + n]
+        tail.copy_(tail.index_select(2, local[b * K:(b + 1) * K]))
+    ops.kv_reorder_beams(kv, K, local, slot0.cuda(), pos, max_new)
+    torch.cuda.synchronize()
+    assert torch.equal(kv, want)
+
+
 def test_gemm_skinny_rejects_unsupported(ops):
     a, b = rnd(8, 72, seed=1).cuda(), rnd(16, 72, seed=2).cuda()
     with pytest.raises(Exception):

@@ -239,6 +239,43 @@ extern "C" int unimp_decode_rope_append(void* qkv, int64_t row_stride, int64_t h
   return unimp_check_launch("decode_rope_append");
 }
 
+// ------------------------------------------------------------------------------------------- beam search: the cache rows follow their hypotheses
+// transformers' beam search reorders past_key_values with index_select after every step (GenerationMixin._reorder_cache; eval_rec.py:100-110 runs
+// K = 10 beams).  The prompt's K / V are shared by a prompt's beams, so only the GENERATED tail moves: block (slot, plane = layer x {k, v}, group) permutes
+// the K rows of one cache slot in place -- every thread reads its 16-byte chunk of all K source rows, then writes them -- and slots the decode has not
+// reached yet (>= pos_idx of the group's first row) return at once.  One launch and one pass over the bytes where tail.copy_(tail.index_select(...))
+// was two launches and two passes over the WHOLE reserved tail (237 us of a 4.6 ms step at K = 10).
+template <int KMAX>
+__global__ __launch_bounds__(256) void kv_reorder_beams_kernel(bf16* __restrict__ kv, long s_plane, long s_row, long s_slot, int chunks, int K,
+                                                               const int64_t* __restrict__ src_local, const int32_t* __restrict__ slot0,
+                                                               const int64_t* __restrict__ pos_idx) {
+  const int grp = blockIdx.z, plane = blockIdx.y;
+  const int slot = slot0[grp] + blockIdx.x;
+  if (slot >= (int)pos_idx[(long)grp * K]) return;                     // nothing generated there yet
+  bf16* base = kv + (long)plane * s_plane + (long)grp * K * s_row + (long)slot * s_slot;
+  for (int c = threadIdx.x; c < chunks; c += blockDim.x) {
+    u32x4 v[KMAX];
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) if (j < K) v[j] = *(const u32x4*)(base + src_local[(long)grp * K + j] * s_row + c * 8);
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) if (j < K) *(u32x4*)(base + (long)j * s_row + c * 8) = v[j];
+  }
+}
+
+extern "C" int unimp_kv_reorder_beams(void* kv, int64_t s_plane, int n_planes, int64_t s_row, int64_t s_slot, int row_elems, int K, int n_groups,
+                                      const int64_t* src_local, const int32_t* slot0, const int64_t* pos_idx, int max_new, void* stream) {
+  if (!kv || !src_local || !slot0 || !pos_idx) return unimp_set_error(UNIMP_ERR_ARG, "kv_reorder_beams: null pointer");
+  if (n_planes <= 0 || n_groups <= 0 || max_new <= 0 || K <= 1) return UNIMP_OK;
+  if (K > 16 || (row_elems & 7) || ((s_plane | s_row | s_slot) & 7) || ((uintptr_t)kv & 15))
+    return unimp_set_error(UNIMP_ERR_SHAPE, "kv_reorder_beams: at most 16 beams, row length and strides multiples of 8 elements, 16-byte aligned cache");
+  dim3 grid(max_new, n_planes, n_groups);
+  hipStream_t s = (hipStream_t)stream;
+  if (K <= 4) hipLaunchKernelGGL((kv_reorder_beams_kernel<4>), grid, dim3(256), 0, s, (bf16*)kv, (long)s_plane, (long)s_row, (long)s_slot, row_elems >> 3, K, src_local, slot0, pos_idx);
+  else if (K <= 8) hipLaunchKernelGGL((kv_reorder_beams_kernel<8>), grid, dim3(256), 0, s, (bf16*)kv, (long)s_plane, (long)s_row, (long)s_slot, row_elems >> 3, K, src_local, slot0, pos_idx);
+  else hipLaunchKernelGGL((kv_reorder_beams_kernel<16>), grid, dim3(256), 0, s, (bf16*)kv, (long)s_plane, (long)s_row, (long)s_slot, row_elems >> 3, K, src_local, slot0, pos_idx);
+  return unimp_check_launch("kv_reorder_beams");
+}
+
 // ------------------------------------------------------------------------------------------- embedding
 __global__ void embedding_fwd_kernel(const int64_t* __restrict__ ids, const bf16* __restrict__ W, long ldw,
                                      const int64_t* __restrict__ pos, const bf16* __restrict__ P, long ldp,

@@ -10,6 +10,7 @@ reads the logits.
 import torch
 
 from . import functional as F_
+from . import ops
 
 
 class DecodeSession:
@@ -68,6 +69,7 @@ class DecodeSession:
         self.tok = torch.zeros((R, 1), dtype=torch.long, device=dev)
         self.src = torch.arange(R, dtype=torch.long, device=dev)
         self.base = (torch.arange(R, device=dev) // K) * K               # first row of each row's beam group
+        self.slot0 = torch.tensor(self.host_len, dtype=torch.int32, device=dev)      # first slot of every group's generated tail
         return logits
 
     # -- one token per row
@@ -75,9 +77,13 @@ class DecodeSession:
         c = self.cache
         if self.reorder:          # generated tail only (a group's rows share their prompt), group by group: tails start at the prompt lengths
             local = self.src - self.base
-            for b, L0 in enumerate(self.host_len):
-                tail = c.kv[:, :, b * self.beams:(b + 1) * self.beams, L0:L0 + self.max_new]
-                tail.copy_(tail.index_select(2, local[b * self.beams:(b + 1) * self.beams]))
+            if F_.DECODE_FUSED and self.beams <= 16 and c.kv.is_contiguous() and (c.kv.shape[4] * c.kv.shape[5]) % 8 == 0:
+                # one launch, one pass, only the slots generated so far (csrc/elementwise.hip kv_reorder_beams_kernel)
+                ops.kv_reorder_beams(c.kv, self.beams, local, self.slot0, c.step.pos_idx, self.max_new)
+            else:
+                for b, L0 in enumerate(self.host_len):
+                    tail = c.kv[:, :, b * self.beams:(b + 1) * self.beams, L0:L0 + self.max_new]
+                    tail.copy_(tail.index_select(2, local[b * self.beams:(b + 1) * self.beams]))
         self.model._condition_cached_media(c, 1)
         out = self.lm(input_ids=self.tok, past_key_values=c, use_cache=True)
         c.step.advance()

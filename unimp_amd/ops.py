@@ -596,6 +596,16 @@ def decode_rope_append(qkv2d, heads, head_stride, hd, offs, rot, cos_rows, sin_r
                                                kcache.stride(0), kcache.stride(1), kcache.stride(2), pos_idx.data_ptr(), _stream()), "decode_rope_append")
 
 
+def kv_reorder_beams(kv, K, src_local, slot0, pos_idx, max_new):
+    """beam search: row j of every beam group takes the generated tail of row src_local[group * K + j] (index inside the group), in place, for all
+    layers and both of K / V in ONE launch.  kv [layers, 2, rows, capacity, nh, hd] (the decode cache's tensor); slot0 int32 [groups] = first tail slot
+    (the prompt's length); pos_idx int64 [rows] = the slot the current step will write (slots below it hold generated tokens)."""
+    Lr, two, R, cap, nh, hd = kv.shape
+    assert kv.is_contiguous() and two == 2 and R % K == 0 and src_local.dtype == torch.int64 and slot0.dtype == torch.int32 and pos_idx.dtype == torch.int64
+    check(_lib.lib().unimp_kv_reorder_beams(_dev(kv).data_ptr(), kv.stride(1), Lr * 2, kv.stride(2), kv.stride(3), nh * hd, K, R // K,
+                                             src_local.data_ptr(), slot0.data_ptr(), pos_idx.data_ptr(), int(max_new), _stream()), "kv_reorder_beams")
+
+
 def decode_rope_append_ok(hd, rot, head_stride, offs, qkv2d, kcache):
     return (hd % 8 == 0 and rot % 16 == 0 and rot <= hd and head_stride % 8 == 0 and all(o % 8 == 0 for o in offs) and qkv2d.stride(0) % 8 == 0
             and qkv2d.data_ptr() % 16 == 0 and kcache.data_ptr() % 16 == 0 and all(s_ % 8 == 0 for s_ in kcache.stride()[:3]))
