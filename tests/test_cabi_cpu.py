@@ -147,7 +147,7 @@ def test_kernel_register_budgets():
     # kept packed across the statistics' barriers), and the cfg2 forms -- 8 waves x 5 chunks -- keep two workgroups per CU (4 waves per SIMD)
     g1 = remarks("gemm.hip", vg)
     sk = {k: r for k, r in g1.items() if "gemm_skinny2_kernel" in k or "gemm_skinny2_long_kernel" in k}
-    assert len(sk) == 32, sorted(sk)              # x 2: default-policy and nontemporal weight loads (A/B switch UNIMP_SKINNY_NT)
+    assert len(sk) == 15, sorted(sk)
     for k, r in sk.items():
         assert r["ScratchSize"] == 0, (k, r)
         if "ILi8E" in k:

@@ -355,12 +355,10 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(GemmParams p) {
 // weight rows 4 g .. 4 g + 3.  Deterministic: fixed summation order over chunks and waves.
 // (A PERSISTENT form -- one workgroup per CU walking its tiles with a ring of loads in flight -- was built first and measured slower:
 // profiles/r06_negative_results_decode_and_mx.txt.)
-template <bool NT> __device__ __forceinline__ u32x4 sk2_ldw(const bf16* q) {
-  if (NT) return __builtin_nontemporal_load((const u32x4*)q);
-  return *(const u32x4*)q;
-}
+// weight loads use the DEFAULT cache policy: nontemporal loads measured 10 - 25 % slower on every shape (profiles/r06_negative_results_decode_and_mx.txt)
+__device__ __forceinline__ u32x4 sk2_ldw(const bf16* q) { return *(const u32x4*)q; }
 
-template <int NW, int CW, bool LN, bool NT>
+template <int NW, int CW, bool LN>
 __global__ __launch_bounds__(64 * NW) void gemm_skinny2_kernel(GemmParams p) {
   __shared__ f32x4 red[NW * 64];
   __shared__ float stat[2][NW][16];
@@ -396,8 +394,8 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny2_kernel(GemmParams p) {
   for (int u = 0; u < CW; ++u) {
     const int c = w + NW * u;
     if (c < nchunk) {                      // wave-uniform
-      wv[u][0] = sk2_ldw<NT>(wp + (long)c * 64);
-      wv[u][1] = sk2_ldw<NT>(wp + (long)c * 64 + 32);
+      wv[u][0] = sk2_ldw(wp + (long)c * 64);
+      wv[u][1] = sk2_ldw(wp + (long)c * 64 + 32);
     } else { wv[u][0] = u32x4{0, 0, 0, 0}; wv[u][1] = u32x4{0, 0, 0, 0}; }
   }
   if (LN) __builtin_amdgcn_sched_barrier(0);
@@ -478,18 +476,14 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny2_kernel(GemmParams p) {
 // the same for a LONG contraction (K > 4096, no LayerNorm: the down-projections, K = 10 240 / 16 384): 16 waves, rounds of CW chunks per wave with the
 // NEXT round's weights and activation fragments issued before the current round's MFMAs (two register sets, no barrier inside the loop) -- the
 // round-3 loop drained its loads between iterations (four dependent memory round trips per workgroup at K = 10 240: 20 us for 52 MB).
-// ROWS = 8 (measurement build, off by default): a workgroup owns EIGHT weight rows (lanes r >= 8 load nothing and feed zeros): N = 2560 gives 320
-// workgroups instead of 160.  Measured SLOWER (N = 2560, K = 10 240, M = 1: 17.0 -> 21.9 us; M = 10: 20.4 -> 28.6): a load instruction that fetches
-// eight half lines costs what one fetching sixteen does -- the launch is bound by load instructions issued, not by the CUs it leaves idle.
-template <int CW, bool NT, int ROWS>
+template <int CW>
 __global__ __launch_bounds__(1024) void gemm_skinny2_long_kernel(GemmParams p) {
   constexpr int NW = 16;
   __shared__ f32x4 red[NW * 64];
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, r = lane & 15;
-  const int n0 = blockIdx.x * ROWS, nchunk = p.K >> 6;
-  const bool wrow = r < ROWS;
-  const bf16* wp = p.B + (long)min(n0 + (wrow ? r : 0), p.N - 1) * p.ldb + g * 8;
+  const int n0 = blockIdx.x * 16, nchunk = p.K >> 6;
+  const bf16* wp = p.B + (long)min(n0 + r, p.N - 1) * p.ldb + g * 8;
   const bf16* xp = p.A + (long)min(r, p.M - 1) * p.lda + g * 8;
   const int nrounds = ((nchunk + NW - 1) / NW + CW - 1) / CW;
   u32x4 wb[2][CW][2];
@@ -498,14 +492,12 @@ __global__ __launch_bounds__(1024) void gemm_skinny2_long_kernel(GemmParams p) {
 #pragma unroll
     for (int u = 0; u < CW; ++u) {
       const int c = w + NW * (rd * CW + u);
-      wv[u][0] = u32x4{0, 0, 0, 0}; wv[u][1] = u32x4{0, 0, 0, 0};
       if (c < nchunk) {                    // wave-uniform
-        if (ROWS == 16 || wrow) {
-          wv[u][0] = sk2_ldw<NT>(wp + (long)c * 64);
-          wv[u][1] = sk2_ldw<NT>(wp + (long)c * 64 + 32);
-        }
+        wv[u][0] = sk2_ldw(wp + (long)c * 64);
+        wv[u][1] = sk2_ldw(wp + (long)c * 64 + 32);
         xv[u][0] = *(const bf16x8*)(xp + (long)c * 64); xv[u][1] = *(const bf16x8*)(xp + (long)c * 64 + 32);
       } else {
+        wv[u][0] = u32x4{0, 0, 0, 0}; wv[u][1] = u32x4{0, 0, 0, 0};
         xv[u][0] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; xv[u][1] = xv[u][0];
       }
     }
@@ -528,7 +520,7 @@ __global__ __launch_bounds__(1024) void gemm_skinny2_long_kernel(GemmParams p) {
     f32x4 a = red[lane];
 #pragma unroll
     for (int ww = 1; ww < NW; ++ww) a += red[ww * 64 + lane];
-    if (n0 < p.N && g * 4 < ROWS) {
+    if (n0 < p.N) {
       float gate = 1.f;
       if (p.gate) gate = tanhf(bf2f(*p.gate));
       const bool fast = ((p.N & 3) == 0) && (((p.ldc | p.ldres | p.ldaux | p.ldpre) & 3) == 0);
@@ -545,29 +537,17 @@ static bool skinny2_ok(const unimp_gemm_desc* d) {
 
 static void launch_skinny2(const unimp_gemm_desc* d, GemmParams& p, void* stream) {
   const int nchunk = d->K >> 6;
-  static const int nt = [] { const char* e = getenv("UNIMP_SKINNY_NT"); return e ? atoi(e) : 0; }();     // weight loads: 0 = default cache policy, 1 = nontemporal (A/B)
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((d->N + 15) / 16);
-  if (d->K > 4096) {
-    static const int rows8 = [] { const char* e = getenv("UNIMP_SKINNY_ROWS8"); return e ? atoi(e) : 0; }();   // measurement switch: NEGATIVE (17.0 -> 21.9 us at N = 2560, K = 10 240)
-    if (rows8 && d->N <= 3200) {           // fewer 16-row tiles than CUs: eight rows per workgroup give 320 workgroups -- and half-empty load instructions
-      dim3 g8((d->N + 7) / 8);
-      if (nt) hipLaunchKernelGGL((gemm_skinny2_long_kernel<3, true, 8>), g8, dim3(1024), 0, s, p);
-      else hipLaunchKernelGGL((gemm_skinny2_long_kernel<3, false, 8>), g8, dim3(1024), 0, s, p);
-    } else if (nt) hipLaunchKernelGGL((gemm_skinny2_long_kernel<3, true, 16>), grid, dim3(1024), 0, s, p);
-    else hipLaunchKernelGGL((gemm_skinny2_long_kernel<3, false, 16>), grid, dim3(1024), 0, s, p);
-    return;
-  }
+  if (d->K > 4096) { hipLaunchKernelGGL((gemm_skinny2_long_kernel<3>), grid, dim3(1024), 0, s, p); return; }
   // K <= 2560: 8 waves with up to five chunks each (two workgroups per CU at <= 128 registers: 640 tiles of the up-projection meet 512 slots, not 256);
   // beyond: 16 waves with three or four
   const int nw = nchunk <= 40 ? 8 : 16, cw = (nchunk + nw - 1) / nw;
-#define SK2_GO_(NW_, CW_, LN_) do { if (nt) hipLaunchKernelGGL((gemm_skinny2_kernel<NW_, CW_, LN_, true>), grid, dim3(64 * NW_), 0, s, p);  \
-                                    else hipLaunchKernelGGL((gemm_skinny2_kernel<NW_, CW_, LN_, false>), grid, dim3(64 * NW_), 0, s, p); } while (0)
-#define SK2_GO(NW_, CW_) do { if (d->ln_gamma) SK2_GO_(NW_, CW_, true); else SK2_GO_(NW_, CW_, false); } while (0)
+#define SK2_GO(NW_, CW_) do { if (d->ln_gamma) hipLaunchKernelGGL((gemm_skinny2_kernel<NW_, CW_, true>), grid, dim3(64 * NW_), 0, s, p);  \
+                              else hipLaunchKernelGGL((gemm_skinny2_kernel<NW_, CW_, false>), grid, dim3(64 * NW_), 0, s, p); } while (0)
   if (nw == 8) { switch (cw) { case 1: SK2_GO(8, 1); break; case 2: SK2_GO(8, 2); break; case 3: SK2_GO(8, 3); break; case 4: SK2_GO(8, 4); break; default: SK2_GO(8, 5); break; } }
   else if (cw <= 3) SK2_GO(16, 3); else SK2_GO(16, 4);
 #undef SK2_GO
-#undef SK2_GO_
 }
 
 static bool skinny_ok(const unimp_gemm_desc* d) {

@@ -4,7 +4,6 @@ Every tensor must live on a HIP device; nothing here has a CPU or eager-PyTorch 
 """
 import ctypes as C
 import json
-import math
 import os
 import torch
 
@@ -273,8 +272,6 @@ def _tune_packed(M, N, K, a_ks, device, reads_mn, unpacked_variant, b_ks):
 
 
 TAIL_SPLIT = os.environ.get("UNIMP_GEMM_TAIL_SPLIT", "1") != "0"
-ROUND_TAIL = os.environ.get("UNIMP_GEMM_ROUND_TAIL", "0") != "0"      # round 6 experiment: the partial last round of a many-round GEMM as its own launch (see gemm())
-ROUND_TAIL_VARIANT = os.environ.get("UNIMP_GEMM_ROUND_TAIL_VARIANT", "pp128a")
 
 
 ROPE_VARIANTS = (4, 9, 10, 12, 13, 15, 18)  # pp256 / pp256p, their one-set forms and the whole-row-A form: the kernels with a rotary-epilogue instantiation (gemm3.hip, gemm6.hip)
@@ -378,25 +375,6 @@ def gemm(a, b, *, a_ks=False, b_ks=False, bias=None, act=None, res=None, aux=Non
                 gemm(a, b[:, :cut], out=out[:, :cut], _splits=0, **kw)
                 gemm(a, b[:, cut:], out=out[:, cut:], _splits=S, **kw)
             return out
-    if (ROUND_TAIL and variant is None and _splits is None and not a_ks and rope is None and b_pk is None and not accumulate and M >= 16 * 256
-            and N >= 256 and N % 128 == 0 and K % 64 == 0 and K >= 256):
-        # a problem of r full rounds of 256 x 256 tiles over the 256 CUs plus a FEW tiles (the ViT at b = 64: 514 x 4 = 8 rounds + 8 tiles, each of
-        # which costs a whole ninth round): the row tiles of the partial round run as their own launch on 256 x 128 tiles -- a quarter of the tail's
-        # time on a few dozen CUs instead of a full tile time on eight.  Same bits (every variant sums k in the same order: tests/test_kernels_gpu.py).
-        nbm, nbn = (M + 255) // 256, N // 256 if N % 256 == 0 else 0
-        if nbn:
-            tiles = nbm * nbn
-            step = 256 // math.gcd(nbn, 256)             # row tiles per whole number of rounds
-            main = nbm // step * step
-            extra = (nbm - main) * nbn
-            if main >= 4 * step and 0 < extra <= 48 and main * 256 < M:
-                cut = main * 256
-                sl = lambda t: None if t is None else t[:cut]
-                sr = lambda t: None if t is None else t[cut:]
-                kw = dict(b_ks=b_ks, bias=bias, act=act, dact=dact, gate=gate, alpha=alpha, pre_deriv=pre_deriv)
-                gemm(a[:cut], b, res=sl(res), aux=sl(aux), pre=sl(pre), out=out[:cut], _splits=0, **kw)
-                gemm(a[cut:], b, res=sr(res), aux=sr(aux), pre=sr(pre), out=out[cut:], _splits=0, variant=ROUND_TAIL_VARIANT, **kw)
-                return out
     tuned_rope = False               # the rotary path resolves its variant through the tuner too: the persistent-twin mapping applies to it
     d = GemmDesc()
     d.A, d.B, d.C = a.data_ptr(), b.data_ptr(), _dev(out).data_ptr()
