@@ -106,6 +106,8 @@ enum { UNIMP_GEMM_AUTO = 0, UNIMP_GEMM_V1 = 1, UNIMP_GEMM_DMA256 = 2, UNIMP_GEMM
                               (gemm7.hip); k-contiguous A, K % 64 == 0; other forms are refused */,
        UNIMP_GEMM_W4X_S1 = 16 /* measurement build of W4X: its first schedule (one release barrier per stage, separate M0 writes) */,
        UNIMP_GEMM_PP256B = 18, UNIMP_GEMM_PP128B = 19 /* measurement builds: PP256A / PP128A with the steady-state L phase spelled in asm (M0 writes fused with the fragment reads) */,
+       UNIMP_GEMM_DW = 20 /* round 6: 128 x 256 tiles, 4 waves (the ping-pong kernel's 128 x 64 wave tile), 72 KiB of LDS: TWO independent workgroups per CU -- one
+                                 multiplies while the other is between tiles (gemm9.hip); every operand form, fixed epilogue kinds, no rotary epilogue, no packed B */,
        UNIMP_GEMM_W4X_PF = 17 /* measurement build of W4X: each workgroup prefetches its share of the A / B panels' lines into L2 two stages ahead of the DMA */
        /* PP256 / PP128 / PP256P with ONE fragment register set: the L phase of a half-step reads that half-step's own fragments
           (before its LDS-DMA issue) and leaves two half-stages in flight instead of one -- 48 registers fewer, same bits */ };

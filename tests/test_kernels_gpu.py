@@ -193,6 +193,50 @@ def test_gemm_w4x_equals_pingpong_bit_for_bit(ops, M, N, K, b_ks, w4x):
         assert torch.equal(acc_g, acc_w)
 
 
+@pytest.mark.parametrize("M,N,K", [(128 * 5 + 40, 256 * 3 + 136, 32 * 21), (1024, 2560, 2560), (2048, 768, 64 * 37), (512, 512, 96), (300, 264, 192), (64, 1024, 1024)])
+@pytest.mark.parametrize("b_ks", [False, True])
+def test_gemm_dw_two_workgroups_per_cu_equals_pingpong_bit_for_bit(ops, M, N, K, b_ks):
+    """gemm9.hip (variant dw, round 6 experiment): 128 x 256 tiles, 4 waves, 72 KiB of LDS -- TWO independent workgroups per CU -- and its packed-B form
+    (dwpk: the B fragments of a pre-packed frozen weight go global -> registers, three sets, no LDS).  Same k grouping inside every MFMA, same k order
+    per accumulator, the ping-pong kernels' epilogue code: BIT FOR BIT the ping-pong kernel's results under every epilogue kind, both B layouts, ragged
+    M / N / K (21 half-stages: the one-step tail; 3 = the shortest the packed form serves), a k-strided A (the weight-gradient form), repeated launches
+    (ring hazards).  The rotary epilogue is refused."""
+    a, b = rnd(M, K, seed=21), rnd(N, K, seed=22, scale=0.2)
+    bias, res = rnd(N, seed=23), rnd(M, N, seed=24)
+    ad, bd, biasd, resd = a.cuda(), (b.t().contiguous() if b_ks else b).cuda(), bias.cuda(), res.cuda()
+    pk = ops.pack_b(bd, b_ks)
+    gate = torch.tensor([0.3], dtype=bf16, device="cuda")
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    aux8 = torch.randint(0, 256, (M, N), dtype=torch.uint8, device="cuda", generator=g)
+    kws = [dict(), dict(bias=biasd), dict(bias=biasd, act="gelu"), dict(bias=biasd, act="quick_gelu"), dict(res=resd), dict(bias=biasd, res=resd, gate=gate),
+           dict(aux=resd, dact="deriv"), dict(out_f32=True), dict(alpha=0.125, bias=biasd), dict(gate=gate)]
+    if N % 8 == 0:
+        kws.append(dict(aux=aux8, dact="deriv"))
+    for kw in kws:
+        want = ops.gemm(ad, bd, b_ks=b_ks, variant="pp256", **kw)
+        for _ in range(3):
+            got = ops.gemm(ad, bd, b_ks=b_ks, variant="dw", **kw)
+            assert torch.equal(got, want), f"dw != pp256 for {sorted(kw)} ({int((got != want).sum())} elements)"
+            got = ops.gemm(ad, bd, b_ks=b_ks, variant="dwpk", b_pk=pk, **kw)
+            assert torch.equal(got, want), f"dwpk != pp256 for {sorted(kw)} ({int((got != want).sum())} elements)"
+    close(ops.gemm(ad, bd, b_ks=b_ks, variant="dw"), a.float() @ b.float().t(), name="dw vs fp32")
+    if N % 8 == 0:
+        pre_w = torch.empty(M, N, dtype=torch.uint8, device="cuda"); pre_g = torch.empty_like(pre_w); pre_p = torch.empty_like(pre_w)
+        want = ops.gemm(ad, bd, b_ks=b_ks, variant="pp256", bias=biasd, act="gelu", pre=pre_w, pre_deriv=True)
+        got = ops.gemm(ad, bd, b_ks=b_ks, variant="dw", bias=biasd, act="gelu", pre=pre_g, pre_deriv=True)
+        gotp = ops.gemm(ad, bd, b_ks=b_ks, variant="dwpk", b_pk=pk, bias=biasd, act="gelu", pre=pre_p, pre_deriv=True)
+        assert torch.equal(got, want) and torch.equal(pre_g, pre_w) and torch.equal(gotp, want) and torch.equal(pre_p, pre_w)
+    if M % 8 == 0 and N % 8 == 0 and b_ks:                                # both operands k-strided: the weight-gradient form
+        at = ad.t().contiguous()
+        for kw in (dict(), dict(gate=gate), dict(out_f32=True)):
+            want = ops.gemm(at, bd, a_ks=True, b_ks=True, variant="pp256", **kw)
+            got = ops.gemm(at, bd, a_ks=True, b_ks=True, variant="dw", **kw)
+            assert torch.equal(got, want), f"dw (dW form) != pp256 for {sorted(kw)}"
+    if N % 8 == 0 and K % 8 == 0:
+        with pytest.raises(Exception):
+            ops.gemm(ad, bd, b_ks=b_ks, bias=biasd, rope=dict(rot=8, hd=8, period=24, span=16, L=64, log2_base=13.0), variant="dw")
+
+
 def test_gemm_w4x_rotary_epilogue_equals_pingpong(ops):
     M, H, hd, L = 1024, 8, 80, 512
     a, b, bias = rnd(M, H * hd, seed=7).cuda(), rnd(3 * H * hd, H * hd, seed=8, scale=0.05).cuda(), rnd(3 * H * hd, seed=9).cuda()

@@ -67,9 +67,12 @@ def make(M, N, K, aks, bks, epi):
 
 def once(a, b, kw, v, n):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if v in ("dwpk", "pk256", "pk128") and "b_pk" not in kw:
+        return float("inf")
     e0.record()
+    vv = None if v == "table" else v          # "table": the autotune table's pick for the shape (variant=None), split-K and all
     for _ in range(n):
-        ops.gemm(a, b, variant=v, **kw)
+        ops.gemm(a, b, variant=vv, **kw)
     e1.record(); e1.synchronize()
     return e0.elapsed_time(e1) / n
 
@@ -79,12 +82,14 @@ for name, M, N, K, aks, bks, epi in SHAPES:
     if FILT and FILT not in name:
         continue
     a, b, kw, out, extra = make(M, N, K, aks, bks, epi)
+    if any(v in ("dwpk", "pk256", "pk128") for v in VARIANTS) and not epi.startswith("rope"):
+        kw["b_pk"] = ops.pack_b(b, bool(bks))          # the pre-packed image of the same weight (frozen weights only in the product)
     fl = 2.0 * M * N * K
     vs = [v for v in VARIANTS if not (epi.startswith("rope") and v in ("w8", "pp128", "pp128x", "pp128a"))]
     ref, same, times = None, {}, {v: [] for v in vs}
     for v in vs:
         try:
-            ops.gemm(a, b, variant=v, **kw); torch.cuda.synchronize()
+            ops.gemm(a, b, variant=None if v == "table" else v, **kw); torch.cuda.synchronize()
         except Exception as e:                                   # a variant that does not serve this form
             print(f"  {name} {v}: {str(e)[:80]}"); times.pop(v); continue
         snap = (out.clone(), [x.clone() for x in extra])

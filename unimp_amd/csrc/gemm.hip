@@ -626,6 +626,7 @@ extern "C" int unimp_gemm3b_launch(const unimp_gemm_desc* d, int bn, void* strea
 extern "C" int unimp_gemm7_launch(const unimp_gemm_desc* d, void* stream);           // gemm7.hip: one wave per SIMD, hand-ordered two-set main loop, 64-k stages
 extern "C" int unimp_gemm7o_launch(const unimp_gemm_desc* d, void* stream);          // ... its first schedule (A/B partner)
 extern "C" int unimp_gemm7p_launch(const unimp_gemm_desc* d, void* stream);          // ... with the L2 prefetch of the panels' shares
+extern "C" int unimp_gemm9_launch(const unimp_gemm_desc* d, void* stream);           // gemm9.hip: 128 x 256 tiles, 4 waves, TWO workgroups per CU
 
 static int check_operand(const void* p, long ld, int ks, int rows) {
   if (((uintptr_t)p & 15) != 0) return UNIMP_ERR_ALIGN;
@@ -738,8 +739,8 @@ extern "C" int unimp_gemm_bf16_variant(const unimp_gemm_desc* d, int variant, vo
   if (variant == UNIMP_GEMM_AUTO) variant = auto_variant(d);
   if (d->ln_gamma && variant != UNIMP_GEMM_SKINNY)
     return unimp_set_error(UNIMP_ERR_UNSUPPORTED, "gemm: a fused LayerNorm of the A rows (ln_gamma) is served by the decode-row kernel only (variant skinny, M <= 16)");
-  if (d->b_kstrided == 2 && variant != UNIMP_GEMM_PP256 && variant != UNIMP_GEMM_PP128)
-    return unimp_set_error(UNIMP_ERR_UNSUPPORTED, "gemm: a pre-packed B operand is served by the ping-pong kernels only (variants pp256 / pp128)");
+  if (d->b_kstrided == 2 && variant != UNIMP_GEMM_PP256 && variant != UNIMP_GEMM_PP128 && variant != UNIMP_GEMM_DW)
+    return unimp_set_error(UNIMP_ERR_UNSUPPORTED, "gemm: a pre-packed B operand is served by the ping-pong kernels (variants pp256 / pp128) and dw only");
   if (((d->pre && d->pre_deriv == 2) || d->dact == ACT_DERIV_U8) &&
       (variant == UNIMP_GEMM_DMA256 || variant == UNIMP_GEMM_DMA128 || variant == UNIMP_GEMM_W4 || variant == UNIMP_GEMM_SKINNY))   // (w4x has the kinds)
     return unimp_set_error(UNIMP_ERR_UNSUPPORTED, "gemm: the uint8 derivative is served by variants v1 / pp256 / pp128 / w8 / pp256p (kernels with the specialised epilogue kinds)");
@@ -773,6 +774,9 @@ extern "C" int unimp_gemm_bf16_variant(const unimp_gemm_desc* d, int variant, vo
       int ok = variant == UNIMP_GEMM_W4X ? unimp_gemm7_launch(d, stream) : variant == UNIMP_GEMM_W4X_S1 ? unimp_gemm7o_launch(d, stream) : unimp_gemm7p_launch(d, stream);
       if (!ok) return unimp_set_error(UNIMP_ERR_UNSUPPORTED, "gemm: variant w4x serves a k-contiguous A operand, an unpacked B operand, K % 64 == 0, K >= 128, operands below 4 GiB");
       break; }
+    case UNIMP_GEMM_DW:
+      if (!unimp_gemm9_launch(d, stream)) return unimp_set_error(UNIMP_ERR_UNSUPPORTED, "gemm: variant dw has no rotary epilogue; its packed-B form needs K % 32 == 0, K >= 96");
+      break;
     case UNIMP_GEMM_SKINNY:
       if (!skinny_ok(d)) return unimp_set_error(UNIMP_ERR_UNSUPPORTED, "gemm: the skinny kernel needs M <= 64, k-contiguous operands, K %% 64 == 0");
       if (d->ln_gamma && !(skinny2_on() && skinny2_ok(d)))

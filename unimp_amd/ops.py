@@ -20,7 +20,7 @@ bf16 = torch.bfloat16
 GEMM_PROFILE = None      # bench.py sets this to a list: (start_event, end_event, flops) per GEMM launch
 GEMM_AUTOTUNE = True     # time the kernel variants once per (M, N, K, layout) on scratch operands and keep the fastest
 GEMM_VARIANTS = {"auto": 0, "v1": 1, "dma256": 2, "dma128": 3, "pp256": 4, "pp128": 5, "skinny": 6, "w4": 7, "w8": 8, "pp256p": 9,
-                 "pp256x": 10, "pp128x": 11, "pp256px": 12, "pp256a": 13, "pp128a": 14, "w4x": 15, "w4x_s1": 16, "w4x_pf": 17, "pp256b": 18, "pp128b": 19}
+                 "pp256x": 10, "pp128x": 11, "pp256px": 12, "pp256a": 13, "pp128a": 14, "w4x": 15, "w4x_s1": 16, "w4x_pf": 17, "pp256b": 18, "pp128b": 19, "dw": 20}
 _GEMM_CHOICE = {}
 # The autotune table is DATA: the one the published numbers were measured with ships INSIDE the package (unimp_amd/gemm_autotune_gfx950.json;
 # profiles/gemm_autotune_gfx950.json is the measured copy the profiles cite -- tests/test_cabi_cpu.py keeps the two identical),
@@ -448,7 +448,7 @@ def gemm(a, b, *, a_ks=False, b_ks=False, bias=None, act=None, res=None, aux=Non
             e1.record()
             GEMM_PROFILE.append((e0, e1, 2.0 * M * N * K, (M, N, K, int(a_ks), int(b_ks), -splits)))
         return out
-    forced_pk = {"pk256": 4, "pk128": 5}.get(variant) if isinstance(variant, str) else None
+    forced_pk = {"pk256": 4, "pk128": 5, "dwpk": 20}.get(variant) if isinstance(variant, str) else None
     if forced_pk is not None:
         v = forced_pk
     else:
