@@ -24,6 +24,14 @@
 #define G9_BN 256
 #define G9_NST 3
 #define G9_FENCE() do { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); } while (0)
+// issue priority between the two co-resident workgroups' waves of a SIMD (measurement switch): 1 = the MFMA block runs at raised priority (the ping-pong
+// kernels' setting), 2 = the MEMORY side of a step does (fragment reads, B loads, LDS-DMA go out between the other workgroup's MFMAs), 0 = none.
+// Measured (gpurun r06_o, dwpk on the step's shapes): the three settings are within 1 % of each other; 0 is the default
+#ifndef G9_PRIO
+#define G9_PRIO 0
+#endif
+#define G9_PRIO_MFMA(x) do { if (G9_PRIO == 1) __builtin_amdgcn_s_setprio(x); } while (0)
+#define G9_PRIO_MEM(x) do { if (G9_PRIO == 2) __builtin_amdgcn_s_setprio(x); } while (0)
 
 template <bool AKS, bool BKS, int EPI = -1>
 __global__ __launch_bounds__(256, 2) void gemm9_bf16_kernel(Gemm2Params p) {
@@ -71,13 +79,13 @@ __global__ __launch_bounds__(256, 2) void gemm9_bf16_kernel(Gemm2Params p) {
     _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                \
       if (AKS) frag_ks32_asm<G9_BM>(lbA + ub_, i, la0[i], ha0[i]);                                                 \
       else ra0[i] = frag_kc32(b_, i * 16); } } while (0)
-#define MFMAS() do { __builtin_amdgcn_s_setprio(1);                                                                \
+#define MFMAS() do { G9_PRIO_MFMA(1);                                                                \
     bf16x8 fb_[NJ];                                                                                                \
     _Pragma("unroll") for (int j = 0; j < NJ; ++j) fb_[j] = BKS ? join_halves(lb0[j], hb0[j]) : rb0[j];            \
     _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                \
       bf16x8 fa_ = AKS ? join_halves(la0[i], ha0[i]) : ra0[i];                                                     \
       _Pragma("unroll") for (int j = 0; j < NJ; ++j) acc[i][j] = MFMA16(fb_[j], fa_, acc[i][j]); }                 \
-    __builtin_amdgcn_s_setprio(0); } while (0)
+    G9_PRIO_MFMA(0); } while (0)
 
 #define DMAF(H) do { char* b_ = smem + ((H) % G9_NST) * SUB;                                                            \
     dma_full<AKS, G9_BM, 4>(p.A, p.lda, (H), b_, wave, aoff);                                                      \
@@ -205,18 +213,20 @@ __global__ __launch_bounds__(256, 2) void gemm9pk_bf16_kernel(Gemm2Params p) {
     _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                \
       if (AKS) frag_ks32_asm<G9_BM>(lbA + ub_, i, la0[i], ha0[i]);                                                 \
       else ra0[i] = frag_kc32(b_, i * 16); } } while (0)
-#define MFMAS(S) do { __builtin_amdgcn_s_setprio(1);                                                               \
+#define MFMAS(S) do { G9_PRIO_MFMA(1);                                                               \
     _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                \
       bf16x8 fa_ = AKS ? join_halves(la0[i], ha0[i]) : ra0[i];                                                     \
       _Pragma("unroll") for (int j = 0; j < NJ; ++j) acc[i][j] = MFMA16(rb##S[j], fa_, acc[i][j]); }               \
-    __builtin_amdgcn_s_setprio(0); } while (0)
+    G9_PRIO_MFMA(0); } while (0)
 // step H on B set SC, loading B(H + 2) into set SN (= the set of H - 1, consumed one step ago).  (A second A-fragment set -- the reads of H + 1 under the
 // MFMAs of H -- was tried: 240 + registers, 12 - 144 bytes of scratch per lane; the two co-resident workgroups are what hides this wave's LDS latency.)
 #define STEP(H, SC, SN) do {                                                                                        \
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                                \
     G9_FENCE(); __builtin_amdgcn_s_barrier(); G9_FENCE();                                                           \
+    G9_PRIO_MEM(1);                                                                                                 \
     LOAD_A(H);                                                                                                      \
     G9_FENCE(); LOAD_B(SN, (H) + 2); DMA_A((H) + 3); G9_FENCE();                                                    \
+    G9_PRIO_MEM(0);                                                                                                 \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); G9_FENCE();                                                  \
     MFMAS(SC); } while (0)
   // virtual steps -3 .. -1: A(0) | B(0), A(1) | B(1), A(2)
