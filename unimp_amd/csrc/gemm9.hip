@@ -30,6 +30,9 @@
 #ifndef G9_PRIO
 #define G9_PRIO 0
 #endif
+#ifndef G9_PIPE
+#define G9_PIPE 1          // packed-B form, k-contiguous A: the rolling half-set pipeline (0: the plain one-set steps; A/B switch)
+#endif
 #define G9_PRIO_MFMA(x) do { if (G9_PRIO == 1) __builtin_amdgcn_s_setprio(x); } while (0)
 #define G9_PRIO_MEM(x) do { if (G9_PRIO == 2) __builtin_amdgcn_s_setprio(x); } while (0)
 
@@ -233,9 +236,43 @@ __global__ __launch_bounds__(256, 2) void gemm9pk_bf16_kernel(Gemm2Params p) {
   DMA_A(0); LOAD_B(0, 0); DMA_A(1); LOAD_B(1, 1); DMA_A(2);
   G9_FENCE();
   int h = 0;
+#if G9_PIPE
+  if constexpr (!AKS) {
+    // ROLLING half-set software pipeline (k-contiguous A): the eight A fragments live in ONE register set whose halves turn over half a step apart --
+    // rows 4 - 7 of step h are read under the MFMAs of rows 0 - 3, rows 0 - 3 of step h + 1 (whose registers those MFMAs just released) under the MFMAs of
+    // rows 4 - 7, behind the step's one barrier; the B loads of h + 2 and the A half-stage h + 3 go out between the last two MFMA groups.  A wave never waits
+    // for its own fragment reads with the matrix pipe empty.  Waits: A(h + 1) before the barrier (6 youngest in flight), B(h + 1) at the step's end (8).
+#define LOAD_A_HALF(H, I0) do { const char* b_ = smem + ((H) % NSTA) * A_SUB;                                           \
+      _Pragma("unroll") for (int i = (I0); i < (I0) + 4; ++i) ra0[i] = frag_kc32(b_, i * 16); } while (0)
+#define MF_ROWS(S, I0, I1) do { _Pragma("unroll") for (int i = (I0); i < (I1); ++i) {                                  \
+      _Pragma("unroll") for (int j = 0; j < NJ; ++j) acc[i][j] = MFMA16(rb##S[j], ra0[i], acc[i][j]); } } while (0)
+#define PSTEP(H, SC, SN) do {                                                                                       \
+      LOAD_A_HALF(H, 4); G9_FENCE();                                                                                \
+      MF_ROWS(SC, 0, 4); G9_FENCE();                                                                                \
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                              \
+      G9_FENCE(); __builtin_amdgcn_s_barrier(); G9_FENCE();                                                         \
+      LOAD_A_HALF((H) + 1, 0); G9_FENCE();                                                                          \
+      MF_ROWS(SC, 4, 6); G9_FENCE();                                                                                \
+      LOAD_B(SN, (H) + 2); DMA_A((H) + 3); G9_FENCE();                                                              \
+      MF_ROWS(SC, 6, 8); G9_FENCE();                                                                                \
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); G9_FENCE(); } while (0)
+    // (B three half-steps ahead -- a fourth register set -- measured the same: the B loads' latency is not what this loop waits for)
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");          // A(0), B(0) have landed
+    G9_FENCE(); __builtin_amdgcn_s_barrier(); G9_FENCE();
+    LOAD_A_HALF(0, 0); G9_FENCE();
 #pragma unroll 1
-  for (; h + 3 <= nh; h += 3) { STEP(h, 0, 2); STEP(h + 1, 1, 0); STEP(h + 2, 2, 1); }
-  if (h < nh) { STEP(h, 0, 2); ++h; if (h < nh) { STEP(h, 1, 0); } }
+    for (; h + 3 <= nh; h += 3) { PSTEP(h, 0, 2); PSTEP(h + 1, 1, 0); PSTEP(h + 2, 2, 1); }
+    if (h < nh) { PSTEP(h, 0, 2); ++h; if (h < nh) { PSTEP(h, 1, 0); } }
+#undef LOAD_A_HALF
+#undef MF_ROWS
+#undef PSTEP
+  } else
+#endif
+  {
+#pragma unroll 1
+    for (; h + 3 <= nh; h += 3) { STEP(h, 0, 2); STEP(h + 1, 1, 0); STEP(h + 2, 2, 1); }
+    if (h < nh) { STEP(h, 0, 2); ++h; if (h < nh) { STEP(h, 1, 0); } }
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the clamped look-ahead loads and DMAs past the end of K
   G9_FENCE(); __builtin_amdgcn_s_barrier(); G9_FENCE();
 #undef DMA_A
