@@ -532,18 +532,26 @@ def test_gemm_skinny2_persistent_decode_rows(ops, M, N, K):
         L.unimp_gemm_set_skinny2(1)
 
 
-@pytest.mark.parametrize("M", [1, 3, 10, 16])
+@pytest.mark.parametrize("M", [1, 2, 3, 6, 10, 13, 16])
 @pytest.mark.parametrize("N,K,beta", [(7680, 2560, True), (10240, 2560, True), (512, 2560, True), (74053, 2560, True), (12288, 4096, False),
-                                      (4096, 1024, True), (1005, 512, False), (333, 1536, True), (256, 3072, False), (128, 768, True)])
+                                      (4096, 1024, True), (1005, 512, False), (333, 1536, True), (256, 3072, False), (128, 2048, True)])
 def test_gemm_skinny2_fused_layernorm(ops, M, N, K, beta):
-    """ops.gemm(ln=...): the LayerNorm in front of a decode-step projection runs inside the weight-streaming GEMM.  Against the two-launch
+    """ops.gemm(ln=...): the LayerNorm in front of a decode-step projection runs inside the weight-streaming GEMM (gemm_skinny2_ln_kernel: the
+    workgroup normalises the M real rows once, in 512-element units spread over its waves, and the waves read their MFMA fragments from LDS;
+    every K it takes -- 512 ... 3072 and 4096 -- and every units-per-wave form: M = 1 ... 16).  Against the two-launch
     form on the same operands (unimp_layernorm_fwd then the same kernel: the normalised rows differ at most by the statistics' summation
     order, i.e. a bf16 ulp on a few elements) and against fp32 math; with and without beta (MPT's LayerNorm has none); bias + GELU on top
-    (the up-projection); refusals: RMS-free contract, K beyond 4096, more than 16 rows."""
+    (the up-projection); launching twice gives the same bits; refusals: K beyond 4096 or not in whole 512s, more than 16 rows, and the one
+    shape whose row image does not fit the CU's LDS (K = 4096 with 15 or 16 rows)."""
     x, w = rnd(M, K, seed=41, scale=2.0) + 0.5, rnd(N, K, seed=42, scale=0.05)
     g, b_, bias = (rnd(K, seed=43, scale=0.2) + 1.0).to(bf16), rnd(K, seed=44, scale=0.3), rnd(N, seed=45)
     eps = 1e-5
     xd, wd, gd, bd = x.cuda(), w.cuda(), g.cuda(), (b_.cuda() if beta else None)
+    if K == 4096 and M == 16:
+        assert not ops.skinny_ln_ok(M, K)
+        with pytest.raises(Exception):
+            ops.gemm(xd, wd, ln=(gd, bd, eps))
+        return
     assert ops.skinny_ln_ok(M, K)
     h, _, _ = ops.layernorm_fwd(xd, gd, bd, eps)
     want2 = ops.gemm(h, wd)
@@ -551,9 +559,10 @@ def test_gemm_skinny2_fused_layernorm(ops, M, N, K, beta):
     hf = torch.nn.functional.layer_norm(x.float(), (K,), g.float(), b_.float() if beta else None, eps).to(bf16).float()
     close(got, hf @ w.float().t(), name="fused LN vs fp32")
     close(got, want2.float(), rel=2 ** -8, name="fused LN vs layernorm_fwd + gemm")
+    assert torch.equal(got, ops.gemm(xd, wd, ln=(gd, bd, eps))), "fused LN: two launches differ"
     got = ops.gemm(xd, wd, bias=bias.cuda(), act="gelu", ln=(gd, bd, eps))
     close(got, torch.nn.functional.gelu(hf @ w.float().t() + bias.float()), name="fused LN + bias + gelu")
-    assert not ops.skinny_ln_ok(17, K) and not ops.skinny_ln_ok(M, 8192) and not ops.skinny_ln_ok(M, 2560 + 32)
+    assert not ops.skinny_ln_ok(17, K) and not ops.skinny_ln_ok(M, 8192) and not ops.skinny_ln_ok(M, 2560 + 64) and not ops.skinny_ln_ok(M, 3584)
     with pytest.raises(Exception):
         ops.gemm(rnd(32, K, seed=1).cuda(), wd, ln=(gd, bd, eps))
 

@@ -358,105 +358,14 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(GemmParams p) {
 // weight loads use the DEFAULT cache policy: nontemporal loads measured 10 - 25 % slower on every shape (profiles/r06_negative_results_decode_and_mx.txt)
 __device__ __forceinline__ u32x4 sk2_ldw(const bf16* q) { return *(const u32x4*)q; }
 
-template <int NW, int CW, bool LN>
-__global__ __launch_bounds__(64 * NW) void gemm_skinny2_kernel(GemmParams p) {
-  __shared__ f32x4 red[NW * 64];
-  __shared__ float stat[2][NW][16];
-  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+// a workgroup barrier that waits for THIS wave's LDS operations only: __syncthreads() also drains vmcnt -- here that is the 10 KB of weights in flight, i.e. the
+// LayerNorm's statistics would start AFTER the weights have landed instead of under their flight
+#define SK2_LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+
+// the epilogue shared by the decode-row kernels: the waves' partial tiles meet in LDS, wave 0 sums them in wave order and stores
+template <int NW>
+__device__ __forceinline__ void sk2_finish(const GemmParams& p, f32x4 (&red)[NW * 64], f32x4 acc, int w, int lane, int n0) {
   const int g = lane >> 4, r = lane & 15;
-  const int n0 = blockIdx.x * 16, nchunk = p.K >> 6;
-  // lane (r, g) holds k = 8 g .. 8 g + 7 of each 32-k half of the chunk: one load instruction of the wave covers a contiguous 64-byte half line of each
-  // of its 16 rows (the round-3 map -- 16 consecutive k per lane -- made every instruction touch both halves of every line; with streaming (nt) loads
-  // that measured as twice the requests: profiles/r06_negative_results_decode_and_mx.txt)
-  const bf16* wp = p.B + (long)min(n0 + r, p.N - 1) * p.ldb + g * 8;
-  const bf16* xp = p.A + (long)min(r, p.M - 1) * p.lda + g * 8;
-  u32x4 wv[CW][2];
-  bf16x8 xv[CW][2];
-  // ISSUE ORDER matters: a wave's loads return in order.  With the LayerNorm the activation fragments and gamma / beta go out FIRST (L2 hits), the
-  // weights behind them: the statistics, their two barriers and the normalisation then run under the weights' flight instead of behind it (with the
-  // weights first every later load -- the gamma / beta pieces of the normalisation most of all -- queued behind 10 KB of HBM reads per wave:
-  // 19 us per launch in the step where the plain form took 14).  gamma / beta reach the lanes through LDS (one 16-byte piece per thread).
-  __shared__ __attribute__((aligned(16))) bf16 gbs[LN ? 2 * 4096 : 8];
-  bf16x8 gmr = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}, btr = gmr;
-  const bool gb_mine = LN && (int)threadIdx.x < (p.K >> 3);       // K / 8 pieces <= the workgroup's threads (launch_skinny2: 8 waves up to K = 2560, 16 up to 4096)
-  if (gb_mine) {
-    gmr = *(const bf16x8*)(p.ln_gamma + threadIdx.x * 8);
-    if (p.ln_beta) btr = *(const bf16x8*)(p.ln_beta + threadIdx.x * 8);
-  }
-#pragma unroll
-  for (int u = 0; u < CW; ++u) {
-    const int c = w + NW * u;
-    if (c < nchunk) { xv[u][0] = *(const bf16x8*)(xp + (long)c * 64); xv[u][1] = *(const bf16x8*)(xp + (long)c * 64 + 32); }
-    else { xv[u][0] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; xv[u][1] = xv[u][0]; }
-  }
-  if (LN) __builtin_amdgcn_sched_barrier(0);          // the loads above stay above the weight loads
-#pragma unroll
-  for (int u = 0; u < CW; ++u) {
-    const int c = w + NW * u;
-    if (c < nchunk) {                      // wave-uniform
-      wv[u][0] = sk2_ldw(wp + (long)c * 64);
-      wv[u][1] = sk2_ldw(wp + (long)c * 64 + 32);
-    } else { wv[u][0] = u32x4{0, 0, 0, 0}; wv[u][1] = u32x4{0, 0, 0, 0}; }
-  }
-  if (LN) __builtin_amdgcn_sched_barrier(0);
-  if (gb_mine) { *(bf16x8*)(gbs + threadIdx.x * 8) = gmr; *(bf16x8*)(gbs + 4096 + threadIdx.x * 8) = btr; }      // waits for the two oldest loads only
-  if (LN) {
-    const float inv_d = 1.f / (float)p.K;
-    float s = 0.f;
-#pragma unroll
-    for (int u = 0; u < CW; ++u)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) s += bf2f(xv[u][0][j]) + bf2f(xv[u][1][j]);          // chunks beyond K hold zeros
-    s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);                          // over the four lane groups of row r
-    if (g == 0) stat[0][w][r] = s;
-#pragma unroll
-    for (int u = 0; u < CW; ++u) { asm volatile("" : "+v"(xv[u][0])); asm volatile("" : "+v"(xv[u][1])); }   // the fragments stay bf16 across the barrier (their fp32 widenings would be 32 registers per chunk)
-    __syncthreads();
-    float tot = 0.f;
-#pragma unroll
-    for (int ww = 0; ww < NW; ++ww) tot += stat[0][ww][r];
-    const float mu = tot * inv_d;
-    float q = 0.f;
-#pragma unroll
-    for (int u = 0; u < CW; ++u) {
-      if (w + NW * u < nchunk) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { float d0 = bf2f(xv[u][0][j]) - mu, d1 = bf2f(xv[u][1][j]) - mu; q += d0 * d0 + d1 * d1; }
-      }
-    }
-    q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
-    if (g == 0) stat[1][w][r] = q;
-#pragma unroll
-    for (int u = 0; u < CW; ++u) { asm volatile("" : "+v"(xv[u][0])); asm volatile("" : "+v"(xv[u][1])); }
-    __syncthreads();
-    float qt = 0.f;
-#pragma unroll
-    for (int ww = 0; ww < NW; ++ww) qt += stat[1][ww][r];
-    const float rs = rsqrtf(qt * inv_d + p.ln_eps);
-#pragma unroll
-    for (int u = 0; u < CW; ++u) {
-      const int c = w + NW * u;
-      if (c < nchunk) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int ko = c * 64 + h * 32 + g * 8;
-          bf16x8 gm = *(const bf16x8*)(gbs + ko), bt = *(const bf16x8*)(gbs + 4096 + ko), o;      // written before the statistics' first barrier
-#pragma unroll
-          for (int j = 0; j < 8; ++j) o[j] = f2bf((bf2f(xv[u][h][j]) - mu) * rs * bf2f(gm[j]) + bf2f(bt[j]));
-          xv[u][h] = o;
-          __builtin_amdgcn_sched_barrier(0);          // one 8-element piece at a time: left alone the scheduler widens every gamma / beta piece to fp32 at once
-        }
-      }
-    }
-  }
-  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int u = 0; u < CW; ++u) {
-    if (w + NW * u < nchunk) {
-      acc = MFMA16(wv[u][0], xv[u][0], acc);
-      acc = MFMA16(wv[u][1], xv[u][1], acc);
-    }
-  }
   red[w * 64 + lane] = acc;
   __syncthreads();
   if (w == 0) {
@@ -471,6 +380,150 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny2_kernel(GemmParams p) {
       else epi_tile<false>(p, a, r, n0 + g * 4, gate);
     }
   }
+}
+
+template <int NW, int CW>
+__global__ __launch_bounds__(64 * NW) void gemm_skinny2_kernel(GemmParams p) {
+  __shared__ f32x4 red[NW * 64];
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, r = lane & 15;
+  const int n0 = blockIdx.x * 16, nchunk = p.K >> 6;
+  // lane (r, g) holds k = 8 g .. 8 g + 7 of each 32-k half of the chunk: one load instruction of the wave covers a contiguous 64-byte half line of each
+  // of its 16 rows (the round-3 map -- 16 consecutive k per lane -- made every instruction touch both halves of every line; with streaming (nt) loads
+  // that measured as twice the requests: profiles/r06_negative_results_decode_and_mx.txt)
+  const bf16* wp = p.B + (long)min(n0 + r, p.N - 1) * p.ldb + g * 8;
+  const bf16* xp = p.A + (long)min(r, p.M - 1) * p.lda + g * 8;
+  u32x4 wv[CW][2];
+  bf16x8 xv[CW][2];
+  // STRAIGHT-LINE issue (no branch between the first load and the last, so that hipcc's wait counts stay exact): a wave whose last chunk lies beyond K
+  // loads the last real chunk again and zeroes its activation fragment with a select
+#pragma unroll
+  for (int u = 0; u < CW; ++u) {
+    const long c = min(w + NW * u, nchunk - 1);
+    wv[u][0] = sk2_ldw(wp + c * 64);
+    wv[u][1] = sk2_ldw(wp + c * 64 + 32);
+    xv[u][0] = *(const bf16x8*)(xp + c * 64); xv[u][1] = *(const bf16x8*)(xp + c * 64 + 32);
+  }
+  const bf16x8 z8 = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  {                                                     // only the last chunk of a wave can lie beyond K (host: CW = ceil(nchunk / NW))
+    const bool live = w + NW * (CW - 1) < nchunk;
+    xv[CW - 1][0] = live ? xv[CW - 1][0] : z8; xv[CW - 1][1] = live ? xv[CW - 1][1] : z8;
+  }
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < CW; ++u) {
+    acc = MFMA16(wv[u][0], xv[u][0], acc);
+    acc = MFMA16(wv[u][1], xv[u][1], acc);
+  }
+  sk2_finish<NW>(p, red, acc, w, lane, n0);
+}
+
+// ---- the same with the LayerNorm of the rows fused in front (unimp_gemm_desc.ln_gamma): K = 64 NW CW exactly (512 ... 2560 with 8 waves, 3072 / 4096 with 16)
+// The workgroup normalises the M REAL rows once, cooperatively, and the waves read their MFMA fragments of the result from LDS.  A UNIT is one 512-element
+// segment of one row (one 16-byte piece per lane); wave w owns units w, w + NW, ... (UM of them at most; template, so that the loads are straight-line
+// code).  The first form of this fusion normalised in the MFMA layout -- every lane the 16 k-values x CW chunks of "its" row, rows beyond M included:
+// 16 K element-normalisations per workgroup whatever M is, about 1000 VALU instructions per wave, 640 workgroups each: + 4 us on a 14 us launch at M = 1.
+// Here the work is M K per workgroup (M = 1: one piece per lane in five waves).
+// ISSUE ORDER matters: a wave's loads return in order.  The unit pieces and gamma / beta go out FIRST (L2 hits), the weights behind them: statistics,
+// barriers and normalisation run under the weights' flight.  No branch between the first load and the last (hipcc's wait counts go to vmcnt(0) at
+// control-flow joins): units beyond the last are clamped to it and recomputed (same values to the same LDS addresses).
+template <int CTRL> __device__ __forceinline__ float sk2_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float sk2_wave_sum(float v) {       // fixed order; the total in every lane (through SGPRs)
+  v += sk2_dpp<0xB1>(v);            // quad_perm [1, 0, 3, 2]
+  v += sk2_dpp<0x4E>(v);            // quad_perm [2, 3, 0, 1]
+  v += sk2_dpp<0x141>(v);           // row_half_mirror: the other quad of the eight
+  v += sk2_dpp<0x140>(v);           // row_mirror: the other eight of the row -> all 16 lanes of a row hold the row's sum
+  const int vi = __builtin_bit_cast(int, v);
+  const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 0)), b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 16));
+  const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 32)), d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 48));
+  return (a + b) + (c + d);
+}
+
+template <int NW, int CW, int UM>
+__global__ __launch_bounds__(64 * NW) void gemm_skinny2_ln_kernel(GemmParams p) {
+  constexpr int S = NW * CW / 8, K = 64 * NW * CW, LDX = K + 8;         // segments per row; the row pitch in LDS shifts consecutive rows by four banks
+  __shared__ f32x4 red[NW * 64];
+  __shared__ float stat[2][16][8];
+  extern __shared__ __attribute__((aligned(16))) char sk_smem[];
+  bf16* gbs = (bf16*)sk_smem;                 // gamma [K], beta [K]
+  bf16* xs = gbs + 2 * K;                     // the normalised rows [M][LDX]
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, r = lane & 15;
+  const int n0 = blockIdx.x * 16, nunits = p.M * S;
+  const bf16* wp = p.B + (long)min(n0 + r, p.N - 1) * p.ldb + g * 8;
+  bf16x8 xu[UM];
+  int urow[UM], useg[UM];
+#pragma unroll
+  for (int i = 0; i < UM; ++i) {
+    const int u = min(w + NW * i, nunits - 1);
+    urow[i] = u / S; useg[i] = u - urow[i] * S;
+    xu[i] = *(const bf16x8*)(p.A + (long)urow[i] * p.lda + useg[i] * 512 + lane * 8);
+  }
+  const int gbi = min((int)threadIdx.x, K / 8 - 1) * 8;                // K / 8 pieces <= 64 NW threads
+  bf16x8 gmr = *(const bf16x8*)(p.ln_gamma + gbi);
+  bf16x8 btr = *(const bf16x8*)((p.ln_beta ? p.ln_beta : p.ln_gamma) + gbi);
+  __builtin_amdgcn_sched_barrier(0);          // the loads above stay above the weight loads
+  u32x4 wv[CW][2];
+#pragma unroll
+  for (int u = 0; u < CW; ++u) {
+    const long c = w + NW * u;
+    wv[u][0] = sk2_ldw(wp + c * 64);
+    wv[u][1] = sk2_ldw(wp + c * 64 + 32);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  const bf16x8 z8 = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  if (!p.ln_beta) btr = z8;
+  *(bf16x8*)(gbs + gbi) = gmr; *(bf16x8*)(gbs + K + gbi) = btr;
+  const float inv_d = 1.f / (float)K;
+#pragma unroll
+  for (int i = 0; i < UM; ++i) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += bf2f(xu[i][j]);
+    s = sk2_wave_sum(s);
+    if (lane == 0) stat[0][urow[i]][useg[i]] = s;
+  }
+  SK2_LDS_BARRIER();
+  float mu[UM];
+#pragma unroll
+  for (int i = 0; i < UM; ++i) {
+    float tot = 0.f;
+#pragma unroll
+    for (int sg = 0; sg < S; ++sg) tot += stat[0][urow[i]][sg];
+    mu[i] = tot * inv_d;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float d = bf2f(xu[i][j]) - mu[i]; q += d * d; }
+    q = sk2_wave_sum(q);
+    if (lane == 0) stat[1][urow[i]][useg[i]] = q;
+  }
+  SK2_LDS_BARRIER();
+#pragma unroll
+  for (int i = 0; i < UM; ++i) {
+    float qt = 0.f;
+#pragma unroll
+    for (int sg = 0; sg < S; ++sg) qt += stat[1][urow[i]][sg];
+    const float rs = rsqrtf(qt * inv_d + p.ln_eps);
+    const int ko = useg[i] * 512 + lane * 8;
+    const bf16x8 gm = *(const bf16x8*)(gbs + ko), bt = *(const bf16x8*)(gbs + K + ko);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = f2bf((bf2f(xu[i][j]) - mu[i]) * rs * bf2f(gm[j]) + bf2f(bt[j]));
+    *(bf16x8*)(xs + urow[i] * LDX + ko) = o;
+  }
+  SK2_LDS_BARRIER();
+  const bf16* xr = xs + min(r, p.M - 1) * LDX + g * 8;
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < CW; ++u) {
+    const int c = w + NW * u;
+    const bf16x8 x0 = *(const bf16x8*)(xr + c * 64), x1 = *(const bf16x8*)(xr + c * 64 + 32);
+    acc = MFMA16(wv[u][0], x0, acc);
+    acc = MFMA16(wv[u][1], x1, acc);
+  }
+  sk2_finish<NW>(p, red, acc, w, lane, n0);
 }
 
 // the same for a LONG contraction (K > 4096, no LayerNorm: the down-projections, K = 10 240 / 16 384): 16 waves, rounds of CW chunks per wave with the
@@ -530,21 +583,52 @@ __global__ __launch_bounds__(1024) void gemm_skinny2_long_kernel(GemmParams p) {
   }
 }
 
+// a fused LayerNorm: K = 64 NW CW exactly (whole 512-element segments), the gamma / beta and normalised-row images inside the CU's LDS
+static int skinny2_ln_lds(int M, int K) { return (2 * K + M * (K + 8)) * 2; }
+static bool skinny2_ln_ok(int M, int K) {
+  if (M < 1 || M > 16 || (K & 511) || K < 512 || K > 4096 || K == 3584) return false;
+  if (K > 2560 && (M * (K >> 9) + 15) / 16 > 7) return false;        // 16 waves of 128 registers: seven units per wave at most (K = 4096, M = 15, 16)
+  return skinny2_ln_lds(M, K) + 16 * 1024 + 1024 + 1024 <= 160 * 1024;
+}
 static bool skinny2_ok(const unimp_gemm_desc* d) {
-  // M <= 16 decode rows, k-contiguous operands, whole 64-k chunks; a fused LayerNorm needs the row inside one round (K <= 4096)
-  return d->M <= 16 && !d->a_kstrided && !d->b_kstrided && !(d->K & 63) && d->K >= 64 && (d->K <= 4096 || !d->ln_gamma);
+  // M <= 16 decode rows, k-contiguous operands, whole 64-k chunks
+  if (d->M > 16 || d->a_kstrided || d->b_kstrided || (d->K & 63) || d->K < 64) return false;
+  return !d->ln_gamma || skinny2_ln_ok(d->M, d->K);
+}
+
+template <int NW, int CW>
+static void launch_skinny2_ln(const unimp_gemm_desc* d, GemmParams& p, hipStream_t s) {
+  using kern_t = void (*)(GemmParams);
+  const int um = (d->M * (NW * CW / 8) + NW - 1) / NW;           // units per wave
+  const int b = um <= 1 ? 0 : um <= 2 ? 1 : um <= 4 ? 2 : um <= 7 ? 3 : 4;
+  static const kern_t kerns[5] = {gemm_skinny2_ln_kernel<NW, CW, 1>, gemm_skinny2_ln_kernel<NW, CW, 2>, gemm_skinny2_ln_kernel<NW, CW, 4>,
+                                  gemm_skinny2_ln_kernel<NW, CW, 7>, gemm_skinny2_ln_kernel<NW, CW, NW == 16 ? 7 : 10>};   // 16 waves: never more than 7 (skinny2_ln_ok)
+  static bool attr[5] = {false, false, false, false, false};
+  if (!attr[b]) { (void)hipFuncSetAttribute((const void*)kerns[b], hipFuncAttributeMaxDynamicSharedMemorySize, 142 * 1024); attr[b] = true; }
+  hipLaunchKernelGGL(kerns[b], dim3((d->N + 15) / 16), dim3(64 * NW), skinny2_ln_lds(d->M, d->K), s, p);
 }
 
 static void launch_skinny2(const unimp_gemm_desc* d, GemmParams& p, void* stream) {
   const int nchunk = d->K >> 6;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((d->N + 15) / 16);
+  if (d->ln_gamma) {
+    switch (d->K) {
+      case 512: launch_skinny2_ln<8, 1>(d, p, s); break;
+      case 1024: launch_skinny2_ln<8, 2>(d, p, s); break;
+      case 1536: launch_skinny2_ln<8, 3>(d, p, s); break;
+      case 2048: launch_skinny2_ln<8, 4>(d, p, s); break;
+      case 2560: launch_skinny2_ln<8, 5>(d, p, s); break;
+      case 3072: launch_skinny2_ln<16, 3>(d, p, s); break;
+      default: launch_skinny2_ln<16, 4>(d, p, s); break;          // 4096
+    }
+    return;
+  }
   if (d->K > 4096) { hipLaunchKernelGGL((gemm_skinny2_long_kernel<3>), grid, dim3(1024), 0, s, p); return; }
   // K <= 2560: 8 waves with up to five chunks each (two workgroups per CU at <= 128 registers: 640 tiles of the up-projection meet 512 slots, not 256);
   // beyond: 16 waves with three or four
   const int nw = nchunk <= 40 ? 8 : 16, cw = (nchunk + nw - 1) / nw;
-#define SK2_GO(NW_, CW_) do { if (d->ln_gamma) hipLaunchKernelGGL((gemm_skinny2_kernel<NW_, CW_, true>), grid, dim3(64 * NW_), 0, s, p);  \
-                              else hipLaunchKernelGGL((gemm_skinny2_kernel<NW_, CW_, false>), grid, dim3(64 * NW_), 0, s, p); } while (0)
+#define SK2_GO(NW_, CW_) hipLaunchKernelGGL((gemm_skinny2_kernel<NW_, CW_>), grid, dim3(64 * NW_), 0, s, p)
   if (nw == 8) { switch (cw) { case 1: SK2_GO(8, 1); break; case 2: SK2_GO(8, 2); break; case 3: SK2_GO(8, 3); break; case 4: SK2_GO(8, 4); break; default: SK2_GO(8, 5); break; } }
   else if (cw <= 3) SK2_GO(16, 3); else SK2_GO(16, 4);
 #undef SK2_GO
@@ -780,7 +864,7 @@ extern "C" int unimp_gemm_bf16_variant(const unimp_gemm_desc* d, int variant, vo
     case UNIMP_GEMM_SKINNY:
       if (!skinny_ok(d)) return unimp_set_error(UNIMP_ERR_UNSUPPORTED, "gemm: the skinny kernel needs M <= 64, k-contiguous operands, K %% 64 == 0");
       if (d->ln_gamma && !(skinny2_on() && skinny2_ok(d)))
-        return unimp_set_error(UNIMP_ERR_UNSUPPORTED, "gemm: a fused LayerNorm (ln_gamma) needs M <= 16, K %% 64 == 0, K <= 4096 (unimp_gemm_skinny_ln_ok)");
+        return unimp_set_error(UNIMP_ERR_UNSUPPORTED, "gemm: a fused LayerNorm (ln_gamma) needs M <= 16 and K = 512 ... 3072 or 4096 in whole 512s (unimp_gemm_skinny_ln_ok)");
       launch_skinny(d, stream); break;
     default: return unimp_set_error(UNIMP_ERR_ARG, "gemm: unknown variant");
   }
