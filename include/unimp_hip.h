@@ -241,6 +241,30 @@ int unimp_attn_decode(const unimp_attn_desc* d, float* workspace, int splits, vo
  * shared_len[g] to kv_len[b] as above.  group <= 16; workspace B*H*2*splits*(D+2) floats.  group = 1 is unimp_attn_decode. */
 int unimp_attn_decode_grouped(const unimp_attn_desc* d, float* workspace, int splits, int group, const int* shared_len, void* stream);
 int unimp_attn_decode_splits(int B, int H, int Sk);
+/* The whole self-attention of a cached decode step in ONE launch (ABI 8; transformers' GPTNeoXAttention / MPT attention with layer_past inside
+ * Flamingo.generate -- eval_rec.py:100-110, eval_img_gen.py:102-111, eval_exp.py:103-113): what unimp_decode_rope_append followed by
+ * unimp_attn_decode compute, bit for bit -- rotate the new token's q and k (row r with ITS table row; rot = 0: none), write the rotated k and v
+ * to cache slot pos_idx[r], attend the keys [0, pos_idx[r]] (ALiBi slopes optional) -- in unimp_attn_decode's grid (the keys of a (row, head)
+ * split over unimp_attn_decode_splits(rows, heads, capacity) workgroups); the last workgroup of a (row, head) to arrive merges the partials (fixed
+ * order; the hand-over uses agent-scope accesses, no fence).  A decode step is bound by its launches, not by the K / V bytes.  qkv is NOT modified
+ * (the rotated q / k exist in registers and in the cache only).  workspace: rows*heads*splits*(hd+2) floats; arrived: rows*heads uint32, ZERO
+ * before the first launch (every launch leaves them zero).  All strides in elements. */
+typedef struct {
+  const void* qkv;                 /* bf16 [rows][heads][head_stride]: q / k / v at q_off / k_off / v_off inside a head slot */
+  int64_t row_stride, head_stride;
+  int q_off, k_off, v_off;
+  int rows, heads, hd, rot;
+  const float* cos_rows; const float* sin_rows;     /* fp32 [rows][rot / 2] */
+  void* kcache; void* vcache;      /* bf16 [rows][capacity][heads][hd] views: strides below */
+  int64_t c_row_stride, c_slot_stride, c_head_stride;
+  int capacity;                    /* slots per row: sizes the launch (never the positions: graph-capturable) */
+  const int64_t* pos_idx;          /* [rows], device: slot of the new token (< capacity) */
+  float scale; const float* alibi_slopes;           /* fp32 [heads] or NULL */
+  void* out;                       /* bf16 [rows][heads][hd] */
+  int64_t o_row_stride, o_head_stride;
+  float* workspace; void* arrived;
+} unimp_decode_step_desc;
+int unimp_attn_decode_step(const unimp_decode_step_desc* d, void* stream);
 /* tuning / test knob: which generation of attention kernels serves the calls above.  2 (default; env UNIMP_ATTN_GEN):
  * the 32x32x16-MFMA / LDS-DMA kernels of attention2.hip for the forward and dQ; dK/dV by attention3.hip (64 keys per wave, one
  * wave per SIMD) where it serves the form -- head dim 80, causal / no mask, Sq and Sk multiples of 32, padded rows, a (batch,

@@ -603,6 +603,62 @@ def test_decode_rope_append(ops, R, nh, hd, rot, interleaved):
     assert torch.equal(kc, want_k) and torch.equal(vc, want_v), "cache slots"
 
 
+@pytest.mark.parametrize("R,nh,hd,rot,interleaved,cap,alibi", [(1, 32, 80, 80, True, 530, False), (10, 32, 80, 80, True, 530, False), (5, 8, 64, 32, True, 300, False),
+                                                               (3, 32, 128, 0, False, 1100, True), (16, 12, 64, 64, False, 90, False), (2, 4, 80, 80, True, 2100, True)])
+def test_attn_decode_step_one_launch(ops, R, nh, hd, rot, interleaved, cap, alibi):
+    """unimp_attn_decode_step: the self-attention of a cached decode step in one launch -- against unimp_decode_rope_append followed by the
+    split-key unimp_attn_decode on the same operands: the cache afterwards holds the same bits (rotated k, v in slot pos[r]; nothing else moves),
+    the outputs are bit-identical (same key chunks, same merge order; the last workgroup of a (row, head) merges, handed the partials through
+    agent-scope accesses) and agree with fp32 math; rows sit at different positions incl. 0 (one key: the new one) and the last slot; GPT-NeoX
+    interleaved and [3, nh, hd] layouts, partial rotation, no rotation + ALiBi (MPT), head dims 64 / 80 / 128, 1 ... 17 key chunks; fifty more
+    launches give the same bits (the hand-over has no lucky timing); a row alone gives the bits it gives in the batch."""
+    H = nh * hd
+    g = torch.Generator().manual_seed(R * 11 + hd + cap)
+    qkv = torch.randn(R, 3 * H, generator=g).to(bf16).cuda()
+    pos = torch.randint(0, cap, (R,), generator=g)
+    pos[0] = cap - 1
+    if R > 1:
+        pos[1] = 0
+    pos = pos.cuda()
+    kc = torch.randn(R, cap, nh, hd, generator=g).to(bf16).cuda()
+    vc = torch.randn(R, cap, nh, hd, generator=g).to(bf16).cuda()
+    half = rot // 2
+    cos = torch.rand(R, max(half, 1), generator=g).cuda() if rot else None
+    sin = torch.rand(R, max(half, 1), generator=g).cuda() if rot else None
+    slopes = (0.5 ** torch.arange(1, nh + 1).float() * 4).cuda() if alibi else None
+    hs, offs = (3 * hd, (0, hd, 2 * hd)) if interleaved else (hd, (0, H, 2 * H))
+    scale = hd ** -0.5
+    # the three-launch form
+    q2, k2, v2 = qkv.clone(), kc.clone(), vc.clone()
+    ops.decode_rope_append(q2, nh, hs, hd, offs, rot, cos, sin, k2, v2, pos)
+    qv = q2.view(R, 1, nh, 3 * hd)[..., :hd] if interleaved else q2.view(R, 1, 3, nh, hd)[:, :, 0]
+    want = ops.attn_decode(qv, k2, v2, scale, (pos + 1).int(), slopes)
+    # one launch
+    q1, k1, v1 = qkv.clone(), kc.clone(), vc.clone()
+    got = ops.attn_decode_step(q1, nh, hs, hd, offs, rot, cos, sin, k1, v1, pos, scale, slopes)
+    torch.cuda.synchronize()
+    assert torch.equal(q1, qkv), "qkv must stay as it was"
+    assert torch.equal(k1, k2) and torch.equal(v1, v2), "cache after the step"
+    assert torch.equal(got, want), "one launch vs rope_append + split-key decode: same chunks, same orders, same bits"
+    # fp32 math on the cache the step left behind
+    kf, vf, qf = k2.float(), v2.float(), qv.float()[:, 0]
+    for r in range(R):
+        n = int(pos[r]) + 1
+        sc = torch.einsum("hd,khd->hk", qf[r], kf[r, :n]) * scale
+        if alibi:
+            sc = sc + slopes[:, None] * torch.arange(n, device="cuda")[None, :].float()
+        ref = torch.einsum("hk,khd->hd", torch.softmax(sc, -1), vf[r, :n])
+        close(got[r, 0], ref, name=f"row {r} vs fp32")
+    k3, v3 = kc.clone(), vc.clone()
+    for _ in range(50):
+        again = ops.attn_decode_step(qkv, nh, hs, hd, offs, rot, cos, sin, k3, v3, pos, scale, slopes)
+        assert torch.equal(got, again), "two launches differ"
+    r = R - 1
+    alone = ops.attn_decode_step(qkv[r:r + 1].clone(), nh, hs, hd, offs, rot, cos[r:r + 1].contiguous() if rot else None, sin[r:r + 1].contiguous() if rot else None,
+                                 kc[r:r + 1].clone(), vc[r:r + 1].clone(), pos[r:r + 1].contiguous(), scale, slopes)
+    assert torch.equal(alone[0], got[r]), "a row alone and in the batch"
+
+
 @pytest.mark.parametrize("K,groups,nh,hd", [(10, 1, 32, 80), (5, 3, 8, 64), (3, 2, 12, 64), (16, 1, 4, 128)])
 def test_kv_reorder_beams(ops, K, groups, nh, hd):
     """unimp_kv_reorder_beams against transformers' _reorder_cache as decode.py ran it before (tail.copy_(tail.index_select(2, local)) per

@@ -22,6 +22,15 @@ class GemmDesc(C.Structure):
                 ("rope_pos", c_p), ("ln_gamma", c_p), ("ln_beta", c_p), ("ln_eps", c_f)]
 
 
+class DecodeStepDesc(C.Structure):
+    """include/unimp_hip.h unimp_decode_step_desc"""
+    _fields_ = [("qkv", c_p), ("row_stride", c_l), ("head_stride", c_l), ("q_off", c_i), ("k_off", c_i), ("v_off", c_i),
+                ("rows", c_i), ("heads", c_i), ("hd", c_i), ("rot", c_i), ("cos_rows", c_p), ("sin_rows", c_p),
+                ("kcache", c_p), ("vcache", c_p), ("c_row_stride", c_l), ("c_slot_stride", c_l), ("c_head_stride", c_l), ("capacity", c_i),
+                ("pos_idx", c_p), ("scale", C.c_float), ("alibi_slopes", c_p), ("out", c_p), ("o_row_stride", c_l), ("o_head_stride", c_l),
+                ("workspace", c_p), ("arrived", c_p)]
+
+
 class AttnDesc(C.Structure):
     _fields_ = [("q", c_p), ("k", c_p), ("v", c_p), ("o", c_p), ("lse", c_p)] + \
                [(n, c_l) for n in ("q_bs", "q_ss", "q_hs", "k_bs", "k_ss", "k_hs", "v_bs", "v_ss", "v_hs",
@@ -56,6 +65,7 @@ _SIGS = {
     "unimp_rope_halfsplit_pos": [c_p, c_l, c_l, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p],
     "unimp_decode_rope_append": [c_p, c_l, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_p, c_p],
     "unimp_kv_reorder_beams": [c_p, c_l, c_i, c_l, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p],
+    "unimp_attn_decode_step": [C.POINTER(DecodeStepDesc), c_p],
     "unimp_attn_fwd": [C.POINTER(AttnDesc), c_p],
     "unimp_attn_bwd": [C.POINTER(AttnDesc), c_p],
     "unimp_attn_decode": [C.POINTER(AttnDesc), c_p, c_i, c_p],

@@ -282,6 +282,238 @@ extern "C" int unimp_attn_decode_splits(int B, int H, int Sk) {
   return s < 1 ? 1 : s;
 }
 
+// ------------------------------------------------------------------------------------------- the whole attention of a decode step in ONE launch
+// A cached decode step is bound by its launches (a graph node costs about 5 us, the K / V bytes of a 500-key row about 1): rotating the new q / k and
+// appending k / v (decode_rope_append_kernel), the split-key partials and their merge were three nodes per layer.  Here block (split, head, row) of
+// attn_decode_partial's grid does all of it: it rotates the row's new q (its lanes' 16-byte chunks; same arithmetic, rounded to bf16 like the stored
+// form); the block whose chunk holds slot pos also rotates the new k, takes that key's K / V from its registers instead of the cache (the slot is
+// being written by this very block) and writes them to the cache; the partial (m, l, o[D]) goes to the workspace and the LAST block of a (row, head)
+// to arrive merges the partials in slot order -- same chunks, same orders: the same bits as the three launches.
+// The hand-over between workgroups (which sit on different XCDs, each with its own L2) uses agent-scope accesses on exactly the words that cross:
+// partials are written with sc1 stores (write-through), the arrival counter is an agent-scope atomic, the merging block reads with sc1 loads.  A
+// __threadfence() per block instead writes back and invalidates the WHOLE L2 of its XCD -- measured 16.5 -> 295 us per launch
+// (profiles/r06_negative_results_decode_and_mx.txt).
+// (A first form gave each (row, head) ONE workgroup of 16 waves and no cross-block step at all: 11.8 us per launch at K = 1 where the three launches
+// took 15.1, and 25.8 at K = 10 -- a CU keeps too few misses in flight to stream 166 KB of strided 160-byte key rows; the keys have to be spread.)
+struct DecStepP {
+  const bf16* qkv; long row_stride, head_stride; int q_off, k_off, v_off;
+  int rows, H, D, half;                   // half = rot / 2 (0: no rotation)
+  const float* cs; const float* sn;       // fp32 [rows][half]: the table row of every row's position
+  bf16* kc; bf16* vc; long c_row, c_slot, c_head;
+  const int64_t* pos_idx;                 // [rows] slot of the new token = keys visible - 1
+  float scale_log2; const float* alibi;
+  bf16* o; long o_bs, o_hs;
+  float* ws; unsigned* arrived;           // [rows][H][splits][D + 2]; [rows][H] arrival counters (zero between launches)
+  int splits, chunk;
+};
+
+// chunk c (8 elements) of the rotated vector at `vec` (half-split rope: pairs (i, i + half) for i < half; elements >= 2 half pass through)
+__device__ __forceinline__ bf16x8 rope_chunk8(const bf16* vec, int c, int half, const float* cr, const float* sr) {
+  const int P = half >> 3;
+  const bool lo = c < P, rotd = c < 2 * P;
+  const int cc = rotd ? (lo ? c : c - P) : 0;
+  const bf16x8 own = *(const bf16x8*)(vec + c * 8);
+  if (half == 0) return own;                                       // uniform
+  const bf16x8 par = *(const bf16x8*)(vec + (rotd ? (lo ? c + P : c - P) : c) * 8);
+  const f32x4 c0 = *(const f32x4*)(cr + cc * 8), c1 = *(const f32x4*)(cr + cc * 8 + 4), s0 = *(const f32x4*)(sr + cc * 8), s1 = *(const f32x4*)(sr + cc * 8 + 4);
+  bf16x8 out;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float co = j < 4 ? c0[j & 3] : c1[j & 3], si = j < 4 ? s0[j & 3] : s1[j & 3];
+    const float x1 = lo ? bf2f(own[j]) : bf2f(par[j]), x2 = lo ? bf2f(par[j]) : bf2f(own[j]);
+    const bf16 a = f2bf(x1 * co - x2 * si), b = f2bf(x2 * co + x1 * si);
+    out[j] = rotd ? (lo ? a : b) : own[j];
+  }
+  return out;
+}
+
+__device__ __forceinline__ void st_agent(float* q, float v) { __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_agent(const float* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// an agent-scope load the compiler does not serialise: the caller waits once for a batch (sc1_wait names the registers, so no use moves above the wait)
+__device__ __forceinline__ float ld_sc1(const float* q) { float v; asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v) : "v"(q) : "memory"); return v; }
+__device__ __forceinline__ void sc1_wait(float (&v)[8]) {
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) :: "memory");
+}
+
+template <int G, int U>
+__global__ __launch_bounds__(256) void attn_decode_step_kernel(DecStepP p) {
+  constexpr int KPL = 64 / G;
+  __shared__ float sm[4 * KPL * (128 + 2)];
+  __shared__ unsigned last_s;
+  const int split = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int slot = lane / G, c = lane % G;
+  const bool act = c * 8 < p.D;
+  const int ca = act ? c : 0;                       // idle lanes of a group (D = 80: chunks 10 .. 15) redo chunk 0, never beyond the row
+  const int pos = (int)p.pos_idx[b], n = pos + 1;
+  const int k0 = split * p.chunk + wave * (p.chunk >> 2), k1 = min(split * p.chunk + (wave + 1) * (p.chunk >> 2), n);
+  const bf16* base = p.qkv + (long)b * p.row_stride + (long)h * p.head_stride;
+  const float* cr = p.cs + (long)b * p.half; const float* sr = p.sn + (long)b * p.half;
+  const bf16x8 qn = rope_chunk8(base + p.q_off, ca, p.half, cr, sr);
+  const long cslot = (long)b * p.c_row + (long)h * p.c_head + ca * 8;
+  const bool mine = pos >= k0 && pos < k1;          // wave-uniform: this wave's keys include the new one
+  u32x4 kn = u32x4{0u, 0u, 0u, 0u}, vn = kn;
+  if (mine) {
+    kn = __builtin_bit_cast(u32x4, rope_chunk8(base + p.k_off, ca, p.half, cr, sr));
+    vn = *(const u32x4*)(base + p.v_off + ca * 8);
+    if (slot == 0 && act) { *(u32x4*)(p.kc + cslot + (long)pos * p.c_slot) = kn; *(u32x4*)(p.vc + cslot + (long)pos * p.c_slot) = vn; }
+  }
+  float qf[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) qf[i] = bf2f(qn[i]) * p.scale_log2;
+  const float slope = p.alibi ? p.alibi[h] * 1.4426950408889634f : 0.f;
+  const bf16* kb = p.kc + cslot; const bf16* vb = p.vc + cslot;
+
+  float m = -INFINITY, l = 0.f, acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  for (int kk = k0; kk < k1; kk += KPL * U) {
+    u32x4 kr[U], vr[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {                   // all loads of the round go out before the first use
+      const int key = kk + u * KPL + slot;
+      const int kc_ = key < k1 && key != pos ? key : k0 < pos ? k0 : 0;      // clamped, masked below; never the slot being written
+      kr[u] = *(const u32x4*)(kb + (long)kc_ * p.c_slot);
+      vr[u] = *(const u32x4*)(vb + (long)kc_ * p.c_slot);
+    }
+    if (mine) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const bool isnew = kk + u * KPL + slot == pos;
+        kr[u] = isnew ? kn : kr[u];
+        vr[u] = isnew ? vn : vr[u];
+      }
+    }
+    float s[U];
+    float mx = m;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float kf[8];
+      widen8(kr[u], kf);
+      float d = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) d = fmaf(qf[i], kf[i], d);
+      if (!act) d = 0.f;
+      d = group_sum<G>(d);
+      const int key = kk + u * KPL + slot;
+      s[u] = key < k1 ? d + slope * (float)key : -INFINITY;
+      mx = fmaxf(mx, s[u]);
+    }
+    if (mx > m) {
+      const float r = m == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m - mx);
+      l *= r;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] *= r;
+      m = mx;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float pe = s[u] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(s[u] - m);
+      l += pe;
+      float vf[8];
+      widen8(vr[u], vf);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] = fmaf(pe, vf[i], acc[i]);
+    }
+  }
+  // slot partials -> LDS: [wave * KPL + slot][D + 2]; merged in a fixed order, one thread per dim (attn_decode_partial's arithmetic)
+  const int DS = p.D + 2;
+  float* mn = sm + (wave * KPL + slot) * DS;
+  if (act) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) mn[2 + c * 8 + i] = acc[i];
+    if (c == 0) { mn[0] = m; mn[1] = l; }
+  }
+  __syncthreads();
+  const int d = threadIdx.x;
+  float M = -INFINITY, L = 0.f, O = 0.f;
+  if (d < p.D) {
+    for (int j = 0; j < 4 * KPL; ++j) M = fmaxf(M, sm[j * DS]);
+    for (int j = 0; j < 4 * KPL; ++j) {
+      const float mj = sm[j * DS];
+      const float w = mj == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mj - M);
+      L = fmaf(w, sm[j * DS + 1], L);
+      O = fmaf(w, sm[j * DS + 2 + d], O);
+    }
+  }
+  if (p.splits == 1) {
+    if (d < p.D) p.o[(long)b * p.o_bs + (long)h * p.o_hs + d] = f2bf(L > 0.f ? O / L : 0.f);
+    return;
+  }
+  float* wsp = p.ws + ((long)b * p.H + h) * p.splits * DS;
+  if (d < p.D) {
+    st_agent(wsp + split * DS + 2 + d, O);
+    if (d == 0) { st_agent(wsp + split * DS, M); st_agent(wsp + split * DS + 1, L); }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this thread's partial has reached the coherence point
+  __syncthreads();
+  if (threadIdx.x == 0)
+    last_s = __hip_atomic_fetch_add(p.arrived + (long)b * p.H + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)p.splits - 1;
+  __syncthreads();
+  if (!last_s) return;
+  if (threadIdx.x == 0) __hip_atomic_store(p.arrived + (long)b * p.H + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
+  if (d < p.D) {                                    // attn_decode_merge's arithmetic; the partials of eight slots at a time, all loads in flight before the first use
+    // (relaxed atomic loads are not reordered by hipcc: one memory round trip per load -- about twenty in a row here)
+    float MM = -INFINITY;
+    for (int s0 = 0; s0 < p.splits; s0 += 8) {
+      float ms[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ms[j] = ld_sc1(wsp + min(s0 + j, p.splits - 1) * DS);
+      sc1_wait(ms);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) MM = fmaxf(MM, ms[j]);
+    }
+    float LL = 0.f, OO = 0.f;
+    for (int s0 = 0; s0 < p.splits; s0 += 8) {
+      float ms[8], ls[8], os[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float* q = wsp + min(s0 + j, p.splits - 1) * DS;
+        ms[j] = ld_sc1(q); ls[j] = ld_sc1(q + 1); os[j] = ld_sc1(q + 2 + d);
+      }
+      sc1_wait(ms); sc1_wait(ls); sc1_wait(os);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (s0 + j < p.splits) {
+          const float e = ms[j] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(ms[j] - MM);
+          LL = fmaf(e, ls[j], LL);
+          OO = fmaf(e, os[j], OO);
+        }
+      }
+    }
+    p.o[(long)b * p.o_bs + (long)h * p.o_hs + d] = f2bf(LL > 0.f ? OO / LL : 0.f);
+  }
+}
+
+extern "C" int unimp_attn_decode_step(const unimp_decode_step_desc* d, void* stream) {
+  if (!d || !d->qkv || !d->kcache || !d->vcache || !d->pos_idx || !d->out) return unimp_set_error(UNIMP_ERR_ARG, "attn_decode_step: null pointer");
+  if (d->rot > 0 && (!d->cos_rows || !d->sin_rows)) return unimp_set_error(UNIMP_ERR_ARG, "attn_decode_step: rot > 0 needs the cos / sin rows");
+  if (d->rows <= 0 || d->heads <= 0) return UNIMP_OK;
+  const int half = d->rot / 2;
+  if (d->hd % 8 || d->hd > 128 || d->hd < 8 || d->rot < 0 || d->rot > d->hd || (half & 7))
+    return unimp_set_error(UNIMP_ERR_SHAPE, "attn_decode_step: head dim a multiple of 8, <= 128; rot / 2 a multiple of 8, rot <= head dim");
+  if (((d->row_stride | d->head_stride | d->c_row_stride | d->c_slot_stride | d->c_head_stride | d->o_row_stride | d->o_head_stride) & 7) ||
+      ((d->q_off | d->k_off | d->v_off) & 7) || (((uintptr_t)d->qkv | (uintptr_t)d->kcache | (uintptr_t)d->vcache) & 15) ||
+      (d->rot > 0 && (((uintptr_t)d->cos_rows | (uintptr_t)d->sin_rows) & 15)))
+    return unimp_set_error(UNIMP_ERR_ALIGN, "attn_decode_step: strides and offsets must be multiples of 8 elements, pointers 16-byte aligned");
+  if (d->capacity <= 0) return unimp_set_error(UNIMP_ERR_SHAPE, "attn_decode_step: capacity <= 0");
+  const int splits = unimp_attn_decode_splits(d->rows, d->heads, d->capacity);
+  if (splits > 1 && (!d->workspace || !d->arrived)) return unimp_set_error(UNIMP_ERR_ARG, "attn_decode_step: needs the workspace (rows*heads*splits*(hd+2) floats) and the zeroed arrival counters (rows*heads)");
+  DecStepP p;
+  p.qkv = (const bf16*)d->qkv; p.row_stride = d->row_stride; p.head_stride = d->head_stride; p.q_off = d->q_off; p.k_off = d->k_off; p.v_off = d->v_off;
+  p.rows = d->rows; p.H = d->heads; p.D = d->hd; p.half = half; p.cs = d->cos_rows; p.sn = d->sin_rows;
+  p.kc = (bf16*)d->kcache; p.vc = (bf16*)d->vcache; p.c_row = d->c_row_stride; p.c_slot = d->c_slot_stride; p.c_head = d->c_head_stride;
+  p.pos_idx = d->pos_idx; p.scale_log2 = d->scale * 1.4426950408889634f; p.alibi = d->alibi_slopes;
+  p.o = (bf16*)d->out; p.o_bs = d->o_row_stride; p.o_hs = d->o_head_stride;
+  p.ws = d->workspace; p.arrived = (unsigned*)d->arrived; p.splits = splits; p.chunk = DEC_CHUNK;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(splits, d->heads, d->rows);
+  if (d->hd <= 64) hipLaunchKernelGGL((attn_decode_step_kernel<8, 4>), grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((attn_decode_step_kernel<16, 8>), grid, dim3(256), 0, s, p);
+  return unimp_check_launch("attn_decode_step");
+}
+
 extern "C" int unimp_attn_decode_grouped(const unimp_attn_desc* d, float* workspace, int splits, int group, const int* shared_len, void* stream) {
   if (!d || !d->q || !d->k || !d->v || !d->o) return unimp_set_error(UNIMP_ERR_ARG, "attn_decode: null pointer");
   if (d->Sq != 1) return unimp_set_error(UNIMP_ERR_SHAPE, "attn_decode: one query row per (batch row, head) (Sq == 1)");

@@ -684,6 +684,10 @@ def self_attn_block(x, ln_w, ln_b, wqkv, bqkv, wd, bd, nh, *, rope=None, kv_len=
 DECODE_FUSED = _os.environ.get("UNIMP_DECODE_FUSED", "1") != "0"      # round 6: fused decode-step kernels (rope + cache append; LN inside the skinny GEMM); 0 = the round-5 launches (A/B, tests)
 
 
+# the decode step's self-attention as one launch (rope + append + attention; UNIMP_DECODE_STEP_ATTN=0: rope-append, split-key partials, merge)
+DECODE_STEP_ATTN = _os.environ.get("UNIMP_DECODE_STEP_ATTN", "1") != "0"
+
+
 def _ln_fusable(rows, D, rms):
     """decode rows whose LayerNorm the weight-streaming GEMM can take (ops.gemm(ln=...)): M <= 16, D % 512 == 0, D <= 4096, LayerNorm (not RMSNorm)"""
     return DECODE_FUSED and not rms and rows <= 16 and ops.skinny_ln_ok(rows, D)
@@ -817,7 +821,13 @@ def self_attn_block_cached(x, ln_w, ln_b, wqkv, bqkv, wd, bd, nh, lc, pos0, *, r
             raise NotImplementedError("a static decode step feeds one new token per row")
         rot = rope[2] if rope is not None else 0
         o3 = (offs[0], offs[1], (2 * hd) if interleaved else 2 * H)       # q, k, v element offsets inside a head slot (_split_qkv)
-        if DECODE_FUSED and qk_ln is None and ops.decode_rope_append_ok(hd, rot, hs, o3, qkv, lc.k):
+        fused = DECODE_FUSED and qk_ln is None and ops.decode_rope_append_ok(hd, rot, hs, o3, qkv, lc.k)
+        if fused and DECODE_STEP_ATTN and ops.DECODE_ATTN and hd <= 128 and not (ops.DECODE_SHARED_PREFIX and lc.owner.group > 1):
+            # the whole attention in ONE launch: rope of the new q / k, the append, every cached key (csrc/decode_attn.hip attn_decode_step_kernel)
+            o = ops.attn_decode_step(qkv, nh, hs, hd, o3, rot, rope[0] if rot else None, rope[1] if rot else None, lc.k, lc.v, step.pos_idx,
+                                     scale, alibi)
+            return ops.gemm(o.view(R, H), wd, bias=bd, res=r2).view(R, 1, H)
+        if fused:
             # one launch: rotate q / k (row r at its own position) and write the rotated k and v into their cache slots
             ops.decode_rope_append(qkv, nh, hs, hd, o3, rot, rope[0] if rot else None, rope[1] if rot else None, lc.k, lc.v, step.pos_idx)
         else:

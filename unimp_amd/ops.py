@@ -584,6 +584,41 @@ def kv_reorder_beams(kv, K, src_local, slot0, pos_idx, max_new):
                                              src_local.data_ptr(), slot0.data_ptr(), pos_idx.data_ptr(), int(max_new), _stream()), "kv_reorder_beams")
 
 
+_DECODE_STEP_WS = {}
+
+
+def attn_decode_step(qkv2d, heads, head_stride, hd, offs, rot, cos_rows, sin_rows, kcache, vcache, pos_idx, scale, alibi=None):
+    """the self-attention of a cached decode step in ONE launch (csrc/decode_attn.hip attn_decode_step_kernel): rotate the new q / k, write the
+    rotated k and v to cache slot pos_idx[r], attend keys [0, pos_idx[r]] -- the bits of decode_rope_append + attn_decode.  Same arguments as
+    decode_rope_append (+ scale / ALiBi slopes); qkv2d is left unrotated.  Returns o [rows, 1, heads, hd]."""
+    rows, cap = qkv2d.shape[0], kcache.shape[1]
+    assert kcache.stride(3) == 1 and vcache.stride() == kcache.stride() and pos_idx.dtype == torch.int64 and pos_idx.is_contiguous()
+    if rot:
+        assert cos_rows.dtype == torch.float32 and cos_rows.is_contiguous() and sin_rows.is_contiguous() and cos_rows.shape == (rows, rot // 2)
+    if alibi is not None:
+        assert alibi.dtype == torch.float32 and alibi.numel() == heads and alibi.is_contiguous()
+    L = _lib.lib()
+    splits = L.unimp_attn_decode_splits(rows, heads, cap)
+    key = (qkv2d.device, rows, heads, splits, hd)
+    if key not in _DECODE_STEP_WS:          # per shape, kept: the arrival counters must be zero at the first launch and are left zero by every launch
+        _DECODE_STEP_WS[key] = (torch.empty(rows * heads * splits * (hd + 2), device=qkv2d.device, dtype=torch.float32),
+                                torch.zeros(rows * heads, device=qkv2d.device, dtype=torch.int32))
+    ws, arrived = _DECODE_STEP_WS[key]
+    o = torch.empty((rows, 1, heads, hd), device=qkv2d.device, dtype=bf16)
+    d = _lib.DecodeStepDesc()
+    d.qkv, d.row_stride, d.head_stride = _dev(qkv2d).data_ptr(), qkv2d.stride(0), head_stride
+    d.q_off, d.k_off, d.v_off = offs
+    d.rows, d.heads, d.hd, d.rot = rows, heads, hd, rot
+    d.cos_rows, d.sin_rows = (_p(cos_rows), _p(sin_rows)) if rot else (None, None)
+    d.kcache, d.vcache = kcache.data_ptr(), vcache.data_ptr()
+    d.c_row_stride, d.c_slot_stride, d.c_head_stride, d.capacity = kcache.stride(0), kcache.stride(1), kcache.stride(2), cap
+    d.pos_idx, d.scale, d.alibi_slopes = pos_idx.data_ptr(), scale, _p(alibi)
+    d.out, d.o_row_stride, d.o_head_stride = o.data_ptr(), o.stride(0), o.stride(2)
+    d.workspace, d.arrived = ws.data_ptr(), arrived.data_ptr()
+    check(L.unimp_attn_decode_step(C.byref(d), _stream()), "attn_decode_step")
+    return o
+
+
 def decode_rope_append_ok(hd, rot, head_stride, offs, qkv2d, kcache):
     return (hd % 8 == 0 and rot % 16 == 0 and rot <= hd and head_stride % 8 == 0 and all(o % 8 == 0 for o in offs) and qkv2d.stride(0) % 8 == 0
             and qkv2d.data_ptr() % 16 == 0 and kcache.data_ptr() % 16 == 0 and all(s_ % 8 == 0 for s_ in kcache.stride()[:3]))
