@@ -492,15 +492,16 @@ def test_gemm_skinny_decode_rows(ops, M, N, K):
     close(got, z, rel=1e-5, name="skinny f32")
 
 
-@pytest.mark.parametrize("M", [1, 5, 10, 16])
-@pytest.mark.parametrize("N,K", [(2560, 2560), (7680, 2560), (10240, 2560), (2560, 10240), (2560, 512), (512, 2560), (74053, 2560), (4096, 4096),
+@pytest.mark.parametrize("M", [1, 5, 8, 10, 16])
+@pytest.mark.parametrize("N,K", [(2560, 2560), (7680, 2560), (10240, 2560), (2560, 10240), (2560, 512), (512, 2560), (74053, 2560), (4096, 4096), (2052, 6400), (4099, 8192),
                                  (1005, 1024), (24, 512), (5133, 1536), (777, 3072), (640, 64), (512, 2624), (1024, 16384), (520, 4160), (40, 7744)])
 def test_gemm_skinny2_persistent_decode_rows(ops, M, N, K):
     """round 6: the second-generation weight-streaming kernel (gemm.hip skinny2: every load of a wave issued before its first wait, 8 waves x
     up to five 64-k chunks or 16 x up to four) that serves M <= 16 decode rows with K <= 4096 -- the cfg2 / cfg5 decode shapes, the head's
     4 629 tiles, N = 24, ragged N with a padded ldc, every chunk count per wave incl. a ragged last one (K = 1536: 24 chunks on 8 waves) -- and its
     long-K form (K > 4096: rounds of three chunks per wave, the next round's loads issued before this round's MFMAs; K = 10 240, 16 384, a
-    ragged 4 160 and 7 744) -- against fp32 and against the round-3 kernel on the same operands (different partial-sum
+    ragged 4 160 and 7 744); the weight rows per workgroup follow N (the busiest CU's rows are minimised: 10 for N = 2560 and 10 240, 15 for
+    7680, 16 for the head, 6 for N = 24, ragged last workgroups at N = 1005 / 777 / 2052 / 4099) -- against fp32 and against the round-3 kernel on the same operands (different partial-sum
     grouping: bf16-level agreement), all epilogue flavours of the decode step; launching twice gives the same bits (fixed summation order)."""
     from unimp_amd import _lib
     L = _lib.lib()

@@ -363,47 +363,57 @@ __device__ __forceinline__ u32x4 sk2_ldw(const bf16* q) { return *(const u32x4*)
 #define SK2_LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 
 // the epilogue shared by the decode-row kernels: the waves' partial tiles meet in LDS, wave 0 sums them in wave order and stores
+// R: weight rows per workgroup (<= 16; the tile's columns beyond R are not stored)
 template <int NW>
-__device__ __forceinline__ void sk2_finish(const GemmParams& p, f32x4 (&red)[NW * 64], f32x4 acc, int w, int lane, int n0) {
+__device__ __forceinline__ void sk2_finish(const GemmParams& p, f32x4 (&red)[NW * 64], f32x4 acc, int w, int lane, int n0, int R) {
   const int g = lane >> 4, r = lane & 15;
   red[w * 64 + lane] = acc;
   __syncthreads();
   if (w == 0) {
     f32x4 a = red[lane];
-#pragma unroll
+#pragma unroll 4
     for (int ww = 1; ww < NW; ++ww) a += red[ww * 64 + lane];
     if (n0 < p.N) {
       float gate = 1.f;
       if (p.gate) gate = tanhf(bf2f(*p.gate));
-      const bool fast = ((p.N & 3) == 0) && (((p.ldc | p.ldres | p.ldaux | p.ldpre) & 3) == 0);
-      if (fast) epi_tile<true>(p, a, r, n0 + g * 4, gate);
-      else epi_tile<false>(p, a, r, n0 + g * 4, gate);
+      GemmParams q = p;
+      q.N = min(p.N, n0 + R);                       // epi_tile's column bound
+      const bool fast = ((q.N & 3) == 0) && ((R & 3) == 0) && (((p.ldc | p.ldres | p.ldaux | p.ldpre) & 3) == 0);
+      if (fast) epi_tile<true>(q, a, r, n0 + g * 4, gate);
+      else epi_tile<false>(q, a, r, n0 + g * 4, gate);
     }
   }
 }
 
+// ROWS PER WORKGROUP (R <= 16, kernel argument): a CU streams weights at about 1 / 256 of the chip's HBM rate whatever it runs, so the launch takes as
+// long as the CU with the most rows.  With 16-row tiles N = 2560 is 160 workgroups (96 CUs idle, 16.2 us for 52 MB where N = 10 240 took 12.4) and
+// N = 10 240 is 640 (2.5 per CU: 48 rows on the busiest CU where 40 is the mean).  The host picks R so that ceil(ceil(N / R) / 256) * R is smallest:
+// 10 rows x 256 workgroups for N = 2560, 15 x 512 for N = 7680, 4 x 128 for N = 512 (below two 16-row workgroups per CU only: skinny2_rows).  Lanes r >= R of the MFMA tile re-read row R - 1 (the
+// same addresses in the same instruction: no traffic) and their columns are not stored.
+// (8-row tiles whose lanes r >= 8 hold the other k-half of rows r - 8 -- twice the workgroups, one MFMA per chunk, M <= 8 only -- were built first:
+// 16.2 us where the 16-row tiles took 17.2, i.e. the workgroup count was not what mattered; profiles/r06_negative_results_decode_and_mx.txt.)
 template <int NW, int CW>
-__global__ __launch_bounds__(64 * NW) void gemm_skinny2_kernel(GemmParams p) {
+__global__ __launch_bounds__(64 * NW) void gemm_skinny2_kernel(GemmParams p, int R) {
   __shared__ f32x4 red[NW * 64];
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, r = lane & 15;
-  const int n0 = blockIdx.x * 16, nchunk = p.K >> 6;
+  const int n0 = blockIdx.x * R, nchunk = p.K >> 6;
   // lane (r, g) holds k = 8 g .. 8 g + 7 of each 32-k half of the chunk: one load instruction of the wave covers a contiguous 64-byte half line of each
   // of its 16 rows (the round-3 map -- 16 consecutive k per lane -- made every instruction touch both halves of every line; with streaming (nt) loads
   // that measured as twice the requests: profiles/r06_negative_results_decode_and_mx.txt)
-  const bf16* wp = p.B + (long)min(n0 + r, p.N - 1) * p.ldb + g * 8;
+  const bf16* wp = p.B + (long)min(n0 + min(r, R - 1), p.N - 1) * p.ldb + g * 8;
   const bf16* xp = p.A + (long)min(r, p.M - 1) * p.lda + g * 8;
   u32x4 wv[CW][2];
   bf16x8 xv[CW][2];
-  // STRAIGHT-LINE issue (no branch between the first load and the last, so that hipcc's wait counts stay exact): a wave whose last chunk lies beyond K
-  // loads the last real chunk again and zeroes its activation fragment with a select
+  // STRAIGHT-LINE issue (no branch between the first load and the last, so that hipcc's wait counts stay exact): a wave whose chunks lie beyond K
+  // loads the last real chunk again and zeroes the activation fragment with a select
 #pragma unroll
   for (int u = 0; u < CW; ++u) {
     const long c = min(w + NW * u, nchunk - 1);
-    wv[u][0] = sk2_ldw(wp + c * 64);
-    wv[u][1] = sk2_ldw(wp + c * 64 + 32);
-    xv[u][0] = *(const bf16x8*)(xp + c * 64); xv[u][1] = *(const bf16x8*)(xp + c * 64 + 32);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) { wv[u][h] = sk2_ldw(wp + c * 64 + h * 32); xv[u][h] = *(const bf16x8*)(xp + c * 64 + h * 32); }
   }
+  __builtin_amdgcn_sched_barrier(0);          // every load of the wave goes out before its first wait (left alone hipcc folds the late loads into the MFMA chain)
   const bf16x8 z8 = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
   {                                                     // only the last chunk of a wave can lie beyond K (host: CW = ceil(nchunk / NW))
     const bool live = w + NW * (CW - 1) < nchunk;
@@ -411,11 +421,10 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny2_kernel(GemmParams p) {
   }
   f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int u = 0; u < CW; ++u) {
-    acc = MFMA16(wv[u][0], xv[u][0], acc);
-    acc = MFMA16(wv[u][1], xv[u][1], acc);
-  }
-  sk2_finish<NW>(p, red, acc, w, lane, n0);
+  for (int u = 0; u < CW; ++u)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) acc = MFMA16(wv[u][h], xv[u][h], acc);
+  sk2_finish<NW>(p, red, acc, w, lane, n0, R);
 }
 
 // ---- the same with the LayerNorm of the rows fused in front (unimp_gemm_desc.ln_gamma): K = 64 NW CW exactly (512 ... 2560 with 8 waves, 3072 / 4096 with 16)
@@ -442,7 +451,7 @@ __device__ __forceinline__ float sk2_wave_sum(float v) {       // fixed order; t
 }
 
 template <int NW, int CW, int UM>
-__global__ __launch_bounds__(64 * NW) void gemm_skinny2_ln_kernel(GemmParams p) {
+__global__ __launch_bounds__(64 * NW) void gemm_skinny2_ln_kernel(GemmParams p, int R) {
   constexpr int S = NW * CW / 8, K = 64 * NW * CW, LDX = K + 8;         // segments per row; the row pitch in LDS shifts consecutive rows by four banks
   __shared__ f32x4 red[NW * 64];
   __shared__ float stat[2][16][8];
@@ -451,8 +460,8 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny2_ln_kernel(GemmParams p) 
   bf16* xs = gbs + 2 * K;                     // the normalised rows [M][LDX]
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, r = lane & 15;
-  const int n0 = blockIdx.x * 16, nunits = p.M * S;
-  const bf16* wp = p.B + (long)min(n0 + r, p.N - 1) * p.ldb + g * 8;
+  const int n0 = blockIdx.x * R, nunits = p.M * S;
+  const bf16* wp = p.B + (long)min(n0 + min(r, R - 1), p.N - 1) * p.ldb + g * 8;
   bf16x8 xu[UM];
   int urow[UM], useg[UM];
 #pragma unroll
@@ -523,20 +532,20 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny2_ln_kernel(GemmParams p) 
     acc = MFMA16(wv[u][0], x0, acc);
     acc = MFMA16(wv[u][1], x1, acc);
   }
-  sk2_finish<NW>(p, red, acc, w, lane, n0);
+  sk2_finish<NW>(p, red, acc, w, lane, n0, R);
 }
 
 // the same for a LONG contraction (K > 4096, no LayerNorm: the down-projections, K = 10 240 / 16 384): 16 waves, rounds of CW chunks per wave with the
 // NEXT round's weights and activation fragments issued before the current round's MFMAs (two register sets, no barrier inside the loop) -- the
 // round-3 loop drained its loads between iterations (four dependent memory round trips per workgroup at K = 10 240: 20 us for 52 MB).
 template <int CW>
-__global__ __launch_bounds__(1024) void gemm_skinny2_long_kernel(GemmParams p) {
+__global__ __launch_bounds__(1024) void gemm_skinny2_long_kernel(GemmParams p, int R) {
   constexpr int NW = 16;
   __shared__ f32x4 red[NW * 64];
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, r = lane & 15;
-  const int n0 = blockIdx.x * 16, nchunk = p.K >> 6;
-  const bf16* wp = p.B + (long)min(n0 + r, p.N - 1) * p.ldb + g * 8;
+  const int n0 = blockIdx.x * R, nchunk = p.K >> 6;
+  const bf16* wp = p.B + (long)min(n0 + min(r, R - 1), p.N - 1) * p.ldb + g * 8;
   const bf16* xp = p.A + (long)min(r, p.M - 1) * p.lda + g * 8;
   const int nrounds = ((nchunk + NW - 1) / NW + CW - 1) / CW;
   u32x4 wb[2][CW][2];
@@ -567,23 +576,24 @@ __global__ __launch_bounds__(1024) void gemm_skinny2_long_kernel(GemmParams p) {
     if (rd + 2 < nrounds) load(wb[0], xb[0], rd + 2);
     if (rd + 1 < nrounds) mm(wb[1], xb[1]);
   }
-  red[w * 64 + lane] = acc;
-  __syncthreads();
-  if (w == 0) {
-    f32x4 a = red[lane];
-#pragma unroll
-    for (int ww = 1; ww < NW; ++ww) a += red[ww * 64 + lane];
-    if (n0 < p.N) {
-      float gate = 1.f;
-      if (p.gate) gate = tanhf(bf2f(*p.gate));
-      const bool fast = ((p.N & 3) == 0) && (((p.ldc | p.ldres | p.ldaux | p.ldpre) & 3) == 0);
-      if (fast) epi_tile<true>(p, a, r, n0 + g * 4, gate);
-      else epi_tile<false>(p, a, r, n0 + g * 4, gate);
-    }
-  }
+  sk2_finish<NW>(p, red, acc, w, lane, n0, R);
 }
 
-// a fused LayerNorm: K = 64 NW CW exactly (whole 512-element segments), the gamma / beta and normalised-row images inside the CU's LDS
+// weight rows per workgroup: the busiest CU's rows = ceil(workgroups / 256) * R, smallest over R = 4 .. 16 (ties: the larger R, fewer workgroups)
+static int g_skinny2_rows = -1;
+static int skinny2_rows(int N) {
+  if (g_skinny2_rows < 0) { const char* e = getenv("UNIMP_SKINNY2_ROWS"); g_skinny2_rows = e ? atoi(e) : 0; }
+  if (g_skinny2_rows >= 1 && g_skinny2_rows <= 16) return g_skinny2_rows;          // A/B knob: 16 = the fixed tiles
+  // from two 16-row workgroups per CU on the balance no longer decides: measured, R = 10 x 1024 workgroups at N = 10 240 was 14.1 us where 16 x 640 took 13.0
+  // (18.2 against 15.7 at M = 10: every workgroup re-reads the M rows), and the head (4629 tiles) lost a quarter
+  if ((N + 15) / 16 >= 512) return 16;
+  int best = 16; long cost = -1;
+  for (int R = 16; R >= 4; --R) {
+    const long wgs = (N + R - 1) / R, c = ((wgs + 255) / 256) * R;
+    if (cost < 0 || c < cost) { cost = c; best = R; }
+  }
+  return best;
+}
 static int skinny2_ln_lds(int M, int K) { return (2 * K + M * (K + 8)) * 2; }
 static bool skinny2_ln_ok(int M, int K) {
   if (M < 1 || M > 16 || (K & 511) || K < 512 || K > 4096 || K == 3584) return false;
@@ -598,20 +608,22 @@ static bool skinny2_ok(const unimp_gemm_desc* d) {
 
 template <int NW, int CW>
 static void launch_skinny2_ln(const unimp_gemm_desc* d, GemmParams& p, hipStream_t s) {
-  using kern_t = void (*)(GemmParams);
+  using kern_t = void (*)(GemmParams, int);
   const int um = (d->M * (NW * CW / 8) + NW - 1) / NW;           // units per wave
   const int b = um <= 1 ? 0 : um <= 2 ? 1 : um <= 4 ? 2 : um <= 7 ? 3 : 4;
   static const kern_t kerns[5] = {gemm_skinny2_ln_kernel<NW, CW, 1>, gemm_skinny2_ln_kernel<NW, CW, 2>, gemm_skinny2_ln_kernel<NW, CW, 4>,
                                   gemm_skinny2_ln_kernel<NW, CW, 7>, gemm_skinny2_ln_kernel<NW, CW, NW == 16 ? 7 : 10>};   // 16 waves: never more than 7 (skinny2_ln_ok)
   static bool attr[5] = {false, false, false, false, false};
   if (!attr[b]) { (void)hipFuncSetAttribute((const void*)kerns[b], hipFuncAttributeMaxDynamicSharedMemorySize, 142 * 1024); attr[b] = true; }
-  hipLaunchKernelGGL(kerns[b], dim3((d->N + 15) / 16), dim3(64 * NW), skinny2_ln_lds(d->M, d->K), s, p);
+  const int R = skinny2_rows(d->N);
+  hipLaunchKernelGGL(kerns[b], dim3((d->N + R - 1) / R), dim3(64 * NW), skinny2_ln_lds(d->M, d->K), s, p, R);
 }
 
 static void launch_skinny2(const unimp_gemm_desc* d, GemmParams& p, void* stream) {
   const int nchunk = d->K >> 6;
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid((d->N + 15) / 16);
+  const int R = skinny2_rows(d->N);
+  dim3 grid((d->N + R - 1) / R);
   if (d->ln_gamma) {
     switch (d->K) {
       case 512: launch_skinny2_ln<8, 1>(d, p, s); break;
@@ -624,11 +636,10 @@ static void launch_skinny2(const unimp_gemm_desc* d, GemmParams& p, void* stream
     }
     return;
   }
-  if (d->K > 4096) { hipLaunchKernelGGL((gemm_skinny2_long_kernel<3>), grid, dim3(1024), 0, s, p); return; }
-  // K <= 2560: 8 waves with up to five chunks each (two workgroups per CU at <= 128 registers: 640 tiles of the up-projection meet 512 slots, not 256);
-  // beyond: 16 waves with three or four
+  if (d->K > 4096) { hipLaunchKernelGGL((gemm_skinny2_long_kernel<3>), grid, dim3(1024), 0, s, p, R); return; }
+  // K <= 2560: 8 waves with up to five chunks each (two workgroups per CU at <= 128 registers); beyond: 16 waves with three or four
   const int nw = nchunk <= 40 ? 8 : 16, cw = (nchunk + nw - 1) / nw;
-#define SK2_GO(NW_, CW_) hipLaunchKernelGGL((gemm_skinny2_kernel<NW_, CW_>), grid, dim3(64 * NW_), 0, s, p)
+#define SK2_GO(NW_, CW_) hipLaunchKernelGGL((gemm_skinny2_kernel<NW_, CW_>), grid, dim3(64 * NW_), 0, s, p, R)
   if (nw == 8) { switch (cw) { case 1: SK2_GO(8, 1); break; case 2: SK2_GO(8, 2); break; case 3: SK2_GO(8, 3); break; case 4: SK2_GO(8, 4); break; default: SK2_GO(8, 5); break; } }
   else if (cw <= 3) SK2_GO(16, 3); else SK2_GO(16, 4);
 #undef SK2_GO
