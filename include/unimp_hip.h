@@ -320,6 +320,10 @@ int unimp_swiglu_bwd(const void* gate_up, int64_t ld, const void* dout, int64_t 
 /* out[0] += sum(a*b) over n elements (fp32; out is fp32[1 + 1024]: out[0] zeroed by the caller, out[1..1025) scratch for the ordered
  * two-stage reduction -- no float atomics): d tanh-gate = dot(dy, y_pre_gate) */
 int unimp_dot_bf16(const void* a, const void* b, int64_t n, float* out, void* stream);
+/* decode (ABI 8): read `bytes` at p and discard them -- launched on a second stream beside a weight-streaming GEMM it pulls the NEXT GEMM's weights
+ * into the memory-side cache (256 MB Infinity Cache) while the launch gaps and tails of the chain leave HBM idle.  `blocks` workgroups of 256 threads
+ * (<= 0: 256); sink: any 4 writable bytes (never written in practice) or NULL. */
+int unimp_prefetch(const void* p, int64_t bytes, int blocks, void* sink, void* stream);
 /* out[r] = src[r % period] (Perceiver latents repeat "n d -> b T n d") and its adjoint out[j] = sum_{r%period==j} src[r] (bf16) */
 int unimp_bcast_rows(const void* src, void* out, int64_t ldo, int rows, int period, int D, void* stream);
 int unimp_reduce_rows_periodic(const void* src, int64_t lds_, void* out, int rows, int period, int D, void* stream);

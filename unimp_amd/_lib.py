@@ -82,6 +82,7 @@ _SIGS = {
     "unimp_swiglu_fwd": [c_p, c_l, c_p, c_l, c_i, c_i, c_p],
     "unimp_swiglu_bwd": [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_p],
     "unimp_dot_bf16": [c_p, c_p, c_l, c_p, c_p],
+    "unimp_prefetch": [c_p, c_l, c_i, c_p, c_p],
     "unimp_bcast_rows": [c_p, c_p, c_l, c_i, c_i, c_i, c_p],
     "unimp_reduce_rows_periodic": [c_p, c_l, c_p, c_i, c_i, c_i, c_p],
     "unimp_label_mask": [c_p, c_p, c_p, c_i, c_i, c_l, c_l, c_l, c_l, c_p],

@@ -276,6 +276,31 @@ extern "C" int unimp_kv_reorder_beams(void* kv, int64_t s_plane, int n_planes, i
   return unimp_check_launch("kv_reorder_beams");
 }
 
+// ------------------------------------------------------------------------------------------- decode: pull the NEXT weights into the memory-side cache
+// A decode step is a chain of weight-streaming GEMMs, each a graph node: between two of them HBM idles for the launch, the first-byte latency and the
+// tail (about 4 of 12 us at 52 MB).  This kernel, launched on a SECOND stream beside GEMM i, reads the weights of GEMM i + 1 and throws them away: the
+// 256 MB Infinity Cache (memory side: every read allocates) then holds them when GEMM i + 1 starts.  `blocks` small workgroups; sixteen 16-byte loads per
+// lane in flight.
+__global__ __launch_bounds__(256) void prefetch_kernel(const u32x4* __restrict__ p, long n16, unsigned* sink) {
+  const long stride = (long)gridDim.x * 256;
+  u32x4 acc = u32x4{0u, 0u, 0u, 0u};
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride * 8) {
+    u32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const long j = i + u * stride; v[u] = p[j < n16 ? j : i]; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc ^= v[u];
+  }
+  if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x9e3779b9u && sink) *sink = 1u;      // keeps the loads alive; practically never true
+}
+extern "C" int unimp_prefetch(const void* p, int64_t bytes, int blocks, void* sink, void* stream) {
+  if (!p || bytes < 16) return UNIMP_OK;
+  if ((uintptr_t)p & 15) return unimp_set_error(UNIMP_ERR_ALIGN, "prefetch: 16-byte aligned pointer");
+  if (blocks <= 0) blocks = 256;
+  hipLaunchKernelGGL(prefetch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u32x4*)p, (long)(bytes >> 4), (unsigned*)sink);
+  return unimp_check_launch("prefetch");
+}
+
 // ------------------------------------------------------------------------------------------- embedding
 __global__ void embedding_fwd_kernel(const int64_t* __restrict__ ids, const bf16* __restrict__ W, long ldw,
                                      const int64_t* __restrict__ pos, const bf16* __restrict__ P, long ldp,
