@@ -263,6 +263,8 @@ typedef struct {
   void* out;                       /* bf16 [rows][heads][hd] */
   int64_t o_row_stride, o_head_stride;
   float* workspace; void* arrived;
+  int group; const int32_t* shared_len;             /* beam search as in unimp_attn_decode_grouped (group <= 1: none): the keys below shared_len[g] are read
+                                                     * once per prompt, by extra workgroups of the same launch; workspace then rows*heads*2*splits*(hd+2) */
 } unimp_decode_step_desc;
 int unimp_attn_decode_step(const unimp_decode_step_desc* d, void* stream);
 /* tuning / test knob: which generation of attention kernels serves the calls above.  2 (default; env UNIMP_ATTN_GEN):

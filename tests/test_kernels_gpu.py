@@ -660,6 +660,46 @@ def test_attn_decode_step_one_launch(ops, R, nh, hd, rot, interleaved, cap, alib
     assert torch.equal(alone[0], got[r]), "a row alone and in the batch"
 
 
+@pytest.mark.parametrize("K,groups,nh,hd,rot,cap", [(10, 1, 32, 80, 80, 530), (4, 3, 8, 64, 32, 300), (16, 1, 4, 128, 0, 700), (7, 2, 12, 64, 64, 140), (2, 2, 4, 80, 80, 1100)])
+def test_attn_decode_step_grouped_beams(ops, K, groups, nh, hd, rot, cap):
+    """unimp_attn_decode_step with beam groups: the prompt's keys (identical in the K rows of a group below shared_len[g]) are read once per prompt by
+    the prefix workgroups of the same launch, the rows' own tails and the new key by the tail workgroups -- bit-identical with
+    unimp_decode_rope_append + unimp_attn_decode_grouped (same chunks, same slot order in the merge), the same cache afterwards; close to the
+    ungrouped one-launch form (another partition: fp32 rounding) ; groups sit at different prompt lengths; 1 ... 4 queries per prefix wave;
+    thirty more launches give the same bits."""
+    R, H = K * groups, nh * hd
+    g = torch.Generator().manual_seed(K * 13 + hd + cap)
+    qkv = torch.randn(R, 3 * H, generator=g).to(bf16).cuda()
+    shared = torch.tensor([cap - 60 - 17 * i for i in range(groups)], dtype=torch.int32)
+    done = torch.randint(0, 50, (groups,), generator=g)
+    pos = (shared.long() + done).repeat_interleave(K).cuda()
+    kc = torch.randn(R, cap, nh, hd, generator=g).to(bf16)
+    vc = torch.randn(R, cap, nh, hd, generator=g).to(bf16)
+    for gi in range(groups):                                  # the beams of a prompt share the prompt's K / V
+        n = int(shared[gi])
+        kc[gi * K:(gi + 1) * K, :n] = kc[gi * K, :n]
+        vc[gi * K:(gi + 1) * K, :n] = vc[gi * K, :n]
+    kc, vc, shared = kc.cuda(), vc.cuda(), shared.cuda()
+    half = rot // 2
+    cos = torch.rand(R, max(half, 1), generator=g).cuda() if rot else None
+    sin = torch.rand(R, max(half, 1), generator=g).cuda() if rot else None
+    hs, offs = 3 * hd, (0, hd, 2 * hd)
+    scale = hd ** -0.5
+    q2, k2, v2 = qkv.clone(), kc.clone(), vc.clone()
+    ops.decode_rope_append(q2, nh, hs, hd, offs, rot, cos, sin, k2, v2, pos)
+    qv = q2.view(R, 1, nh, 3 * hd)[..., :hd]
+    want = ops.attn_decode(qv, k2, v2, scale, (pos + 1).int(), None, group=K, shared_len=shared)
+    k1, v1 = kc.clone(), vc.clone()
+    got = ops.attn_decode_step(qkv, nh, hs, hd, offs, rot, cos, sin, k1, v1, pos, scale, None, K, shared)
+    torch.cuda.synchronize()
+    assert torch.equal(k1, k2) and torch.equal(v1, v2), "cache after the step"
+    assert torch.equal(got, want), "one launch vs rope_append + grouped split-key decode"
+    flat = ops.attn_decode_step(qkv, nh, hs, hd, offs, rot, cos, sin, kc.clone(), vc.clone(), pos, scale, None)
+    close(got, flat.float(), rel=2 ** -7, name="grouped vs ungrouped")
+    for _ in range(30):
+        assert torch.equal(got, ops.attn_decode_step(qkv, nh, hs, hd, offs, rot, cos, sin, k1, v1, pos, scale, None, K, shared)), "two launches differ"
+
+
 @pytest.mark.parametrize("K,groups,nh,hd", [(10, 1, 32, 80), (5, 3, 8, 64), (3, 2, 12, 64), (16, 1, 4, 128)])
 def test_kv_reorder_beams(ops, K, groups, nh, hd):
     """unimp_kv_reorder_beams against transformers' _reorder_cache as decode.py ran it before (tail.copy_(tail.index_select(2, local)) per

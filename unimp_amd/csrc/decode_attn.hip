@@ -303,8 +303,9 @@ struct DecStepP {
   const int64_t* pos_idx;                 // [rows] slot of the new token = keys visible - 1
   float scale_log2; const float* alibi;
   bf16* o; long o_bs, o_hs;
-  float* ws; unsigned* arrived;           // [rows][H][splits][D + 2]; [rows][H] arrival counters (zero between launches)
-  int splits, chunk;
+  float* ws; unsigned* arrived;           // [rows][H][nslots][D + 2]; [rows][H] arrival counters (zero between launches)
+  int splits, chunk, nslots;              // nslots = splits, or 2 splits grouped (prefix | tail)
+  int group; const int* shared_len;       // beam search: rows per prompt, int32 [rows / group] shared prefix length
 };
 
 // chunk c (8 elements) of the rotated vector at `vec` (half-split rope: pairs (i, i + half) for i < half; elements >= 2 half pass through)
@@ -336,18 +337,175 @@ __device__ __forceinline__ void sc1_wait(float (&v)[8]) {
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) :: "memory");
 }
 
-template <int G, int U>
+// the partials of (row b, head h) -> its output row: attn_decode_merge's arithmetic, eight slots at a time with all their loads in flight before one wait
+// (relaxed atomic loads are not reordered by hipcc: one memory round trip per load -- about twenty in a row for five slots)
+__device__ __forceinline__ void dec_merge_row(const DecStepP& p, int b, int h, int d) {
+  const int DS = p.D + 2;
+  const float* wsp = p.ws + ((long)b * p.H + h) * p.nslots * DS;
+  float MM = -INFINITY;
+  for (int s0 = 0; s0 < p.nslots; s0 += 8) {
+    float ms[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ms[j] = ld_sc1(wsp + min(s0 + j, p.nslots - 1) * DS);
+    sc1_wait(ms);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) MM = fmaxf(MM, ms[j]);
+  }
+  float LL = 0.f, OO = 0.f;
+  for (int s0 = 0; s0 < p.nslots; s0 += 8) {
+    float ms[8], ls[8], os[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float* q = wsp + min(s0 + j, p.nslots - 1) * DS;
+      ms[j] = ld_sc1(q); ls[j] = ld_sc1(q + 1); os[j] = ld_sc1(q + 2 + d);
+    }
+    sc1_wait(ms); sc1_wait(ls); sc1_wait(os);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (s0 + j < p.nslots) {
+        const float e = ms[j] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(ms[j] - MM);
+        LL = fmaf(e, ls[j], LL);
+        OO = fmaf(e, os[j], OO);
+      }
+    }
+  }
+  p.o[(long)b * p.o_bs + (long)h * p.o_hs + d] = f2bf(LL > 0.f ? OO / LL : 0.f);
+}
+
+// this workgroup's partial of (b, h) is in the workspace (every thread waited for its stores): count it; true for the LAST of the nslots to arrive
+__device__ __forceinline__ bool dec_arrive(const DecStepP& p, int b, int h) {
+  unsigned* cnt = p.arrived + (long)b * p.H + h;
+  const bool last = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)p.nslots - 1;
+  if (last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+  return last;
+}
+
+// GROUPED (beam search): the shared-prefix pass of attn_decode_prefix as workgroups (split, head, rows + group index) of the same launch: the keys below
+// shared_len[g] are read once per prompt, from the group's first row, for all its queries (NQ per wave, rotated here); partial slots [0, splits) of
+// every row of the group.  Its arrival counts for each of the group's rows; whatever rows it completes it merges, 256 / D rows at a time.
+template <int G, int U, int NQ>
+__device__ __forceinline__ void dec_step_prefix(const DecStepP& p, float* sm, unsigned* last_s) {
+  constexpr int KPL = 64 / G;
+  const int split = blockIdx.x, h = blockIdx.y, gi = blockIdx.z - p.rows;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int slot = lane / G, c = lane % G;
+  const bool act = c * 8 < p.D;
+  const int ca = act ? c : 0;
+  const int b0 = gi * p.group;
+  const int n = p.shared_len[gi];
+  const int k0 = split * p.chunk, k1 = min(k0 + p.chunk, n);
+  float qf[NQ][8], m[NQ], l[NQ], acc[NQ][8];
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    const int qi = min(wave + 4 * j, p.group - 1);                   // idle query slots redo the last row, never stored
+    const bf16* base = p.qkv + (long)(b0 + qi) * p.row_stride + (long)h * p.head_stride;
+    const bf16x8 qn = rope_chunk8(base + p.q_off, ca, p.half, p.cs + (long)(b0 + qi) * p.half, p.sn + (long)(b0 + qi) * p.half);
+    m[j] = -INFINITY; l[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { qf[j][i] = bf2f(qn[i]) * p.scale_log2; acc[j][i] = 0.f; }
+  }
+  const float slope = p.alibi ? p.alibi[h] * 1.4426950408889634f : 0.f;
+  const bf16* kb = p.kc + (long)b0 * p.c_row + (long)h * p.c_head + ca * 8;
+  const bf16* vb = p.vc + (long)b0 * p.c_row + (long)h * p.c_head + ca * 8;
+  for (int kk = k0; kk < k1; kk += KPL * U) {
+    u32x4 kr[U], vr[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int key = kk + u * KPL + slot;
+      const int kc_ = key < k1 ? key : k0;
+      kr[u] = *(const u32x4*)(kb + (long)kc_ * p.c_slot);
+      vr[u] = *(const u32x4*)(vb + (long)kc_ * p.c_slot);
+    }
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+      float s[U];
+      float mx = m[j];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float kf[8];
+        widen8(kr[u], kf);
+        float d = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) d = fmaf(qf[j][i], kf[i], d);
+        if (!act) d = 0.f;
+        d = group_sum<G>(d);
+        const int key = kk + u * KPL + slot;
+        s[u] = key < k1 ? d + slope * (float)key : -INFINITY;
+        mx = fmaxf(mx, s[u]);
+      }
+      if (mx > m[j]) {
+        const float r = m[j] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m[j] - mx);
+        l[j] *= r;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[j][i] *= r;
+        m[j] = mx;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float pe = s[u] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(s[u] - m[j]);
+        l[j] += pe;
+        float vf[8];
+        widen8(vr[u], vf);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[j][i] = fmaf(pe, vf[i], acc[j][i]);
+      }
+    }
+  }
+  const int DS = p.D + 2;
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    float* mine = sm + ((wave * NQ + j) * KPL + slot) * DS;
+    if (act) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) mine[2 + c * 8 + i] = acc[j][i];
+      if (c == 0) { mine[0] = m[j]; mine[1] = l[j]; }
+    }
+  }
+  __syncthreads();
+  for (int j = 0; j < NQ; ++j) {                    // attn_decode_prefix's merge of a query's KPL slots, by the wave that owns the query
+    const int qi = wave + 4 * j;
+    if (qi >= p.group) break;
+    const float* base = sm + (wave * NQ + j) * KPL * DS;
+    float* w = p.ws + (((long)(b0 + qi) * p.H + h) * p.nslots + split) * DS;
+    for (int d = lane; d < p.D; d += 64) {
+      float M = -INFINITY;
+      for (int t = 0; t < KPL; ++t) M = fmaxf(M, base[t * DS]);
+      float L = 0.f, O = 0.f;
+      for (int t = 0; t < KPL; ++t) {
+        const float mt = base[t * DS];
+        const float e = mt == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mt - M);
+        L = fmaf(e, base[t * DS + 1], L);
+        O = fmaf(e, base[t * DS + 2 + d], O);
+      }
+      st_agent(w + 2 + d, O);
+      if (d == 0) { st_agent(w, M); st_agent(w + 1, L); }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if ((int)threadIdx.x < p.group) last_s[threadIdx.x] = dec_arrive(p, b0 + threadIdx.x, h);
+  __syncthreads();
+  const int per = 256 / p.D, sub = threadIdx.x / p.D, d = threadIdx.x - sub * p.D;        // rows merged at a time (D = 80: 3)
+  for (int j0 = 0; j0 < p.group; j0 += per) {
+    const int j = j0 + sub;
+    if (sub < per && j < p.group && last_s[j]) dec_merge_row(p, b0 + j, h, d);
+  }
+}
+
+template <int G, int U, int UP, int NQ>          // U / UP: keys-in-flight factor of the tail / prefix rounds (attn_decode_partial's / attn_decode_prefix's); NQ = 0: no groups
 __global__ __launch_bounds__(256) void attn_decode_step_kernel(DecStepP p) {
   constexpr int KPL = 64 / G;
-  __shared__ float sm[4 * KPL * (128 + 2)];
-  __shared__ unsigned last_s;
+  __shared__ float sm[4 * (NQ > 1 ? NQ : 1) * KPL * (128 + 2)];
+  __shared__ unsigned last_s[16];
+  if (NQ > 0 && (int)blockIdx.z >= p.rows) { dec_step_prefix<G, UP, NQ ? NQ : 1>(p, sm, last_s); return; }
   const int split = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int slot = lane / G, c = lane % G;
   const bool act = c * 8 < p.D;
   const int ca = act ? c : 0;                       // idle lanes of a group (D = 80: chunks 10 .. 15) redo chunk 0, never beyond the row
   const int pos = (int)p.pos_idx[b], n = pos + 1;
-  const int k0 = split * p.chunk + wave * (p.chunk >> 2), k1 = min(split * p.chunk + (wave + 1) * (p.chunk >> 2), n);
+  const int ks = NQ > 0 ? min(p.shared_len[b / p.group], n) : 0;          // grouped: the keys below ks belong to the prefix workgroups
+  const int k0 = max(split * p.chunk + wave * (p.chunk >> 2), ks), k1 = min(split * p.chunk + (wave + 1) * (p.chunk >> 2), n);
   const bf16* base = p.qkv + (long)b * p.row_stride + (long)h * p.head_stride;
   const float* cr = p.cs + (long)b * p.half; const float* sr = p.sn + (long)b * p.half;
   const bf16x8 qn = rope_chunk8(base + p.q_off, ca, p.half, cr, sr);
@@ -437,53 +595,20 @@ __global__ __launch_bounds__(256) void attn_decode_step_kernel(DecStepP p) {
       O = fmaf(w, sm[j * DS + 2 + d], O);
     }
   }
-  if (p.splits == 1) {
+  if (p.nslots == 1) {
     if (d < p.D) p.o[(long)b * p.o_bs + (long)h * p.o_hs + d] = f2bf(L > 0.f ? O / L : 0.f);
     return;
   }
-  float* wsp = p.ws + ((long)b * p.H + h) * p.splits * DS;
+  float* wsp = p.ws + (((long)b * p.H + h) * p.nslots + (NQ > 0 ? p.splits : 0) + split) * DS;      // grouped: tails in slots [splits, 2 splits)
   if (d < p.D) {
-    st_agent(wsp + split * DS + 2 + d, O);
-    if (d == 0) { st_agent(wsp + split * DS, M); st_agent(wsp + split * DS + 1, L); }
+    st_agent(wsp + 2 + d, O);
+    if (d == 0) { st_agent(wsp, M); st_agent(wsp + 1, L); }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this thread's partial has reached the coherence point
   __syncthreads();
-  if (threadIdx.x == 0)
-    last_s = __hip_atomic_fetch_add(p.arrived + (long)b * p.H + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)p.splits - 1;
+  if (threadIdx.x == 0) last_s[0] = dec_arrive(p, b, h);
   __syncthreads();
-  if (!last_s) return;
-  if (threadIdx.x == 0) __hip_atomic_store(p.arrived + (long)b * p.H + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
-  if (d < p.D) {                                    // attn_decode_merge's arithmetic; the partials of eight slots at a time, all loads in flight before the first use
-    // (relaxed atomic loads are not reordered by hipcc: one memory round trip per load -- about twenty in a row here)
-    float MM = -INFINITY;
-    for (int s0 = 0; s0 < p.splits; s0 += 8) {
-      float ms[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) ms[j] = ld_sc1(wsp + min(s0 + j, p.splits - 1) * DS);
-      sc1_wait(ms);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) MM = fmaxf(MM, ms[j]);
-    }
-    float LL = 0.f, OO = 0.f;
-    for (int s0 = 0; s0 < p.splits; s0 += 8) {
-      float ms[8], ls[8], os[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float* q = wsp + min(s0 + j, p.splits - 1) * DS;
-        ms[j] = ld_sc1(q); ls[j] = ld_sc1(q + 1); os[j] = ld_sc1(q + 2 + d);
-      }
-      sc1_wait(ms); sc1_wait(ls); sc1_wait(os);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        if (s0 + j < p.splits) {
-          const float e = ms[j] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(ms[j] - MM);
-          LL = fmaf(e, ls[j], LL);
-          OO = fmaf(e, os[j], OO);
-        }
-      }
-    }
-    p.o[(long)b * p.o_bs + (long)h * p.o_hs + d] = f2bf(LL > 0.f ? OO / LL : 0.f);
-  }
+  if (last_s[0] && d < p.D) dec_merge_row(p, b, h, d);
 }
 
 extern "C" int unimp_attn_decode_step(const unimp_decode_step_desc* d, void* stream) {
@@ -499,18 +624,29 @@ extern "C" int unimp_attn_decode_step(const unimp_decode_step_desc* d, void* str
     return unimp_set_error(UNIMP_ERR_ALIGN, "attn_decode_step: strides and offsets must be multiples of 8 elements, pointers 16-byte aligned");
   if (d->capacity <= 0) return unimp_set_error(UNIMP_ERR_SHAPE, "attn_decode_step: capacity <= 0");
   const int splits = unimp_attn_decode_splits(d->rows, d->heads, d->capacity);
-  if (splits > 1 && (!d->workspace || !d->arrived)) return unimp_set_error(UNIMP_ERR_ARG, "attn_decode_step: needs the workspace (rows*heads*splits*(hd+2) floats) and the zeroed arrival counters (rows*heads)");
+  const bool grouped = d->group > 1;
+  if (grouped && (!d->shared_len || d->rows % d->group || d->group > 16)) return unimp_set_error(UNIMP_ERR_ARG, "attn_decode_step: grouped form needs shared_len, rows % group == 0 and group <= 16");
+  const int nslots = grouped ? 2 * splits : splits;
+  if (nslots > 1 && (!d->workspace || !d->arrived)) return unimp_set_error(UNIMP_ERR_ARG, "attn_decode_step: needs the workspace (rows*heads*nslots*(hd+2) floats) and the zeroed arrival counters (rows*heads)");
   DecStepP p;
   p.qkv = (const bf16*)d->qkv; p.row_stride = d->row_stride; p.head_stride = d->head_stride; p.q_off = d->q_off; p.k_off = d->k_off; p.v_off = d->v_off;
   p.rows = d->rows; p.H = d->heads; p.D = d->hd; p.half = half; p.cs = d->cos_rows; p.sn = d->sin_rows;
   p.kc = (bf16*)d->kcache; p.vc = (bf16*)d->vcache; p.c_row = d->c_row_stride; p.c_slot = d->c_slot_stride; p.c_head = d->c_head_stride;
   p.pos_idx = d->pos_idx; p.scale_log2 = d->scale * 1.4426950408889634f; p.alibi = d->alibi_slopes;
   p.o = (bf16*)d->out; p.o_bs = d->o_row_stride; p.o_hs = d->o_head_stride;
-  p.ws = d->workspace; p.arrived = (unsigned*)d->arrived; p.splits = splits; p.chunk = DEC_CHUNK;
+  p.ws = d->workspace; p.arrived = (unsigned*)d->arrived; p.splits = splits; p.chunk = DEC_CHUNK; p.nslots = nslots;
+  p.group = grouped ? d->group : 1; p.shared_len = grouped ? d->shared_len : nullptr;
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid(splits, d->heads, d->rows);
-  if (d->hd <= 64) hipLaunchKernelGGL((attn_decode_step_kernel<8, 4>), grid, dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((attn_decode_step_kernel<16, 8>), grid, dim3(256), 0, s, p);
+  dim3 grid(splits, d->heads, d->rows + (grouped ? d->rows / d->group : 0));          // tails (one per row), then the prefix workgroups (one per group)
+  const int nq = grouped ? (d->group + 3) / 4 : 0;                                    // queries per wave of a prefix workgroup
+#define STEP(G_, U_) do { switch (nq) {                                                                                  \
+    case 0: hipLaunchKernelGGL((attn_decode_step_kernel<G_, U_, 4, 0>), grid, dim3(256), 0, s, p); break;                  \
+    case 1: hipLaunchKernelGGL((attn_decode_step_kernel<G_, U_, 4, 1>), grid, dim3(256), 0, s, p); break;                  \
+    case 2: hipLaunchKernelGGL((attn_decode_step_kernel<G_, U_, 4, 2>), grid, dim3(256), 0, s, p); break;                  \
+    case 3: hipLaunchKernelGGL((attn_decode_step_kernel<G_, U_, 4, 3>), grid, dim3(256), 0, s, p); break;                  \
+    default: hipLaunchKernelGGL((attn_decode_step_kernel<G_, U_, 4, 4>), grid, dim3(256), 0, s, p); break; } } while (0)
+  if (d->hd <= 64) STEP(8, 4); else STEP(16, 8);
+#undef STEP
   return unimp_check_launch("attn_decode_step");
 }
 

@@ -686,6 +686,11 @@ DECODE_FUSED = _os.environ.get("UNIMP_DECODE_FUSED", "1") != "0"      # round 6:
 
 # the decode step's self-attention as one launch (rope + append + attention; UNIMP_DECODE_STEP_ATTN=0: rope-append, split-key partials, merge)
 DECODE_STEP_ATTN = _os.environ.get("UNIMP_DECODE_STEP_ATTN", "1") != "0"
+# beams: the shared prompt keys once per prompt inside that launch.  OFF by default: at the reference's sizes (469-token prompt, 10 beams) the prefix
+# workgroups -- 160 of them, each wave walking its 128 keys in eight rounds for three queries, the last one merging up to ten rows -- make the launch
+# 40 us where the ungrouped one takes 22 (K = 10 token-step 4.29 | 3.68 ms, profiles/r06_negative_results_decode_and_mx.txt); it pays with long
+# prompts (the ungrouped form reads the prompt's K / V once per BEAM)
+DECODE_STEP_GROUPED = _os.environ.get("UNIMP_DECODE_STEP_GROUPED", "0") != "0"
 
 
 def _ln_fusable(rows, D, rms):
@@ -822,10 +827,12 @@ def self_attn_block_cached(x, ln_w, ln_b, wqkv, bqkv, wd, bd, nh, lc, pos0, *, r
         rot = rope[2] if rope is not None else 0
         o3 = (offs[0], offs[1], (2 * hd) if interleaved else 2 * H)       # q, k, v element offsets inside a head slot (_split_qkv)
         fused = DECODE_FUSED and qk_ln is None and ops.decode_rope_append_ok(hd, rot, hs, o3, qkv, lc.k)
-        if fused and DECODE_STEP_ATTN and ops.DECODE_ATTN and hd <= 128 and not (ops.DECODE_SHARED_PREFIX and lc.owner.group > 1):
-            # the whole attention in ONE launch: rope of the new q / k, the append, every cached key (csrc/decode_attn.hip attn_decode_step_kernel)
+        if fused and DECODE_STEP_ATTN and ops.DECODE_ATTN and hd <= 128:
+            # the whole attention in ONE launch: rope of the new q / k, the append, every cached key (csrc/decode_attn.hip attn_decode_step_kernel);
+            # beam search: the prompt's keys once per prompt, by extra workgroups of the same launch
+            grp = lc.owner.group if DECODE_STEP_GROUPED else 1
             o = ops.attn_decode_step(qkv, nh, hs, hd, o3, rot, rope[0] if rot else None, rope[1] if rot else None, lc.k, lc.v, step.pos_idx,
-                                     scale, alibi)
+                                     scale, alibi, grp, lc.owner.shared_len if grp > 1 else None)
             return ops.gemm(o.view(R, H), wd, bias=bd, res=r2).view(R, 1, H)
         if fused:
             # one launch: rotate q / k (row r at its own position) and write the rotated k and v into their cache slots

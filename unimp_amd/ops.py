@@ -587,10 +587,11 @@ def kv_reorder_beams(kv, K, src_local, slot0, pos_idx, max_new):
 _DECODE_STEP_WS = {}
 
 
-def attn_decode_step(qkv2d, heads, head_stride, hd, offs, rot, cos_rows, sin_rows, kcache, vcache, pos_idx, scale, alibi=None):
+def attn_decode_step(qkv2d, heads, head_stride, hd, offs, rot, cos_rows, sin_rows, kcache, vcache, pos_idx, scale, alibi=None, group=1, shared_len=None):
     """the self-attention of a cached decode step in ONE launch (csrc/decode_attn.hip attn_decode_step_kernel): rotate the new q / k, write the
     rotated k and v to cache slot pos_idx[r], attend keys [0, pos_idx[r]] -- the bits of decode_rope_append + attn_decode.  Same arguments as
-    decode_rope_append (+ scale / ALiBi slopes); qkv2d is left unrotated.  Returns o [rows, 1, heads, hd]."""
+    decode_rope_append (+ scale / ALiBi slopes); qkv2d is left unrotated.  group > 1 with shared_len (int32 [rows // group]): beam search as in
+    attn_decode -- the keys below shared_len[g] are read once per prompt, by extra workgroups of the same launch.  Returns o [rows, 1, heads, hd]."""
     rows, cap = qkv2d.shape[0], kcache.shape[1]
     assert kcache.stride(3) == 1 and vcache.stride() == kcache.stride() and pos_idx.dtype == torch.int64 and pos_idx.is_contiguous()
     if rot:
@@ -599,9 +600,11 @@ def attn_decode_step(qkv2d, heads, head_stride, hd, offs, rot, cos_rows, sin_row
         assert alibi.dtype == torch.float32 and alibi.numel() == heads and alibi.is_contiguous()
     L = _lib.lib()
     splits = L.unimp_attn_decode_splits(rows, heads, cap)
-    key = (qkv2d.device, rows, heads, splits, hd)
+    grouped = group > 1 and shared_len is not None and rows % group == 0 and group <= 16
+    nslots = 2 * splits if grouped else splits
+    key = (qkv2d.device, rows, heads, nslots, hd)
     if key not in _DECODE_STEP_WS:          # per shape, kept: the arrival counters must be zero at the first launch and are left zero by every launch
-        _DECODE_STEP_WS[key] = (torch.empty(rows * heads * splits * (hd + 2), device=qkv2d.device, dtype=torch.float32),
+        _DECODE_STEP_WS[key] = (torch.empty(rows * heads * nslots * (hd + 2), device=qkv2d.device, dtype=torch.float32),
                                 torch.zeros(rows * heads, device=qkv2d.device, dtype=torch.int32))
     ws, arrived = _DECODE_STEP_WS[key]
     o = torch.empty((rows, 1, heads, hd), device=qkv2d.device, dtype=bf16)
@@ -615,6 +618,11 @@ def attn_decode_step(qkv2d, heads, head_stride, hd, offs, rot, cos_rows, sin_row
     d.pos_idx, d.scale, d.alibi_slopes = pos_idx.data_ptr(), scale, _p(alibi)
     d.out, d.o_row_stride, d.o_head_stride = o.data_ptr(), o.stride(0), o.stride(2)
     d.workspace, d.arrived = ws.data_ptr(), arrived.data_ptr()
+    if grouped:
+        assert shared_len.dtype == torch.int32 and shared_len.numel() == rows // group
+        d.group, d.shared_len = group, shared_len.data_ptr()
+    else:
+        d.group, d.shared_len = 1, None
     check(L.unimp_attn_decode_step(C.byref(d), _stream()), "attn_decode_step")
     return o
 
