@@ -296,6 +296,13 @@ int unimp_embedding_fwd(const int64_t* ids, const void* W, int64_t ldw, const in
                         void* out, int64_t ldo, int rows, int D, int vocab, void* stream);
 int unimp_embedding_bwd(const int64_t* ids, const void* dout, int64_t lddo, float* dW32, int64_t lddw,
                         int rows, int D, int vocab, void* stream);
+/* the same, bit-reproducible (ABI 8): the caller passes the ids SORTED (stable) and perm[t] = the row at sorted position t; the rows of an id are
+ * summed in a fixed order (row order inside segments of 64 sorted positions, the segments of a run in order) by one writer per element, no
+ * atomics.  (The atomic form's sums into a hot row -- pad, <image> -- depend on the order the adds land in: other last bits in 3 of 20 launches at
+ * the cfg2 shape.)  scratch: unimp_embedding_bwd_sorted_scratch(rows, D) floats.  The package uses this one. */
+int64_t unimp_embedding_bwd_sorted_scratch(int rows, int D);
+int unimp_embedding_bwd_sorted(const int64_t* sorted_ids, const int64_t* perm, const void* dout, int64_t lddo, float* dW32, int64_t lddw,
+                               float* scratch, int rows, int D, int vocab, void* stream);
 
 /* ---- ViT input path: conv1(k=s=P, no bias) as im2col + GEMM, class token, position embedding ------------
  * (clip.py:60-84).  patchify: pixels [N,3,Hi,Wi] (fp32 or bf16) -> cols [N*g*g][ldc] bf16, k = c*P*P+py*P+px,

@@ -73,6 +73,8 @@ _SIGS = {
     "unimp_attn_decode_splits": [c_i, c_i, c_i],
     "unimp_embedding_fwd": [c_p, c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p],
     "unimp_embedding_bwd": [c_p, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p],
+    "unimp_embedding_bwd_sorted": [c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_i, c_i, c_i, c_p],
+    "unimp_embedding_bwd_sorted_scratch": [c_i, c_i],
     "unimp_vit_patchify": [c_p, c_i, c_p, c_l, c_i, c_i, c_i, c_i, c_p],
     "unimp_vit_assemble": [c_p, c_l, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "unimp_marker": [c_i, c_p],
@@ -128,6 +130,7 @@ def lib():
         for name, args in _SIGS.items():
             fn = getattr(L, name)
             fn.argtypes, fn.restype = args, c_i
+        L.unimp_embedding_bwd_sorted_scratch.restype = c_l
         if L.unimp_abi_version() != ABI_VERSION:
             raise ImportError(f"{LIB_PATH}: ABI version {L.unimp_abi_version()}, this package binds version {ABI_VERSION} -- a stale build; "
                               "rebuild with `make -C unimp_amd/csrc`")

@@ -339,6 +339,57 @@ __global__ void embedding_bwd_kernel(const int64_t* __restrict__ ids, const bf16
   }
 }
 
+// the same WITHOUT atomics, bit-reproducible: the rows arrive sorted by id (stable: equal ids in row order; perm[t] = the row at sorted position t).
+// (With fp32 atomicAdd the order of the adds into a hot row -- the pad token, <image> -- changes from launch to launch: 3 of 20 launches of the
+// cfg2 shape gave other last bits, and a resumed run was bit-identical with the uninterrupted one only most of the time.)
+// Pass A: block (segment s of EMB_SEG sorted positions, column group) sums every piece of equal ids inside its segment in row order; a piece that
+// STARTS its run is added to dW by this block (one writer), the one piece that continues a run from the previous segment goes to partial[s].
+// Pass B: the block of the FIRST continuation segment of a run adds the partials of the run's segments in segment order.  (One block per run with a
+// serial walk was 6.2 ms at the cfg2 shape -- a 4 256-row run of <image> tokens, two dependent loads per row; the atomic form 1.3 ms.)
+#define EMB_SEG 64
+__global__ __launch_bounds__(256) void embedding_bwd_sorted_a(const int64_t* __restrict__ sid, const int64_t* __restrict__ perm, const bf16* __restrict__ dout,
+                                                              long lddo, float* __restrict__ dW, long lddw, float* __restrict__ partial, int rows, int D, int vocab) {
+  __shared__ long ps[EMB_SEG], is[EMB_SEG];
+  const int s = blockIdx.x, t0 = s * EMB_SEG, n = min(EMB_SEG, rows - t0);
+  if ((int)threadIdx.x < n) { ps[threadIdx.x] = perm[t0 + threadIdx.x]; is[threadIdx.x] = sid[t0 + threadIdx.x]; }
+  __syncthreads();
+  const int c = blockIdx.y * blockDim.x + threadIdx.x;
+  if (c >= (D >> 2)) return;
+  const bool cont0 = t0 > 0 && sid[t0 - 1] == is[0];             // the segment's first piece continues a run
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int piece0 = 0;
+  for (int t = 0; t < n; ++t) {
+    const long id = is[t];
+    const bf16x4 v = *(const bf16x4*)(dout + ps[t] * lddo + c * 4);
+    a0 += bf2f(v[0]); a1 += bf2f(v[1]); a2 += bf2f(v[2]); a3 += bf2f(v[3]);
+    if (t == n - 1 || is[t + 1] != id) {                          // the piece ends here
+      if (id >= 0 && id < vocab) {
+        float* d = (piece0 == 0 && cont0) ? partial + (long)s * D + c * 4 : dW + id * lddw + c * 4;
+        if (piece0 == 0 && cont0) { d[0] = a0; d[1] = a1; d[2] = a2; d[3] = a3; }
+        else { d[0] += a0; d[1] += a1; d[2] += a2; d[3] += a3; }
+      }
+      a0 = a1 = a2 = a3 = 0.f;
+      piece0 = t + 1;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void embedding_bwd_sorted_b(const int64_t* __restrict__ sid, float* __restrict__ dW, long lddw, const float* __restrict__ partial,
+                                                              int rows, int D, int vocab) {
+  const int s = blockIdx.x, nseg = gridDim.x;
+  const long id = sid[(long)s * EMB_SEG];
+  if (s == 0 || id < 0 || id >= vocab || sid[(long)s * EMB_SEG - 1] != id) return;                        // not a continuation
+  if (s > 1 && sid[(long)(s - 1) * EMB_SEG] == id && sid[(long)(s - 1) * EMB_SEG - 1] == id) return;      // not the FIRST continuation of its run
+  const int c = blockIdx.y * blockDim.x + threadIdx.x;
+  if (c >= (D >> 2)) return;
+  float* d = dW + id * lddw + c * 4;
+  float a0 = d[0], a1 = d[1], a2 = d[2], a3 = d[3];
+  for (int q = s; q < nseg && sid[(long)q * EMB_SEG] == id; ++q) {       // sorted: a segment that begins with id after one that ended with it continues the run
+    const float* pp = partial + (long)q * D + c * 4;
+    a0 += pp[0]; a1 += pp[1]; a2 += pp[2]; a3 += pp[3];
+  }
+  d[0] = a0; d[1] = a1; d[2] = a2; d[3] = a3;
+}
+
 extern "C" int unimp_embedding_fwd(const int64_t* ids, const void* W, int64_t ldw, const int64_t* pos, const void* P, int64_t ldp,
                                    void* out, int64_t ldo, int rows, int D, int vocab, void* stream) {
   if (!ids || !W || !out || (P && !pos)) return unimp_set_error(UNIMP_ERR_ARG, "embedding_fwd: null pointer");
@@ -358,6 +409,21 @@ extern "C" int unimp_embedding_bwd(const int64_t* ids, const void* dout, int64_t
   long total = (long)rows * (D >> 2);
   hipLaunchKernelGGL(embedding_bwd_kernel, GRID1D(total, 256), dim3(256), 0, (hipStream_t)stream, ids, (const bf16*)dout, (long)lddo,
                      dW32, (long)lddw, rows, D, vocab);
+  return unimp_check_launch("embedding_bwd");
+}
+
+extern "C" int64_t unimp_embedding_bwd_sorted_scratch(int rows, int D) {          // floats
+  return rows <= 0 ? 0 : (int64_t)((rows + EMB_SEG - 1) / EMB_SEG) * D;
+}
+extern "C" int unimp_embedding_bwd_sorted(const int64_t* sorted_ids, const int64_t* perm, const void* dout, int64_t lddo, float* dW32, int64_t lddw,
+                                          float* scratch, int rows, int D, int vocab, void* stream) {
+  if (!sorted_ids || !perm || !dout || !dW32 || !scratch) return unimp_set_error(UNIMP_ERR_ARG, "embedding_bwd_sorted: null pointer");
+  if ((D & 3) || (lddo & 3) || (lddw & 3)) return unimp_set_error(UNIMP_ERR_SHAPE, "embedding_bwd_sorted: D, ld must be multiples of 4");
+  if (rows <= 0) return UNIMP_OK;
+  dim3 grid((rows + EMB_SEG - 1) / EMB_SEG, ((D >> 2) + 255) / 256);
+  hipLaunchKernelGGL(embedding_bwd_sorted_a, grid, dim3(256), 0, (hipStream_t)stream, sorted_ids, perm, (const bf16*)dout, (long)lddo,
+                     dW32, (long)lddw, scratch, rows, D, vocab);
+  hipLaunchKernelGGL(embedding_bwd_sorted_b, grid, dim3(256), 0, (hipStream_t)stream, sorted_ids, dW32, (long)lddw, (const float*)scratch, rows, D, vocab);
   return unimp_check_launch("embedding_bwd");
 }
 

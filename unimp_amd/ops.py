@@ -794,11 +794,16 @@ def embedding_fwd(ids, W, pos=None, P=None):
 
 
 def embedding_bwd(ids, dout, vocab):
-    """dense bf16 [vocab, D] gradient of the embedding table (fp32 scatter-add, then cast)."""
+    """dense bf16 [vocab, D] gradient of the embedding table (fp32 sums in row order, then cast).  Bit-reproducible: the ids are sorted (stable)
+    and every table row is summed by one writer (csrc/elementwise.hip embedding_bwd_sorted_kernel); the fp32-atomic form it replaces gave other
+    last bits in 3 of 20 launches at the cfg2 shape (tools/check_embedding_bwd_determinism.py)."""
     rows, D = dout.shape
     acc = torch.zeros((vocab, D), dtype=torch.float32, device=dout.device)
-    check(_lib.lib().unimp_embedding_bwd(ids.data_ptr(), dout.data_ptr(), dout.stride(0), acc.data_ptr(), D, rows, D, vocab,
-                                          _stream()), "embedding_bwd")
+    sid, perm = torch.sort(ids.reshape(-1), stable=True)
+    L = _lib.lib()
+    scratch = torch.empty(max(1, L.unimp_embedding_bwd_sorted_scratch(rows, D)), dtype=torch.float32, device=dout.device)
+    check(L.unimp_embedding_bwd_sorted(sid.data_ptr(), perm.data_ptr(), dout.data_ptr(), dout.stride(0), acc.data_ptr(), D, scratch.data_ptr(), rows, D,
+                                       vocab, _stream()), "embedding_bwd")
     return cast_bf16(acc)
 
 
