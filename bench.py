@@ -459,7 +459,7 @@ def decode_leg(model, layout, dev, T=8, L=512):
     out["frac"] = out["eval_img_gen_greedy_600new"]["frac"]
     out["note"] = ("bound = hbm: a token-step multiplies M <= 10 rows with every weight once; bytes_per_step = weights streamed + cached K / V read (mid-decode) -- algorithmic bytes, "
                    "not a counter; frac = bytes_per_step / ms_per_step_decode_only / 8 TB/s (frac_whole_call: against ms_per_token_step, which also pays the vision encoder, the "
-                   "prefill and the host's beam bookkeeping).  Kernels: gemm.hip skinny2 (persistent weight stream, LayerNorm fused), decode_attn.hip, one HIP graph per step")
+                   "prefill and the host's beam bookkeeping).  Kernels: gemm.hip skinny2 (every load of a wave in flight before its first wait, LayerNorm fused, weight rows per workgroup by N), decode_attn.hip attn_decode_step_kernel (rope + cache append + split-key attention + merge in one launch), one HIP graph per step")
     return out
 
 
