@@ -450,17 +450,21 @@ __device__ __forceinline__ float sk2_wave_sum(float v) {       // fixed order; t
   return (a + b) + (c + d);
 }
 
-template <int NW, int CW, int UM>
+// NT = 2: the workgroup serves TWO tiles of R weight rows with one normalisation (the second tile's weights are issued when the units are dead, i.e.
+// behind the normalisation, and fly under the first tile's MFMAs): at M = 10 the normalisation is 7 units per wave, about 1 000 VALU instructions in
+// each of 640 workgroups -- as much VALU time as the launch has -- and every workgroup re-reads the M rows; 2 x 10 rows x 512 workgroups is also the
+// balanced split of N = 10 240 over 256 CUs (40 rows each; 16-row tiles: 48 on the busiest).
+template <int NW, int CW, int UM, int NT>
 __global__ __launch_bounds__(64 * NW) void gemm_skinny2_ln_kernel(GemmParams p, int R) {
   constexpr int S = NW * CW / 8, K = 64 * NW * CW, LDX = K + 8;         // segments per row; the row pitch in LDS shifts consecutive rows by four banks
-  __shared__ f32x4 red[NW * 64];
+  __shared__ f32x4 red[NT][NW * 64];
   __shared__ float stat[2][16][8];
   extern __shared__ __attribute__((aligned(16))) char sk_smem[];
   bf16* gbs = (bf16*)sk_smem;                 // gamma [K], beta [K]
   bf16* xs = gbs + 2 * K;                     // the normalised rows [M][LDX]
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, r = lane & 15;
-  const int n0 = blockIdx.x * R, nunits = p.M * S;
+  const int n0 = blockIdx.x * (NT * R), nunits = p.M * S;
   const bf16* wp = p.B + (long)min(n0 + min(r, R - 1), p.N - 1) * p.ldb + g * 8;
   bf16x8 xu[UM];
   int urow[UM], useg[UM];
@@ -474,12 +478,12 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny2_ln_kernel(GemmParams p, 
   bf16x8 gmr = *(const bf16x8*)(p.ln_gamma + gbi);
   bf16x8 btr = *(const bf16x8*)((p.ln_beta ? p.ln_beta : p.ln_gamma) + gbi);
   __builtin_amdgcn_sched_barrier(0);          // the loads above stay above the weight loads
-  u32x4 wv[CW][2];
+  u32x4 wv[NT][CW][2];
 #pragma unroll
   for (int u = 0; u < CW; ++u) {
     const long c = w + NW * u;
-    wv[u][0] = sk2_ldw(wp + c * 64);
-    wv[u][1] = sk2_ldw(wp + c * 64 + 32);
+    wv[0][u][0] = sk2_ldw(wp + c * 64);
+    wv[0][u][1] = sk2_ldw(wp + c * 64 + 32);
   }
   __builtin_amdgcn_sched_barrier(0);
   const bf16x8 z8 = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
@@ -522,17 +526,43 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny2_ln_kernel(GemmParams p, 
     for (int j = 0; j < 8; ++j) o[j] = f2bf((bf2f(xu[i][j]) - mu[i]) * rs * bf2f(gm[j]) + bf2f(bt[j]));
     *(bf16x8*)(xs + urow[i] * LDX + ko) = o;
   }
+  if (NT > 1) {                                 // the second tile's weights: the units are dead, the registers are free
+    const bf16* wp1 = p.B + (long)min(n0 + R + min(r, R - 1), p.N - 1) * p.ldb + g * 8;
+#pragma unroll
+    for (int u = 0; u < CW; ++u) {
+      const long c = w + NW * u;
+      wv[NT - 1][u][0] = sk2_ldw(wp1 + c * 64);
+      wv[NT - 1][u][1] = sk2_ldw(wp1 + c * 64 + 32);
+    }
+  }
   SK2_LDS_BARRIER();
   const bf16* xr = xs + min(r, p.M - 1) * LDX + g * 8;
-  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int u = 0; u < CW; ++u) {
-    const int c = w + NW * u;
-    const bf16x8 x0 = *(const bf16x8*)(xr + c * 64), x1 = *(const bf16x8*)(xr + c * 64 + 32);
-    acc = MFMA16(wv[u][0], x0, acc);
-    acc = MFMA16(wv[u][1], x1, acc);
+  for (int t = 0; t < NT; ++t) {
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < CW; ++u) {
+      const int c = w + NW * u;
+      const bf16x8 x0 = *(const bf16x8*)(xr + c * 64), x1 = *(const bf16x8*)(xr + c * 64 + 32);
+      acc = MFMA16(wv[t][u][0], x0, acc);
+      acc = MFMA16(wv[t][u][1], x1, acc);
+    }
+    red[t][w * 64 + lane] = acc;
   }
-  sk2_finish<NW>(p, red, acc, w, lane, n0, R);
+  __syncthreads();
+  if (w < NT && n0 + w * R < p.N) {             // wave t finishes tile t
+    f32x4 a = red[w][lane];
+#pragma unroll 4
+    for (int ww = 1; ww < NW; ++ww) a += red[w][ww * 64 + lane];
+    const int nt0 = n0 + w * R;
+    float gate = 1.f;
+    if (p.gate) gate = tanhf(bf2f(*p.gate));
+    GemmParams q = p;
+    q.N = min(p.N, nt0 + R);                      // epi_tile's column bound
+    const bool fast = ((q.N & 3) == 0) && ((R & 3) == 0) && (((p.ldc | p.ldres | p.ldaux | p.ldpre) & 3) == 0);
+    if (fast) epi_tile<true>(q, a, r, nt0 + g * 4, gate);
+    else epi_tile<false>(q, a, r, nt0 + g * 4, gate);
+  }
 }
 
 // the same for a LONG contraction (K > 4096, no LayerNorm: the down-projections, K = 10 240 / 16 384): 16 waves, rounds of CW chunks per wave with the
@@ -579,26 +609,33 @@ __global__ __launch_bounds__(1024) void gemm_skinny2_long_kernel(GemmParams p, i
   sk2_finish<NW>(p, red, acc, w, lane, n0, R);
 }
 
-// weight rows per workgroup: the busiest CU's rows = ceil(workgroups / 256) * R, smallest over R = 4 .. 16 (ties: the larger R, fewer workgroups)
+// weight rows per workgroup: the busiest CU's rows = ceil(workgroups / 256) * rows per workgroup, smallest over R = 4 .. 16 (x NT tiles where the kernel
+// has a two-tile form); ties: the larger workgroup
 static int g_skinny2_rows = -1;
-static int skinny2_rows(int N) {
+static int skinny2_rows(int N, int max_nt, int* nt_out) {
+  if (nt_out) *nt_out = 1;
   if (g_skinny2_rows < 0) { const char* e = getenv("UNIMP_SKINNY2_ROWS"); g_skinny2_rows = e ? atoi(e) : 0; }
-  if (g_skinny2_rows >= 1 && g_skinny2_rows <= 16) return g_skinny2_rows;          // A/B knob: 16 = the fixed tiles
-  // from two 16-row workgroups per CU on the balance no longer decides: measured, R = 10 x 1024 workgroups at N = 10 240 was 14.1 us where 16 x 640 took 13.0
-  // (18.2 against 15.7 at M = 10: every workgroup re-reads the M rows), and the head (4629 tiles) lost a quarter
-  if ((N + 15) / 16 >= 512) return 16;
-  int best = 16; long cost = -1;
-  for (int R = 16; R >= 4; --R) {
-    const long wgs = (N + R - 1) / R, c = ((wgs + 255) / 256) * R;
-    if (cost < 0 || c < cost) { cost = c; best = R; }
-  }
+  if (g_skinny2_rows >= 1 && g_skinny2_rows <= 16) return g_skinny2_rows;          // A/B knob: 16 = the fixed tiles, one per workgroup
+  // from two 16-row workgroups per CU on the balance no longer decides with ONE tile per workgroup: measured, R = 10 x 1024 workgroups at N = 10 240 was
+  // 14.1 us where 16 x 640 took 13.0 (18.2 against 15.7 at M = 10: every workgroup re-reads the M rows), and the head (4629 tiles) lost a quarter.
+  // Two tiles per workgroup keep the count down: searched up to 2048 tiles.
+  const int tiles16 = (N + 15) / 16;
+  if (tiles16 >= (max_nt > 1 ? 2048 : 512)) return 16;
+  int best = 16, best_nt = 1; long cost = -1;
+  for (int nt = 1; nt <= max_nt; ++nt)          // ties: one tile
+    for (int R = 16; R >= 4; --R) {
+      if (nt == 1 && tiles16 >= 512 && R < 16) continue;         // the one-tile rule stops at 512 tiles (above)
+      const long wgs = (N + nt * R - 1) / (nt * R), c = ((wgs + 255) / 256) * nt * R;
+      if (cost < 0 || c < cost) { cost = c; best = R; best_nt = nt; }
+    }
+  if (nt_out) *nt_out = best_nt;
   return best;
 }
 static int skinny2_ln_lds(int M, int K) { return (2 * K + M * (K + 8)) * 2; }
 static bool skinny2_ln_ok(int M, int K) {
   if (M < 1 || M > 16 || (K & 511) || K < 512 || K > 4096 || K == 3584) return false;
   if (K > 2560 && (M * (K >> 9) + 15) / 16 > 7) return false;        // 16 waves of 128 registers: seven units per wave at most (K = 4096, M = 15, 16)
-  return skinny2_ln_lds(M, K) + 16 * 1024 + 1024 + 1024 <= 160 * 1024;
+  return skinny2_ln_lds(M, K) + 2 * 16 * 1024 + 1024 + 1024 <= 160 * 1024;        // + the two reduction tiles of the two-tile form
 }
 static bool skinny2_ok(const unimp_gemm_desc* d) {
   // M <= 16 decode rows, k-contiguous operands, whole 64-k chunks
@@ -606,33 +643,43 @@ static bool skinny2_ok(const unimp_gemm_desc* d) {
   return !d->ln_gamma || skinny2_ln_ok(d->M, d->K);
 }
 
-template <int NW, int CW>
-static void launch_skinny2_ln(const unimp_gemm_desc* d, GemmParams& p, hipStream_t s) {
+template <int NW, int CW, int NT>
+static void launch_skinny2_ln_nt(const unimp_gemm_desc* d, GemmParams& p, hipStream_t s, int R) {
   using kern_t = void (*)(GemmParams, int);
   const int um = (d->M * (NW * CW / 8) + NW - 1) / NW;           // units per wave
   const int b = um <= 1 ? 0 : um <= 2 ? 1 : um <= 4 ? 2 : um <= 7 ? 3 : 4;
-  static const kern_t kerns[5] = {gemm_skinny2_ln_kernel<NW, CW, 1>, gemm_skinny2_ln_kernel<NW, CW, 2>, gemm_skinny2_ln_kernel<NW, CW, 4>,
-                                  gemm_skinny2_ln_kernel<NW, CW, 7>, gemm_skinny2_ln_kernel<NW, CW, NW == 16 ? 7 : 10>};   // 16 waves: never more than 7 (skinny2_ln_ok)
+  static const kern_t kerns[5] = {gemm_skinny2_ln_kernel<NW, CW, 1, NT>, gemm_skinny2_ln_kernel<NW, CW, 2, NT>, gemm_skinny2_ln_kernel<NW, CW, 4, NT>,
+                                  gemm_skinny2_ln_kernel<NW, CW, 7, NT>, gemm_skinny2_ln_kernel<NW, CW, NW == 16 ? 7 : 10, NT>};   // 16 waves: never more than 7 (skinny2_ln_ok)
   static bool attr[5] = {false, false, false, false, false};
-  if (!attr[b]) { (void)hipFuncSetAttribute((const void*)kerns[b], hipFuncAttributeMaxDynamicSharedMemorySize, 142 * 1024); attr[b] = true; }
-  const int R = skinny2_rows(d->N);
-  hipLaunchKernelGGL(kerns[b], dim3((d->N + R - 1) / R), dim3(64 * NW), skinny2_ln_lds(d->M, d->K), s, p, R);
+  if (!attr[b]) { (void)hipFuncSetAttribute((const void*)kerns[b], hipFuncAttributeMaxDynamicSharedMemorySize, 142 * 1024 - (NT - 1) * NW * 1024); attr[b] = true; }
+  hipLaunchKernelGGL(kerns[b], dim3((d->N + NT * R - 1) / (NT * R)), dim3(64 * NW), skinny2_ln_lds(d->M, d->K), s, p, R);
+}
+template <int NW, int CW, bool TWO>
+static void launch_skinny2_ln(const unimp_gemm_desc* d, GemmParams& p, hipStream_t s) {
+  int nt = 1;
+  static int max_nt = -1;
+  if (max_nt < 0) { const char* e = getenv("UNIMP_SKINNY2_NT"); max_nt = e ? atoi(e) : 2; }          // A/B knob: 1 = one tile per workgroup
+  // two tiles only where the normalisation weighs (M >= 4 rows): at M = 1 it is one unit per wave and the two-tile form measured 1 % slower in the
+  // greedy token-step (2.476 | 2.453 ms, alternating) while K = 10 gained 4 % (3.55 | 3.71)
+  const int R = skinny2_rows(d->N, TWO && max_nt >= 2 && d->M >= 4 ? 2 : 1, &nt);
+  if (TWO && nt == 2) launch_skinny2_ln_nt<NW, CW, TWO ? 2 : 1>(d, p, s, R);
+  else launch_skinny2_ln_nt<NW, CW, 1>(d, p, s, R);
 }
 
 static void launch_skinny2(const unimp_gemm_desc* d, GemmParams& p, void* stream) {
   const int nchunk = d->K >> 6;
   hipStream_t s = (hipStream_t)stream;
-  const int R = skinny2_rows(d->N);
+  const int R = skinny2_rows(d->N, 1, nullptr);
   dim3 grid((d->N + R - 1) / R);
   if (d->ln_gamma) {
     switch (d->K) {
-      case 512: launch_skinny2_ln<8, 1>(d, p, s); break;
-      case 1024: launch_skinny2_ln<8, 2>(d, p, s); break;
-      case 1536: launch_skinny2_ln<8, 3>(d, p, s); break;
-      case 2048: launch_skinny2_ln<8, 4>(d, p, s); break;
-      case 2560: launch_skinny2_ln<8, 5>(d, p, s); break;
-      case 3072: launch_skinny2_ln<16, 3>(d, p, s); break;
-      default: launch_skinny2_ln<16, 4>(d, p, s); break;          // 4096
+      case 512: launch_skinny2_ln<8, 1, false>(d, p, s); break;
+      case 1024: launch_skinny2_ln<8, 2, false>(d, p, s); break;
+      case 1536: launch_skinny2_ln<8, 3, false>(d, p, s); break;
+      case 2048: launch_skinny2_ln<8, 4, false>(d, p, s); break;
+      case 2560: launch_skinny2_ln<8, 5, true>(d, p, s); break;          // two-tile forms for the cfg2 / cfg5 widths
+      case 3072: launch_skinny2_ln<16, 3, false>(d, p, s); break;
+      default: launch_skinny2_ln<16, 4, true>(d, p, s); break;           // 4096
     }
     return;
   }
