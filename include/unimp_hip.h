@@ -264,9 +264,11 @@ typedef struct {
   int64_t o_row_stride, o_head_stride;
   float* workspace; void* arrived;
   int group; const int32_t* shared_len;             /* beam search as in unimp_attn_decode_grouped (group <= 1: none): the keys below shared_len[g] are read
-                                                     * once per prompt, by extra workgroups of the same launch; workspace then rows*heads*2*splits*(hd+2) */
+                                                     * once per prompt, in chunks of 32 keys by extra workgroups of the same launch (workspace:
+                                                     * unimp_attn_decode_step_slots) */
 } unimp_decode_step_desc;
 int unimp_attn_decode_step(const unimp_decode_step_desc* d, void* stream);
+int unimp_attn_decode_step_slots(int rows, int heads, int capacity, int group);      /* partial slots per (row, head): workspace = slots * rows*heads*(hd+2) floats */
 /* tuning / test knob: which generation of attention kernels serves the calls above.  2 (default; env UNIMP_ATTN_GEN):
  * the 32x32x16-MFMA / LDS-DMA kernels of attention2.hip for the forward and dQ; dK/dV by attention3.hip (64 keys per wave, one
  * wave per SIMD) where it serves the form -- head dim 80, causal / no mask, Sq and Sk multiples of 32, padded rows, a (batch,

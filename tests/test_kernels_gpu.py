@@ -662,15 +662,16 @@ def test_attn_decode_step_one_launch(ops, R, nh, hd, rot, interleaved, cap, alib
 
 @pytest.mark.parametrize("K,groups,nh,hd,rot,cap", [(10, 1, 32, 80, 80, 530), (4, 3, 8, 64, 32, 300), (16, 1, 4, 128, 0, 700), (7, 2, 12, 64, 64, 140), (2, 2, 4, 80, 80, 1100)])
 def test_attn_decode_step_grouped_beams(ops, K, groups, nh, hd, rot, cap):
-    """unimp_attn_decode_step with beam groups: the prompt's keys (identical in the K rows of a group below shared_len[g]) are read once per prompt by
-    the prefix workgroups of the same launch, the rows' own tails and the new key by the tail workgroups -- bit-identical with
-    unimp_decode_rope_append + unimp_attn_decode_grouped (same chunks, same slot order in the merge), the same cache afterwards; close to the
-    ungrouped one-launch form (another partition: fp32 rounding) ; groups sit at different prompt lengths; 1 ... 4 queries per prefix wave;
-    thirty more launches give the same bits."""
+    """unimp_attn_decode_step with beam groups: the prompt's keys (identical in the K rows of a group below shared_len[g]) are read once per prompt, in
+    chunks of 32 keys by the prefix workgroups of the same launch; the rows' own tails and the new key by the tail workgroups; a row's arrival target
+    is the number of workgroups that hold keys of it (derived from shared_len / pos on the device: empty workgroups neither publish nor arrive).
+    Against the ungrouped one-launch form on the same operands (another partition of the keys: fp32 rounding) and fp32 math; the same cache
+    afterwards, bit for bit; groups sit at different prompt lengths incl. one that ends on a chunk boundary; tails that cross a 128-key boundary;
+    1 ... 4 queries per prefix wave; thirty more launches give the same bits."""
     R, H = K * groups, nh * hd
     g = torch.Generator().manual_seed(K * 13 + hd + cap)
     qkv = torch.randn(R, 3 * H, generator=g).to(bf16).cuda()
-    shared = torch.tensor([cap - 60 - 17 * i for i in range(groups)], dtype=torch.int32)
+    shared = torch.tensor([(cap - 60 - 17 * i) // (32 if i == 1 else 1) * (32 if i == 1 else 1) for i in range(groups)], dtype=torch.int32)
     done = torch.randint(0, 50, (groups,), generator=g)
     pos = (shared.long() + done).repeat_interleave(K).cuda()
     kc = torch.randn(R, cap, nh, hd, generator=g).to(bf16)
@@ -685,17 +686,20 @@ def test_attn_decode_step_grouped_beams(ops, K, groups, nh, hd, rot, cap):
     sin = torch.rand(R, max(half, 1), generator=g).cuda() if rot else None
     hs, offs = 3 * hd, (0, hd, 2 * hd)
     scale = hd ** -0.5
-    q2, k2, v2 = qkv.clone(), kc.clone(), vc.clone()
-    ops.decode_rope_append(q2, nh, hs, hd, offs, rot, cos, sin, k2, v2, pos)
-    qv = q2.view(R, 1, nh, 3 * hd)[..., :hd]
-    want = ops.attn_decode(qv, k2, v2, scale, (pos + 1).int(), None, group=K, shared_len=shared)
+    k2, v2 = kc.clone(), vc.clone()
+    flat = ops.attn_decode_step(qkv, nh, hs, hd, offs, rot, cos, sin, k2, v2, pos, scale, None)
     k1, v1 = kc.clone(), vc.clone()
     got = ops.attn_decode_step(qkv, nh, hs, hd, offs, rot, cos, sin, k1, v1, pos, scale, None, K, shared)
     torch.cuda.synchronize()
     assert torch.equal(k1, k2) and torch.equal(v1, v2), "cache after the step"
-    assert torch.equal(got, want), "one launch vs rope_append + grouped split-key decode"
-    flat = ops.attn_decode_step(qkv, nh, hs, hd, offs, rot, cos, sin, kc.clone(), vc.clone(), pos, scale, None)
     close(got, flat.float(), rel=2 ** -7, name="grouped vs ungrouped")
+    q2 = qkv.clone()
+    ops.decode_rope_append(q2, nh, hs, hd, offs, rot, cos, sin, kc.clone(), vc.clone(), pos)
+    qf, kf, vf = q2.view(R, nh, 3 * hd)[..., :hd].float(), k1.float(), v1.float()
+    for r in range(R):
+        n = int(pos[r]) + 1
+        sc = torch.einsum("hd,khd->hk", qf[r], kf[r, :n]) * scale
+        close(got[r, 0], torch.einsum("hk,khd->hd", torch.softmax(sc, -1), vf[r, :n]), name=f"row {r} vs fp32")
     for _ in range(30):
         assert torch.equal(got, ops.attn_decode_step(qkv, nh, hs, hd, offs, rot, cos, sin, k1, v1, pos, scale, None, K, shared)), "two launches differ"
 

@@ -66,6 +66,7 @@ _SIGS = {
     "unimp_decode_rope_append": [c_p, c_l, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_p, c_p],
     "unimp_kv_reorder_beams": [c_p, c_l, c_i, c_l, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p],
     "unimp_attn_decode_step": [C.POINTER(DecodeStepDesc), c_p],
+    "unimp_attn_decode_step_slots": [c_i, c_i, c_i, c_i],
     "unimp_attn_fwd": [C.POINTER(AttnDesc), c_p],
     "unimp_attn_bwd": [C.POINTER(AttnDesc), c_p],
     "unimp_attn_decode": [C.POINTER(AttnDesc), c_p, c_i, c_p],

@@ -304,9 +304,26 @@ struct DecStepP {
   float scale_log2; const float* alibi;
   bf16* o; long o_bs, o_hs;
   float* ws; unsigned* arrived;           // [rows][H][nslots][D + 2]; [rows][H] arrival counters (zero between launches)
-  int splits, chunk, nslots;              // nslots = splits, or 2 splits grouped (prefix | tail)
+  int splits, chunk, nslots;              // nslots = splits; grouped: psplits prefix slots (pchunk keys each) + splits tail slots
   int group; const int* shared_len;       // beam search: rows per prompt, int32 [rows / group] shared prefix length
+  int psplits, pchunk;
 };
+
+// grouped: which slots of row b hold a partial in this launch -- the prefix chunks below its group's shared length and the tail chunks that meet
+// [shared length, pos]; every workgroup of the row derives the same count from shared_len / pos_idx, so empty workgroups neither publish nor arrive
+struct DecSlots { int pv, t_lo, nv; };           // prefix slots [0, pv), tail slots psplits + t_lo ..., nv in all
+__device__ __forceinline__ DecSlots dec_slots(const DecStepP& p, int b) {
+  DecSlots v;
+  if (p.group <= 1) { v.pv = 0; v.t_lo = 0; v.nv = p.splits; return v; }
+  const int pos = (int)p.pos_idx[b], ks = min(p.shared_len[b / p.group], pos);
+  v.pv = (ks + p.pchunk - 1) / p.pchunk;
+  v.t_lo = ks / p.chunk;
+  v.nv = v.pv + pos / p.chunk - v.t_lo + 1;
+  return v;
+}
+__device__ __forceinline__ int dec_slot_of(const DecStepP& p, const DecSlots& v, int i) {      // i-th valid slot -> workspace slot
+  return p.group <= 1 ? i : (i < v.pv ? i : p.psplits + v.t_lo + (i - v.pv));
+}
 
 // chunk c (8 elements) of the rotated vector at `vec` (half-split rope: pairs (i, i + half) for i < half; elements >= 2 half pass through)
 __device__ __forceinline__ bf16x8 rope_chunk8(const bf16* vec, int c, int half, const float* cr, const float* sr) {
@@ -332,7 +349,9 @@ __device__ __forceinline__ void st_agent(float* q, float v) { __hip_atomic_store
 __device__ __forceinline__ float ld_agent(const float* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // an agent-scope load the compiler does not serialise: the caller waits once for a batch (sc1_wait names the registers, so no use moves above the wait)
-__device__ __forceinline__ float ld_sc1(const float* q) { float v; asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v) : "v"(q) : "memory"); return v; }
+// (no memory clobber on the load itself: with one, everything the address needs from LDS is re-read in front of EVERY load -- 64 loads of a merge batch
+// became 64 LDS round trips; volatile keeps the loads behind the arrival atomic and in order, the wait below carries the clobber)
+__device__ __forceinline__ float ld_sc1(const float* q) { float v; asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v) : "v"(q)); return v; }
 __device__ __forceinline__ void sc1_wait(float (&v)[8]) {
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) :: "memory");
 }
@@ -342,27 +361,28 @@ __device__ __forceinline__ void sc1_wait(float (&v)[8]) {
 __device__ __forceinline__ void dec_merge_row(const DecStepP& p, int b, int h, int d) {
   const int DS = p.D + 2;
   const float* wsp = p.ws + ((long)b * p.H + h) * p.nslots * DS;
+  const DecSlots sl = dec_slots(p, b);
   float MM = -INFINITY;
-  for (int s0 = 0; s0 < p.nslots; s0 += 8) {
+  for (int s0 = 0; s0 < sl.nv; s0 += 8) {
     float ms[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) ms[j] = ld_sc1(wsp + min(s0 + j, p.nslots - 1) * DS);
+    for (int j = 0; j < 8; ++j) ms[j] = ld_sc1(wsp + dec_slot_of(p, sl, min(s0 + j, sl.nv - 1)) * DS);
     sc1_wait(ms);
 #pragma unroll
     for (int j = 0; j < 8; ++j) MM = fmaxf(MM, ms[j]);
   }
   float LL = 0.f, OO = 0.f;
-  for (int s0 = 0; s0 < p.nslots; s0 += 8) {
+  for (int s0 = 0; s0 < sl.nv; s0 += 8) {
     float ms[8], ls[8], os[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float* q = wsp + min(s0 + j, p.nslots - 1) * DS;
+      const float* q = wsp + dec_slot_of(p, sl, min(s0 + j, sl.nv - 1)) * DS;
       ms[j] = ld_sc1(q); ls[j] = ld_sc1(q + 1); os[j] = ld_sc1(q + 2 + d);
     }
     sc1_wait(ms); sc1_wait(ls); sc1_wait(os);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      if (s0 + j < p.nslots) {
+      if (s0 + j < sl.nv) {
         const float e = ms[j] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(ms[j] - MM);
         LL = fmaf(e, ls[j], LL);
         OO = fmaf(e, os[j], OO);
@@ -375,25 +395,120 @@ __device__ __forceinline__ void dec_merge_row(const DecStepP& p, int b, int h, i
 // this workgroup's partial of (b, h) is in the workspace (every thread waited for its stores): count it; true for the LAST of the nslots to arrive
 __device__ __forceinline__ bool dec_arrive(const DecStepP& p, int b, int h) {
   unsigned* cnt = p.arrived + (long)b * p.H + h;
-  const bool last = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)p.nslots - 1;
+  const bool last = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)dec_slots(p, b).nv - 1;
   if (last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
   return last;
 }
 
-// GROUPED (beam search): the shared-prefix pass of attn_decode_prefix as workgroups (split, head, rows + group index) of the same launch: the keys below
-// shared_len[g] are read once per prompt, from the group's first row, for all its queries (NQ per wave, rotated here); partial slots [0, splits) of
-// every row of the group.  Its arrival counts for each of the group's rows; whatever rows it completes it merges, 256 / D rows at a time.
+// grouped: merge every row of the group that this workgroup completed (flags[j]), all 256 threads together, in TWO memory round trips whatever the
+// number of rows: (1) the (m, l) of every valid slot of those rows -> LDS, softmax weights per slot there; (2) the o values: a thread owns up to four
+// (row, dim) pairs and has all their slots' loads in flight before one wait.  (Row after row through dec_merge_row the last prefix workgroup of a head --
+// it completes ALL rows of its group at once -- spent 4 x 7 us here.)  sm: >= 2 * 16 * DEC_MAXNV floats, free at this point.
+#define DEC_MAXNV 64
+__device__ __forceinline__ void dec_merge_group(const DecStepP& p, int b0, int h, const unsigned* flags, float* sm) {
+  const int DS = p.D + 2, tid = threadIdx.x;
+  float* gm = sm; float* gl = sm + 16 * DEC_MAXNV;
+  // the rows' slot lists ONCE, in LDS: dec_slots() reads pos_idx / shared_len from memory, and behind the asm memory clobbers of the sc1 loads hipcc
+  // reloads them at every call -- a dozen dependent round trips per merge, 40 us per launch
+  __shared__ int s_pv[16], s_tlo[16], s_nv[16];
+  if (tid < 16) {
+    DecSlots sl; sl.pv = 0; sl.t_lo = 0; sl.nv = 0;
+    if (tid < p.group && flags[tid]) sl = dec_slots(p, b0 + tid);
+    s_pv[tid] = sl.pv; s_tlo[tid] = sl.t_lo; s_nv[tid] = sl.nv;       // nv = 0: the row is not ours
+  }
+  __syncthreads();
+  {
+    float mv[4], lv[4];
+    int jj[4], pv[4], tl[4], nn[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { jj[u] = (tid + 256 * u) / DEC_MAXNV; pv[u] = s_pv[jj[u]]; tl[u] = s_tlo[jj[u]]; nn[u] = s_nv[jj[u]]; }      // rows beyond the group: nv = 0
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {                    // 16 rows x 64 slots = 1024 (row, slot) pairs over 256 threads
+      const int i = (tid + 256 * u) % DEC_MAXNV;
+      mv[u] = -INFINITY; lv[u] = 0.f;
+      if (i < nn[u]) {
+        const float* q = p.ws + (((long)(b0 + jj[u]) * p.H + h) * p.nslots + (i < pv[u] ? i : p.psplits + tl[u] + (i - pv[u]))) * DS;
+        mv[u] = ld_sc1(q); lv[u] = ld_sc1(q + 1);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(mv[0]), "+v"(mv[1]), "+v"(mv[2]), "+v"(mv[3]), "+v"(lv[0]), "+v"(lv[1]), "+v"(lv[2]), "+v"(lv[3]) :: "memory");
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { gm[tid + 256 * u] = mv[u]; gl[tid + 256 * u] = lv[u]; }
+  }
+  __syncthreads();
+  if (tid < 16 && s_nv[tid] > 0) {                   // softmax weights of the row's slots (slot order), their sum in gl[row][0]
+    const int nv = s_nv[tid];
+    float* m = gm + tid * DEC_MAXNV; float* l = gl + tid * DEC_MAXNV;
+    float MM = -INFINITY;
+    for (int i = 0; i < nv; ++i) MM = fmaxf(MM, m[i]);
+    float LL = 0.f;
+    for (int i = 0; i < nv; ++i) { const float e = m[i] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m[i] - MM); m[i] = e; LL = fmaf(e, l[i], LL); }
+    l[0] = LL;
+  }
+  __syncthreads();
+  // the o values: loads without a branch around them (a load inside `if (slot < nv)` costs twenty instructions of exec-mask handling: 64 of them per
+  // batch were 3 us of issue) -- slots beyond the row's count re-read its last one and are dropped by a select
+  constexpr int SB = 24;
+  float os[4][SB];
+  for (int tb = 0; tb < p.group * p.D; tb += 1024)   // (row, dim) pairs, 1024 at a time
+  for (int i0 = 0; i0 < DEC_MAXNV; i0 += SB) {       // SB slots x four (row, dim) pairs in flight
+    int pv[4], tl[4], nn[4], jr[4];
+    const float* bs[4];
+    bool any = false;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {                    // everything the addresses need, out of LDS before the first load
+      const int t = tb + tid + 256 * u, j = min(t / p.D, p.group - 1), d = t - (t / p.D) * p.D;      // pairs beyond the group: its last row, dropped (nn = 0)
+      jr[u] = j; pv[u] = s_pv[j]; tl[u] = s_tlo[j]; nn[u] = t / p.D < p.group ? s_nv[j] : 0;
+      bs[u] = p.ws + ((long)(b0 + j) * p.H + h) * p.nslots * DS + 2 + d;
+      any |= i0 < nn[u];
+    }
+    if (!__syncthreads_or(any)) break;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int i = 0; i < SB; ++i) {
+        const int ii = max(min(i0 + i, nn[u] - 1), 0);
+        os[u][i] = ld_sc1(bs[u] + (ii < pv[u] ? ii : p.psplits + tl[u] + (ii - pv[u])) * DS);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(os[u][0]), "+v"(os[u][1]), "+v"(os[u][2]), "+v"(os[u][3]), "+v"(os[u][4]), "+v"(os[u][5]), "+v"(os[u][6]), "+v"(os[u][7]),
+                   "+v"(os[u][8]), "+v"(os[u][9]), "+v"(os[u][10]), "+v"(os[u][11]), "+v"(os[u][12]), "+v"(os[u][13]), "+v"(os[u][14]), "+v"(os[u][15]),
+                   "+v"(os[u][16]), "+v"(os[u][17]), "+v"(os[u][18]), "+v"(os[u][19]), "+v"(os[u][20]), "+v"(os[u][21]), "+v"(os[u][22]), "+v"(os[u][23]) :: "memory");
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = tb + tid + 256 * u, j = jr[u], d = t - (t / p.D) * p.D, nv = nn[u];
+      if (nv == 0 || i0 >= nv) continue;
+      float* accp = gl + 16 * DEC_MAXNV + t;         // running o of the pair across slot batches (third LDS plane: 16 rows x D <= 2048 floats)
+      float OO = i0 ? *accp : 0.f;
+#pragma unroll
+      for (int i = 0; i < SB; ++i) OO = fmaf(i0 + i < nv ? gm[j * DEC_MAXNV + i0 + i] : 0.f, i0 + i < nv ? os[u][i] : 0.f, OO);
+      if (i0 + SB < nv) *accp = OO;
+      else { const float LL = gl[j * DEC_MAXNV]; p.o[(long)(b0 + j) * p.o_bs + (long)h * p.o_hs + d] = f2bf(LL > 0.f ? OO / LL : 0.f); }
+    }
+  }
+}
+
+// GROUPED (beam search): the shared prefix as workgroups (prefix chunk, head, rows + group index) of the same launch: the keys below shared_len[g] are
+// read once per prompt, from the group's first row, for all its queries (wave w: queries w, w + 4, ...: NQ per wave, rotated here) in chunks of
+// pchunk = 32 keys -- ONE round of loads per workgroup, as short as a tail workgroup (with attn_decode_prefix's 128-key chunks a wave walked eight
+// rounds for three queries and the launch took 40 us where the ungrouped one took 22); a partial slot per (row, prefix chunk).  Its arrival counts for
+// each of the group's rows; whatever rows it completes it merges, 256 / D rows at a time.
 template <int G, int U, int NQ>
 __device__ __forceinline__ void dec_step_prefix(const DecStepP& p, float* sm, unsigned* last_s) {
   constexpr int KPL = 64 / G;
-  const int split = blockIdx.x, h = blockIdx.y, gi = blockIdx.z - p.rows;
+  const int npre = p.psplits * (p.rows / p.group);            // grouped grid: x = [prefix (chunk, group) pairs | tail (split, row) pairs], y = head
+  const int split = blockIdx.x % p.psplits, h = blockIdx.y, gi = blockIdx.x / p.psplits;
+  (void)npre;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int slot = lane / G, c = lane % G;
   const bool act = c * 8 < p.D;
   const int ca = act ? c : 0;
   const int b0 = gi * p.group;
-  const int n = p.shared_len[gi];
-  const int k0 = split * p.chunk, k1 = min(k0 + p.chunk, n);
+  const int n = min(p.shared_len[gi], (int)p.pos_idx[b0]);
+  const int k0 = split * p.pchunk, k1 = min(k0 + p.pchunk, n);
+  if (k0 >= n) return;                              // beyond the prefix: no slot, no arrival (dec_slots)
   float qf[NQ][8], m[NQ], l[NQ], acc[NQ][8];
 #pragma unroll
   for (int j = 0; j < NQ; ++j) {
@@ -485,26 +600,30 @@ __device__ __forceinline__ void dec_step_prefix(const DecStepP& p, float* sm, un
   __syncthreads();
   if ((int)threadIdx.x < p.group) last_s[threadIdx.x] = dec_arrive(p, b0 + threadIdx.x, h);
   __syncthreads();
-  const int per = 256 / p.D, sub = threadIdx.x / p.D, d = threadIdx.x - sub * p.D;        // rows merged at a time (D = 80: 3)
-  for (int j0 = 0; j0 < p.group; j0 += per) {
-    const int j = j0 + sub;
-    if (sub < per && j < p.group && last_s[j]) dec_merge_row(p, b0 + j, h, d);
-  }
+  bool any = false;
+  for (int j = 0; j < p.group; ++j) any |= last_s[j] != 0;
+  if (any) dec_merge_group(p, b0, h, last_s, sm);
 }
 
 template <int G, int U, int UP, int NQ>          // U / UP: keys-in-flight factor of the tail / prefix rounds (attn_decode_partial's / attn_decode_prefix's); NQ = 0: no groups
 __global__ __launch_bounds__(256) void attn_decode_step_kernel(DecStepP p) {
   constexpr int KPL = 64 / G;
-  __shared__ float sm[4 * (NQ > 1 ? NQ : 1) * KPL * (128 + 2)];
+  constexpr int SM_F = 4 * (NQ > 1 ? NQ : 1) * KPL * (128 + 2), SM_G = 2 * 16 * DEC_MAXNV + 16 * 128;      // slot partials | the group merge's planes
+  __shared__ float sm[NQ > 0 && SM_G > SM_F ? SM_G : SM_F];
   __shared__ unsigned last_s[16];
-  if (NQ > 0 && (int)blockIdx.z >= p.rows) { dec_step_prefix<G, UP, NQ ? NQ : 1>(p, sm, last_s); return; }
-  const int split = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  // grouped grid: x = [prefix (chunk, group) pairs, the long ones first | tail (split, row) pairs], y = head -- no workgroup without a possible key
+  // range (a (max(psplits, splits), heads, rows + groups) grid started 5984 workgroups of which 800 had keys: 40 us per launch)
+  const int npre = NQ > 0 ? p.psplits * (p.rows / p.group) : 0;
+  if (NQ > 0 && (int)blockIdx.x < npre) { dec_step_prefix<G, UP, NQ ? NQ : 1>(p, sm, last_s); return; }
+  const int xt = NQ > 0 ? blockIdx.x - npre : 0;
+  const int split = NQ > 0 ? xt % p.splits : blockIdx.x, h = blockIdx.y, b = NQ > 0 ? xt / p.splits : blockIdx.z;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int slot = lane / G, c = lane % G;
   const bool act = c * 8 < p.D;
   const int ca = act ? c : 0;                       // idle lanes of a group (D = 80: chunks 10 .. 15) redo chunk 0, never beyond the row
   const int pos = (int)p.pos_idx[b], n = pos + 1;
-  const int ks = NQ > 0 ? min(p.shared_len[b / p.group], n) : 0;          // grouped: the keys below ks belong to the prefix workgroups
+  const int ks = NQ > 0 ? min(p.shared_len[b / p.group], pos) : 0;        // grouped: the keys below ks belong to the prefix workgroups
+  if (NQ > 0 && (split >= p.splits || (split + 1) * p.chunk <= ks || split * p.chunk > pos)) return;      // no key of [ks, pos] here: no slot, no arrival
   const int k0 = max(split * p.chunk + wave * (p.chunk >> 2), ks), k1 = min(split * p.chunk + (wave + 1) * (p.chunk >> 2), n);
   const bf16* base = p.qkv + (long)b * p.row_stride + (long)h * p.head_stride;
   const float* cr = p.cs + (long)b * p.half; const float* sr = p.sn + (long)b * p.half;
@@ -599,18 +718,31 @@ __global__ __launch_bounds__(256) void attn_decode_step_kernel(DecStepP p) {
     if (d < p.D) p.o[(long)b * p.o_bs + (long)h * p.o_hs + d] = f2bf(L > 0.f ? O / L : 0.f);
     return;
   }
-  float* wsp = p.ws + (((long)b * p.H + h) * p.nslots + (NQ > 0 ? p.splits : 0) + split) * DS;      // grouped: tails in slots [splits, 2 splits)
+  float* wsp = p.ws + (((long)b * p.H + h) * p.nslots + (NQ > 0 ? p.psplits : 0) + split) * DS;     // grouped: tails behind the prefix slots
   if (d < p.D) {
     st_agent(wsp + 2 + d, O);
     if (d == 0) { st_agent(wsp, M); st_agent(wsp + 1, L); }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this thread's partial has reached the coherence point
   __syncthreads();
+  if (NQ > 0) {                                     // grouped: the two-round-trip merge (a row has 15 - 20 slots)
+    if ((int)threadIdx.x < 16) last_s[threadIdx.x] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) last_s[b % p.group] = dec_arrive(p, b, h);
+    __syncthreads();
+    if (last_s[b % p.group]) dec_merge_group(p, b - b % p.group, h, last_s, sm);
+    return;
+  }
   if (threadIdx.x == 0) last_s[0] = dec_arrive(p, b, h);
   __syncthreads();
   if (last_s[0] && d < p.D) dec_merge_row(p, b, h, d);
 }
 
+#define DEC_PCHUNK 32          // prefix keys per workgroup of the grouped one-launch form: one round of loads (64 / G * U keys: 32 for both head-dim classes)
+extern "C" int unimp_attn_decode_step_slots(int rows, int heads, int capacity, int group) {       // partial slots per (row, head): sizes the workspace
+  const int ps = (capacity + DEC_PCHUNK - 1) / DEC_PCHUNK, sp = unimp_attn_decode_splits(rows, heads, capacity);
+  return sp + (group > 1 && ps + sp <= DEC_MAXNV ? ps : 0);
+}
 extern "C" int unimp_attn_decode_step(const unimp_decode_step_desc* d, void* stream) {
   if (!d || !d->qkv || !d->kcache || !d->vcache || !d->pos_idx || !d->out) return unimp_set_error(UNIMP_ERR_ARG, "attn_decode_step: null pointer");
   if (d->rot > 0 && (!d->cos_rows || !d->sin_rows)) return unimp_set_error(UNIMP_ERR_ARG, "attn_decode_step: rot > 0 needs the cos / sin rows");
@@ -624,10 +756,11 @@ extern "C" int unimp_attn_decode_step(const unimp_decode_step_desc* d, void* str
     return unimp_set_error(UNIMP_ERR_ALIGN, "attn_decode_step: strides and offsets must be multiples of 8 elements, pointers 16-byte aligned");
   if (d->capacity <= 0) return unimp_set_error(UNIMP_ERR_SHAPE, "attn_decode_step: capacity <= 0");
   const int splits = unimp_attn_decode_splits(d->rows, d->heads, d->capacity);
-  const bool grouped = d->group > 1;
-  if (grouped && (!d->shared_len || d->rows % d->group || d->group > 16)) return unimp_set_error(UNIMP_ERR_ARG, "attn_decode_step: grouped form needs shared_len, rows % group == 0 and group <= 16");
-  const int nslots = grouped ? 2 * splits : splits;
-  if (nslots > 1 && (!d->workspace || !d->arrived)) return unimp_set_error(UNIMP_ERR_ARG, "attn_decode_step: needs the workspace (rows*heads*nslots*(hd+2) floats) and the zeroed arrival counters (rows*heads)");
+  const bool grouped = d->group > 1 && (d->capacity + DEC_PCHUNK - 1) / DEC_PCHUNK + splits <= DEC_MAXNV;      // more prefix chunks than the merge holds: ungrouped (same result up to fp32 rounding)
+  if (d->group > 1 && (!d->shared_len || d->rows % d->group || d->group > 16)) return unimp_set_error(UNIMP_ERR_ARG, "attn_decode_step: grouped form needs shared_len, rows % group == 0 and group <= 16");
+  const int psplits = grouped ? (d->capacity + DEC_PCHUNK - 1) / DEC_PCHUNK : 0;
+  const int nslots = psplits + splits;
+  if (nslots > 1 && (!d->workspace || !d->arrived)) return unimp_set_error(UNIMP_ERR_ARG, "attn_decode_step: needs the workspace (unimp_attn_decode_step_slots(...) * rows*heads*(hd+2) floats) and the zeroed arrival counters (rows*heads)");
   DecStepP p;
   p.qkv = (const bf16*)d->qkv; p.row_stride = d->row_stride; p.head_stride = d->head_stride; p.q_off = d->q_off; p.k_off = d->k_off; p.v_off = d->v_off;
   p.rows = d->rows; p.H = d->heads; p.D = d->hd; p.half = half; p.cs = d->cos_rows; p.sn = d->sin_rows;
@@ -635,16 +768,17 @@ extern "C" int unimp_attn_decode_step(const unimp_decode_step_desc* d, void* str
   p.pos_idx = d->pos_idx; p.scale_log2 = d->scale * 1.4426950408889634f; p.alibi = d->alibi_slopes;
   p.o = (bf16*)d->out; p.o_bs = d->o_row_stride; p.o_hs = d->o_head_stride;
   p.ws = d->workspace; p.arrived = (unsigned*)d->arrived; p.splits = splits; p.chunk = DEC_CHUNK; p.nslots = nslots;
-  p.group = grouped ? d->group : 1; p.shared_len = grouped ? d->shared_len : nullptr;
+  p.group = grouped ? d->group : 1; p.shared_len = grouped ? d->shared_len : nullptr; p.psplits = psplits; p.pchunk = DEC_PCHUNK;
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid(splits, d->heads, d->rows + (grouped ? d->rows / d->group : 0));          // tails (one per row), then the prefix workgroups (one per group)
+  dim3 grid(splits, d->heads, d->rows);
+  if (grouped) grid = dim3(psplits * (d->rows / d->group) + splits * d->rows, d->heads, 1);          // prefix (chunk, group) pairs, then tail (split, row) pairs
   const int nq = grouped ? (d->group + 3) / 4 : 0;                                    // queries per wave of a prefix workgroup
 #define STEP(G_, U_) do { switch (nq) {                                                                                  \
-    case 0: hipLaunchKernelGGL((attn_decode_step_kernel<G_, U_, 4, 0>), grid, dim3(256), 0, s, p); break;                  \
-    case 1: hipLaunchKernelGGL((attn_decode_step_kernel<G_, U_, 4, 1>), grid, dim3(256), 0, s, p); break;                  \
-    case 2: hipLaunchKernelGGL((attn_decode_step_kernel<G_, U_, 4, 2>), grid, dim3(256), 0, s, p); break;                  \
-    case 3: hipLaunchKernelGGL((attn_decode_step_kernel<G_, U_, 4, 3>), grid, dim3(256), 0, s, p); break;                  \
-    default: hipLaunchKernelGGL((attn_decode_step_kernel<G_, U_, 4, 4>), grid, dim3(256), 0, s, p); break; } } while (0)
+    case 0: hipLaunchKernelGGL((attn_decode_step_kernel<G_, U_, U_, 0>), grid, dim3(256), 0, s, p); break;                 \
+    case 1: hipLaunchKernelGGL((attn_decode_step_kernel<G_, U_, U_, 1>), grid, dim3(256), 0, s, p); break;                 \
+    case 2: hipLaunchKernelGGL((attn_decode_step_kernel<G_, U_, U_, 2>), grid, dim3(256), 0, s, p); break;                 \
+    case 3: hipLaunchKernelGGL((attn_decode_step_kernel<G_, U_, U_, 3>), grid, dim3(256), 0, s, p); break;                 \
+    default: hipLaunchKernelGGL((attn_decode_step_kernel<G_, U_, U_, 4>), grid, dim3(256), 0, s, p); break; } } while (0)
   if (d->hd <= 64) STEP(8, 4); else STEP(16, 8);
 #undef STEP
   return unimp_check_launch("attn_decode_step");

@@ -686,10 +686,10 @@ DECODE_FUSED = _os.environ.get("UNIMP_DECODE_FUSED", "1") != "0"      # round 6:
 
 # the decode step's self-attention as one launch (rope + append + attention; UNIMP_DECODE_STEP_ATTN=0: rope-append, split-key partials, merge)
 DECODE_STEP_ATTN = _os.environ.get("UNIMP_DECODE_STEP_ATTN", "1") != "0"
-# beams: the shared prompt keys once per prompt inside that launch.  OFF by default: at the reference's sizes (469-token prompt, 10 beams) the prefix
-# workgroups -- 160 of them, each wave walking its 128 keys in eight rounds for three queries, the last one merging up to ten rows -- make the launch
-# 40 us where the ungrouped one takes 22 (K = 10 token-step 4.29 | 3.68 ms, profiles/r06_negative_results_decode_and_mx.txt); it pays with long
-# prompts (the ungrouped form reads the prompt's K / V once per BEAM)
+# beams: the shared prompt keys once per prompt inside that launch (prefix workgroups of 32 keys each, three queries per wave; a two-round-trip
+# merge of all the rows a workgroup completes).  OFF by default: at the reference's sizes (469-token prompt, 10 beams) the launch takes 30 us where the
+# ungrouped one takes 22 (K = 10 token-step 3.91 | 3.60 ms, K = 5 3.32 | 3.01; profiles/r06_negative_results_decode_and_mx.txt): the 48 MB of repeated
+# prompt K / V per layer cost less than 480 prefix workgroups and 16-slot merges do; it pays with long prompts
 DECODE_STEP_GROUPED = _os.environ.get("UNIMP_DECODE_STEP_GROUPED", "0") != "0"
 
 

@@ -601,7 +601,7 @@ def attn_decode_step(qkv2d, heads, head_stride, hd, offs, rot, cos_rows, sin_row
     L = _lib.lib()
     splits = L.unimp_attn_decode_splits(rows, heads, cap)
     grouped = group > 1 and shared_len is not None and rows % group == 0 and group <= 16
-    nslots = 2 * splits if grouped else splits
+    nslots = L.unimp_attn_decode_step_slots(rows, heads, cap, group if grouped else 1)
     key = (qkv2d.device, rows, heads, nslots, hd)
     if key not in _DECODE_STEP_WS:          # per shape, kept: the arrival counters must be zero at the first launch and are left zero by every launch
         _DECODE_STEP_WS[key] = (torch.empty(rows * heads * nslots * (hd + 2), device=qkv2d.device, dtype=torch.float32),
