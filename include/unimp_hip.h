@@ -263,6 +263,9 @@ typedef struct {
   void* out;                       /* bf16 [rows][heads][hd] */
   int64_t o_row_stride, o_head_stride;
   float* workspace; void* arrived;
+  int group_mode;                                   /* 0: by ADDRESS -- every row reads the keys below shared_len[g] from its group's FIRST row (identical
+                                                     * copies: the bits of group = 1; the repeated lines come from L2 / the memory-side cache);
+                                                     * 1: by prefix workgroups (below) */
   int group; const int32_t* shared_len;             /* beam search as in unimp_attn_decode_grouped (group <= 1: none): the keys below shared_len[g] are read
                                                      * once per prompt, in chunks of 32 keys by extra workgroups of the same launch (workspace:
                                                      * unimp_attn_decode_step_slots) */

@@ -689,10 +689,18 @@ def test_attn_decode_step_grouped_beams(ops, K, groups, nh, hd, rot, cap):
     k2, v2 = kc.clone(), vc.clone()
     flat = ops.attn_decode_step(qkv, nh, hs, hd, offs, rot, cos, sin, k2, v2, pos, scale, None)
     k1, v1 = kc.clone(), vc.clone()
-    got = ops.attn_decode_step(qkv, nh, hs, hd, offs, rot, cos, sin, k1, v1, pos, scale, None, K, shared)
+    got = ops.attn_decode_step(qkv, nh, hs, hd, offs, rot, cos, sin, k1, v1, pos, scale, None, K, shared, group_mode=1)
     torch.cuda.synchronize()
     assert torch.equal(k1, k2) and torch.equal(v1, v2), "cache after the step"
     close(got, flat.float(), rel=2 ** -7, name="grouped vs ungrouped")
+    # groups by ADDRESS: the prompt's keys of every row come from the group's first row -- poison the other rows' copies to prove it; the bits of the ungrouped form
+    k3, v3 = kc.clone(), vc.clone()
+    for gi in range(groups):
+        n = int(shared[gi])
+        k3[gi * K + 1:(gi + 1) * K, :n] = float("nan")
+        v3[gi * K + 1:(gi + 1) * K, :n] = float("nan")
+    byaddr = ops.attn_decode_step(qkv, nh, hs, hd, offs, rot, cos, sin, k3, v3, pos, scale, None, K, shared, group_mode=0)
+    assert torch.equal(byaddr, flat), "groups by address: same keys, same partition, same bits as ungrouped"
     q2 = qkv.clone()
     ops.decode_rope_append(q2, nh, hs, hd, offs, rot, cos, sin, kc.clone(), vc.clone(), pos)
     qf, kf, vf = q2.view(R, nh, 3 * hd)[..., :hd].float(), k1.float(), v1.float()
@@ -701,7 +709,7 @@ def test_attn_decode_step_grouped_beams(ops, K, groups, nh, hd, rot, cap):
         sc = torch.einsum("hd,khd->hk", qf[r], kf[r, :n]) * scale
         close(got[r, 0], torch.einsum("hk,khd->hd", torch.softmax(sc, -1), vf[r, :n]), name=f"row {r} vs fp32")
     for _ in range(30):
-        assert torch.equal(got, ops.attn_decode_step(qkv, nh, hs, hd, offs, rot, cos, sin, k1, v1, pos, scale, None, K, shared)), "two launches differ"
+        assert torch.equal(got, ops.attn_decode_step(qkv, nh, hs, hd, offs, rot, cos, sin, k1, v1, pos, scale, None, K, shared, group_mode=1)), "two launches differ"
 
 
 @pytest.mark.parametrize("K,groups,nh,hd", [(10, 1, 32, 80), (5, 3, 8, 64), (3, 2, 12, 64), (16, 1, 4, 128)])

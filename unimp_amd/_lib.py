@@ -28,7 +28,7 @@ class DecodeStepDesc(C.Structure):
                 ("rows", c_i), ("heads", c_i), ("hd", c_i), ("rot", c_i), ("cos_rows", c_p), ("sin_rows", c_p),
                 ("kcache", c_p), ("vcache", c_p), ("c_row_stride", c_l), ("c_slot_stride", c_l), ("c_head_stride", c_l), ("capacity", c_i),
                 ("pos_idx", c_p), ("scale", C.c_float), ("alibi_slopes", c_p), ("out", c_p), ("o_row_stride", c_l), ("o_head_stride", c_l),
-                ("workspace", c_p), ("arrived", c_p), ("group", c_i), ("shared_len", c_p)]
+                ("workspace", c_p), ("arrived", c_p), ("group_mode", c_i), ("group", c_i), ("shared_len", c_p)]
 
 
 class AttnDesc(C.Structure):

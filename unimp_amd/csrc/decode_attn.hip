@@ -307,6 +307,7 @@ struct DecStepP {
   int splits, chunk, nslots;              // nslots = splits; grouped: psplits prefix slots (pchunk keys each) + splits tail slots
   int group; const int* shared_len;       // beam search: rows per prompt, int32 [rows / group] shared prefix length
   int psplits, pchunk;
+  int alias;                              // beam groups by ADDRESS: the keys below shared_len[g] are read from the group's first row by every row (no prefix workgroups)
 };
 
 // grouped: which slots of row b hold a partial in this launch -- the prefix chunks below its group's shared length and the tail chunks that meet
@@ -314,7 +315,7 @@ struct DecStepP {
 struct DecSlots { int pv, t_lo, nv; };           // prefix slots [0, pv), tail slots psplits + t_lo ..., nv in all
 __device__ __forceinline__ DecSlots dec_slots(const DecStepP& p, int b) {
   DecSlots v;
-  if (p.group <= 1) { v.pv = 0; v.t_lo = 0; v.nv = p.splits; return v; }
+  if (p.group <= 1 || p.alias) { v.pv = 0; v.t_lo = 0; v.nv = p.splits; return v; }
   const int pos = (int)p.pos_idx[b], ks = min(p.shared_len[b / p.group], pos);
   v.pv = (ks + p.pchunk - 1) / p.pchunk;
   v.t_lo = ks / p.chunk;
@@ -322,7 +323,7 @@ __device__ __forceinline__ DecSlots dec_slots(const DecStepP& p, int b) {
   return v;
 }
 __device__ __forceinline__ int dec_slot_of(const DecStepP& p, const DecSlots& v, int i) {      // i-th valid slot -> workspace slot
-  return p.group <= 1 ? i : (i < v.pv ? i : p.psplits + v.t_lo + (i - v.pv));
+  return p.group <= 1 || p.alias ? i : (i < v.pv ? i : p.psplits + v.t_lo + (i - v.pv));
 }
 
 // chunk c (8 elements) of the rotated vector at `vec` (half-split rope: pairs (i, i + half) for i < half; elements >= 2 half pass through)
@@ -641,6 +642,11 @@ __global__ __launch_bounds__(256) void attn_decode_step_kernel(DecStepP p) {
   for (int i = 0; i < 8; ++i) qf[i] = bf2f(qn[i]) * p.scale_log2;
   const float slope = p.alibi ? p.alibi[h] * 1.4426950408889634f : 0.f;
   const bf16* kb = p.kc + cslot; const bf16* vb = p.vc + cslot;
+  // beam groups BY ADDRESS (p.alias): the K rows of a prompt hold identical K / V below shared_len[g], so every row reads those keys from the group's
+  // FIRST row -- the ten copies of a 469-token prompt (48 of the 53 MB a layer's decode attention reads at K = 10) become one set of lines that L2 and
+  // the memory-side cache serve ten times.  Same keys, same values, same partition: the bits of the ungrouped form.  No extra workgroup, slot or merge.
+  const int ka = (NQ == 0 && p.alias) ? min(p.shared_len[b / p.group], pos) : 0;
+  const long to_first = (NQ == 0 && p.alias) ? -(long)(b % p.group) * p.c_row : 0;
 
   float m = -INFINITY, l = 0.f, acc[8];
 #pragma unroll
@@ -651,8 +657,9 @@ __global__ __launch_bounds__(256) void attn_decode_step_kernel(DecStepP p) {
     for (int u = 0; u < U; ++u) {                   // all loads of the round go out before the first use
       const int key = kk + u * KPL + slot;
       const int kc_ = key < k1 && key != pos ? key : k0 < pos ? k0 : 0;      // clamped, masked below; never the slot being written
-      kr[u] = *(const u32x4*)(kb + (long)kc_ * p.c_slot);
-      vr[u] = *(const u32x4*)(vb + (long)kc_ * p.c_slot);
+      const long off = (long)kc_ * p.c_slot + (kc_ < ka ? to_first : 0);
+      kr[u] = *(const u32x4*)(kb + off);
+      vr[u] = *(const u32x4*)(vb + off);
     }
     if (mine) {
 #pragma unroll
@@ -739,7 +746,7 @@ __global__ __launch_bounds__(256) void attn_decode_step_kernel(DecStepP p) {
 }
 
 #define DEC_PCHUNK 32          // prefix keys per workgroup of the grouped one-launch form: one round of loads (64 / G * U keys: 32 for both head-dim classes)
-extern "C" int unimp_attn_decode_step_slots(int rows, int heads, int capacity, int group) {       // partial slots per (row, head): sizes the workspace
+extern "C" int unimp_attn_decode_step_slots(int rows, int heads, int capacity, int group) {       // partial slots per (row, head): sizes the workspace (either group mode)
   const int ps = (capacity + DEC_PCHUNK - 1) / DEC_PCHUNK, sp = unimp_attn_decode_splits(rows, heads, capacity);
   return sp + (group > 1 && ps + sp <= DEC_MAXNV ? ps : 0);
 }
@@ -756,7 +763,9 @@ extern "C" int unimp_attn_decode_step(const unimp_decode_step_desc* d, void* str
     return unimp_set_error(UNIMP_ERR_ALIGN, "attn_decode_step: strides and offsets must be multiples of 8 elements, pointers 16-byte aligned");
   if (d->capacity <= 0) return unimp_set_error(UNIMP_ERR_SHAPE, "attn_decode_step: capacity <= 0");
   const int splits = unimp_attn_decode_splits(d->rows, d->heads, d->capacity);
-  const bool grouped = d->group > 1 && (d->capacity + DEC_PCHUNK - 1) / DEC_PCHUNK + splits <= DEC_MAXNV;      // more prefix chunks than the merge holds: ungrouped (same result up to fp32 rounding)
+  // beam groups: by address (default; group_mode 0) or by prefix workgroups (group_mode 1: UNIMP_DECODE_STEP_GROUPED=2 in the package; needs the merge to hold the slots)
+  const bool alias = d->group > 1 && d->group_mode == 0;
+  const bool grouped = d->group > 1 && !alias && (d->capacity + DEC_PCHUNK - 1) / DEC_PCHUNK + splits <= DEC_MAXNV;
   if (d->group > 1 && (!d->shared_len || d->rows % d->group || d->group > 16)) return unimp_set_error(UNIMP_ERR_ARG, "attn_decode_step: grouped form needs shared_len, rows % group == 0 and group <= 16");
   const int psplits = grouped ? (d->capacity + DEC_PCHUNK - 1) / DEC_PCHUNK : 0;
   const int nslots = psplits + splits;
@@ -768,7 +777,8 @@ extern "C" int unimp_attn_decode_step(const unimp_decode_step_desc* d, void* str
   p.pos_idx = d->pos_idx; p.scale_log2 = d->scale * 1.4426950408889634f; p.alibi = d->alibi_slopes;
   p.o = (bf16*)d->out; p.o_bs = d->o_row_stride; p.o_hs = d->o_head_stride;
   p.ws = d->workspace; p.arrived = (unsigned*)d->arrived; p.splits = splits; p.chunk = DEC_CHUNK; p.nslots = nslots;
-  p.group = grouped ? d->group : 1; p.shared_len = grouped ? d->shared_len : nullptr; p.psplits = psplits; p.pchunk = DEC_PCHUNK;
+  p.group = grouped || alias ? d->group : 1; p.shared_len = grouped || alias ? d->shared_len : nullptr; p.psplits = psplits; p.pchunk = DEC_PCHUNK;
+  p.alias = alias ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(splits, d->heads, d->rows);
   if (grouped) grid = dim3(psplits * (d->rows / d->group) + splits * d->rows, d->heads, 1);          // prefix (chunk, group) pairs, then tail (split, row) pairs

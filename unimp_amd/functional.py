@@ -686,11 +686,11 @@ DECODE_FUSED = _os.environ.get("UNIMP_DECODE_FUSED", "1") != "0"      # round 6:
 
 # the decode step's self-attention as one launch (rope + append + attention; UNIMP_DECODE_STEP_ATTN=0: rope-append, split-key partials, merge)
 DECODE_STEP_ATTN = _os.environ.get("UNIMP_DECODE_STEP_ATTN", "1") != "0"
-# beams: the shared prompt keys once per prompt inside that launch (prefix workgroups of 32 keys each, three queries per wave; a two-round-trip
-# merge of all the rows a workgroup completes).  OFF by default: at the reference's sizes (469-token prompt, 10 beams) the launch takes 30 us where the
-# ungrouped one takes 22 (K = 10 token-step 3.91 | 3.60 ms, K = 5 3.32 | 3.01; profiles/r06_negative_results_decode_and_mx.txt): the 48 MB of repeated
-# prompt K / V per layer cost less than 480 prefix workgroups and 16-slot merges do; it pays with long prompts
-DECODE_STEP_GROUPED = _os.environ.get("UNIMP_DECODE_STEP_GROUPED", "0") != "0"
+# beams: the K rows of a prompt hold identical K / V for the prompt's positions.  1 (default): by ADDRESS -- every row reads those keys from its group's
+# first row, so the ten copies of the prompt become one set of lines that L2 and the memory-side cache serve ten times (the bits of the ungrouped form);
+# 2: by prefix workgroups of 32 keys inside the same launch (three forms measured, all behind the ungrouped launch at the reference's sizes:
+# profiles/r06_negative_results_decode_and_mx.txt); 0: every row reads its own copy
+DECODE_STEP_GROUPED = int(_os.environ.get("UNIMP_DECODE_STEP_GROUPED", "1"))
 
 
 def _ln_fusable(rows, D, rms):
@@ -832,7 +832,7 @@ def self_attn_block_cached(x, ln_w, ln_b, wqkv, bqkv, wd, bd, nh, lc, pos0, *, r
             # beam search: the prompt's keys once per prompt, by extra workgroups of the same launch
             grp = lc.owner.group if DECODE_STEP_GROUPED else 1
             o = ops.attn_decode_step(qkv, nh, hs, hd, o3, rot, rope[0] if rot else None, rope[1] if rot else None, lc.k, lc.v, step.pos_idx,
-                                     scale, alibi, grp, lc.owner.shared_len if grp > 1 else None)
+                                     scale, alibi, grp, lc.owner.shared_len if grp > 1 else None, group_mode=1 if DECODE_STEP_GROUPED == 2 else 0)
             return ops.gemm(o.view(R, H), wd, bias=bd, res=r2).view(R, 1, H)
         if fused:
             # one launch: rotate q / k (row r at its own position) and write the rotated k and v into their cache slots

@@ -587,11 +587,14 @@ def kv_reorder_beams(kv, K, src_local, slot0, pos_idx, max_new):
 _DECODE_STEP_WS = {}
 
 
-def attn_decode_step(qkv2d, heads, head_stride, hd, offs, rot, cos_rows, sin_rows, kcache, vcache, pos_idx, scale, alibi=None, group=1, shared_len=None):
+def attn_decode_step(qkv2d, heads, head_stride, hd, offs, rot, cos_rows, sin_rows, kcache, vcache, pos_idx, scale, alibi=None, group=1, shared_len=None,
+                     group_mode=0):
     """the self-attention of a cached decode step in ONE launch (csrc/decode_attn.hip attn_decode_step_kernel): rotate the new q / k, write the
     rotated k and v to cache slot pos_idx[r], attend keys [0, pos_idx[r]] -- the bits of decode_rope_append + attn_decode.  Same arguments as
     decode_rope_append (+ scale / ALiBi slopes); qkv2d is left unrotated.  group > 1 with shared_len (int32 [rows // group]): beam search as in
-    attn_decode -- the keys below shared_len[g] are read once per prompt, by extra workgroups of the same launch.  Returns o [rows, 1, heads, hd]."""
+    attn_decode -- the rows of a group hold identical K / V below shared_len[g]; group_mode 0: every row reads them from the group's first row (the
+    bits of group = 1, the repeated lines served by the caches), 1: once per prompt by extra workgroups of the same launch.
+    Returns o [rows, 1, heads, hd]."""
     rows, cap = qkv2d.shape[0], kcache.shape[1]
     assert kcache.stride(3) == 1 and vcache.stride() == kcache.stride() and pos_idx.dtype == torch.int64 and pos_idx.is_contiguous()
     if rot:
@@ -620,9 +623,9 @@ def attn_decode_step(qkv2d, heads, head_stride, hd, offs, rot, cos_rows, sin_row
     d.workspace, d.arrived = ws.data_ptr(), arrived.data_ptr()
     if grouped:
         assert shared_len.dtype == torch.int32 and shared_len.numel() == rows // group
-        d.group, d.shared_len = group, shared_len.data_ptr()
+        d.group, d.shared_len, d.group_mode = group, shared_len.data_ptr(), int(group_mode)
     else:
-        d.group, d.shared_len = 1, None
+        d.group, d.shared_len, d.group_mode = 1, None, 0
     check(L.unimp_attn_decode_step(C.byref(d), _stream()), "attn_decode_step")
     return o
 
