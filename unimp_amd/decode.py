@@ -13,6 +13,11 @@ from . import functional as F_
 from . import ops
 
 
+# step signatures that have run eagerly once in this process: everything lazy behind them (live GEMM tuning, kernel attributes, the decode attention's
+# workspace) exists, so a later session of the same signature captures its FIRST step instead of running it eagerly (8 - 10 ms per generate() call)
+_WARM = set()
+
+
 class DecodeSession:
     def __init__(self, model, max_new_tokens, reorder, graph=True, beams=1):
         """model: Flamingo with the vision features of the PROMPTS already conditioned (``_encode_vision_x``, one row per
@@ -98,10 +103,12 @@ class DecodeSession:
         self.tok.copy_(tokens.view(-1, 1))
         if src is not None:
             self.src.copy_(src)
+        sig = (id(self.model), tuple(c.kv.shape), self.beams, bool(self.reorder), F_.DECODE_FUSED, F_.DECODE_STEP_ATTN, F_.DECODE_STEP_GROUPED)
         if not self.use_graph:
             logits = self._step_body()
-        elif self.steps == 0:
-            logits = self._step_body()          # first step eagerly: warms every lazy initialisation outside the capture
+        elif self.graph is None and sig not in _WARM:
+            logits = self._step_body()          # first step of this signature eagerly: warms every lazy initialisation outside the capture
+            _WARM.add(sig)
         else:
             if self.graph is None:
                 self.graph = torch.cuda.CUDAGraph()
