@@ -334,6 +334,14 @@ int unimp_swiglu_bwd(const void* gate_up, int64_t ld, const void* dout, int64_t 
 /* out[0] += sum(a*b) over n elements (fp32; out is fp32[1 + 1024]: out[0] zeroed by the caller, out[1..1025) scratch for the ordered
  * two-stage reduction -- no float atomics): d tanh-gate = dot(dy, y_pre_gate) */
 int unimp_dot_bf16(const void* a, const void* b, int64_t n, float* out, void* stream);
+/* beam search step (ABI 8; transformers GenerationMixin.beam_search inside Flamingo.generate: eval_rec.py:100-110 K = 10, eval_exp.py:103-113 K = 5):
+ * out = top-C (sorted, descending; ties to the smaller index) of log_softmax(logits[r]) + beam_scores[r] over the K rows of every prompt viewed as one
+ * [K * V] vector -- scores fp32 and flat indices r_in_group * V + token (int64), [rows / K][C] each.  logits bf16 (logits_f32 = 0) or fp32 [rows][ld];
+ * beam_scores fp32 [rows]; scratch unimp_beam_topk_scratch(rows) bytes.  Two launches instead of a float copy, log_softmax, an add and a sort-based
+ * top-k over K * V elements (233 -> about 40 us per token-step at K = 10, V = 74 053).  K <= 16, C <= 32. */
+int64_t unimp_beam_topk_scratch(int rows);
+int unimp_beam_topk(const void* logits, int logits_f32, int64_t ld, int rows, int V, int K, int C, const float* beam_scores, void* scratch,
+                    float* out_scores, int64_t* out_idx, void* stream);
 /* decode (ABI 8): read `bytes` at p and discard them -- launched on a second stream beside a weight-streaming GEMM it pulls the NEXT GEMM's weights
  * into the memory-side cache (256 MB Infinity Cache) while the launch gaps and tails of the chain leave HBM idle.  `blocks` workgroups of 256 threads
  * (<= 0: 256); sink: any 4 writable bytes (never written in practice) or NULL. */

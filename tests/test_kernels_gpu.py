@@ -1272,6 +1272,40 @@ def test_attention_bwd_adjacent_inverse_rope(ops, attn_gen, B, H, S, D, rot):
     assert torch.equal(fused[..., 2, :], plain[..., 2, :])
 
 
+@pytest.mark.parametrize("rows,K,V,dt", [(10, 10, 74053, "bf16"), (5, 5, 50432, "bf16"), (12, 4, 1000, "f32"), (16, 16, 32000, "bf16"), (3, 1, 74053, "f32")])
+def test_beam_topk_step(ops, rows, K, V, dt):
+    """unimp_beam_topk against the torch ops it replaces in generate.beam_search -- log_softmax(logits.float()) + beam_scores, viewed [prompts, K * V],
+    torch.topk(2 K, sorted): the same sorted scores to fp32 rounding of the normaliser, every returned index holding its score, no index twice,
+    and -- where the top 2K hold no equal scores (fp32 logits) -- the same indices in the same order (bf16 logits tie inside the top 2K of 740 530
+    values; torch.topk's order among equals is unspecified, this kernel's is the smaller flat index); a row that cannot win (beam score -1e9, as in the first step), ties (equal logits in two rows: the smaller flat index first), bf16
+    and fp32 logits, several prompts per call; two launches give the same bits."""
+    g = torch.Generator().manual_seed(rows * 7 + V)
+    logits = (torch.randn(rows, V, generator=g) * 3).to(bf16 if dt == "bf16" else torch.float32).cuda()
+    beam = (torch.randn(rows, generator=g) * 2).cuda()
+    if K > 1:
+        beam[1] = -1e9
+    C = 2 * K
+    assert ops.beam_topk_ok(logits, K, C)
+    got_s, got_i = ops.beam_topk(logits, beam, K, C)
+    scores = (torch.log_softmax(logits.float(), -1) + beam.view(-1, 1)).view(rows // K, K * V)
+    want_s, want_i = torch.topk(scores, C, dim=1, largest=True, sorted=True)
+    tol = 2e-6 * want_s.abs().max().item() + 1e-6
+    assert (got_s - want_s).abs().max().item() <= tol
+    assert (scores.gather(1, got_i) - got_s).abs().max().item() <= tol, "an index does not hold its score"
+    assert all(len(set(r)) == C for r in got_i.tolist()), "an index twice"
+    if all(len(set(r)) == C for r in want_s.tolist()):            # no equal scores among the winners: the order is determined
+        assert torch.equal(got_i, want_i), (got_i, want_i)
+    again_s, again_i = ops.beam_topk(logits, beam, K, C)
+    assert torch.equal(again_s, got_s) and torch.equal(again_i, got_i)
+    # ties: two rows with identical logits and beam scores -> the smaller flat index first
+    if K >= 2:
+        l2 = logits.clone(); l2[0] = l2[K - 1]
+        b2 = beam.clone(); b2[0] = b2[K - 1] = 100.0          # the two equal rows lead
+        s2, i2 = ops.beam_topk(l2, b2, K, C)
+        first = i2[0].tolist()
+        assert first[0] < first[1] and first[1] - first[0] == (K - 1) * V and float(s2[0, 0]) == float(s2[0, 1])
+
+
 # ------------------------------------------------------------------------------------------------- embedding / misc
 def test_embedding_fwd_bwd(ops):
     V, D, n = 50, 64, 300

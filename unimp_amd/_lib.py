@@ -86,6 +86,8 @@ _SIGS = {
     "unimp_swiglu_bwd": [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_p],
     "unimp_dot_bf16": [c_p, c_p, c_l, c_p, c_p],
     "unimp_prefetch": [c_p, c_l, c_i, c_p, c_p],
+    "unimp_beam_topk": [c_p, c_i, c_l, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p],
+    "unimp_beam_topk_scratch": [c_i],
     "unimp_bcast_rows": [c_p, c_p, c_l, c_i, c_i, c_i, c_p],
     "unimp_reduce_rows_periodic": [c_p, c_l, c_p, c_i, c_i, c_i, c_p],
     "unimp_label_mask": [c_p, c_p, c_p, c_i, c_i, c_l, c_l, c_l, c_l, c_p],
@@ -132,6 +134,7 @@ def lib():
             fn = getattr(L, name)
             fn.argtypes, fn.restype = args, c_i
         L.unimp_embedding_bwd_sorted_scratch.restype = c_l
+        L.unimp_beam_topk_scratch.restype = c_l
         if L.unimp_abi_version() != ABI_VERSION:
             raise ImportError(f"{LIB_PATH}: ABI version {L.unimp_abi_version()}, this package binds version {ABI_VERSION} -- a stale build; "
                               "rebuild with `make -C unimp_amd/csrc`")

@@ -301,6 +301,127 @@ extern "C" int unimp_prefetch(const void* p, int64_t bytes, int blocks, void* si
   return unimp_check_launch("prefetch");
 }
 
+// ------------------------------------------------------------------------------------------- beam search: log_softmax + beam scores + top-2K in two launches
+// transformers' BeamSearchScorer step (GenerationMixin.beam_search; eval_rec.py:100-110, K = 10): next_token_scores = log_softmax(logits) + beam_scores,
+// viewed as [prompts, K * V], torch.topk(2 K).  As torch ops that is a float copy, log_softmax, an add and a sort-based top-k over 740 530 elements:
+// 233 us per token-step where the decode step itself takes 3.5 ms.  Here: pass A, block (slice, row) reads its slice of the row's logits ONCE -- row
+// maximum and sum of exponentials of the slice (online), and the slice's C largest logits (a row's order does not depend on its normaliser) by C
+// rounds of a block-wide argmax; pass B, one block per prompt: the rows' normalisers from the slice partials (slice order), the candidates' scores
+// ((x - max) - log sum) + beam score as torch computes them, and the C best of the K * slices * C candidates, sorted, ties to the smaller flat index.
+#define BTK_SLICES 16
+#define BTK_MAXC 32
+__device__ __forceinline__ void btk_argmax(float& v, int& i) {               // wave-wide (value, index) maximum, ties to the smaller index; result in every lane
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float v2 = __shfl_xor(v, o, 64); const int i2 = __shfl_xor(i, o, 64);
+    if (v2 > v || (v2 == v && i2 < i)) { v = v2; i = i2; }
+  }
+}
+template <typename T, int PER>
+__global__ __launch_bounds__(256) void beam_topk_a(const T* __restrict__ logits, long ld, int V, int C, float* __restrict__ part_ms, float* __restrict__ cand_v,
+                                                   int* __restrict__ cand_i) {
+  __shared__ float sv[4]; __shared__ int si[4]; __shared__ float red[8];
+  const int slice = blockIdx.x, row = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int per = (V + BTK_SLICES - 1) / BTK_SLICES, s0 = slice * per, s1 = min(s0 + per, V);
+  const T* x = logits + (long)row * ld;
+  float v[PER];
+  float m = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) { const int i = s0 + tid + 256 * k; v[k] = i < s1 ? (float)x[i] : -INFINITY; m = fmaxf(m, v[k]); }
+  m = wave_max(m);
+  if (lane == 0) red[w] = m;
+  __syncthreads();
+  const float M = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) sum += v[k] == -INFINITY ? 0.f : __expf(v[k] - M);
+  sum = wave_sum(sum);
+  if (lane == 0) red[4 + w] = sum;
+  __syncthreads();
+  if (tid == 0) { float* o = part_ms + ((long)row * BTK_SLICES + slice) * 2; o[0] = M; o[1] = (red[4] + red[5]) + (red[6] + red[7]); }
+  for (int c = 0; c < C; ++c) {
+    float bv = -INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { const int i = s0 + tid + 256 * k; if (v[k] > bv) { bv = v[k]; bi = i; } }      // ascending i inside a thread: the first maximum wins
+    btk_argmax(bv, bi);
+    if (lane == 0) { sv[w] = bv; si[w] = bi; }
+    __syncthreads();
+    float gv = sv[0]; int gi = si[0];
+#pragma unroll
+    for (int q = 1; q < 4; ++q) if (sv[q] > gv || (sv[q] == gv && si[q] < gi)) { gv = sv[q]; gi = si[q]; }
+    if (tid == 0) { const long o = ((long)row * BTK_SLICES + slice) * BTK_MAXC + c; cand_v[o] = gv; cand_i[o] = gi; }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) if (s0 + tid + 256 * k == gi) v[k] = -INFINITY;
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(256) void beam_topk_b(const float* __restrict__ part_ms, const float* __restrict__ cand_v, const int* __restrict__ cand_i,
+                                                   const float* __restrict__ beam_scores, int K, int V, int C, float* __restrict__ out_s, int64_t* __restrict__ out_i) {
+  __shared__ float rowM[16], rowL[16];
+  __shared__ float sv[4]; __shared__ long si[4];
+  const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid < K) {
+    const float* pm = part_ms + (long)(g * K + tid) * BTK_SLICES * 2;
+    float M = -INFINITY;
+    for (int s_ = 0; s_ < BTK_SLICES; ++s_) M = fmaxf(M, pm[2 * s_]);
+    float S = 0.f;
+    for (int s_ = 0; s_ < BTK_SLICES; ++s_) S += pm[2 * s_ + 1] * __expf(pm[2 * s_] - M);
+    rowM[tid] = M; rowL[tid] = logf(S);
+  }
+  __syncthreads();
+  constexpr int PER = 16 * BTK_SLICES * BTK_MAXC / 256;           // candidates per thread at most (16 rows)
+  float v[PER]; long id[PER];
+  const int n = K * BTK_SLICES * C;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int t = tid + 256 * k;
+    v[k] = -INFINITY; id[k] = 0x7fffffffffffffffL;
+    if (t < n) {
+      const int r = t / (BTK_SLICES * C), rem = t - r * (BTK_SLICES * C), sl = rem / C, c = rem - sl * C;
+      const long o = ((long)(g * K + r) * BTK_SLICES + sl) * BTK_MAXC + c;
+      const float x = cand_v[o];
+      if (x != -INFINITY) { v[k] = ((x - rowM[r]) - rowL[r]) + beam_scores[g * K + r]; id[k] = (long)r * V + cand_i[o]; }
+    }
+  }
+  for (int c = 0; c < C; ++c) {
+    float bv = -INFINITY; long bi = 0x7fffffffffffffffL;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) if (v[k] > bv || (v[k] == bv && id[k] < bi)) { bv = v[k]; bi = id[k]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float v2 = __shfl_xor(bv, o, 64); const long i2 = __shfl_xor(bi, o, 64);
+      if (v2 > bv || (v2 == bv && i2 < bi)) { bv = v2; bi = i2; }
+    }
+    if (lane == 0) { sv[w] = bv; si[w] = bi; }
+    __syncthreads();
+    float gv = sv[0]; long gi = si[0];
+#pragma unroll
+    for (int q = 1; q < 4; ++q) if (sv[q] > gv || (sv[q] == gv && si[q] < gi)) { gv = sv[q]; gi = si[q]; }
+    if (tid == 0) { out_s[(long)g * C + c] = gv; out_i[(long)g * C + c] = gi; }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) if (id[k] == gi) v[k] = -INFINITY;
+    __syncthreads();
+  }
+}
+extern "C" int64_t unimp_beam_topk_scratch(int rows) { return (int64_t)rows * BTK_SLICES * (2 + 2 * BTK_MAXC) * 4; }      // bytes
+extern "C" int unimp_beam_topk(const void* logits, int logits_f32, int64_t ld, int rows, int V, int K, int C, const float* beam_scores, void* scratch,
+                               float* out_scores, int64_t* out_idx, void* stream) {
+  if (!logits || !beam_scores || !scratch || !out_scores || !out_idx) return unimp_set_error(UNIMP_ERR_ARG, "beam_topk: null pointer");
+  if (rows <= 0 || K <= 0 || rows % K || K > 16 || C <= 0 || C > BTK_MAXC || V <= 0) return unimp_set_error(UNIMP_ERR_SHAPE, "beam_topk: rows a multiple of K <= 16, 1 <= C <= 32");
+  const int per = (V + BTK_SLICES - 1) / BTK_SLICES;
+  if (per > 256 * 24 || per < C) return unimp_set_error(UNIMP_ERR_UNSUPPORTED, "beam_topk: vocabulary between 16 C and 98 304");
+  float* part = (float*)scratch; float* cv = part + (long)rows * BTK_SLICES * 2; int* ci = (int*)(cv + (long)rows * BTK_SLICES * BTK_MAXC);
+  hipStream_t s = (hipStream_t)stream;
+  dim3 ga(BTK_SLICES, rows);
+#define BTK_A(T_, P_) hipLaunchKernelGGL((beam_topk_a<T_, P_>), ga, dim3(256), 0, s, (const T_*)logits, (long)ld, V, C, part, cv, ci)
+  const int pt = (per + 255) / 256;
+  if (logits_f32) { if (pt <= 8) BTK_A(float, 8); else if (pt <= 16) BTK_A(float, 16); else BTK_A(float, 24); }
+  else { if (pt <= 8) BTK_A(bf16, 8); else if (pt <= 16) BTK_A(bf16, 16); else BTK_A(bf16, 24); }
+#undef BTK_A
+  hipLaunchKernelGGL(beam_topk_b, dim3(rows / K), dim3(256), 0, s, (const float*)part, (const float*)cv, (const int*)ci, beam_scores, K, V, C, out_scores, out_idx);
+  return unimp_check_launch("beam_topk");
+}
+
 // ------------------------------------------------------------------------------------------- embedding
 __global__ void embedding_fwd_kernel(const int64_t* __restrict__ ids, const bf16* __restrict__ W, long ldw,
                                      const int64_t* __restrict__ pos, const bf16* __restrict__ P, long ldp,

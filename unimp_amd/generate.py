@@ -8,7 +8,22 @@ finished hypotheses scored ``sum_logprobs / generated_len ** length_penalty``, `
 once K hypotheses are finished, remaining beams are finalised at ``max_new_tokens``).  Pinned against the installed
 transformers on a tiny GPT-NeoX in tests/test_generate_cpu.py.  No KV cache yet: every step re-scores the whole sequence.
 """
+import os
+
 import torch
+
+# beam search: log_softmax + beam scores + top-2K of a step in two launches of the HIP library (GPU logits only; 0: the torch ops)
+BEAM_TOPK_FUSED = os.environ.get("UNIMP_BEAM_TOPK_FUSED", "1") != "0"
+
+
+def _fused_topk(logits, beam_scores, K):
+    """(scores, flat indices) of the step's 2K candidates per prompt through ops.beam_topk, or None where it does not apply (CPU logits, shapes)"""
+    if not (BEAM_TOPK_FUSED and logits.is_cuda):
+        return None
+    from . import ops
+    if not ops.beam_topk_ok(logits, K, 2 * K):
+        return None
+    return ops.beam_topk(logits, beam_scores, K, 2 * K)
 
 
 def _ban_repeated_ngrams(seqs, logp, n):
@@ -80,11 +95,16 @@ def beam_search(logits_fn, input_ids, num_beams, max_new_tokens, eos_token_id, p
     src = None
     for step in range(max_new_tokens):
         cur_len = seqs.shape[1]
-        logp = torch.log_softmax((logits_fn(seqs, src) if stateful else logits_fn(seqs)).float(), -1)
-        _ban_repeated_ngrams(seqs, logp, no_repeat_ngram_size)
-        V = logp.shape[-1]
-        scores = (logp + beam_scores.view(-1, 1)).view(B, K * V)
-        top_s, top_i = torch.topk(scores, 2 * K, dim=1, largest=True, sorted=True)
+        logits = logits_fn(seqs, src) if stateful else logits_fn(seqs)
+        V = logits.shape[-1]
+        fused = _fused_topk(logits, beam_scores, K) if no_repeat_ngram_size <= 0 else None
+        if fused is not None:                      # log_softmax + beam scores + top-2K in two launches (csrc/elementwise.hip beam_topk_a / _b)
+            top_s, top_i = fused
+        else:
+            logp = torch.log_softmax(logits.float(), -1)
+            _ban_repeated_ngrams(seqs, logp, no_repeat_ngram_size)
+            scores = (logp + beam_scores.view(-1, 1)).view(B, K * V)
+            top_s, top_i = torch.topk(scores, 2 * K, dim=1, largest=True, sorted=True)
         top_s_h, top_i_h = top_s.tolist(), top_i.tolist()
         if trace is not None:
             trace.append((top_s_h, top_i_h))

@@ -574,6 +574,27 @@ def decode_rope_append(qkv2d, heads, head_stride, hd, offs, rot, cos_rows, sin_r
                                                kcache.stride(0), kcache.stride(1), kcache.stride(2), pos_idx.data_ptr(), _stream()), "decode_rope_append")
 
 
+def beam_topk_ok(logits, K, C):
+    V = logits.shape[-1]
+    return (logits.is_cuda and logits.dim() == 2 and logits.stride(1) == 1 and logits.dtype in (bf16, torch.float32) and logits.shape[0] % K == 0
+            and K <= 16 and C <= 32 and 16 * C <= V <= 98304)
+
+
+def beam_topk(logits, beam_scores, K, C):
+    """one beam-search step's candidate selection: top-C (sorted) of log_softmax(logits) + beam_scores over every prompt's K rows viewed as one
+    [K * V] vector -> (scores fp32 [prompts, C], flat indices int64 [prompts, C] = row_in_group * V + token).  Two launches
+    (csrc/elementwise.hip beam_topk_a / _b) instead of float copy + log_softmax + add + torch.topk."""
+    rows, V = logits.shape
+    L = _lib.lib()
+    scratch = torch.empty(L.unimp_beam_topk_scratch(rows), dtype=torch.uint8, device=logits.device)
+    bs = beam_scores.reshape(-1).float().contiguous()
+    out_s = torch.empty((rows // K, C), dtype=torch.float32, device=logits.device)
+    out_i = torch.empty((rows // K, C), dtype=torch.int64, device=logits.device)
+    check(L.unimp_beam_topk(_dev(logits).data_ptr(), int(logits.dtype == torch.float32), logits.stride(0), rows, V, K, C, bs.data_ptr(), scratch.data_ptr(),
+                            out_s.data_ptr(), out_i.data_ptr(), _stream()), "beam_topk")
+    return out_s, out_i
+
+
 def kv_reorder_beams(kv, K, src_local, slot0, pos_idx, max_new):
     """beam search: row j of every beam group takes the generated tail of row src_local[group * K + j] (index inside the group), in place, for all
     layers and both of K / V in ONE launch.  kv [layers, 2, rows, capacity, nh, hd] (the decode cache's tensor); slot0 int32 [groups] = first tail slot
