@@ -76,6 +76,12 @@ def _tune_gemm(M, N, K, a_ks, b_ks, device, reads_mn=False):
         return v
     if not GEMM_AUTOTUNE or torch.cuda.is_current_stream_capturing():
         return 0
+    if 64 < M < 512 and N >= 128 and K >= 256 and K % 64 == 0 and not a_ks:
+        # a prompt's rows (the prefill of a generate() call: 469 tokens at the reference's sizes; any M, so no table and no live tuning): the 128 x 128
+        # whole-row-A ping-pong kernel -- measured fastest of ten variants at M = 128 / 256 / 469 on all four decoder shapes (v1 + 15 ... 30 %:
+        # [469, 10240] x K = 2560 59 -> 43 us, [469, 2560] x K = 10240 169 -> 131 us; tools/bench_gemm_prefill_rows.py).  Same bits as v1.
+        _GEMM_CHOICE[key] = 14
+        return 14
     cands = [1] if (M < 512 or N < 128 or K < 128) else ([1, 4, 5, 8, 9, 10, 11, 12] if reads_mn == "out2" else [1, 4, 5, 2, 3, 8, 9, 10, 11, 12])   # "out2": the uint8 derivative
     if len(cands) > 1 and not a_ks and K % 64 == 0 and K >= 256:
         cands += [13, 14, 18, 19]               # whole-row A staging (k-contiguous A, 64-k stages); other forms would only re-run the X kernels.
