@@ -187,7 +187,14 @@ def backward_scope(fn):
     return wrapped
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """the current HIP stream's handle.  torch.cuda.current_stream() builds a Stream object through three Python layers -- 8 us per call, once per
+    launch: 5 of the 29 ms of host time of a 469-token prefill; the raw getter returns the same handle in a fraction of a microsecond."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
