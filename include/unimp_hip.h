@@ -117,6 +117,10 @@ int unimp_gemm_bf16_variant(const unimp_gemm_desc* d, int variant, void* stream)
  * UNIMP_SKINNY2); returns the previous setting.  skinny_ln_ok: may a decode GEMM of M rows, depth K take ln_gamma? */
 int unimp_gemm_set_skinny2(int on);
 int unimp_gemm_skinny_ln_ok(int M, int K);
+/* how the decode-row GEMM splits N weight rows over workgroups (host arithmetic only): rows per MFMA tile (<= 16; the busiest CU's rows are minimised
+ * below 512 sixteen-row tiles: 10 for N = 2560, 15 for 7680) and, through *tiles_per_workgroup, 1 or 2 tiles per workgroup (max_tiles = 2: the
+ * fused-LayerNorm forms at M >= 4).  UNIMP_SKINNY2_ROWS = 1 ... 16 fixes the rows. */
+int unimp_gemm_skinny_rows(int N, int max_tiles, int* tiles_per_workgroup);
 /* split-K form for outputs much smaller than the chip (weight gradients of narrow projections): `splits` K slices into
  * f32 slabs [splits][M][N] (caller-provided workspace), then an ordered reduction applying alpha*tanh(gate).  Only the
  * alpha / gate epilogue is allowed. */

@@ -158,6 +158,30 @@ def test_kernel_register_budgets():
             assert r["Occupancy"] >= 4, (k, r)
 
 
+def test_decode_row_gemm_split_and_decode_attention_slots_host_rules():
+    """host arithmetic of the decode path, callable without a GPU: (1) unimp_gemm_skinny_rows -- the weight rows per MFMA tile minimise the busiest CU's
+    rows below 512 sixteen-row tiles (10 x 256 workgroups for N = 2560, 15 x 512 for 7680, 4 x 128 for 512), stay 16 from there on with one tile per
+    workgroup, and with two tiles allowed (the fused-LayerNorm forms at M >= 4) N = 10 240 becomes 2 x 10 rows x 512 workgroups, 7680 2 x 15 x 256;
+    the head keeps 16-row single tiles; (2) unimp_attn_decode_step_slots -- one partial slot per 128-key chunk, plus one per 32-key prefix chunk with
+    beam groups while the merge can hold them (64), none beyond."""
+    import ctypes as C
+    from unimp_amd import _lib
+    L = _lib.lib()
+    def rows(N, mt):
+        nt = C.c_int(0)
+        return L.unimp_gemm_skinny_rows(N, mt, C.byref(nt)), nt.value
+    assert rows(2560, 1) == (10, 1) and rows(7680, 1) == (15, 1) and rows(512, 1) == (4, 1) and rows(10240, 1) == (16, 1) and rows(74053, 1) == (16, 1)
+    assert rows(10240, 2) == (10, 2) and rows(7680, 2) == (15, 2) and rows(2560, 2) == (10, 1) and rows(74053, 2) == (16, 1)
+    for N in (24, 1005, 2560, 5120, 7680, 10240, 12288):
+        for mt in (1, 2):
+            R, nt = rows(N, mt)
+            assert 4 <= R <= 16 and nt in (1, 2) and nt <= mt
+            wgs = -(-N // (R * nt))
+            assert -(-wgs // 256) * R * nt <= -(-(-(-N // 16)) // 256) * 16, (N, mt, R, nt)       # never more rows on the busiest CU than 16-row tiles put there
+    assert L.unimp_attn_decode_step_slots(10, 32, 527, 1) == 5 and L.unimp_attn_decode_step_slots(10, 32, 527, 10) == 5 + 17
+    assert L.unimp_attn_decode_step_slots(10, 32, 4000, 10) == 32 and L.unimp_attn_decode_splits(10, 32, 4000) == 32
+
+
 def test_gemm_kernel_code_fits_the_instruction_cache():
     """The large-tile GEMM kernels must stay inside the 64 KiB instruction cache two CUs share: with the row-group loop of
     the epilogue unrolled around the fully general per-element code they were 191 KiB, and a 256 x 256 tile spent 15 us in its

@@ -88,6 +88,7 @@ _SIGS = {
     "unimp_prefetch": [c_p, c_l, c_i, c_p, c_p],
     "unimp_beam_topk": [c_p, c_i, c_l, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p],
     "unimp_beam_topk_scratch": [c_i],
+    "unimp_gemm_skinny_rows": [c_i, c_i, c_p],
     "unimp_bcast_rows": [c_p, c_p, c_l, c_i, c_i, c_i, c_p],
     "unimp_reduce_rows_periodic": [c_p, c_l, c_p, c_i, c_i, c_i, c_p],
     "unimp_label_mask": [c_p, c_p, c_p, c_i, c_i, c_l, c_l, c_l, c_l, c_p],

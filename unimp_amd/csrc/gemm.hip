@@ -622,11 +622,12 @@ static int skinny2_rows(int N, int max_nt, int* nt_out) {
   const int tiles16 = (N + 15) / 16;
   if (tiles16 >= (max_nt > 1 ? 2048 : 512)) return 16;
   int best = 16, best_nt = 1; long cost = -1;
-  for (int nt = 1; nt <= max_nt; ++nt)          // ties: one tile
+  for (int nt = 1; nt <= max_nt; ++nt)
     for (int R = 16; R >= 4; --R) {
       if (nt == 1 && tiles16 >= 512 && R < 16) continue;         // the one-tile rule stops at 512 tiles (above)
       const long wgs = (N + nt * R - 1) / (nt * R), c = ((wgs + 255) / 256) * nt * R;
-      if (cost < 0 || c < cost) { cost = c; best = R; best_nt = nt; }
+      // ties: two tiles where they are allowed (the caller allows them where the normalisation weighs) and the tiles stay at least 8 rows high
+      if (cost < 0 || c < cost || (c == cost && nt > best_nt && R >= 8)) { cost = c; best = R; best_nt = nt; }
     }
   if (nt_out) *nt_out = best_nt;
   return best;
@@ -701,6 +702,9 @@ static int skinny2_on() {
   if (g_skinny2 < 0) { const char* e = getenv("UNIMP_SKINNY2"); g_skinny2 = e ? (atoi(e) != 0) : 1; }
   return g_skinny2;
 }
+// the split of N weight rows over workgroups the decode-row GEMM takes (tests, tools): rows per tile; *tiles_per_workgroup = 1 or 2 (max_tiles = 2: the
+// fused-LayerNorm forms of K = 2560 / 4096 at M >= 4)
+extern "C" int unimp_gemm_skinny_rows(int N, int max_tiles, int* tiles_per_workgroup) { return skinny2_rows(N, max_tiles >= 2 ? 2 : 1, tiles_per_workgroup); }
 extern "C" int unimp_gemm_set_skinny2(int on) { int old = skinny2_on(); g_skinny2 = on != 0; return old; }
 extern "C" int unimp_gemm_skinny_ln_ok(int M, int K) {      // may a decode GEMM of M rows and depth K take its LayerNorm fused (unimp_gemm_desc.ln_gamma)?
   unimp_gemm_desc d = {};

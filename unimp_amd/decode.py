@@ -103,7 +103,11 @@ class DecodeSession:
         self.tok.copy_(tokens.view(-1, 1))
         if src is not None:
             self.src.copy_(src)
-        sig = (id(self.model), tuple(c.kv.shape), self.beams, bool(self.reorder), F_.DECODE_FUSED, F_.DECODE_STEP_ATTN, F_.DECODE_STEP_GROUPED)
+        # what the lazily created state depends on: the model, the rows, the head geometry and the number of 128-key chunks of the cache (the decode
+        # attention's workspace) -- not the exact capacity, so prompts of other lengths in the same chunk count are warm as well
+        kvs = c.kv.shape
+        sig = (id(self.model), kvs[0], kvs[2], (kvs[3] + 127) // 128, kvs[4], kvs[5], self.beams, bool(self.reorder), F_.DECODE_FUSED, F_.DECODE_STEP_ATTN,
+               F_.DECODE_STEP_GROUPED)
         if not self.use_graph:
             logits = self._step_body()
         elif self.graph is None and sig not in _WARM:
