@@ -30,7 +30,7 @@ enum { UNIMP_ACT_NONE = 0, UNIMP_ACT_GELU = 1, UNIMP_ACT_QUICKGELU = 2, UNIMP_AC
 enum { UNIMP_MASK_NONE = 0, UNIMP_MASK_CAUSAL = 1, UNIMP_MASK_SEGMENT = 2 };
 
 int unimp_abi_version(void);
-int unimp_struct_size(int which);            /* sizeof(unimp_gemm_desc / unimp_attn_desc / unimp_image_desc / unimp_mx_gemm_desc) for which = 0 / 1 / 2 / 3 */
+int unimp_struct_size(int which);            /* sizeof(unimp_gemm_desc / unimp_attn_desc / unimp_image_desc / unimp_mx_gemm_desc / unimp_decode_step_desc) for which = 0 ... 4 */
 const char* unimp_last_error(void);          /* thread-local, valid until the next failing call */
 /* internal helpers shared by the translation units (exported for the tests' benefit only) */
 int unimp_set_error(int code, const char* msg);

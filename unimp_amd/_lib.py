@@ -141,7 +141,7 @@ def lib():
                               "rebuild with `make -C unimp_amd/csrc`")
         # the descriptors are passed by pointer: a layout the library and these ctypes mirrors disagree on would bind silently
         L.unimp_struct_size.restype, L.unimp_struct_size.argtypes = c_i, [c_i]
-        for which, st in ((0, GemmDesc), (1, AttnDesc), (3, MxGemmDesc)):
+        for which, st in ((0, GemmDesc), (1, AttnDesc), (3, MxGemmDesc), (4, DecodeStepDesc)):
             if L.unimp_struct_size(which) != C.sizeof(st):
                 raise ImportError(f"{LIB_PATH}: sizeof descriptor {which} is {L.unimp_struct_size(which)} in the library, "
                                   f"{C.sizeof(st)} in {st.__name__} -- stale build")

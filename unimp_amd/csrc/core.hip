@@ -21,13 +21,14 @@ extern "C" int unimp_check_launch(const char* what) {
   return UNIMP_OK;
 }
 
-// sizeof of the descriptor structs, so a binding can verify its mirror of them (0: gemm, 1: attention, 2: image)
+// sizeof of the descriptor structs, so a binding can verify its mirror of them (0: gemm, 1: attention, 2: image, 3: MX gemm, 4: decode step)
 extern "C" int unimp_struct_size(int which) {
   switch (which) {
     case 0: return (int)sizeof(unimp_gemm_desc);
     case 1: return (int)sizeof(unimp_attn_desc);
     case 2: return (int)sizeof(unimp_image_desc);
     case 3: return (int)sizeof(unimp_mx_gemm_desc);
+    case 4: return (int)sizeof(unimp_decode_step_desc);
     default: return -1;
   }
 }

@@ -499,9 +499,7 @@ __device__ __forceinline__ void dec_merge_group(const DecStepP& p, int b0, int h
 template <int G, int U, int NQ>
 __device__ __forceinline__ void dec_step_prefix(const DecStepP& p, float* sm, unsigned* last_s) {
   constexpr int KPL = 64 / G;
-  const int npre = p.psplits * (p.rows / p.group);            // grouped grid: x = [prefix (chunk, group) pairs | tail (split, row) pairs], y = head
-  const int split = blockIdx.x % p.psplits, h = blockIdx.y, gi = blockIdx.x / p.psplits;
-  (void)npre;
+  const int split = blockIdx.x % p.psplits, h = blockIdx.y, gi = blockIdx.x / p.psplits;      // grouped grid: x = [prefix (chunk, group) pairs | tail (split, row) pairs], y = head
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int slot = lane / G, c = lane % G;
   const bool act = c * 8 < p.D;
