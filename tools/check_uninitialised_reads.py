@@ -40,3 +40,37 @@ for cfg_name in ("TINY",) + tuple(n for n in ("TINY_MPT", "TINY_LLAMA") if hasat
         del tr
     ok = all(o[0] == outs[0][0] and o[1] == outs[0][1] and torch.equal(o[2], outs[0][2]) for o in outs[1:])
     print(f"{cfg_name}: same bits in all three runs: {ok}" + ("" if ok else f"   differing parameters: {[int((o[2] != outs[0][2]).sum()) for o in outs[1:]]}"))
+
+
+# ---- the cached decode: the tokens and last logits of generate() (greedy and 4 beams) under the same poisoning
+if os.environ.get("CHECK_DECODE", "1") != "0":
+    import bench
+    from unimp_amd.synthetic import make_batch
+    from unimp_amd.decode import DecodeSession
+    dev = torch.device("cuda")
+    model, layout = bench.build_cfg2(dev, gate=0.5)
+    model.eval()
+    bt = make_batch(layout, 1, 8, 512, seed=7, device="cuda", vision_dtype=torch.bfloat16)
+    n = int(bt["attention_mask"][0].sum())
+    ids, vx = bt["lang_x"][:1, :n - 2], bt["vision_x"][:1]
+    for K in (1, 10):
+        outs = []
+        for tag, byte in (("as is", None), ("free memory = 0xFF", 0xFF), ("free memory = 0x00", 0x00)):
+            npo = poison(byte) if byte is not None else 0
+            with torch.no_grad():
+                model.lang_encoder._use_cached_vision_x = True
+                model._encode_vision_x(vision_x=vx)
+                s = DecodeSession(model, 24, reorder=K > 1, graph=True, beams=K)
+                lg = s.prefill(ids, None)
+                tok = lg.float().argmax(-1); src = torch.arange(lg.shape[0], device=dev)
+                toks = [tok.clone()]
+                for _ in range(12):
+                    if byte is not None:
+                        poison(byte)
+                    lg = s.step(tok, src if K > 1 else None)
+                    tok = lg.float().argmax(-1); toks.append(tok.clone())
+                model.clear_conditioned_layers(); model.lang_encoder._use_cached_vision_x = False
+            outs.append((torch.stack(toks), lg.clone()))
+            print(f"decode K={K} {tag:22s} poisoned {npo >> 20:6d} MiB  tokens {outs[-1][0][:, 0].tolist()[:8]}")
+        ok = all(torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1]) for o in outs[1:])
+        print(f"decode K={K}: same tokens and last-step logits bits in all three runs: {ok}")
