@@ -50,3 +50,18 @@ def test_no_repeat_ngram(hf):
                        eos_token_id=59, pad_token_id=59, no_repeat_ngram_size=2, early_stopping=True)
     got = beam_search(_logits_fn(hf), ids, 3, 12, 59, 59, 1, early_stopping=True, no_repeat_ngram_size=2)
     assert torch.equal(got, want)
+
+
+def test_fused_beam_topk_is_a_gpu_path_only():
+    """generate.beam_search takes unimp_beam_topk (log_softmax + beam scores + top-2K in two HIP launches) for GPU logits only: on CPU tensors the helper
+    declines and the torch ops run -- the product path has no CPU kernel, and the CPU tests above pin the torch path against transformers."""
+    import torch
+    from unimp_amd import generate
+    logits = torch.randn(4, 1000)
+    assert generate._fused_topk(logits, torch.zeros(1, 4), 4) is None
+    old = generate.BEAM_TOPK_FUSED
+    try:
+        generate.BEAM_TOPK_FUSED = False
+        assert generate._fused_topk(logits, torch.zeros(1, 4), 4) is None
+    finally:
+        generate.BEAM_TOPK_FUSED = old
